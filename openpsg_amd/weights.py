@@ -1,0 +1,147 @@
+"""State-dict schema of the relation head and deterministic weight generators.
+
+Key names are the reference head's own ``state_dict()`` names (prefix ``relation_head.`` inside a
+detector checkpoint): timm ``PatchEmbed.proj``, HF ``InstructBlipQFormerModel``,
+``relation_query`` / ``rel_cls_query`` (V4:87-90), ``binary_rel_cls_pred`` (V4:92),
+``language_projection`` (V4:97-98) and HF ``LlamaForCausalLM`` under ``language_model.``.
+
+Reference checkpoints are partial (part_checkpoint_hook.py:96-116 drops ``language_model.*``), so
+loaders must be ``strict=False``; ``llm_keys`` / ``head_keys`` split the schema accordingly.
+
+There are no model files offline, so tests and the benchmark use seeded random weights:
+``make_weights_numpy`` (numpy PCG64, sorted-key order, bit-reproducible on any box; used for
+parity tests and goldens) and ``make_weights_device`` (torch generator on the GPU; used for the
+7B-shaped benchmark where numpy would take minutes).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .config import PSGConfig
+
+
+def head_shapes(cfg: PSGConfig) -> dict:
+    q = cfg.qformer
+    C, P = cfg.feat_channels, cfg.patch_size
+    s = {
+        "patch_embed.proj.weight": (C, C, P, P),
+        "patch_embed.proj.bias": (C,),
+        "relation_qformer.embeddings.word_embeddings.weight": (q.vocab, q.hidden),
+        "relation_qformer.embeddings.position_embeddings.weight": (q.max_pos, q.hidden),
+        "relation_qformer.embeddings.layernorm.weight": (q.hidden,),
+        "relation_qformer.embeddings.layernorm.bias": (q.hidden,),
+        "relation_query": (1, q.num_query, q.hidden),
+        "rel_cls_query": (1, 1, q.hidden),
+        "binary_rel_cls_pred.weight": (1, q.hidden),
+        "binary_rel_cls_pred.bias": (1,),
+        "language_projection.weight": (cfg.llm.hidden, q.hidden),
+        "language_projection.bias": (cfg.llm.hidden,),
+    }
+    for l in range(q.layers):
+        p = f"relation_qformer.encoder.layer.{l}."
+        for att, kin in (("attention", q.hidden), ("crossattention", q.enc_hidden)):
+            s[p + f"{att}.attention.query.weight"] = (q.hidden, q.hidden)
+            s[p + f"{att}.attention.query.bias"] = (q.hidden,)
+            s[p + f"{att}.attention.key.weight"] = (q.hidden, kin)
+            s[p + f"{att}.attention.key.bias"] = (q.hidden,)
+            s[p + f"{att}.attention.value.weight"] = (q.hidden, kin)
+            s[p + f"{att}.attention.value.bias"] = (q.hidden,)
+            s[p + f"{att}.output.dense.weight"] = (q.hidden, q.hidden)
+            s[p + f"{att}.output.dense.bias"] = (q.hidden,)
+            s[p + f"{att}.output.LayerNorm.weight"] = (q.hidden,)
+            s[p + f"{att}.output.LayerNorm.bias"] = (q.hidden,)
+        for inter, out in (("intermediate", "output"), ("intermediate_query", "output_query")):
+            s[p + f"{inter}.dense.weight"] = (q.inter, q.hidden)
+            s[p + f"{inter}.dense.bias"] = (q.inter,)
+            s[p + f"{out}.dense.weight"] = (q.hidden, q.inter)
+            s[p + f"{out}.dense.bias"] = (q.hidden,)
+            s[p + f"{out}.LayerNorm.weight"] = (q.hidden,)
+            s[p + f"{out}.LayerNorm.bias"] = (q.hidden,)
+    return s
+
+
+def llm_shapes(cfg: PSGConfig) -> dict:
+    m = cfg.llm
+    s = {
+        "language_model.model.embed_tokens.weight": (m.vocab, m.hidden),
+        "language_model.model.norm.weight": (m.hidden,),
+        "language_model.lm_head.weight": (m.vocab, m.hidden),
+    }
+    for l in range(m.layers):
+        p = f"language_model.model.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            s[p + f"self_attn.{n}.weight"] = (m.hidden, m.hidden)
+        s[p + "mlp.gate_proj.weight"] = (m.inter, m.hidden)
+        s[p + "mlp.up_proj.weight"] = (m.inter, m.hidden)
+        s[p + "mlp.down_proj.weight"] = (m.hidden, m.inter)
+        s[p + "input_layernorm.weight"] = (m.hidden,)
+        s[p + "post_attention_layernorm.weight"] = (m.hidden,)
+    return s
+
+
+def all_shapes(cfg: PSGConfig) -> dict:
+    s = head_shapes(cfg)
+    s.update(llm_shapes(cfg))
+    return s
+
+
+def _std_for(key: str, shape) -> tuple[float, float]:
+    """(mean, std) per tensor.  HF's default std=0.02 makes every softmax near-uniform, which would
+    hide masking / ordering bugs; q/k get a larger std so attention is peaky."""
+    if key.endswith("LayerNorm.weight") or key.endswith("layernorm.weight") or key.endswith("norm.weight"):
+        return 1.0, 0.1
+    if key.endswith(".bias"):
+        return 0.0, 0.05
+    if key in ("relation_query", "rel_cls_query"):
+        return 0.0, 1.0                       # torch.randn in the reference (V4:87-90)
+    if "embeddings.weight" in key or key.endswith("embed_tokens.weight"):
+        return 0.0, 1.0
+    fan_in = int(np.prod(shape[1:]))
+    if key.endswith("patch_embed.proj.weight"):
+        return 0.0, 1.0 / np.sqrt(fan_in)     # features ~N(0,1) -> patches ~N(0,1)
+    if ".attention.query." in key or ".attention.key." in key:
+        return 0.0, 2.2 / np.sqrt(fan_in)
+    if "q_proj" in key or "k_proj" in key:
+        return 0.0, 2.0 / np.sqrt(fan_in)
+    if key.endswith("lm_head.weight"):
+        return 0.0, 3.0 / np.sqrt(fan_in)     # logit std ~3 -> argmax margins >> fp32 noise
+    if key.startswith("binary_rel_cls_pred"):
+        return 0.0, 2.0 / np.sqrt(fan_in)
+    return 0.0, 1.0 / np.sqrt(fan_in)
+
+
+def make_weights_numpy(cfg: PSGConfig, seed: int = 0, with_llm: bool = True) -> dict:
+    """fp32 CPU tensors, numpy PCG64, filled in sorted-key order (bit-reproducible)."""
+    shapes = all_shapes(cfg) if with_llm else head_shapes(cfg)
+    rng = np.random.default_rng(seed)
+    out = {}
+    for key in sorted(shapes):
+        mean, std = _std_for(key, shapes[key])
+        a = rng.standard_normal(shapes[key], dtype=np.float32) * np.float32(std) + np.float32(mean)
+        out[key] = torch.from_numpy(a.astype(np.float32))
+    return out
+
+
+def make_weights_device(cfg: PSGConfig, seed: int, device, head_dtype=torch.float32,
+                        llm_dtype=torch.bfloat16, with_llm: bool = True) -> dict:
+    """Random-init weights generated directly in HBM (benchmark use: 7B-shaped LLM)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = {}
+    shapes = all_shapes(cfg) if with_llm else head_shapes(cfg)
+    for key in sorted(shapes):
+        mean, std = _std_for(key, shapes[key])
+        dt = llm_dtype if key.startswith("language_model.") else head_dtype
+        t = torch.empty(shapes[key], device=device, dtype=torch.float32 if len(shapes[key]) < 2 else dt)
+        if t.dtype == torch.float32:
+            t.normal_(mean, std, generator=g)
+        else:
+            # fill in fp32 chunks to keep the distribution exact, then cast
+            flat = t.view(-1)
+            step = 1 << 26
+            for o in range(0, flat.numel(), step):
+                n = min(step, flat.numel() - o)
+                flat[o:o + n] = torch.empty(n, device=device).normal_(mean, std, generator=g).to(dt)
+        out[key] = t.to(dt) if len(shapes[key]) >= 2 else t
+    return out

@@ -1,0 +1,317 @@
+"""Golden-vector capture: drives the REAL reference head (from /root/reference) on the CPU.
+
+Runs ONLY in the build container (needs /root/reference and HF transformers); it never travels to
+the GPU box.  It writes small `.npz` fixtures (inputs + expected outputs, no reference source) to
+tests/golden/.  Recipe:
+
+  1. stub the un-installed mmcv / mmdet / timm modules and pre-register empty `kings_sgg` packages
+     whose __path__ points into /root/reference (the real `relation_heads/__init__.py` imports
+     legacy heads that need transformers <= 4.34);
+  2. import the real `relation_transformer_head_v4` module; build an instance with `__new__`
+     (its __init__ downloads from the hub, V4:85-86, 99-104) and assign the attributes __init__
+     would: HF `InstructBlipQFormerModel` / `LlamaForCausalLM` (eager attention), word-level
+     tokenizers, parameters from `openpsg_amd.weights.make_weights_numpy`;
+  3. hook `binary_rel_cls_pred`, `relation_qformer`, `language_model.generate`; call
+     `head(inputs)`; catch the UnboundLocalError the committed binary branch raises at V4:355
+      - every capture is complete by then.
+
+Usage:  python oracle/capture_reference.py            (writes tests/golden/G*.npz)
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm  # noqa: E402
+from openpsg_amd.synthetic import make_scene  # noqa: E402
+from openpsg_amd.tokenizers import WordTokenizer  # noqa: E402
+from openpsg_amd.weights import make_weights_numpy  # noqa: E402
+from openpsg_amd import categories  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference_head():
+    import transformers  # noqa: F401  (must come first: it probes timm with find_spec)
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    class _PatchEmbed(nn.Module):
+        """timm.layers.PatchEmbed(img_size=None, patch_size, in_chans, embed_dim): conv + flatten."""
+        def __init__(self, img_size=None, patch_size=16, in_chans=3, embed_dim=768, **kw):
+            super().__init__()
+            self.proj = nn.Conv2d(in_chans, embed_dim, patch_size, patch_size)
+
+        def forward(self, x):
+            return self.proj(x).flatten(2).transpose(1, 2)
+
+    _stub("mmcv")
+    _stub("mmcv.runner", BaseModule=nn.Module)
+    _stub("mmdet")
+    _stub("mmdet.core", INSTANCE_OFFSET=1000, bbox2result=None)
+    _stub("mmdet.models")
+    _stub("mmdet.models.builder", HEADS=_Reg(), DETECTORS=_Reg(), build_head=None)
+    _stub("mmdet.models.detectors", Mask2Former=object)
+    _stub("mmdet.models.detectors.single_stage", SingleStageDetector=object)
+    _stub("timm")
+    _stub("timm.layers", PatchEmbed=_PatchEmbed)
+    for pkg in ("kings_sgg", "kings_sgg.models", "kings_sgg.models.relation_heads", "kings_sgg.models.detectors"):
+        m = _stub(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+    # The repo has its own `kings_sgg` shim package; make sure the reference's files win here.
+    mod = importlib.import_module("kings_sgg.models.relation_heads.relation_transformer_head_v4")
+    assert mod.__file__.startswith(REF), mod.__file__
+    assert list(mod.object_categories) == list(categories.object_categories)
+    assert list(mod.relation_categories) == list(categories.relation_categories)
+    return mod
+
+
+class _QFormerShim(nn.Module):
+    """transformers 5.x rejects the reference's [B,33,L] cross mask; all 33 rows are copies of the
+    same [B,L] row (V4:170), so pass that."""
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward(self, input_ids, attention_mask, query_embeds, encoder_hidden_states, encoder_attention_mask):
+        assert encoder_attention_mask.dim() == 3
+        assert bool((encoder_attention_mask == encoder_attention_mask[:, :1]).all())
+        return self.inner(input_ids=input_ids, attention_mask=attention_mask, query_embeds=query_embeds,
+                          encoder_hidden_states=encoder_hidden_states,
+                          encoder_attention_mask=encoder_attention_mask[:, 0, :].to(torch.long))
+
+
+def build_reference_head(mod, cfg: PSGConfig, w: dict):
+    from transformers import InstructBlipQFormerConfig, InstructBlipQFormerModel, LlamaConfig, LlamaForCausalLM
+    H = mod.RelationTransformerHeadV4
+    h = H.__new__(H)
+    nn.Module.__init__(h)
+    q, m = cfg.qformer, cfg.llm
+    # config attributes (V4:51-70)
+    h.qformer_instruction = 'Is there a relation between {} and {}?'
+    h.patch_size = cfg.patch_size
+    h.qformer_layer_num = q.layers
+    h.qformer_feature_size = q.hidden
+    h.rel_cls_type = 'binary'
+    h.llm_instruction = 'What are the relations between {} and {}? Assistant: '
+    h.llm_truncate_num = -1
+    h.llm_feature_size = m.hidden
+    h.max_llm_forward_num = 4
+    h.pair_selector_threshold = 0.5
+    h.num_object_classes = 133
+    h.object_feature_size = cfg.feat_channels
+    h.relation_classes = mod.relation_categories
+    h.num_relation_classes = len(mod.relation_categories)
+    h.max_object_num = cfg.max_object_num
+    # modules (V4:75-105)
+    PatchEmbed = sys.modules["timm.layers"].PatchEmbed
+    h.patch_embed = PatchEmbed(None, cfg.patch_size, cfg.feat_channels, cfg.feat_channels)
+    qc = InstructBlipQFormerConfig(hidden_size=q.hidden, num_hidden_layers=q.layers, cross_attention_frequency=1,
+                                   encoder_hidden_size=q.enc_hidden, vocab_size=q.vocab,
+                                   max_position_embeddings=q.max_pos)
+    qc._attn_implementation = "eager"
+    h.relation_qformer = _QFormerShim(InstructBlipQFormerModel(qc))
+    h.relation_qformer_tokenizer = WordTokenizer("bert")
+    h.relation_query = nn.Parameter(torch.zeros(1, q.num_query, q.hidden))
+    h.rel_cls_query = nn.Parameter(torch.zeros(1, 1, q.hidden))
+    h.binary_rel_cls_pred = nn.Linear(q.hidden, 1)
+    h.language_projection = nn.Linear(q.hidden, m.hidden)
+    lc = LlamaConfig(hidden_size=m.hidden, intermediate_size=m.inter, num_hidden_layers=m.layers,
+                     num_attention_heads=m.heads, num_key_value_heads=m.heads, vocab_size=m.vocab,
+                     rms_norm_eps=m.rms_eps, max_position_embeddings=4096, bos_token_id=m.bos,
+                     eos_token_id=m.eos, pad_token_id=None, tie_word_embeddings=False)
+    lc._attn_implementation = "eager"
+    h.language_model = LlamaForCausalLM(lc)
+    h.llm_tokenizer = WordTokenizer("llama")
+    h.llm_tokenizer.pad_token = h.llm_tokenizer.unk_token
+    # load the seeded weights under the reference's own names
+    sd = {}
+    for k, v in w.items():
+        sd[k.replace("relation_qformer.", "relation_qformer.inner.")] = v
+    missing, unexpected = h.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary_emb" in k or "position_ids" in k for k in missing), missing
+    h.eval()
+    return h
+
+
+def run_reference(mod, cfg, w, scene, suppress_eos=False):
+    """Calls the real forward and captures intermediates."""
+    h = build_reference_head(mod, cfg, w)
+    cap = dict(generate=[])
+    h.binary_rel_cls_pred.register_forward_hook(lambda m_, i, o: cap.__setitem__("exist_logit", o.detach().clone()))
+    h.relation_qformer.register_forward_hook(
+        lambda m_, i, o: cap.__setitem__("qformer_out", o["last_hidden_state"].detach().clone()))
+    real_generate = h.language_model.generate
+
+    def generate(**kw):
+        kw = dict(kw)
+        kw["do_sample"] = False
+        if suppress_eos:
+            kw["suppress_tokens"] = [cfg.llm.eos]
+        out = real_generate(**kw)
+        cap["generate"].append(dict(inputs_embeds=kw["inputs_embeds"].detach().clone(),
+                                    attention_mask=kw["attention_mask"].detach().clone(),
+                                    sequences=out.sequences.detach().clone(),
+                                    first_scores=out.scores[0].detach().clone()))
+        return out
+    h.language_model.generate = generate
+    # With random weights the model never emits '<s>', and V4:315-316 then raises IndexError after
+    # the first generate.  Prefix the DECODED STRING (harness side, not the reference) so the loop
+    # visits all selected pairs; token captures above are unaffected.
+    real_decode = h.llm_tokenizer.batch_decode
+    h.llm_tokenizer.batch_decode = lambda seqs: ["<s> " + t for t in real_decode(seqs)]
+    prep = {}
+    real_prepare = h.prepare_inference
+
+    def prepare(*a, **k):
+        patches, pm = real_prepare(*a, **k)
+        prep["patches"], prep["pair_masks"] = patches.detach().clone(), pm.detach().clone()
+        return patches, pm
+    h.prepare_inference = prepare
+    torch.Tensor.cuda = lambda self, *a, **k: self           # V4:151-152 etc. call .cuda()
+    inputs = dict(mask_features=scene["mask_features"], img_metas=[scene["img_meta"]],
+                  object_info=[dict(object_id_list=scene["object_id_list"], pan_results=scene["pan_results"])])
+    err = None
+    with torch.no_grad():
+        try:
+            out = h(inputs)
+            cap["output"] = out
+        except UnboundLocalError as e:                        # V4:355, binary mode
+            err = str(e)
+        except IndexError as e:                               # V4:315-316: no '<s>' generated
+            err = "IndexError: " + str(e)
+    cap.update(prep)
+    cap["error"] = err
+    return cap
+
+
+def case_config(llm):
+    return PSGConfig(qformer=QFormerConfig(vocab=512), llm=llm, max_object_num=30)
+
+
+def pack_bits(mask_bool: torch.Tensor) -> np.ndarray:
+    return np.packbits(mask_bool.numpy().astype(np.uint8), axis=-1, bitorder="little")
+
+
+def capture_scene_case(mod, name, scene_kw, llm, weight_seed, keep_pairs, suppress_eos):
+    cfg = case_config(llm)
+    w = make_weights_numpy(cfg, seed=weight_seed)
+    scene = make_scene(**scene_kw)
+    cap = run_reference(mod, cfg, w, scene, suppress_eos=suppress_eos)
+    n = len(scene["object_id_list"])
+    B = n * n
+    assert cap["exist_logit"].shape == (B, 1)
+    assert "rel_pred_list" in (cap["error"] or "") or cap["error"].startswith("IndexError"), cap["error"]
+    logit = cap["exist_logit"][:, 0]
+    pm = cap["pair_masks"][:, 0, :]
+    empty = (~pm).all(dim=1).nonzero().flatten().tolist()
+    keep = sorted(set(keep_pairs + empty[:2]))
+    gens = cap["generate"]
+    maxlen = max(g["sequences"].shape[1] for g in gens)
+    toks = np.full((len(gens), maxlen), -1, dtype=np.int64)
+    top8_idx = np.zeros((len(gens), 8), dtype=np.int64)
+    top8_val = np.zeros((len(gens), 8), dtype=np.float32)
+    prompt_len = np.zeros(len(gens), dtype=np.int64)
+    for i, g in enumerate(gens):
+        s = g["sequences"][0]
+        toks[i, :len(s)] = s.numpy()
+        tv, ti = torch.topk(g["first_scores"][0], 8)
+        top8_idx[i], top8_val[i] = ti.numpy(), tv.numpy()
+        prompt_len[i] = int(g["attention_mask"].sum())
+    out = dict(
+        weight_seed=np.int64(weight_seed), suppress_eos=np.bool_(suppress_eos),
+        llm_hidden=np.int64(llm.hidden), llm_layers=np.int64(llm.layers), llm_inter=np.int64(llm.inter),
+        llm_vocab=np.int64(llm.vocab),
+        scene_kw=np.array(repr(scene_kw)),
+        pan_results=scene["pan_results"].numpy().astype(np.int32),
+        object_ids=np.array([int(i) for i in scene["object_id_list"]], dtype=np.int32),
+        img_shape=np.array(scene["img_meta"]["img_shape"]), pad_shape=np.array(scene["img_meta"]["pad_shape"]),
+        pair_masks_bits=pack_bits(pm), num_patches=np.int64(pm.shape[1]),
+        patches_sample=cap["patches"][0, ::37, ::29].numpy(),
+        exist_logit=logit.numpy(),
+        kept_pairs=np.array(keep, dtype=np.int64),
+        qformer_out_kept=cap["qformer_out"][keep, :33].numpy(),
+        empty_pairs=np.array(empty, dtype=np.int64),
+        gen_tokens=toks, gen_top8_idx=top8_idx, gen_top8_val=top8_val, gen_valid_len=prompt_len,
+        gen_first_embeds_sample=gens[0]["inputs_embeds"][0, ::5, ::31].numpy(),
+        reference_error=np.array(cap["error"]),
+    )
+    # the selection the reference made = order of generate calls (V4:235-237, 293)
+    sel = torch.sigmoid(logit).topk(B).indices.tolist()[:20]
+    out["selected"] = np.array(sel, dtype=np.int64)
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: B={B} L={pm.shape[1]} empty={len(empty)} gens={len(gens)} err={cap['error']!r} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def capture_mask_grid_case(mod):
+    """G3: mask -> patch grid only, on awkward geometries (incl. the C5 1000x1333 -> 1024x1344 one)."""
+    H = mod.RelationTransformerHeadV4
+    out = {}
+    geos = [((480, 640), (1000, 1333), (1024, 1344)), ((375, 500), (800, 1067), (800, 1088)),
+            ((512, 512), (512, 512), (512, 512)), ((427, 640), (683, 1024), (704, 1024)),
+            ((1024, 1024), (1024, 1024), (1024, 1024)), ((333, 500), (666, 1000), (672, 1024))]
+    for gi, (ori, img, pad) in enumerate(geos):
+        scene = make_scene(pad, 14, seed=100 + gi, ori_hw=ori, img_hw=img, void_id=0, force_id0=True,
+                           features=False)
+        feat = torch.zeros(1, 4, pad[0] // 4, pad[1] // 4)
+        ns = types.SimpleNamespace(patch_embed=lambda x: x.new_zeros(1, 1, 1), patch_size=16)
+        _, pm = H.prepare_inference(ns, feat, scene["img_meta"], scene["object_id_list"], scene["pan_results"])
+        n = len(scene["object_id_list"])
+        diag = pm[:, 0, :][torch.arange(n) * n + torch.arange(n)]       # pair (i,i) == object mask i
+        out[f"g{gi}_pan"] = scene["pan_results"].numpy().astype(np.int32)
+        out[f"g{gi}_ids"] = np.array([int(i) for i in scene["object_id_list"]], dtype=np.int32)
+        out[f"g{gi}_shapes"] = np.array([ori, img, pad])
+        out[f"g{gi}_grid_hw"] = np.array([pad[0] // 4 // 16, pad[1] // 4 // 16])
+        out[f"g{gi}_obj_masks_bits"] = pack_bits(diag)
+        out[f"g{gi}_pair_masks_bits"] = pack_bits(pm[:, 0, :])
+    out["num_cases"] = np.int64(len(geos))
+    path = os.path.join(REPO, "tests", "golden", "G3_mask_grid.npz")
+    np.savez_compressed(path, **out)
+    print(f"G3_mask_grid: {len(geos)} geometries -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    mod = import_reference_head()
+    os.makedirs(os.path.join(REPO, "tests", "golden"), exist_ok=True)
+    capture_mask_grid_case(mod)
+    # G1 = BASELINE config C1 (512x512, 10 masks), void aliased with person#0, one vanishing object
+    capture_scene_case(mod, "G1_c1_512_n10",
+                       dict(pad_hw=(512, 512), num_objects=10, seed=1, void_id=0, force_id0=True, tiny_object=True),
+                       tiny_llm(256, 2, 512, 512), weight_seed=11, keep_pairs=[0, 7, 55, 99], suppress_eos=False)
+    # G2 = resized + padded geometry, L = 12*16 = 192 (not a multiple of 64/128), N=12
+    capture_scene_case(mod, "G2_768x1024_n12",
+                       dict(pad_hw=(768, 1024), num_objects=12, seed=2, ori_hw=(720, 960), img_hw=(750, 1000),
+                            void_id=133, tiny_object=True),
+                       tiny_llm(256, 2, 512, 512), weight_seed=12, keep_pairs=[0, 13, 77, 143], suppress_eos=True)
+    # G4 = wider / deeper LLM (8 heads x 128, 3 layers), natural EOS
+    capture_scene_case(mod, "G4_llm_wide_n6",
+                       dict(pad_hw=(512, 512), num_objects=6, seed=4, void_id=133),
+                       tiny_llm(1024, 3, 2752, 512), weight_seed=14, keep_pairs=[0, 35], suppress_eos=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,345 @@
+"""CPU ORACLE for the OpenPSG relation-query + LMM-decode path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain fp32 PyTorch on the CPU, the arithmetic the reference executes for
+`RelationTransformerHeadV4.forward` in eval mode.  It is the checker the HIP path is compared
+against; it is never the thing measured or shipped.  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under ``openpsg_amd/`` does.
+
+Parity pin: the reference has NO tests or golden vectors of its own, so this oracle is
+pinned against OUTPUTS OF THE REFERENCE ITSELF run in the build container:
+``oracle/capture_reference.py`` stub-imports the real ``RelationTransformerHeadV4`` from
+/root/reference, drives it with HF ``InstructBlipQFormerModel`` / ``LlamaForCausalLM``
+(transformers 5.15.0, eager attention) and writes ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks every function here against those captures.
+
+Reference anchors (file:line; V4 = kings_sgg/models/relation_heads/relation_transformer_head_v4.py,
+HF-IB = transformers/models/instructblip/modeling_instructblip.py, HF-LL = .../llama/modeling_llama.py,
+both third-party and absent from /root/reference; the reference pins no version):
+
+  patch_embed            V4:410 (timm PatchEmbed = Conv2d(k=16,s=16) + flatten(2).transpose(1,2))
+  mask_grid              V4:416-423 (nearest -> zero pad -> nearest)
+  object_masks/pair_masks V4:425-433
+  qformer_embeddings     HF-IB:728-757
+  qformer self/cross att HF-IB:446-515 (eager: 176-196), output blocks 519-530
+  qformer FFN            HF-IB:563-596, 664-672
+  existence head         V4:206-209
+  selector               V4:235-237
+  llm inputs             V4:294-301
+  llama forward          HF-LL:53-67 (RMSNorm), 130-160 (rotary), 191-214 (eager attention), 163-177 (MLP)
+  greedy generate        V4:305-312 (HF generate, num_beams=1, do_sample forced False)
+  parse                  V4:313-326
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+FMIN = torch.finfo(torch.float32).min
+
+
+# --------------------------------------------------------------------------------------------
+# A4: prepare_inference
+# --------------------------------------------------------------------------------------------
+def patch_embed(w: dict, feat: torch.Tensor, patch: int = 16) -> torch.Tensor:
+    """V4:410 -> [1, L, C]."""
+    x = F.conv2d(feat, w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], stride=patch)
+    return x.flatten(2).transpose(1, 2)
+
+
+def mask_grid(pan: torch.Tensor, img_shape, pad_shape, grid_hw) -> torch.Tensor:
+    """V4:416-423: id map -> nearest(img) -> zero pad(pad) -> nearest(grid).  float32 [gh, gw]."""
+    img_h, img_w = img_shape[:2]
+    pad_h, pad_w = pad_shape[:2]
+    x = F.interpolate(pan[None, None].float(), size=(img_h, img_w), mode="nearest").squeeze()
+    x = F.pad(x[None, None], (0, pad_w - img_w, 0, pad_h - img_h), value=0).squeeze()
+    x = F.interpolate(x[None, None].float(), size=tuple(grid_hw), mode="nearest")
+    return x.reshape(grid_hw[0], grid_hw[1])
+
+
+def mask_grid_closed_form(pan: torch.Tensor, img_shape, pad_shape, grid_hw) -> torch.Tensor:
+    """Same map as `mask_grid` without materialising the intermediates.
+    ATen legacy 'nearest': src = min(floor(dst * float32(in/out)), in-1), scale in float32."""
+    import numpy as np
+    H0, W0 = pan.shape
+    img_h, img_w = img_shape[:2]
+    pad_h, pad_w = pad_shape[:2]
+    gh, gw = grid_hw
+    out = torch.zeros(gh, gw, dtype=torch.float32)
+    sy2, sx2 = np.float32(pad_h) / np.float32(gh), np.float32(pad_w) / np.float32(gw)
+    sy1, sx1 = np.float32(H0) / np.float32(img_h), np.float32(W0) / np.float32(img_w)
+    for r in range(gh):
+        y1 = min(int(np.floor(np.float32(r) * sy2)), pad_h - 1)
+        for c in range(gw):
+            x1 = min(int(np.floor(np.float32(c) * sx2)), pad_w - 1)
+            if y1 >= img_h or x1 >= img_w:
+                continue
+            y0 = min(int(np.floor(np.float32(y1) * sy1)), H0 - 1)
+            x0 = min(int(np.floor(np.float32(x1) * sx1)), W0 - 1)
+            out[r, c] = float(pan[y0, x0])
+    return out
+
+
+def object_masks(grid: torch.Tensor, object_ids) -> torch.Tensor:
+    """V4:425-429 -> bool [N, L]."""
+    flat = grid.reshape(-1)
+    return torch.stack([flat == float(int(i)) for i in object_ids], dim=0)
+
+
+def pair_masks(obj_masks: torch.Tensor) -> torch.Tensor:
+    """V4:430-433 -> bool [N*N, L], pair p = i*N + j."""
+    n = obj_masks.shape[0]
+    return (obj_masks[:, None, :] | obj_masks[None, :, :]).reshape(n * n, -1)
+
+
+# --------------------------------------------------------------------------------------------
+# A6: relation Q-Former (HF InstructBlipQFormerModel, eager, legacy additive masks)
+# --------------------------------------------------------------------------------------------
+def _lin(w, prefix, x):
+    return F.linear(x, w[prefix + ".weight"], w[prefix + ".bias"])
+
+
+def _ln(w, prefix, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), w[prefix + ".weight"], w[prefix + ".bias"], eps)
+
+
+def _mha(q, k, v, add_mask, heads):
+    """q [B,Sq,D], k/v [B or 1,Sk,D], add_mask broadcastable to [B,1,Sq,Sk] (HF-IB:176-196)."""
+    B, Sq, D = q.shape
+    hd = D // heads
+    qh = q.view(B, Sq, heads, hd).transpose(1, 2)
+    kh = k.view(k.shape[0], -1, heads, hd).transpose(1, 2)
+    vh = v.view(v.shape[0], -1, heads, hd).transpose(1, 2)
+    s = torch.matmul(qh, kh.transpose(-1, -2)) * (hd ** -0.5)
+    s = s + add_mask
+    p = torch.softmax(s, dim=-1)
+    o = torch.matmul(p, vh)
+    return o.transpose(1, 2).reshape(B, Sq, D)
+
+
+def qformer_embeddings(w, cfg, input_ids):
+    """HF-IB:728-757 -> [B, 33+T, hidden]; query rows are pair independent."""
+    q = cfg.qformer
+    B, T = input_ids.shape
+    pre = "relation_qformer.embeddings."
+    query = torch.cat([w["rel_cls_query"], w["relation_query"]], dim=1).expand(B, -1, -1)   # V4:155-157
+    emb = w[pre + "word_embeddings.weight"][input_ids] + w[pre + "position_embeddings.weight"][:T][None]
+    x = torch.cat([query, emb], dim=1)
+    return _ln(w, pre + "layernorm", x, q.ln_eps)
+
+
+def qformer_forward(w, cfg, input_ids, text_mask, patches, pmask, chunk: int = 256,
+                    return_layers: bool = False):
+    """Relation Q-Former for B pairs.
+
+    input_ids [B,T] int64, text_mask [B,T] {0,1}, patches [L, enc_hidden] (shared by every pair:
+    V4:168 only `expand`s), pmask bool [B, L] (V4:170 expands it over the 33 query rows).
+    Returns last_hidden_state[:, :33]  (V4:185)  [B, 33, hidden].
+    """
+    q = cfg.qformer
+    nq = q.q_rows
+    outs, layer_dump = [], []
+    for s0 in range(0, input_ids.shape[0], chunk):
+        ids = input_ids[s0:s0 + chunk]
+        tm = text_mask[s0:s0 + chunk]
+        pm = pmask[s0:s0 + chunk]
+        B = ids.shape[0]
+        h = qformer_embeddings(w, cfg, ids)
+        self_mask = torch.cat([torch.ones(B, nq), tm.float()], dim=1)            # V4:158-159
+        add_self = ((1.0 - self_mask) * FMIN)[:, None, None, :]
+        if cfg.empty_row_policy == "uniform":
+            add_cross = ((1.0 - pm.float()) * FMIN)[:, None, None, :]
+        else:
+            add_cross = ((1.0 - pm.float()) * -10000.0)[:, None, None, :]
+        dump = []
+        for l in range(q.layers):
+            p = f"relation_qformer.encoder.layer.{l}."
+            # self attention over all S tokens
+            a = _mha(_lin(w, p + "attention.attention.query", h), _lin(w, p + "attention.attention.key", h),
+                     _lin(w, p + "attention.attention.value", h), add_self, q.heads)
+            a = _ln(w, p + "attention.output.LayerNorm", _lin(w, p + "attention.output.dense", a) + h, q.ln_eps)
+            # cross attention for the 33 query rows; K/V are the same for every pair
+            q33 = a[:, :nq]
+            kx = _lin(w, p + "crossattention.attention.key", patches)[None]
+            vx = _lin(w, p + "crossattention.attention.value", patches)[None]
+            c = _mha(_lin(w, p + "crossattention.attention.query", q33), kx, vx, add_cross, q.heads)
+            c = _ln(w, p + "crossattention.output.LayerNorm",
+                    _lin(w, p + "crossattention.output.dense", c) + q33, q.ln_eps)
+            # feed forward: query rows / text rows use different weights (HF-IB:664-672)
+            hq = _ln(w, p + "output_query.LayerNorm",
+                     _lin(w, p + "output_query.dense", F.gelu(_lin(w, p + "intermediate_query.dense", c))) + c,
+                     q.ln_eps)
+            at = a[:, nq:]
+            ht = _ln(w, p + "output.LayerNorm",
+                     _lin(w, p + "output.dense", F.gelu(_lin(w, p + "intermediate.dense", at))) + at, q.ln_eps)
+            h = torch.cat([hq, ht], dim=1)
+            if return_layers:
+                dump.append(dict(self_out=a, cross_out=c, hidden=h))
+        outs.append(h[:, :nq])
+        layer_dump.append(dump)
+    out = torch.cat(outs, dim=0)
+    if return_layers:
+        return out, layer_dump
+    return out
+
+
+def existence_head(w, qformer_out):
+    """V4:206-209 -> (logit [B], prob [B])."""
+    logit = F.linear(qformer_out[:, 0], w["binary_rel_cls_pred.weight"], w["binary_rel_cls_pred.bias"]).squeeze(1)
+    return logit, torch.sigmoid(logit)
+
+
+def select_topk(prob: torch.Tensor, k: int = 20):
+    """V4:235-237: full descending sort, first k.  Tie order is unspecified in the reference; the
+    build fixes 'lower pair index first' (stable sort)."""
+    order = torch.sort(prob, descending=True, stable=True).indices
+    return order[:k].tolist()
+
+
+def relation_query(w, cfg, mask_features, img_meta, object_ids, pan, input_ids, text_mask):
+    """The whole relation-query stage (V4:146-215) -> dict of intermediates."""
+    patches = patch_embed(w, mask_features, cfg.patch_size)[0]
+    fh, fw = mask_features.shape[-2:]
+    grid = mask_grid(pan, img_meta["img_shape"], img_meta["pad_shape"], (fh // cfg.patch_size, fw // cfg.patch_size))
+    om = object_masks(grid, object_ids)
+    pm = pair_masks(om)
+    out = qformer_forward(w, cfg, input_ids, text_mask, patches, pm)
+    logit, prob = existence_head(w, out)
+    return dict(patches=patches, grid=grid, obj_masks=om, pair_masks=pm, qformer_out=out,
+                exist_logit=logit, exist_prob=prob, pair_feature=out[:, 1:])
+
+
+# --------------------------------------------------------------------------------------------
+# A9: LMM stage (HF LlamaForCausalLM, eager)
+# --------------------------------------------------------------------------------------------
+def rmsnorm(x, weight, eps):
+    """HF-LL:62-67."""
+    v = x.float().pow(2).mean(-1, keepdim=True)
+    return weight * (x.float() * torch.rsqrt(v + eps)).to(x.dtype)
+
+
+def rope_cos_sin(positions, head_dim, theta):
+    """HF-LL:115-128: half-split layout, emb = cat(freqs, freqs)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = positions.float()[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def _rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+
+
+def llama_forward(w, cfg, x, positions, key_valid, cache, n_layers=None):
+    """One forward over `x` [T, D] appended after the cached keys.
+
+    positions [T] (cumsum(mask)-1, probe-verified), key_valid bool [ctx] marks
+    non-pad keys among cached+new, cache = list of (K [h,ctx0,hd], V) per layer (mutated).
+    Returns final-norm hidden [T, D].
+    """
+    m = cfg.llm
+    T = x.shape[0]
+    hd = m.head_dim
+    cos, sin = rope_cos_sin(positions, hd, m.rope_theta)
+    L = m.layers if n_layers is None else n_layers
+    for l in range(L):
+        p = f"language_model.model.layers.{l}."
+        n1 = rmsnorm(x, w[p + "input_layernorm.weight"], m.rms_eps)
+        qh = F.linear(n1, w[p + "self_attn.q_proj.weight"]).view(T, m.heads, hd).transpose(0, 1)
+        kh = F.linear(n1, w[p + "self_attn.k_proj.weight"]).view(T, m.heads, hd).transpose(0, 1)
+        vh = F.linear(n1, w[p + "self_attn.v_proj.weight"]).view(T, m.heads, hd).transpose(0, 1)
+        qh = qh * cos[None] + _rot_half(qh) * sin[None]
+        kh = kh * cos[None] + _rot_half(kh) * sin[None]
+        if cache[l] is not None:
+            kh = torch.cat([cache[l][0], kh], dim=1)
+            vh = torch.cat([cache[l][1], vh], dim=1)
+        cache[l] = (kh, vh)
+        ctx = kh.shape[1]
+        s = torch.matmul(qh, kh.transpose(1, 2)) * (hd ** -0.5)                     # [h,T,ctx]
+        qpos = torch.arange(ctx - T, ctx)[:, None]
+        allowed = (torch.arange(ctx)[None, :] <= qpos) & key_valid[None, :ctx]
+        s = s + torch.where(allowed, 0.0, FMIN)[None]
+        pr = torch.softmax(s, dim=-1, dtype=torch.float32)
+        o = torch.matmul(pr, vh).transpose(0, 1).reshape(T, m.hidden)
+        x = x + F.linear(o, w[p + "self_attn.o_proj.weight"])
+        n2 = rmsnorm(x, w[p + "post_attention_layernorm.weight"], m.rms_eps)
+        g = F.linear(n2, w[p + "mlp.gate_proj.weight"])
+        u = F.linear(n2, w[p + "mlp.up_proj.weight"])
+        x = x + F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
+    return rmsnorm(x, w["language_model.model.norm.weight"], m.rms_eps)
+
+
+def llm_inputs(w, pair_feature_si, prompt_ids, prompt_mask):
+    """V4:294-301 for one selected pair -> (inputs_embeds [32+T_p, D], attention_mask [32+T_p])."""
+    vis = F.linear(pair_feature_si, w["language_projection.weight"], w["language_projection.bias"])
+    emb = w["language_model.model.embed_tokens.weight"][prompt_ids]
+    x = torch.cat([vis, emb], dim=0)
+    mask = torch.cat([torch.ones(vis.shape[0], dtype=torch.long), prompt_mask.long()], dim=0)
+    return x, mask
+
+
+def llm_generate(w, cfg, inputs_embeds, attention_mask, max_new_tokens=None, n_layers=None,
+                 suppress_eos: bool = False):
+    """Greedy generate for ONE pair (V4:305-312 with do_sample=False).
+
+    Returns (token ids incl. a terminating EOS if one was produced, list of per-step logits [V]).
+    """
+    m = cfg.llm
+    max_new = cfg.max_new_tokens if max_new_tokens is None else max_new_tokens
+    L = m.layers if n_layers is None else n_layers
+    cache = [None] * L
+    mask = attention_mask.bool()
+    pos = torch.cumsum(attention_mask.long(), 0) - 1
+    pos = pos.masked_fill(~mask, 1)                       # HF generate: position_ids.masked_fill_(mask==0, 1)
+    h = llama_forward(w, cfg, inputs_embeds, pos, mask, cache, L)
+    tokens, step_logits = [], []
+    n_valid = int(mask.sum())
+    for step in range(max_new):
+        logits = F.linear(h[-1], w["language_model.lm_head.weight"])
+        if suppress_eos:
+            logits = logits.clone()
+            logits[m.eos] = -float("inf")
+        step_logits.append(logits)
+        tok = int(torch.argmax(logits))
+        tokens.append(tok)
+        if tok == m.eos or step == max_new - 1:
+            break
+        mask = torch.cat([mask, torch.ones(1, dtype=torch.bool)])
+        x = w["language_model.model.embed_tokens.weight"][tok][None]
+        h = llama_forward(w, cfg, x, torch.tensor([n_valid + step]), mask, cache, L)
+    return tokens, step_logits
+
+
+def parse_relations(text: str, si: int, object_num: int, relation_categories, seen: list):
+    """V4:315-326.  Appends new [sub, obj, rel] triples to `seen`; returns the triples added."""
+    pred = text.split("<s>")[1].split("</s>")[0].strip()
+    added = []
+    for name in pred.split("  "):
+        if name in relation_categories:
+            t = [si // object_num, si % object_num, relation_categories.index(name)]
+            if t not in seen:
+                seen.append(t)
+                added.append(t)
+    return added
+
+
+def full_path(w, cfg, mask_features, img_meta, object_ids, pan, input_ids, text_mask,
+              llm_prompt_ids, llm_prompt_mask, n_layers=None, suppress_eos=False):
+    """Relation-query + selection + per-pair greedy decode (V4:146-326 minus string handling).
+
+    llm_prompt_ids / llm_prompt_mask: callables (list of selected pair indices) -> left-padded
+    [K, T_p] id / mask tensors (the Llama tokenizer call at V4:260-266).
+    """
+    rq = relation_query(w, cfg, mask_features, img_meta, object_ids, pan, input_ids, text_mask)
+    sel = select_topk(rq["exist_prob"], cfg.num_selected)
+    pids, pmask = llm_prompt_ids(sel), llm_prompt_mask(sel)
+    gens = []
+    for i, si in enumerate(sel):
+        x, mask = llm_inputs(w, rq["pair_feature"][si], pids[i], pmask[i])
+        toks, logits = llm_generate(w, cfg, x, mask, n_layers=n_layers, suppress_eos=suppress_eos)
+        gens.append(dict(pair=si, tokens=toks, first_logits=logits[0]))
+    rq["selected"] = sel
+    rq["generations"] = gens
+    return rq
