@@ -1,0 +1,149 @@
+/*
+ * psg_hip.h - C ABI of libpsg_hip.so: MI355X (gfx950) kernels for OpenPSG's pairwise
+ * relation-query + LMM relation-decode hot path.
+ *
+ * This is the drop-in boundary.  The reference has no native code: every entry
+ * point below replaces arithmetic that the reference runs through torch / HF transformers /
+ * timm inside `RelationTransformerHeadV4.forward`
+ * (V4 = kings_sgg/models/relation_heads/relation_transformer_head_v4.py; HF-IB / HF-LL = the
+ * un-vendored transformers InstructBLIP Q-Former / Llama modules it instantiates at V4:78-84, 99-100).
+ * The host side that calls this ABI is openpsg_amd/ (ctypes; INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative psg_status otherwise; psg_last_error()
+ *    returns a thread-local message for the last failure on the calling thread;
+ *  - tensor arguments are RAW DEVICE POINTERS with explicit sizes; memory is allocated and owned
+ *    by the caller (torch); the library never allocates, frees or retains caller memory;
+ *  - every launch takes the hipStream_t to enqueue on (void* stream; pass
+ *    torch.cuda.current_stream().cuda_stream); no hidden synchronisation, so calls are HIP-graph
+ *    capturable;
+ *  - `dtype` selects the ACTIVATION storage type (PSG_F32 verification mode / PSG_BF16);
+ *    reductions, softmax and normalisation statistics are always fp32; LayerNorm/RMSNorm
+ *    parameters, biases, embedding tables and the existence-head weights are fp32;
+ *  - a psg_ctx is used by one host thread at a time; different contexts are independent.
+ */
+#ifndef PSG_HIP_H
+#define PSG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psg_ctx psg_ctx;
+
+enum psg_status {
+  PSG_OK = 0,
+  PSG_ERR_INVALID = -1,      /* bad argument (null pointer, unsupported size) */
+  PSG_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels are specialised for */
+  PSG_ERR_HIP = -3,          /* HIP runtime error (message in psg_last_error) */
+  PSG_ERR_NO_DEVICE = -4
+};
+
+enum psg_dtype { PSG_F32 = 0, PSG_BF16 = 1 };
+
+/* cross-attention empty-pair-mask policy: additive finfo.min => uniform softmax */
+enum psg_empty_policy { PSG_EMPTY_UNIFORM = 0, PSG_EMPTY_UNMASKED = 1 };
+
+/* cross-attention implementation: MFMA tiles (default) or the scalar fp32 checker kernel */
+enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1 };
+
+int psg_version(void);
+const char* psg_last_error(void);
+int psg_create(int device, psg_ctx** out);
+int psg_destroy(psg_ctx* ctx);
+/* number of compute units / arch name of the context's device (diagnostics, roofline) */
+int psg_device_info(psg_ctx* ctx, int* num_cu, char* arch, int arch_len);
+
+/* ---- A4 / K2: panoptic id map -> patch grid.  Replaces V4:416-423
+ * (F.interpolate nearest -> F.pad zero -> F.interpolate nearest).  grid[gh*gw] float32 ids. */
+int psg_mask_grid(psg_ctx*, const int32_t* pan, int H0, int W0, int img_h, int img_w,
+                  int pad_h, int pad_w, int gh, int gw, float* grid, void* stream);
+
+/* ---- A4 / K3: per-object patch bitmasks.  Replaces V4:425-433: the N^2 pair masks are never
+ * materialised; pair (i,j) uses bits[i] | bits[j] inside the attention kernel.
+ * bits[N][words] uint64, bit l of object n = (grid[l] == object_ids[n]); words >= ceil(L/64). */
+int psg_object_bitmasks(psg_ctx*, const float* grid, int L, const int32_t* object_ids, int N,
+                        uint64_t* bits, int words, void* stream);
+
+/* ---- K4: Q-Former embeddings, HF-IB:728-757 (called from V4:179-185).
+ * out rows [0, B*nq): LayerNorm(query_rows[r]) for every pair; rows [B*nq, B*(nq+T)):
+ * LayerNorm(word_emb[ids[p][t]] + pos_emb[t]).  ids int32 [B][T]. */
+int psg_qformer_embed(psg_ctx*, const int32_t* ids, int B, int T, const float* word_emb,
+                      const float* pos_emb, const float* query_rows, int nq, const float* ln_w,
+                      const float* ln_b, float eps, int hidden, void* out, int dtype, void* stream);
+
+/* ---- BertSelfOutput / BertOutput tail, HF-IB:519-530, 585-596:
+ * out = LayerNorm(x + bias + residual) * gamma + beta; bias / residual may be NULL; out may alias x. */
+int psg_add_layernorm(psg_ctx*, const void* x, const void* residual, const float* bias,
+                      const float* gamma, const float* beta, float eps, int64_t rows, int hidden,
+                      void* out, int dtype, void* stream);
+
+/* ---- BertIntermediate activation, HF-IB:563-577: out = gelu_erf(x + bias); bias may be NULL. */
+int psg_bias_gelu(psg_ctx*, const void* x, const float* bias, int64_t rows, int cols, void* out,
+                  int dtype, void* stream);
+
+/* ---- K5: Q-Former self-attention, HF-IB:471-515 (eager 176-196).
+ * qkv [(B*nq + B*T)][3*hidden] = [Q|K|V] of the query rows then the text rows; text_mask uint8
+ * [B][T] (V4:158-159; masked keys get additive finfo.min).  nq + T <= 64, head_dim 64.
+ * query_rows_only != 0 computes only the nq query rows of each pair (last layer, V4:185). */
+int psg_qformer_self_attn(psg_ctx*, const void* qkv, const uint8_t* text_mask, int B, int T, int nq,
+                          int heads, int query_rows_only, void* out, int dtype, void* stream);
+
+/* ---- K6: relation-query cross-attention (primary kernel), HF-IB:464-466, 487-496 with the
+ * V4:168-170 expand removed: K/V [L][hidden] are projected ONCE per image and shared by every
+ * pair; the pair mask is bits[i] | bits[j] (pair_index[p] = i*N + j) applied on the fly.
+ * q / out [P*nq][hidden]; scores = q.k/sqrt(64) + mask; fp32 softmax; all-masked => uniform. */
+int psg_qformer_cross_attn(psg_ctx*, const void* q, const void* k, const void* v,
+                           const uint64_t* bits, int words, const int32_t* pair_index, int N, int P,
+                           int L, int nq, int heads, int empty_policy, int variant, void* out,
+                           int dtype, void* stream);
+
+/* ---- K8: pair-existence scoring head, V4:206-209: logit = w . x[p*nq] + b, prob = sigmoid. */
+int psg_exist_head(psg_ctx*, const void* x, const float* w, const float* b, int P, int nq, int hidden,
+                   float* logit, float* prob, int dtype, void* stream);
+
+/* ---- K9: selector, V4:235-237: indices of the k largest scores, descending, ties -> lower index. */
+int psg_topk(psg_ctx*, const float* score, int n, int k, int32_t* out_idx, float* out_val, void* stream);
+
+/* ---- row gather (pair_feature[selected], embed_tokens[ids]; V4:294-297): dst[r] = src[idx[r]];
+ * idx < 0 writes zeros.  src_dtype/dst_dtype allow fp32 tables -> bf16 activations. */
+int psg_gather_rows(psg_ctx*, const void* src, int src_dtype, const int32_t* idx, int64_t n, int cols,
+                    int64_t src_row_stride, void* dst, int dst_dtype, int64_t dst_row_stride, void* stream);
+
+/* ---- K12: Llama RMSNorm, HF-LL:53-67, fused with the residual add of HF-LL decoder layer:
+ * if delta != NULL: resid += delta (written back); out = w * (resid * rsqrt(mean(resid^2)+eps)). */
+int psg_rmsnorm(psg_ctx*, void* resid, const void* delta, const float* w, float eps, int64_t rows,
+                int hidden, void* out, int dtype, void* stream);
+
+/* ---- K13: rotary embedding (half-split, HF-LL:130-160) + KV-cache write.
+ * qkv [rows][3*hidden]; tok_pair / tok_pos int32 [rows] give the cache row (pair) and the
+ * position (= cache slot = cumsum(mask)-1, V4 left-padding removed by compaction); tok_pos < 0
+ * marks a padding row (skipped).  q_out [rows][hidden]; caches [pairs][heads][ctx][head_dim]. */
+int psg_rope_kvwrite(psg_ctx*, const void* qkv, const int32_t* tok_pair, const int32_t* tok_pos,
+                     const float* inv_freq, int64_t rows, int heads, int head_dim, int ctx,
+                     void* q_out, void* k_cache, void* v_cache, int dtype, void* stream);
+
+/* ---- K14: Llama attention over the KV cache (prefill and decode), HF-LL:191-214: query at
+ * (pair, pos) attends cache slots [0, pos]; fp32 softmax; out [rows][hidden]. head_dim 128. */
+int psg_llm_attn(psg_ctx*, const void* q, const void* k_cache, const void* v_cache,
+                 const int32_t* tok_pair, const int32_t* tok_pos, int64_t rows, int heads,
+                 int head_dim, int ctx, void* out, int dtype, void* stream);
+
+/* ---- SwiGLU gate, HF-LL:163-177: out = silu(gate_up[:, :inter]) * gate_up[:, inter:]. */
+int psg_silu_mul(psg_ctx*, const void* gate_up, int64_t rows, int inter, void* out, int dtype,
+                 void* stream);
+
+/* ---- K16: greedy step (HF generate, num_beams=1, do_sample=False; V4:305-312).
+ * logits [K][vocab] (dtype); token = argmax (first maximal index); suppress_token >= 0 is
+ * excluded.  For each pair k not yet done: tokens[k][step] = token, done[k] |= (token == eos),
+ * next_ids[k] = token, tok_pos[k] += 1.  Finished pairs write -1 and keep decoding harmlessly. */
+int psg_greedy_step(psg_ctx*, const void* logits, int K, int vocab, int step, int max_new,
+                    int eos, int suppress_token, int32_t* tokens, int32_t* done, int32_t* next_ids,
+                    int32_t* tok_pos, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSG_HIP_H */

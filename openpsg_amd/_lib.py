@@ -1,0 +1,98 @@
+"""ctypes binding of libpsg_hip.so (the C ABI declared in include/psg_hip.h).
+
+The product path has NO CPU fallback: if the shared object is missing or a call fails, this
+module raises `PsgHipError` - loudly - instead of computing anything on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsg_hip.so")
+
+PSG_F32, PSG_BF16 = 0, 1
+PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED = 0, 1
+PSG_XATTN_MFMA, PSG_XATTN_SIMPLE = 0, 1
+
+
+class PsgHipError(RuntimeError):
+    pass
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes (return type is int unless noted).  Mirrors include/psg_hip.h one to one;
+# tests/test_abi_symbols.py checks the header and this table against the built library.
+SIGNATURES = {
+    "psg_version": [],
+    "psg_create": [_i, C.POINTER(_vp)],
+    "psg_destroy": [_vp],
+    "psg_device_info": [_vp, C.POINTER(_i), C.c_char_p, _i],
+    "psg_mask_grid": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "psg_object_bitmasks": [_vp, _vp, _i, _vp, _i, _vp, _i, _vp],
+    "psg_qformer_embed": [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _vp],
+    "psg_add_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _i, _vp],
+    "psg_bias_gelu": [_vp, _vp, _vp, _i64, _i, _vp, _i, _vp],
+    "psg_qformer_self_attn": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "psg_qformer_cross_attn": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "psg_exist_head": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
+    "psg_topk": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "psg_gather_rows": [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _i, _i64, _vp],
+    "psg_rmsnorm": [_vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _i, _vp],
+    "psg_rope_kvwrite": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "psg_llm_attn": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp],
+    "psg_silu_mul": [_vp, _vp, _i64, _i, _vp, _i, _vp],
+    "psg_greedy_step": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+}
+
+_lib = None
+_ctx = {}
+
+
+def load():
+    """dlopen the library and type every entry point.  Works without a GPU (no HIP call is made)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsgHipError(
+            f"{LIB_PATH} is missing: build it with `python -m openpsg_amd.csrc.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.psg_last_error.restype = C.c_char_p
+    lib.psg_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise PsgHipError(f"{LIB_PATH} does not export {name}; rebuild the library")
+        fn.restype = _i
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().psg_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise PsgHipError(f"{what} failed (status {rc}): {last_error()}")
+
+
+def ctx(device_index: int):
+    """One psg_ctx per device, created on first use."""
+    if device_index not in _ctx:
+        lib = load()
+        h = _vp()
+        check(lib.psg_create(int(device_index), C.byref(h)), "psg_create")
+        _ctx[device_index] = h
+    return _ctx[device_index]
+
+
+def device_info(device_index: int):
+    n = _i(0)
+    buf = C.create_string_buffer(64)
+    check(load().psg_device_info(ctx(device_index), C.byref(n), buf, 64), "psg_device_info")
+    return n.value, buf.value.decode()

@@ -1,0 +1,58 @@
+"""Builds libpsg_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m openpsg_amd.csrc.build [--force] [--save-temps]
+
+The shared object is written next to the package (openpsg_amd/libpsg_hip.so) so that it travels
+with the source tree; it is git-ignored.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIB = os.path.join(PKG, "libpsg_hip.so")
+SOURCES = ["psg_core.hip", "psg_rowops.hip", "psg_attn.hip", "psg_xattn_mfma.hip", "psg_gemm.hip"]
+HEADERS = ["psg_common.h", os.path.join("..", "..", "include", "psg_hip.h")]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(HERE, s) for s in SOURCES + HEADERS if os.path.exists(os.path.join(HERE, s))]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc",
+           "-Wno-unused-result", "-o", LIB] + srcs
+    if save_temps:
+        tmp = os.path.join(HERE, "_temps")
+        os.makedirs(tmp, exist_ok=True)
+        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=HERE)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--save-temps", action="store_true")
+    a = ap.parse_args()
+    print(build(force=a.force, save_temps=a.save_temps))

@@ -1,0 +1,265 @@
+// Attention kernels that are not the MFMA cross-attention:
+//   K5  Q-Former self-attention (S = 33 + T <= 64 keys, 12 heads x 64)      HF-IB:471-515
+//   K6' scalar fp32 cross-attention (checker / fp32 verification variant)     HF-IB:487-496
+//   K14 Llama attention over the KV cache, prefill + decode (head_dim 128)    HF-LL:191-214
+#include "psg_common.h"
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5.  One wave per (pair, head).  Lane j owns key j: K[j][0..63] lives in 64 registers of lane j,
+// V[j][d] for all j lives in lane d.  Per query row: 64 readlane+fma for q.K^T, a wave softmax,
+// 64 readlane+fma for P.V.  No LDS, no inter-wave traffic.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) qformer_self_attn_kernel(const T* __restrict__ qkv,
+                                                                const uint8_t* __restrict__ text_mask, int B, int Tt,
+                                                                int nq, int heads, int q_only, T* __restrict__ out) {
+  const int unit = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (unit >= B * heads) return;
+  const int p = unit / heads, h = unit % heads;
+  const int hidden = heads * 64;
+  const int S = nq + Tt;
+  const int64_t qrow0 = (int64_t)p * nq;                      // query rows of this pair
+  const int64_t trow0 = (int64_t)B * nq + (int64_t)p * Tt;    // text rows of this pair
+  auto row_of = [&](int j) -> int64_t { return j < nq ? qrow0 + j : trow0 + (j - nq); };
+
+  // K^T: lane j reads its own key row (64 contiguous elements)
+  float kreg[64];
+  bool valid = lane < S;
+  if (valid && lane >= nq) valid = text_mask[(int64_t)p * Tt + (lane - nq)] != 0;
+  {
+    const int64_t r = row_of(lane < S ? lane : 0);
+    const T* kp = qkv + r * 3 * hidden + hidden + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      float t[4];
+      Act<T>::ld4(kp, d, t);
+      kreg[d] = t[0]; kreg[d + 1] = t[1]; kreg[d + 2] = t[2]; kreg[d + 3] = t[3];
+    }
+  }
+  // V: lane d reads column d of every key row (coalesced)
+  float vreg[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    vreg[j] = 0.f;
+    if (j < S) vreg[j] = Act<T>::ld(qkv, row_of(j) * 3 * hidden + 2 * hidden + h * 64 + lane);
+  }
+  const int nrows = q_only ? nq : S;
+  for (int i = 0; i < nrows; ++i) {
+    const int64_t r = row_of(i);
+    const float qv = Act<T>::ld(qkv, r * 3 * hidden + h * 64 + lane);
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) s = fmaf(readlane_f(qv, d), kreg[d], s);
+    s *= 0.125f;                                  // 1/sqrt(64)
+    s = valid ? s : PSG_FMIN;                     // additive finfo.min absorbs the score
+    if (lane >= S) s = -INFINITY;                 // not a key at all
+    const float m = wave_max(s);
+    float pr = expf(s - m);
+    const float denom = wave_sum(pr);
+    pr = pr / denom;
+    if (sizeof(T) == 2) pr = bf16_to_f32(f32_to_bf16(pr));
+    float o = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j)
+      if (j < S) o = fmaf(readlane_f(pr, j), vreg[j], o);
+    Act<T>::st(out, r * hidden + h * 64 + lane, o);
+  }
+}
+
+extern "C" int psg_qformer_self_attn(psg_ctx* ctx, const void* qkv, const uint8_t* text_mask, int B, int T_, int nq,
+                                     int heads, int query_rows_only, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && qkv && out && (text_mask || T_ == 0), PSG_ERR_INVALID, "psg_qformer_self_attn: NULL argument");
+  PSG_REQUIRE(B > 0 && T_ >= 0 && nq > 0 && heads > 0, PSG_ERR_INVALID, "psg_qformer_self_attn: B=%d T=%d nq=%d", B,
+              T_, nq);
+  PSG_REQUIRE(nq + T_ <= 64, PSG_ERR_UNSUPPORTED,
+              "psg_qformer_self_attn: %d query rows + %d prompt tokens > 64 keys (one wavefront)", nq, T_);
+  int64_t units = (int64_t)B * heads;
+  PSG_DISPATCH_DTYPE(dtype, "psg_qformer_self_attn",
+                     (qformer_self_attn_kernel<T><<<(unsigned)((units + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+                         (const T*)qkv, text_mask, B, T_, nq, heads, query_rows_only, (T*)out)));
+  PSG_CHECK_LAUNCH("psg_qformer_self_attn");
+  return PSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6' scalar cross-attention: one 256-thread block per (pair, head); fp32 math regardless of the
+// storage dtype.  Scores [nq][Lpad] live in LDS.  Used as the fp32 verification variant and as the
+// on-device checker of the MFMA kernel; never the benchmarked path.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) cross_attn_simple_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                const T* __restrict__ v,
+                                                                const uint64_t* __restrict__ bits, int words,
+                                                                const int32_t* __restrict__ pair_index, int N, int L,
+                                                                int nq, int heads, int policy, T* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int p = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int hidden = heads * 64;
+  const int Lp = (L + 3) & ~3;
+  float* qs = smem;                 // [nq][64]
+  float* sc = smem + nq * 64;       // [nq][Lp]
+  const int tid = threadIdx.x;
+  const int pidx = pair_index[p];
+  const int oi = pidx / N, oj = pidx % N;
+  for (int e = tid; e < nq * 64; e += 256)
+    qs[e] = Act<T>::ld(q, ((int64_t)p * nq + e / 64) * hidden + h * 64 + (e % 64));
+  __syncthreads();
+  const float masked_val = policy == PSG_EMPTY_UNIFORM ? PSG_FMIN : -10000.0f;
+  for (int l0 = 0; l0 < L; l0 += 256) {
+    const int l = l0 + tid;
+    if (l < L) {
+      float kr[64];
+#pragma unroll
+      for (int d = 0; d < 64; d += 4) {
+        float t[4];
+        Act<T>::ld4(k, (int64_t)l * hidden + h * 64 + d, t);
+        kr[d] = t[0]; kr[d + 1] = t[1]; kr[d + 2] = t[2]; kr[d + 3] = t[3];
+      }
+      const uint64_t w = bits[(int64_t)oi * words + (l >> 6)] | bits[(int64_t)oj * words + (l >> 6)];
+      const bool on = (w >> (l & 63)) & 1ull;
+      for (int i = 0; i < nq; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) s = fmaf(qs[i * 64 + d], kr[d], s);
+        s *= 0.125f;
+        // HF adds the mask: s + finfo.min == finfo.min in fp32; s - 10000 for the legacy variant
+        sc[i * Lp + l] = on ? s : (policy == PSG_EMPTY_UNIFORM ? masked_val : s + masked_val);
+      }
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wid = tid >> 6;
+  for (int i = wid; i < nq; i += 4) {
+    float m = -INFINITY;
+    for (int l = lane; l < L; l += 64) m = fmaxf(m, sc[i * Lp + l]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float e = expf(sc[i * Lp + l] - m);
+      sc[i * Lp + l] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int l = lane; l < L; l += 64) {
+      float pv = sc[i * Lp + l] * inv;
+      if (sizeof(T) == 2) pv = bf16_to_f32(f32_to_bf16(pv));
+      sc[i * Lp + l] = pv;
+    }
+  }
+  __syncthreads();
+  for (int i = wid; i < nq; i += 4) {
+    float o = 0.f;
+    for (int l = 0; l < L; ++l) o = fmaf(sc[i * Lp + l], Act<T>::ld(v, (int64_t)l * hidden + h * 64 + lane), o);
+    Act<T>::st(out, ((int64_t)p * nq + i) * hidden + h * 64 + lane, o);
+  }
+}
+
+int psg_cross_attn_simple_launch(const void* q, const void* k, const void* v, const uint64_t* bits, int words,
+                                 const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy,
+                                 void* out, int dtype, hipStream_t st) {
+  const int Lp = (L + 3) & ~3;
+  const size_t lds = (size_t)(nq * 64 + nq * Lp) * sizeof(float);
+  PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "cross_attn(simple): L=%d needs %zu B of LDS", L, lds);
+  PSG_DISPATCH_DTYPE(dtype, "psg_qformer_cross_attn(simple)", {
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)cross_attn_simple_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds);
+    cross_attn_simple_kernel<T><<<P * heads, 256, lds, st>>>((const T*)q, (const T*)k, (const T*)v, bits, words,
+                                                            pair_index, N, L, nq, heads, policy, (T*)out);
+  });
+  PSG_CHECK_LAUNCH("psg_qformer_cross_attn(simple)");
+  return PSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K14.  One wave per (token row, head); head_dim = 128.  Keys are the cache slots [0, pos] of the
+// row's pair (compacted layout: no pad slots, so the causal bound is the only mask).  Lane j owns
+// key j of each 64-key chunk (reads its 128-element row with 16-byte loads); q is broadcast from
+// LDS; softmax is online across chunks in fp32; P.V has lane d own dims d and d+64.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) llm_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
+                                                       const T* __restrict__ vc, const int32_t* __restrict__ tok_pair,
+                                                       const int32_t* __restrict__ tok_pos, int64_t rows, int heads,
+                                                       int ctx, T* __restrict__ out) {
+  __shared__ float s_q[4][128];
+  __shared__ float s_p[4][64];
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (wave >= rows * heads) return;          // whole wave exits together (wave-uniform)
+  const int64_t row = wave / heads;
+  const int h = (int)(wave % heads);
+  const int pos = tok_pos[row];
+  const int hidden = heads * 128;
+  if (pos < 0) {                             // padding row: defined output, never consumed
+    Act<T>::st(out, row * hidden + h * 128 + lane, 0.f);
+    Act<T>::st(out, row * hidden + h * 128 + lane + 64, 0.f);
+    return;
+  }
+  s_q[wid][lane] = Act<T>::ld(q, row * hidden + h * 128 + lane);
+  s_q[wid][lane + 64] = Act<T>::ld(q, row * hidden + h * 128 + lane + 64);
+  __builtin_amdgcn_wave_barrier();
+  const int64_t cbase = ((int64_t)tok_pair[row] * heads + h) * ctx * 128;
+  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+  float m_run = -INFINITY, l_run = 0.f, o1 = 0.f, o2 = 0.f;
+  for (int base = 0; base <= pos; base += 64) {
+    const int j = base + lane;
+    float s = -INFINITY;
+    if (j <= pos) {
+      const T* kp = kc + cbase + (int64_t)j * 128;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < 128; d += 4) {
+        float t[4];
+        Act<T>::ld4(kp, d, t);
+        acc = fmaf(s_q[wid][d], t[0], acc);
+        acc = fmaf(s_q[wid][d + 1], t[1], acc);
+        acc = fmaf(s_q[wid][d + 2], t[2], acc);
+        acc = fmaf(s_q[wid][d + 3], t[3], acc);
+      }
+      s = acc * scale;
+    }
+    const float m_new = fmaxf(m_run, wave_max(s));
+    const float alpha = expf(m_run - m_new);
+    const float pj = expf(s - m_new);
+    l_run = l_run * alpha + wave_sum(pj);
+    o1 *= alpha;
+    o2 *= alpha;
+    s_p[wid][lane] = pj;
+    __builtin_amdgcn_wave_barrier();
+    const int nk = min(64, pos + 1 - base);
+    for (int jj = 0; jj < nk; ++jj) {
+      const float pv = s_p[wid][jj];
+      const T* vp = vc + cbase + (int64_t)(base + jj) * 128;
+      o1 = fmaf(pv, Act<T>::ld(vp, lane), o1);
+      o2 = fmaf(pv, Act<T>::ld(vp, lane + 64), o2);
+    }
+    __builtin_amdgcn_wave_barrier();
+    m_run = m_new;
+  }
+  const float inv = 1.0f / l_run;
+  Act<T>::st(out, row * hidden + h * 128 + lane, o1 * inv);
+  Act<T>::st(out, row * hidden + h * 128 + lane + 64, o2 * inv);
+}
+
+extern "C" int psg_llm_attn(psg_ctx* ctx_, const void* q, const void* k_cache, const void* v_cache,
+                            const int32_t* tok_pair, const int32_t* tok_pos, int64_t rows, int heads, int head_dim,
+                            int ctx, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx_ && q && k_cache && v_cache && tok_pair && tok_pos && out, PSG_ERR_INVALID,
+              "psg_llm_attn: NULL argument");
+  PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_llm_attn: head_dim=%d (kernel is built for 128)", head_dim);
+  if (rows == 0) return PSG_OK;
+  int64_t waves = rows * heads;
+  PSG_DISPATCH_DTYPE(dtype, "psg_llm_attn",
+                     (llm_attn_kernel<T><<<(unsigned)((waves + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+                         (const T*)q, (const T*)k_cache, (const T*)v_cache, tok_pair, tok_pos, rows, heads, ctx,
+                         (T*)out)));
+  PSG_CHECK_LAUNCH("psg_llm_attn");
+  return PSG_OK;
+}

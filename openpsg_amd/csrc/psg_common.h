@@ -1,0 +1,105 @@
+// Shared device/host helpers for libpsg_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/psg_hip.h"
+
+struct psg_ctx {
+  int device;
+  int num_cu;
+  char arch[64];
+};
+
+void psg_set_error(const char* fmt, ...);
+
+#define PSG_REQUIRE(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      psg_set_error(__VA_ARGS__);         \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+#define PSG_CHECK_LAUNCH(name)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      psg_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return PSG_ERR_HIP;                                                   \
+    }                                                                       \
+  } while (0)
+
+// ---- activation storage types -------------------------------------------------------------
+struct bf16_t {
+  uint16_t v;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest even
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T>
+struct Act;
+template <>
+struct Act<float> {
+  static __device__ __forceinline__ float ld(const float* p, int64_t i) { return p[i]; }
+  static __device__ __forceinline__ void st(float* p, int64_t i, float v) { p[i] = v; }
+  static __device__ __forceinline__ void ld4(const float* p, int64_t i, float (&o)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p + i);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+  }
+  static __device__ __forceinline__ void st4(float* p, int64_t i, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <>
+struct Act<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p, int64_t i) { return bf16_to_f32(p[i].v); }
+  static __device__ __forceinline__ void st(bf16_t* p, int64_t i, float v) { p[i].v = f32_to_bf16(v); }
+  static __device__ __forceinline__ void ld4(const bf16_t* p, int64_t i, float (&o)[4]) {
+    ushort4 t = *reinterpret_cast<const ushort4*>(p + i);
+    o[0] = bf16_to_f32(t.x); o[1] = bf16_to_f32(t.y); o[2] = bf16_to_f32(t.z); o[3] = bf16_to_f32(t.w);
+  }
+  static __device__ __forceinline__ void st4(bf16_t* p, int64_t i, const float (&v)[4]) {
+    ushort4 t;
+    t.x = f32_to_bf16(v[0]); t.y = f32_to_bf16(v[1]); t.z = f32_to_bf16(v[2]); t.w = f32_to_bf16(v[3]);
+    *reinterpret_cast<ushort4*>(p + i) = t;
+  }
+};
+
+// ---- wave (64 lanes) reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#define PSG_FMIN (-3.402823466e+38f)  // torch.finfo(float32).min, the legacy additive mask value
+
+// dispatch on the activation dtype enum
+#define PSG_DISPATCH_DTYPE(dtype, NAME, ...)                       \
+  do {                                                             \
+    if ((dtype) == PSG_F32) {                                      \
+      using T = float;                                             \
+      __VA_ARGS__;                                                 \
+    } else if ((dtype) == PSG_BF16) {                              \
+      using T = bf16_t;                                            \
+      __VA_ARGS__;                                                 \
+    } else {                                                       \
+      psg_set_error("%s: unknown dtype %d", NAME, (int)(dtype));   \
+      return PSG_ERR_INVALID;                                      \
+    }                                                              \
+  } while (0)

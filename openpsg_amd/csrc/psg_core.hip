@@ -1,0 +1,237 @@
+// Context, error handling and the integer / byte kernels of the path:
+//   K2 mask -> patch grid, K3 object bitmasks, K9 top-k selector, row gather.
+#include <stdarg.h>
+
+#include "psg_common.h"
+
+static thread_local char g_err[512] = "";
+
+void psg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* psg_last_error(void) { return g_err; }
+extern "C" int psg_version(void) { return 100; }
+
+extern "C" int psg_create(int device, psg_ctx** out) {
+  PSG_REQUIRE(out != nullptr, PSG_ERR_INVALID, "psg_create: out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    psg_set_error("psg_create: no HIP device visible (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    return PSG_ERR_NO_DEVICE;
+  }
+  PSG_REQUIRE(device >= 0 && device < n, PSG_ERR_INVALID, "psg_create: device %d out of range [0,%d)", device, n);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    psg_set_error("psg_create: hipGetDeviceProperties: %s", hipGetErrorString(e));
+    return PSG_ERR_HIP;
+  }
+  psg_ctx* c = new psg_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount;
+  strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
+  c->arch[sizeof(c->arch) - 1] = 0;
+  *out = c;
+  return PSG_OK;
+}
+
+extern "C" int psg_destroy(psg_ctx* ctx) {
+  delete ctx;
+  return PSG_OK;
+}
+
+extern "C" int psg_device_info(psg_ctx* ctx, int* num_cu, char* arch, int arch_len) {
+  PSG_REQUIRE(ctx != nullptr, PSG_ERR_INVALID, "psg_device_info: ctx is NULL");
+  if (num_cu) *num_cu = ctx->num_cu;
+  if (arch && arch_len > 0) {
+    strncpy(arch, ctx->arch, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return PSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: nearest(ori->img) o zero-pad(img->pad) o nearest(pad->grid)   (V4:416-423)
+// ATen legacy 'nearest': src = min(floor(dst * float(in/out)), in - 1), scale in float32.
+// ---------------------------------------------------------------------------------------------
+__global__ void mask_grid_kernel(const int32_t* __restrict__ pan, int H0, int W0, int img_h, int img_w,
+                                 int pad_h, int pad_w, int gh, int gw, float* __restrict__ grid) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= gh * gw) return;
+  int r = idx / gw, c = idx % gw;
+  const float sy2 = (float)pad_h / (float)gh, sx2 = (float)pad_w / (float)gw;
+  const float sy1 = (float)H0 / (float)img_h, sx1 = (float)W0 / (float)img_w;
+  int y1 = min((int)floorf((float)r * sy2), pad_h - 1);
+  int x1 = min((int)floorf((float)c * sx2), pad_w - 1);
+  float v = 0.0f;  // F.pad value=0 (aliases void and category-0 instance-0)
+  if (y1 < img_h && x1 < img_w) {
+    int y0 = min((int)floorf((float)y1 * sy1), H0 - 1);
+    int x0 = min((int)floorf((float)x1 * sx1), W0 - 1);
+    v = (float)pan[(int64_t)y0 * W0 + x0];  // .float() of the id map (exact below 2^24)
+  }
+  grid[idx] = v;
+}
+
+extern "C" int psg_mask_grid(psg_ctx* ctx, const int32_t* pan, int H0, int W0, int img_h, int img_w, int pad_h,
+                             int pad_w, int gh, int gw, float* grid, void* stream) {
+  PSG_REQUIRE(ctx && pan && grid, PSG_ERR_INVALID, "psg_mask_grid: NULL argument");
+  PSG_REQUIRE(H0 > 0 && W0 > 0 && img_h > 0 && img_w > 0 && pad_h >= img_h && pad_w >= img_w && gh > 0 && gw > 0,
+              PSG_ERR_INVALID, "psg_mask_grid: bad shapes ori %dx%d img %dx%d pad %dx%d grid %dx%d", H0, W0, img_h,
+              img_w, pad_h, pad_w, gh, gw);
+  int n = gh * gw;
+  mask_grid_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(pan, H0, W0, img_h, img_w, pad_h, pad_w, gh, gw,
+                                                                     grid);
+  PSG_CHECK_LAUNCH("psg_mask_grid");
+  return PSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: bits[n][w] bit b = (grid[64 w + b] == float(id_n))   (V4:425-429); one wave per word
+// ---------------------------------------------------------------------------------------------
+__global__ void object_bitmasks_kernel(const float* __restrict__ grid, int L, const int32_t* __restrict__ ids, int N,
+                                       uint64_t* __restrict__ bits, int words) {
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (wave >= N * words) return;
+  int n = wave / words, w = wave % words;
+  int l = w * 64 + lane;
+  bool hit = (l < L) && (grid[l] == (float)ids[n]);
+  unsigned long long m = __ballot(hit);
+  if (lane == 0) bits[(int64_t)n * words + w] = (uint64_t)m;
+}
+
+extern "C" int psg_object_bitmasks(psg_ctx* ctx, const float* grid, int L, const int32_t* object_ids, int N,
+                                   uint64_t* bits, int words, void* stream) {
+  PSG_REQUIRE(ctx && grid && object_ids && bits, PSG_ERR_INVALID, "psg_object_bitmasks: NULL argument");
+  PSG_REQUIRE(L > 0 && N > 0 && words * 64 >= L, PSG_ERR_INVALID, "psg_object_bitmasks: L=%d N=%d words=%d", L, N,
+              words);
+  int waves = N * words;
+  int blocks = (waves + 3) / 4;
+  object_bitmasks_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(grid, L, object_ids, N, bits, words);
+  PSG_CHECK_LAUNCH("psg_object_bitmasks");
+  return PSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K9: top-k by k rounds of block arg-max (k = 20, n <= ~10^4: latency-trivial, deterministic).
+// Order: larger score first, ties -> lower index (the reference's tie order is unspecified).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool topk_better(float a, int ia, float b, int ib) {
+  return (a > b) || (a == b && ia < ib);
+}
+
+__global__ void __launch_bounds__(1024) topk_kernel(const float* __restrict__ score, int n, int k,
+                                                    int32_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  __shared__ float s_val[16];
+  __shared__ int s_idx[16];
+  __shared__ float prev_val;
+  __shared__ int prev_idx;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) {
+    prev_val = INFINITY;
+    prev_idx = -1;
+  }
+  __syncthreads();
+  for (int round = 0; round < k; ++round) {
+    const float pv = prev_val;
+    const int pi = prev_idx;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += blockDim.x) {
+      float v = score[i];
+      if (v != v) v = -INFINITY;  // NaN sorts last
+      // strictly after the previous pick in the (value desc, index asc) order
+      bool after = (v < pv) || (v == pv && i > pi);
+      if (after && topk_better(v, i, best, bi)) {
+        best = v;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o, 64);
+      int oi = __shfl_xor(bi, o, 64);
+      if (topk_better(ov, oi, best, bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_val[wid] = best;
+      s_idx[wid] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+        if (topk_better(s_val[w], s_idx[w], best, bi)) {
+          best = s_val[w];
+          bi = s_idx[w];
+        }
+      if (bi == 0x7fffffff) {  // fewer than k candidates
+        out_idx[round] = -1;
+        if (out_val) out_val[round] = -INFINITY;
+      } else {
+        out_idx[round] = bi;
+        if (out_val) out_val[round] = best;
+      }
+      prev_val = best;
+      prev_idx = bi;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int psg_topk(psg_ctx* ctx, const float* score, int n, int k, int32_t* out_idx, float* out_val,
+                        void* stream) {
+  PSG_REQUIRE(ctx && score && out_idx, PSG_ERR_INVALID, "psg_topk: NULL argument");
+  PSG_REQUIRE(n > 0 && k > 0, PSG_ERR_INVALID, "psg_topk: n=%d k=%d", n, k);
+  topk_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(score, n, k, out_idx, out_val);
+  PSG_CHECK_LAUNCH("psg_topk");
+  return PSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row gather: dst[r][:] = src[idx[r]][:]  (idx < 0 -> zeros); one wave per row, 4 elements / lane
+// ---------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ void gather_rows_kernel(const TS* __restrict__ src, const int32_t* __restrict__ idx, int64_t n, int cols,
+                                   int64_t sstride, TD* __restrict__ dst, int64_t dstride) {
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int s = idx[row];
+  for (int c = lane * 4; c < cols; c += 256) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s >= 0) Act<TS>::ld4(src, (int64_t)s * sstride + c, v);
+    Act<TD>::st4(dst, row * dstride + c, v);
+  }
+}
+
+extern "C" int psg_gather_rows(psg_ctx* ctx, const void* src, int src_dtype, const int32_t* idx, int64_t n, int cols,
+                               int64_t src_row_stride, void* dst, int dst_dtype, int64_t dst_row_stride,
+                               void* stream) {
+  PSG_REQUIRE(ctx && src && idx && dst, PSG_ERR_INVALID, "psg_gather_rows: NULL argument");
+  PSG_REQUIRE(n >= 0 && cols > 0 && cols % 4 == 0 && src_row_stride % 4 == 0 && dst_row_stride % 4 == 0,
+              PSG_ERR_INVALID, "psg_gather_rows: cols/strides must be multiples of 4 (cols=%d)", cols);
+  if (n == 0) return PSG_OK;
+  dim3 grid((unsigned)((n + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+#define GR(TS, TD) \
+  gather_rows_kernel<TS, TD><<<grid, 256, 0, st>>>((const TS*)src, idx, n, cols, src_row_stride, (TD*)dst, dst_row_stride)
+  if (src_dtype == PSG_F32 && dst_dtype == PSG_F32) GR(float, float);
+  else if (src_dtype == PSG_F32 && dst_dtype == PSG_BF16) GR(float, bf16_t);
+  else if (src_dtype == PSG_BF16 && dst_dtype == PSG_BF16) GR(bf16_t, bf16_t);
+  else if (src_dtype == PSG_BF16 && dst_dtype == PSG_F32) GR(bf16_t, float);
+  else {
+    psg_set_error("psg_gather_rows: bad dtypes %d -> %d", src_dtype, dst_dtype);
+    return PSG_ERR_INVALID;
+  }
+#undef GR
+  PSG_CHECK_LAUNCH("psg_gather_rows");
+  return PSG_OK;
+}

@@ -1,0 +1,417 @@
+// Row-wise HBM-bound kernels: one wave (64 lanes) per row, 4 contiguous elements per lane per
+// 256-element chunk, statistics by wavefront shuffle reductions in fp32.
+//   K4  Q-Former embeddings + LayerNorm        (HF-IB:728-757)
+//       add + LayerNorm                        (HF-IB:519-530, 585-596)
+//       bias + GELU(erf)                       (HF-IB:563-577)
+//   K8  pair-existence head                    (V4:206-209)
+//   K12 RMSNorm (+ residual add)               (HF-LL:53-67)
+//   K13 rotary + KV-cache write                (HF-LL:130-160)
+//       SwiGLU gate                            (HF-LL:163-177)
+//   K16 greedy argmax step                     (V4:305-312)
+#include "psg_common.h"
+
+// ---- LayerNorm over a row held in registers ---------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ void ln_row(float (&v)[NCH][4], int hidden, float eps, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, int lane) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+  const float mean = wave_sum(s) / (float)hidden;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float d = v[c][e] - mean;
+      q += d * d;
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)hidden + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + col);
+    const float4 b = *reinterpret_cast<const float4*>(beta + col);
+    v[c][0] = (v[c][0] - mean) * rstd * g.x + b.x;
+    v[c][1] = (v[c][1] - mean) * rstd * g.y + b.y;
+    v[c][2] = (v[c][2] - mean) * rstd * g.z + b.z;
+    v[c][3] = (v[c][3] - mean) * rstd * g.w + b.w;
+  }
+}
+
+// ---- K4 ---------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ void qformer_embed_kernel(const int32_t* __restrict__ ids, int B, int Tt, const float* __restrict__ word,
+                                     const float* __restrict__ pos, const float* __restrict__ query, int nq,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     int hidden, T* __restrict__ out) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t nqrows = (int64_t)B * nq;
+  if (row >= nqrows + (int64_t)B * Tt) return;
+  float v[NCH][4];
+  if (row < nqrows) {
+    const int r = (int)(row % nq);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) Act<float>::ld4(query, (int64_t)r * hidden + c * 256 + lane * 4, v[c]);
+  } else {
+    const int64_t tr = row - nqrows;
+    const int t = (int)(tr % Tt);
+    const int id = ids[tr];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float a[4], b[4];
+      Act<float>::ld4(word, (int64_t)id * hidden + c * 256 + lane * 4, a);
+      Act<float>::ld4(pos, (int64_t)t * hidden + c * 256 + lane * 4, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[c][e] = a[e] + b[e];
+    }
+  }
+  ln_row<NCH>(v, hidden, eps, gamma, beta, lane);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) Act<T>::st4(out, row * hidden + c * 256 + lane * 4, v[c]);
+}
+
+extern "C" int psg_qformer_embed(psg_ctx* ctx, const int32_t* ids, int B, int T_, const float* word_emb,
+                                 const float* pos_emb, const float* query_rows, int nq, const float* ln_w,
+                                 const float* ln_b, float eps, int hidden, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && word_emb && pos_emb && query_rows && ln_w && ln_b && out && (ids || T_ == 0), PSG_ERR_INVALID,
+              "psg_qformer_embed: NULL argument");
+  PSG_REQUIRE(hidden == 768, PSG_ERR_UNSUPPORTED, "psg_qformer_embed: hidden=%d (kernel is built for 768)", hidden);
+  PSG_REQUIRE(B > 0 && T_ >= 0 && nq > 0, PSG_ERR_INVALID, "psg_qformer_embed: B=%d T=%d nq=%d", B, T_, nq);
+  int64_t rows = (int64_t)B * (nq + T_);
+  dim3 grid((unsigned)((rows + 3) / 4));
+  PSG_DISPATCH_DTYPE(dtype, "psg_qformer_embed",
+                     (qformer_embed_kernel<T, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
+                         ids, B, T_, word_emb, pos_emb, query_rows, nq, ln_w, ln_b, eps, hidden, (T*)out)));
+  PSG_CHECK_LAUNCH("psg_qformer_embed");
+  return PSG_OK;
+}
+
+// ---- add + LayerNorm --------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ void add_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ bias,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     int64_t rows, int hidden, T* __restrict__ out) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    Act<T>::ld4(x, row * hidden + col, v[c]);
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + col);
+      v[c][0] += b.x; v[c][1] += b.y; v[c][2] += b.z; v[c][3] += b.w;
+    }
+    if (res) {
+      float r[4];
+      Act<T>::ld4(res, row * hidden + col, r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[c][e] += r[e];
+    }
+  }
+  ln_row<NCH>(v, hidden, eps, gamma, beta, lane);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) Act<T>::st4(out, row * hidden + c * 256 + lane * 4, v[c]);
+}
+
+extern "C" int psg_add_layernorm(psg_ctx* ctx, const void* x, const void* residual, const float* bias,
+                                 const float* gamma, const float* beta, float eps, int64_t rows, int hidden, void* out,
+                                 int dtype, void* stream) {
+  PSG_REQUIRE(ctx && x && gamma && beta && out, PSG_ERR_INVALID, "psg_add_layernorm: NULL argument");
+  PSG_REQUIRE(hidden == 768, PSG_ERR_UNSUPPORTED, "psg_add_layernorm: hidden=%d (kernel is built for 768)", hidden);
+  if (rows == 0) return PSG_OK;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  PSG_DISPATCH_DTYPE(dtype, "psg_add_layernorm",
+                     (add_layernorm_kernel<T, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
+                         (const T*)x, (const T*)residual, bias, gamma, beta, eps, rows, hidden, (T*)out)));
+  PSG_CHECK_LAUNCH("psg_add_layernorm");
+  return PSG_OK;
+}
+
+// ---- bias + GELU(erf) -------------------------------------------------------------------------
+template <typename T>
+__global__ void bias_gelu_kernel(const T* __restrict__ x, const float* __restrict__ bias, int64_t n4, int cols,
+                                 T* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[4];
+    Act<T>::ld4(x, i * 4, v);
+    if (bias) {
+      const int col = (int)((i * 4) % cols);
+      const float4 b = *reinterpret_cast<const float4*>(bias + col);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    Act<T>::st4(out, i * 4, v);
+  }
+}
+
+extern "C" int psg_bias_gelu(psg_ctx* ctx, const void* x, const float* bias, int64_t rows, int cols, void* out,
+                             int dtype, void* stream) {
+  PSG_REQUIRE(ctx && x && out, PSG_ERR_INVALID, "psg_bias_gelu: NULL argument");
+  PSG_REQUIRE(cols > 0 && cols % 4 == 0, PSG_ERR_INVALID, "psg_bias_gelu: cols=%d must be a multiple of 4", cols);
+  if (rows == 0) return PSG_OK;
+  int64_t n4 = rows * cols / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  PSG_DISPATCH_DTYPE(dtype, "psg_bias_gelu",
+                     (bias_gelu_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const T*)x, bias, n4,
+                                                                                           cols, (T*)out)));
+  PSG_CHECK_LAUNCH("psg_bias_gelu");
+  return PSG_OK;
+}
+
+// ---- K8 existence head ------------------------------------------------------------------------
+template <typename T>
+__global__ void exist_head_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                  int P, int nq, int hidden, float* __restrict__ logit, float* __restrict__ prob) {
+  const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (p >= P) return;
+  const int64_t base = (int64_t)p * nq * hidden;  // row 0 of the pair = rel_cls_query row (V4:206)
+  float acc = 0.f;
+  for (int c = lane * 4; c < hidden; c += 256) {
+    float v[4];
+    Act<T>::ld4(x, base + c, v);
+    const float4 ww = *reinterpret_cast<const float4*>(w + c);
+    acc += v[0] * ww.x + v[1] * ww.y + v[2] * ww.z + v[3] * ww.w;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float l = acc + b[0];
+    logit[p] = l;
+    if (prob) prob[p] = 1.0f / (1.0f + expf(-l));
+  }
+}
+
+extern "C" int psg_exist_head(psg_ctx* ctx, const void* x, const float* w, const float* b, int P, int nq, int hidden,
+                              float* logit, float* prob, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && x && w && b && logit, PSG_ERR_INVALID, "psg_exist_head: NULL argument");
+  PSG_REQUIRE(hidden % 4 == 0 && P >= 0 && nq > 0, PSG_ERR_INVALID, "psg_exist_head: P=%d nq=%d hidden=%d", P, nq,
+              hidden);
+  if (P == 0) return PSG_OK;
+  PSG_DISPATCH_DTYPE(dtype, "psg_exist_head",
+                     (exist_head_kernel<T><<<(P + 3) / 4, 256, 0, (hipStream_t)stream>>>((const T*)x, w, b, P, nq,
+                                                                                       hidden, logit, prob)));
+  PSG_CHECK_LAUNCH("psg_exist_head");
+  return PSG_OK;
+}
+
+// ---- K12 RMSNorm (+ residual add) -------------------------------------------------------------
+template <typename T, int NCH>
+__global__ void rmsnorm_kernel(T* __restrict__ resid, const T* __restrict__ delta, const float* __restrict__ w,
+                               float eps, int64_t rows, int hidden, T* __restrict__ out) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[NCH][4];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    Act<T>::ld4(resid, row * hidden + col, v[c]);
+    if (delta) {
+      float d[4];
+      Act<T>::ld4(delta, row * hidden + col, d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[c][e] += d[e];
+      // the residual stream is stored in the activation dtype, as HF does (x = residual + attn)
+      Act<T>::st4(resid, row * hidden + col, v[c]);
+      if (sizeof(T) == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c][e] = bf16_to_f32(f32_to_bf16(v[c][e]));
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ss += v[c][e] * v[c][e];
+  }
+  const float inv = 1.0f / sqrtf(wave_sum(ss) / (float)hidden + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    const float4 g = *reinterpret_cast<const float4*>(w + col);
+    float o[4] = {g.x * (v[c][0] * inv), g.y * (v[c][1] * inv), g.z * (v[c][2] * inv), g.w * (v[c][3] * inv)};
+    Act<T>::st4(out, row * hidden + col, o);
+  }
+}
+
+extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, const float* w, float eps, int64_t rows,
+                           int hidden, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && resid && w && out, PSG_ERR_INVALID, "psg_rmsnorm: NULL argument");
+  PSG_REQUIRE(hidden % 256 == 0 && hidden <= 8192, PSG_ERR_UNSUPPORTED,
+              "psg_rmsnorm: hidden=%d must be a multiple of 256 and <= 8192", hidden);
+  if (rows == 0) return PSG_OK;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = hidden / 256;
+#define RN(N)                                                                                                    \
+  PSG_DISPATCH_DTYPE(dtype, "psg_rmsnorm",                                                                       \
+                     (rmsnorm_kernel<T, N><<<grid, 256, 0, st>>>((T*)resid, (const T*)delta, w, eps, rows, hidden, \
+                                                                 (T*)out)))
+  switch (nch) {
+    case 1: RN(1); break;
+    case 2: RN(2); break;
+    case 3: RN(3); break;
+    case 4: RN(4); break;
+    case 8: RN(8); break;
+    case 16: RN(16); break;
+    case 20: RN(20); break;
+    case 32: RN(32); break;
+    default:
+      psg_set_error("psg_rmsnorm: hidden=%d not instantiated (256,512,768,1024,2048,4096,5120,8192)", hidden);
+      return PSG_ERR_UNSUPPORTED;
+  }
+#undef RN
+  PSG_CHECK_LAUNCH("psg_rmsnorm");
+  return PSG_OK;
+}
+
+// ---- K13 rotary (half-split) + KV-cache write -------------------------------------------------
+// One wave per (row, head); head_dim = 128: lane l holds dims l and l + 64 (the rotate_half pair).
+template <typename T>
+__global__ void rope_kvwrite_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ tok_pair,
+                                    const int32_t* __restrict__ tok_pos, const float* __restrict__ inv_freq,
+                                    int64_t rows, int heads, int ctx, T* __restrict__ q_out, T* __restrict__ kc,
+                                    T* __restrict__ vc) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= rows * heads) return;
+  const int64_t row = wave / heads;
+  const int h = (int)(wave % heads);
+  const int pos = tok_pos[row];
+  if (pos < 0) return;  // padding row
+  const int hidden = heads * 128;
+  const int64_t base = row * 3 * hidden + h * 128;
+  const float ang = (float)pos * inv_freq[lane];  // HF: freqs = inv_freq @ position (fp32)
+  const float cs = cosf(ang), sn = sinf(ang);
+  const float q1 = Act<T>::ld(qkv, base + lane), q2 = Act<T>::ld(qkv, base + lane + 64);
+  const float k1 = Act<T>::ld(qkv, base + hidden + lane), k2 = Act<T>::ld(qkv, base + hidden + lane + 64);
+  const float v1 = Act<T>::ld(qkv, base + 2 * hidden + lane), v2 = Act<T>::ld(qkv, base + 2 * hidden + lane + 64);
+  // q*cos + rotate_half(q)*sin, rotate_half(x) = cat(-x2, x1)   (HF-LL:130-160)
+  Act<T>::st(q_out, row * hidden + h * 128 + lane, q1 * cs - q2 * sn);
+  Act<T>::st(q_out, row * hidden + h * 128 + lane + 64, q2 * cs + q1 * sn);
+  const int64_t cbase = (((int64_t)tok_pair[row] * heads + h) * ctx + pos) * 128;
+  Act<T>::st(kc, cbase + lane, k1 * cs - k2 * sn);
+  Act<T>::st(kc, cbase + lane + 64, k2 * cs + k1 * sn);
+  Act<T>::st(vc, cbase + lane, v1);
+  Act<T>::st(vc, cbase + lane + 64, v2);
+}
+
+extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, const int32_t* tok_pair, const int32_t* tok_pos,
+                                const float* inv_freq, int64_t rows, int heads, int head_dim, int ctx, void* q_out,
+                                void* k_cache, void* v_cache, int dtype, void* stream) {
+  PSG_REQUIRE(ctx_ && qkv && tok_pair && tok_pos && inv_freq && q_out && k_cache && v_cache, PSG_ERR_INVALID,
+              "psg_rope_kvwrite: NULL argument");
+  PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_rope_kvwrite: head_dim=%d (kernel is built for 128)",
+              head_dim);
+  if (rows == 0) return PSG_OK;
+  int64_t waves = rows * heads;
+  PSG_DISPATCH_DTYPE(dtype, "psg_rope_kvwrite",
+                     (rope_kvwrite_kernel<T><<<(unsigned)((waves + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+                         (const T*)qkv, tok_pair, tok_pos, inv_freq, rows, heads, ctx, (T*)q_out, (T*)k_cache,
+                         (T*)v_cache)));
+  PSG_CHECK_LAUNCH("psg_rope_kvwrite");
+  return PSG_OK;
+}
+
+// ---- SwiGLU gate ------------------------------------------------------------------------------
+template <typename T>
+__global__ void silu_mul_kernel(const T* __restrict__ gu, int64_t rows, int inter, T* __restrict__ out) {
+  const int64_t n4 = rows * inter / 4;
+  const int i4 = inter / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / i4;
+    const int c = (int)(i % i4) * 4;
+    float g[4], u[4], o[4];
+    Act<T>::ld4(gu, r * 2 * inter + c, g);
+    Act<T>::ld4(gu, r * 2 * inter + inter + c, u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s = g[e] / (1.0f + expf(-g[e]));
+      if (sizeof(T) == 2) s = bf16_to_f32(f32_to_bf16(s));  // HF rounds act_fn(gate) before the product
+      o[e] = s * u[e];
+    }
+    Act<T>::st4(out, r * inter + c, o);
+  }
+}
+
+extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int64_t rows, int inter, void* out, int dtype,
+                            void* stream) {
+  PSG_REQUIRE(ctx && gate_up && out, PSG_ERR_INVALID, "psg_silu_mul: NULL argument");
+  PSG_REQUIRE(inter > 0 && inter % 4 == 0, PSG_ERR_INVALID, "psg_silu_mul: inter=%d must be a multiple of 4", inter);
+  if (rows == 0) return PSG_OK;
+  int64_t blocks = (rows * inter / 4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  PSG_DISPATCH_DTYPE(dtype, "psg_silu_mul",
+                     (silu_mul_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const T*)gate_up, rows,
+                                                                                          inter, (T*)out)));
+  PSG_CHECK_LAUNCH("psg_silu_mul");
+  return PSG_OK;
+}
+
+// ---- K16 greedy step: argmax over the vocabulary + per-pair bookkeeping -------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024) greedy_step_kernel(const T* __restrict__ logits, int vocab, int step,
+                                                           int max_new, int eos, int suppress,
+                                                           int32_t* __restrict__ tokens, int32_t* __restrict__ done,
+                                                           int32_t* __restrict__ next_ids,
+                                                           int32_t* __restrict__ tok_pos) {
+  __shared__ float s_val[16];
+  __shared__ int s_idx[16];
+  const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const T* row = logits + (int64_t)k * vocab;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < vocab; i += blockDim.x) {
+    float v = Act<T>::ld(row, i);
+    if (i == suppress) v = -INFINITY;
+    if (v > best || (v == best && i < bi)) {  // first maximal index, like torch.argmax
+      best = v;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (lane == 0) {
+    s_val[wid] = best;
+    s_idx[wid] = bi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+      if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) {
+        best = s_val[w];
+        bi = s_idx[w];
+      }
+    const int was_done = done[k];
+    tokens[(int64_t)k * max_new + step] = was_done ? -1 : bi;
+    if (!was_done && bi == eos) done[k] = 1;
+    next_ids[k] = bi;
+    tok_pos[k] += 1;
+  }
+}
+
+extern "C" int psg_greedy_step(psg_ctx* ctx, const void* logits, int K, int vocab, int step, int max_new, int eos,
+                               int suppress_token, int32_t* tokens, int32_t* done, int32_t* next_ids, int32_t* tok_pos,
+                               int dtype, void* stream) {
+  PSG_REQUIRE(ctx && logits && tokens && done && next_ids && tok_pos, PSG_ERR_INVALID,
+              "psg_greedy_step: NULL argument");
+  PSG_REQUIRE(K > 0 && vocab > 0 && step >= 0 && step < max_new, PSG_ERR_INVALID,
+              "psg_greedy_step: K=%d vocab=%d step=%d max_new=%d", K, vocab, step, max_new);
+  PSG_DISPATCH_DTYPE(dtype, "psg_greedy_step",
+                     (greedy_step_kernel<T><<<K, 1024, 0, (hipStream_t)stream>>>((const T*)logits, vocab, step, max_new,
+                                                                               eos, suppress_token, tokens, done,
+                                                                               next_ids, tok_pos)));
+  PSG_CHECK_LAUNCH("psg_greedy_step");
+  return PSG_OK;
+}

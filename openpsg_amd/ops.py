@@ -1,0 +1,192 @@
+"""Tensor-level wrappers over the C ABI (include/psg_hip.h).
+
+torch is plumbing here: it owns the HBM allocations and the stream; every wrapper passes raw
+device pointers + sizes to libpsg_hip.so on `torch.cuda.current_stream()`.  There is no host
+fallback: tensors must be CUDA(HIP) tensors, contiguous, of the dtype the kernel expects.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import (PSG_BF16, PSG_F32, PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED, PSG_XATTN_MFMA,
+                   PSG_XATTN_SIMPLE, PsgHipError, check)
+
+_DT = {torch.float32: PSG_F32, torch.bfloat16: PSG_BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise PsgHipError(f"unsupported activation dtype {t.dtype}") from None
+
+
+def _p(t, dtype=None, name="tensor"):
+    """device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PsgHipError(f"{name} must live in HBM (got a {t.device} tensor); this path has no CPU fallback")
+    if not t.is_contiguous():
+        raise PsgHipError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise PsgHipError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _env(t: torch.Tensor):
+    if not t.is_cuda:
+        raise PsgHipError(f"tensor lives on {t.device}: this path runs only on the GPU (no CPU fallback)")
+    return _lib.load(), _lib.ctx(t.device.index or 0), torch.cuda.current_stream(t.device).cuda_stream
+
+
+def mask_grid(pan: torch.Tensor, img_hw, pad_hw, grid_hw) -> torch.Tensor:
+    lib, ctx, st = _env(pan)
+    gh, gw = int(grid_hw[0]), int(grid_hw[1])
+    out = torch.empty(gh * gw, device=pan.device, dtype=torch.float32)
+    check(lib.psg_mask_grid(ctx, _p(pan, torch.int32, "pan_results"), pan.shape[0], pan.shape[1], int(img_hw[0]),
+                            int(img_hw[1]), int(pad_hw[0]), int(pad_hw[1]), gh, gw, _p(out), st), "psg_mask_grid")
+    return out
+
+
+def object_bitmasks(grid: torch.Tensor, object_ids: torch.Tensor) -> torch.Tensor:
+    """-> int64 view of uint64 bits [N, ceil(L/64)]."""
+    lib, ctx, st = _env(grid)
+    L, N = grid.numel(), object_ids.numel()
+    words = (L + 63) // 64
+    bits = torch.empty((N, words), device=grid.device, dtype=torch.int64)
+    check(lib.psg_object_bitmasks(ctx, _p(grid, torch.float32, "grid"), L, _p(object_ids, torch.int32, "object_ids"), N,
+                                  _p(bits), words, st), "psg_object_bitmasks")
+    return bits
+
+
+def qformer_embed(ids, word_emb, pos_emb, query_rows, ln_w, ln_b, eps, out):
+    lib, ctx, st = _env(out)
+    B, T = ids.shape
+    nq, hidden = query_rows.shape
+    assert out.shape == (B * (nq + T), hidden)
+    check(lib.psg_qformer_embed(ctx, _p(ids, torch.int32, "ids"), B, T, _p(word_emb, torch.float32),
+                                _p(pos_emb, torch.float32), _p(query_rows, torch.float32), nq,
+                                _p(ln_w, torch.float32), _p(ln_b, torch.float32), float(eps), hidden, _p(out), _dt(out),
+                                st), "psg_qformer_embed")
+    return out
+
+
+def add_layernorm(x, residual, bias, gamma, beta, eps, out=None):
+    lib, ctx, st = _env(x)
+    out = x if out is None else out
+    rows, hidden = x.shape
+    if residual is not None:
+        assert residual.shape == x.shape and residual.dtype == x.dtype
+    check(lib.psg_add_layernorm(ctx, _p(x), _p(residual), _p(bias, torch.float32), _p(gamma, torch.float32),
+                                _p(beta, torch.float32), float(eps), rows, hidden, _p(out, x.dtype), _dt(x), st),
+          "psg_add_layernorm")
+    return out
+
+
+def bias_gelu(x, bias=None, out=None):
+    lib, ctx, st = _env(x)
+    out = x if out is None else out
+    rows, cols = x.shape
+    check(lib.psg_bias_gelu(ctx, _p(x), _p(bias, torch.float32), rows, cols, _p(out, x.dtype), _dt(x), st),
+          "psg_bias_gelu")
+    return out
+
+
+def qformer_self_attn(qkv, text_mask, B, T, nq, heads, query_rows_only, out):
+    lib, ctx, st = _env(qkv)
+    hidden = qkv.shape[1] // 3
+    assert qkv.shape[0] == B * (nq + T) and out.shape == (B * (nq + T), hidden) and out.dtype == qkv.dtype
+    check(lib.psg_qformer_self_attn(ctx, _p(qkv), _p(text_mask, torch.uint8, "text_mask"), B, T, nq, heads,
+                                    1 if query_rows_only else 0, _p(out), _dt(qkv), st), "psg_qformer_self_attn")
+    return out
+
+
+def qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, out=None, empty_policy=PSG_EMPTY_UNIFORM,
+                       variant=None):
+    lib, ctx, st = _env(q)
+    P = pair_index.numel()
+    L, hidden = k.shape
+    assert q.shape == (P * nq, hidden) and v.shape == k.shape and k.dtype == q.dtype == v.dtype
+    if variant is None:
+        variant = PSG_XATTN_MFMA if q.dtype == torch.bfloat16 else PSG_XATTN_SIMPLE
+    out = torch.empty_like(q) if out is None else out
+    check(lib.psg_qformer_cross_attn(ctx, _p(q), _p(k), _p(v), _p(bits, torch.int64, "bits"), bits.shape[1],
+                                     _p(pair_index, torch.int32, "pair_index"), int(N), P, L, nq, heads,
+                                     int(empty_policy), int(variant), _p(out, q.dtype), _dt(q), st),
+          "psg_qformer_cross_attn")
+    return out
+
+
+def exist_head(x, w, b, P, nq):
+    lib, ctx, st = _env(x)
+    hidden = x.shape[1]
+    logit = torch.empty(P, device=x.device, dtype=torch.float32)
+    prob = torch.empty(P, device=x.device, dtype=torch.float32)
+    check(lib.psg_exist_head(ctx, _p(x), _p(w, torch.float32), _p(b, torch.float32), P, nq, hidden, _p(logit),
+                             _p(prob), _dt(x), st), "psg_exist_head")
+    return logit, prob
+
+
+def topk(score, k):
+    lib, ctx, st = _env(score)
+    idx = torch.empty(k, device=score.device, dtype=torch.int32)
+    val = torch.empty(k, device=score.device, dtype=torch.float32)
+    check(lib.psg_topk(ctx, _p(score, torch.float32, "score"), score.numel(), k, _p(idx), _p(val), st), "psg_topk")
+    return idx, val
+
+
+def gather_rows(src, idx, dst):
+    """dst[r] = src[idx[r]] (rows; idx < 0 -> zeros).  src/dst may be row-strided 2-D views."""
+    lib, ctx, st = _env(src)
+    assert src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
+    if not src.is_cuda or not dst.is_cuda:
+        raise PsgHipError("gather_rows: tensors must live in HBM")
+    n, cols = dst.shape
+    assert idx.numel() == n and src.shape[1] == cols
+    check(lib.psg_gather_rows(ctx, src.data_ptr(), _dt(src), _p(idx, torch.int32, "idx"), n, cols, src.stride(0),
+                              dst.data_ptr(), _dt(dst), dst.stride(0), st), "psg_gather_rows")
+    return dst
+
+
+def rmsnorm(resid, delta, w, eps, out):
+    lib, ctx, st = _env(resid)
+    rows, hidden = resid.shape
+    check(lib.psg_rmsnorm(ctx, _p(resid), _p(delta, resid.dtype) if delta is not None else None,
+                          _p(w, torch.float32), float(eps), rows, hidden, _p(out, resid.dtype), _dt(resid), st),
+          "psg_rmsnorm")
+    return out
+
+
+def rope_kvwrite(qkv, tok_pair, tok_pos, inv_freq, heads, head_dim, ctx_len, q_out, k_cache, v_cache):
+    lib, ctx, st = _env(qkv)
+    rows = qkv.shape[0]
+    check(lib.psg_rope_kvwrite(ctx, _p(qkv), _p(tok_pair, torch.int32), _p(tok_pos, torch.int32),
+                               _p(inv_freq, torch.float32), rows, heads, head_dim, ctx_len, _p(q_out, qkv.dtype),
+                               _p(k_cache, qkv.dtype), _p(v_cache, qkv.dtype), _dt(qkv), st), "psg_rope_kvwrite")
+    return q_out
+
+
+def llm_attn(q, k_cache, v_cache, tok_pair, tok_pos, heads, head_dim, ctx_len, out):
+    lib, ctx, st = _env(q)
+    check(lib.psg_llm_attn(ctx, _p(q), _p(k_cache, q.dtype), _p(v_cache, q.dtype), _p(tok_pair, torch.int32),
+                           _p(tok_pos, torch.int32), q.shape[0], heads, head_dim, ctx_len, _p(out, q.dtype), _dt(q),
+                           st), "psg_llm_attn")
+    return out
+
+
+def silu_mul(gate_up, out):
+    lib, ctx, st = _env(gate_up)
+    rows, two_inter = gate_up.shape
+    check(lib.psg_silu_mul(ctx, _p(gate_up), rows, two_inter // 2, _p(out, gate_up.dtype), _dt(gate_up), st),
+          "psg_silu_mul")
+    return out
+
+
+def greedy_step(logits, step, max_new, eos, suppress_token, tokens, done, next_ids, tok_pos):
+    lib, ctx, st = _env(logits)
+    K, vocab = logits.shape
+    check(lib.psg_greedy_step(ctx, _p(logits), K, vocab, int(step), int(max_new), int(eos), int(suppress_token),
+                              _p(tokens, torch.int32), _p(done, torch.int32), _p(next_ids, torch.int32),
+                              _p(tok_pos, torch.int32), _dt(logits), st), "psg_greedy_step")

@@ -1,0 +1,133 @@
+"""Relation-query engine: prepare_inference + relation Q-Former + existence head + selector.
+
+Host orchestration of the path the reference runs at
+relation_transformer_head_v4.py:146-237 (prepare_inference :408-435, HF InstructBlipQFormerModel
+:179-185, binary head :206-209, selector :235-237), re-organised for one MI355X:
+
+  * the cross-attention K/V projection of the patch tensor is done ONCE per image per layer
+    (the reference `expand`s patches to all N^2 pairs, V4:168, so HF recomputes it per pair);
+  * pair masks are per-object bitmasks OR-ed inside the attention kernel (never materialised);
+  * query rows and text rows live in ONE activation matrix, rows [0, B*33) = query rows
+    (pair-major) and rows [B*33, B*(33+T)) = text rows, so each dense projection is a single
+    hipBLASLt GEMM over all pairs, and the row-wise HIP kernels stream it once;
+  * the last layer computes only what `[:, :33]` (V4:185) can observe: no text-row FFN, no
+    text-row attention output;
+  * nothing synchronises with the host: selection stays on the device.
+
+Dense projections go through torch (`F.linear` -> hipBLASLt); everything else is libpsg_hip.so.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED, PsgHipError
+from .config import PSGConfig
+
+
+class RelationQueryEngine:
+    def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, xattn_variant=None):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise PsgHipError(f"activation dtype must be float32 or bfloat16, got {dtype}")
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.xattn_variant = xattn_variant
+        q = cfg.qformer
+        f32 = lambda k: weights[k].to(device=self.device, dtype=torch.float32).contiguous()  # noqa: E731
+        act = lambda t: t.to(device=self.device, dtype=dtype).contiguous()                   # noqa: E731
+        pre = "relation_qformer.embeddings."
+        self.word_emb = f32(pre + "word_embeddings.weight")
+        self.pos_emb = f32(pre + "position_embeddings.weight")
+        self.emb_ln = (f32(pre + "layernorm.weight"), f32(pre + "layernorm.bias"))
+        self.query_rows = torch.cat([f32("rel_cls_query")[0], f32("relation_query")[0]], dim=0).contiguous()
+        # patch embedding stays fp32: it is one 8.6 GFLOP GEMM per image over fp32 mask_features
+        self.patch_w = f32("patch_embed.proj.weight")
+        self.patch_b = f32("patch_embed.proj.bias")
+        self.exist_w = f32("binary_rel_cls_pred.weight").reshape(-1).contiguous()
+        self.exist_b = f32("binary_rel_cls_pred.bias")
+        self.layers = []
+        for l in range(q.layers):
+            p = f"relation_qformer.encoder.layer.{l}."
+            a, x = p + "attention.", p + "crossattention."
+            L = dict(
+                wqkv=act(torch.cat([weights[a + f"attention.{n}.weight"] for n in ("query", "key", "value")], 0)),
+                bqkv=act(torch.cat([weights[a + f"attention.{n}.bias"] for n in ("query", "key", "value")], 0)),
+                wo=act(weights[a + "output.dense.weight"]), bo=f32(a + "output.dense.bias"),
+                ln_a=(f32(a + "output.LayerNorm.weight"), f32(a + "output.LayerNorm.bias")),
+                wq_x=act(weights[x + "attention.query.weight"]), bq_x=act(weights[x + "attention.query.bias"]),
+                wk_x=act(weights[x + "attention.key.weight"]), bk_x=act(weights[x + "attention.key.bias"]),
+                wv_x=act(weights[x + "attention.value.weight"]), bv_x=act(weights[x + "attention.value.bias"]),
+                wo_x=act(weights[x + "output.dense.weight"]), bo_x=f32(x + "output.dense.bias"),
+                ln_x=(f32(x + "output.LayerNorm.weight"), f32(x + "output.LayerNorm.bias")),
+                w1q=act(weights[p + "intermediate_query.dense.weight"]), b1q=f32(p + "intermediate_query.dense.bias"),
+                w2q=act(weights[p + "output_query.dense.weight"]), b2q=f32(p + "output_query.dense.bias"),
+                ln_q=(f32(p + "output_query.LayerNorm.weight"), f32(p + "output_query.LayerNorm.bias")),
+                w1t=act(weights[p + "intermediate.dense.weight"]), b1t=f32(p + "intermediate.dense.bias"),
+                w2t=act(weights[p + "output.dense.weight"]), b2t=f32(p + "output.dense.bias"),
+                ln_t=(f32(p + "output.LayerNorm.weight"), f32(p + "output.LayerNorm.bias")),
+            )
+            self.layers.append(L)
+        self.empty_policy = PSG_EMPTY_UNIFORM if cfg.empty_row_policy == "uniform" else PSG_EMPTY_UNMASKED
+
+    # ---- A4: prepare_inference (V4:408-435) ----------------------------------------------------
+    def patch_embed(self, mask_features: torch.Tensor) -> torch.Tensor:
+        """[1,C,h,w] fp32 -> patches [L, C] fp32 (timm PatchEmbed: conv k=16 s=16, flatten, transpose)."""
+        x = F.conv2d(mask_features, self.patch_w, self.patch_b, stride=self.cfg.patch_size)
+        return x.flatten(2).transpose(1, 2)[0].contiguous()
+
+    def object_bitmasks(self, pan: torch.Tensor, img_meta: dict, object_ids: torch.Tensor, feat_hw) -> torch.Tensor:
+        gh, gw = feat_hw[0] // self.cfg.patch_size, feat_hw[1] // self.cfg.patch_size
+        grid = ops.mask_grid(pan, img_meta["img_shape"][:2], img_meta["pad_shape"][:2], (gh, gw))
+        return ops.object_bitmasks(grid, object_ids)
+
+    def cross_kv(self, patches: torch.Tensor):
+        """Shared cross-attention K/V, one pair of [L,768] tensors per layer (HF-IB:465-466)."""
+        pa = patches.to(self.dtype)
+        return [(F.linear(pa, L["wk_x"], L["bk_x"]), F.linear(pa, L["wv_x"], L["bv_x"])) for L in self.layers]
+
+    # ---- A6 + A7: Q-Former over a list of pairs ---------------------------------------------------
+    def forward_pairs(self, kv, bits, num_objects, pair_index, ids, text_mask):
+        """pair_index int32 [P] (p = i*N + j), ids int32 [P,T], text_mask uint8 [P,T].
+        Returns (hidden [P*33, 768] in the activation dtype, exist_logit [P] fp32, exist_prob [P] fp32)."""
+        q = self.cfg.qformer
+        nq, H = q.q_rows, q.hidden
+        P, T = ids.shape
+        R, RQ = P * (nq + T), P * nq
+        X = torch.empty((R, H), device=self.device, dtype=self.dtype)
+        ops.qformer_embed(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
+                          q.ln_eps, X)
+        for li, L in enumerate(self.layers):
+            last = li == len(self.layers) - 1
+            qkv = F.linear(X, L["wqkv"], L["bqkv"])
+            ctx = torch.empty((R, H), device=self.device, dtype=self.dtype)
+            ops.qformer_self_attn(qkv, text_mask, P, T, nq, q.heads, last, ctx)
+            del qkv
+            ra = RQ if last else R
+            A = F.linear(ctx[:ra], L["wo"])
+            ops.add_layernorm(A, X[:ra], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+            del ctx
+            qx = F.linear(A[:RQ], L["wq_x"], L["bq_x"])
+            cx = ops.qformer_cross_attn(qx, kv[li][0], kv[li][1], bits, pair_index, num_objects, nq, q.heads,
+                                        empty_policy=self.empty_policy, variant=self.xattn_variant)
+            Cq = F.linear(cx, L["wo_x"])
+            ops.add_layernorm(Cq, A[:RQ], L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
+            del qx, cx
+            Xn = torch.empty((RQ if last else R, H), device=self.device, dtype=self.dtype)
+            iq = F.linear(Cq, L["w1q"])
+            ops.bias_gelu(iq, L["b1q"])
+            hq = F.linear(iq, L["w2q"])
+            ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps, out=Xn[:RQ])
+            del iq, hq
+            if not last and T > 0:
+                it = F.linear(A[RQ:], L["w1t"])
+                ops.bias_gelu(it, L["b1t"])
+                ht = F.linear(it, L["w2t"])
+                ops.add_layernorm(ht, A[RQ:], L["b2t"], L["ln_t"][0], L["ln_t"][1], q.ln_eps, out=Xn[RQ:])
+                del it, ht
+            X = Xn
+        logit, prob = ops.exist_head(X, self.exist_w, self.exist_b, P, nq)
+        return X, logit, prob
+
+    def select(self, prob: torch.Tensor, k: int):
+        """V4:235-237 on the device: descending, ties -> lower pair index.  int32 [k] (-1 if n < k)."""
+        return ops.topk(prob, k)[0]
