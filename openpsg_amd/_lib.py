@@ -55,6 +55,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # The library must share torch's HIP runtime (streams and device pointers come from torch):
+    # torch bundles its own libamdhip64.so.7, and whichever copy is loaded first serves the whole
+    # process, so make sure it is torch's.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PsgHipError(
             f"{LIB_PATH} is missing: build it with `python -m openpsg_amd.csrc.build` "

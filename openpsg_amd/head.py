@@ -228,7 +228,7 @@ class RelationTransformerHeadV4(nn.Module):
             return dict(rel_pred=[], rel_score=[])
         obj_ids = [int(x) for x in object_id_list]
         names = [object_categories[i % INSTANCE_OFFSET] for i in obj_ids]                  # V4:138-139
-        rq = self.relation_query(feat, meta, obj_ids, names, info['pan_results'])
+        rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
         if is_generation is None:
             is_generation = True
         out = self.decode_selected(rq, names) if is_generation else dict(tokens=None)
@@ -236,7 +236,7 @@ class RelationTransformerHeadV4(nn.Module):
         rel_pred, rel_score = self.parse(out["tokens_host"], out["selected_host"], N) if is_generation else ([], [])
         return dict(rel_pred=rel_pred, rel_score=rel_score)
 
-    def relation_query(self, feat, meta, obj_ids, names, pan, pair_range=None):
+    def run_relation_query(self, feat, meta, obj_ids, names, pan, pair_range=None):
         """A4-A8 on the GPU.  pair_range=(p0,p1) restricts the Q-Former to a shard of the pairs."""
         eng = self.rq_engine
         dev = self.device
