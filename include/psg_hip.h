@@ -113,15 +113,18 @@ int psg_gather_rows(psg_ctx*, const void* src, int src_dtype, const int32_t* idx
                     int64_t src_row_stride, void* dst, int dst_dtype, int64_t dst_row_stride, void* stream);
 
 /* ---- K12: Llama RMSNorm, HF-LL:53-67, fused with the residual add of HF-LL decoder layer:
- * if delta != NULL: resid += delta (written back); out = w * (resid * rsqrt(mean(resid^2)+eps)). */
-int psg_rmsnorm(psg_ctx*, void* resid, const void* delta, const float* w, float eps, int64_t rows,
-                int hidden, void* out, int dtype, void* stream);
+ * if delta != NULL: resid += delta (written back); out = w * (resid * rsqrt(mean(resid^2)+eps)).
+ * delta_splits > 0: delta is fp32 split-K partials [delta_splits][rows][hidden] of psg_skinny_gemm
+ * (summed here, rounded once to the activation dtype); 0: delta is an activation-dtype tensor. */
+int psg_rmsnorm(psg_ctx*, void* resid, const void* delta, int delta_splits, const float* w, float eps,
+                int64_t rows, int hidden, void* out, int dtype, void* stream);
 
 /* ---- K13: rotary embedding (half-split, HF-LL:130-160) + KV-cache write.
  * qkv [rows][3*hidden]; tok_pair / tok_pos int32 [rows] give the cache row (pair) and the
  * position (= cache slot = cumsum(mask)-1, V4 left-padding removed by compaction); tok_pos < 0
- * marks a padding row (skipped).  q_out [rows][hidden]; caches [pairs][heads][ctx][head_dim]. */
-int psg_rope_kvwrite(psg_ctx*, const void* qkv, const int32_t* tok_pair, const int32_t* tok_pos,
+ * marks a padding row (skipped).  q_out [rows][hidden]; caches [pairs][heads][ctx][head_dim].
+ * qkv_splits > 0: qkv is fp32 split-K partials [qkv_splits][rows][3*hidden]. */
+int psg_rope_kvwrite(psg_ctx*, const void* qkv, int qkv_splits, const int32_t* tok_pair, const int32_t* tok_pos,
                      const float* inv_freq, int64_t rows, int heads, int head_dim, int ctx,
                      void* q_out, void* k_cache, void* v_cache, int dtype, void* stream);
 
@@ -131,15 +134,32 @@ int psg_llm_attn(psg_ctx*, const void* q, const void* k_cache, const void* v_cac
                  const int32_t* tok_pair, const int32_t* tok_pos, int64_t rows, int heads,
                  int head_dim, int ctx, void* out, int dtype, void* stream);
 
-/* ---- SwiGLU gate, HF-LL:163-177: out = silu(gate_up[:, :inter]) * gate_up[:, inter:]. */
-int psg_silu_mul(psg_ctx*, const void* gate_up, int64_t rows, int inter, void* out, int dtype,
+/* ---- SwiGLU gate, HF-LL:163-177: out = silu(gate_up[:, :inter]) * gate_up[:, inter:].
+ * splits > 0: gate_up is fp32 split-K partials [splits][rows][2*inter]. */
+int psg_silu_mul(psg_ctx*, const void* gate_up, int splits, int64_t rows, int inter, void* out, int dtype,
                  void* stream);
+
+/* ---- K15: weight-streaming skinny GEMM of the batched decode step (HF-LL q/k/v/o/gate/up/down
+ * projections and lm_head, all bias-free Linear layers): y[M][N] = x[M][K] . w[N][K]^T with
+ * M <= 32 rows (the selected pairs), bf16 in / fp32 accumulate; every weight byte is read from
+ * HBM exactly once per call.  N % 16 == 0, K % 64 == 0.
+ * K is split `splits` ways across workgroups (psg_skinny_gemm_plan chooses the count); the kernel
+ * writes fp32 partials part[splits][M][N] and does NOT reduce them: the consumers below
+ * (psg_rmsnorm, psg_rope_kvwrite, psg_silu_mul, psg_greedy_step) take a `*_splits` argument and sum
+ * the slices in split order while loading (deterministic, no atomics, no extra launch);
+ * psg_reduce_partials materialises y for any other consumer. */
+int psg_skinny_gemm_plan(psg_ctx*, int M, int N, int K, int* splits);
+int psg_skinny_gemm(psg_ctx*, const void* x, const void* w, float* part, int M, int N, int K,
+                    int splits, void* stream);
+int psg_reduce_partials(psg_ctx*, const float* part, int splits, int64_t n, void* y, int dtype,
+                        void* stream);
 
 /* ---- K16: greedy step (HF generate, num_beams=1, do_sample=False; V4:305-312).
  * logits [K][vocab] (dtype); token = argmax (first maximal index); suppress_token >= 0 is
  * excluded.  For each pair k not yet done: tokens[k][step] = token, done[k] |= (token == eos),
- * next_ids[k] = token, tok_pos[k] += 1.  Finished pairs write -1 and keep decoding harmlessly. */
-int psg_greedy_step(psg_ctx*, const void* logits, int K, int vocab, int step, int max_new,
+ * next_ids[k] = token, tok_pos[k] += 1.  Finished pairs write -1 and keep decoding harmlessly.
+ * splits > 0: logits is fp32 split-K partials [splits][K][vocab] (summed before the argmax). */
+int psg_greedy_step(psg_ctx*, const void* logits, int splits, int K, int vocab, int step, int max_new,
                     int eos, int suppress_token, int32_t* tokens, int32_t* done, int32_t* next_ids,
                     int32_t* tok_pos, int dtype, void* stream);
 

@@ -39,11 +39,14 @@ SIGNATURES = {
     "psg_exist_head": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "psg_topk": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "psg_gather_rows": [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _i, _i64, _vp],
-    "psg_rmsnorm": [_vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _i, _vp],
-    "psg_rope_kvwrite": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "psg_rmsnorm": [_vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _i, _vp],
+    "psg_rope_kvwrite": [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "psg_llm_attn": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp],
-    "psg_silu_mul": [_vp, _vp, _i64, _i, _vp, _i, _vp],
-    "psg_greedy_step": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "psg_silu_mul": [_vp, _vp, _i, _i64, _i, _vp, _i, _vp],
+    "psg_skinny_gemm_plan": [_vp, _i, _i, _i, C.POINTER(_i)],
+    "psg_skinny_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "psg_reduce_partials": [_vp, _vp, _i, _i64, _vp, _i, _vp],
+    "psg_greedy_step": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
 }
 
 _lib = None

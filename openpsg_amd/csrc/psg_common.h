@@ -87,6 +87,8 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+#define PSG_MAX_SPLITS 16  // split-K slices a consumer kernel can sum (psg_skinny_gemm_plan stays below)
+
 #define PSG_FMIN (-3.402823466e+38f)  // torch.finfo(float32).min, the legacy additive mask value
 
 // dispatch on the activation dtype enum

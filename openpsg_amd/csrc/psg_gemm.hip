@@ -1,0 +1,255 @@
+// K15: weight-streaming "skinny" GEMM for the batched LMM decode step.
+//
+//   part[s][M][N] = x[M][Ks] . w[N][Ks]^T      M <= 32 rows (the selected pairs), bf16 in, fp32 out
+//   y = sum_s part[s]                           (summed, in split order, by the CONSUMER kernel)
+//
+// Replaces the HF Linear layers of the Llama decoder (q/k/v/o_proj, gate/up/down_proj, lm_head;
+// HF-LL:163-177, 243-281) for the decode steps of V4:305-312.  The reference runs them at batch 1,
+// once per selected pair; here all selected pairs share one pass, so each weight byte leaves HBM
+// once per step.  The kernel is HBM-bound by construction (2*M flops per weight element); its
+// roofline is the HBM stream of w.
+//
+// What measurements on MI355X dictated (tools/membench, tools/bench_kernels.py):
+//   * the MFMA-A-layout weight read (16 rows x 64 B per instruction) streams at 5.1-5.4 TB/s by
+//     itself, but a first version that fetched the x operand from L2 with per-lane loads ran at
+//     2.7 TB/s: x costs 2.25x the weight bytes through L2->L1 and 2 of every 3 vector-memory
+//     issue slots.  With x hoisted out of the loop the same kernel reached 4.8-5.25 TB/s.
+//   => x must come from LDS, which needs waves that share a K range: so K is split ACROSS
+//      workgroups (grid.y) and a workgroup = 4 waves x 16-row slabs that walk the same K range.
+//   * the split-K partials are not reduced here: every consumer of a decode projection is one of
+//     our own row kernels (rmsnorm, rotary+KV write, SwiGLU gate, greedy step), which sum the S
+//     fp32 slices in a fixed order while loading - deterministic, no atomics, no extra launch.
+//
+// Work layout (gfx950):
+//   * grid = (G, S); workgroup (gx, by) owns the K blocks (64 elements each)
+//     [KB by / S, KB (by+1) / S) and walks the 64-row slabs gx, gx + G, ... persistently; wave w owns
+//     rows 16 w .. 16 w + 15 of each slab;
+//   * x[0..M)[K range] is staged ONCE per workgroup into LDS (row stride padded by 16 B) and reused
+//     for every slab; the first weight batch is already in flight while that happens;
+//   * lane (n = lane&15, kq = lane>>4) reads bytes [32 kq, 32 kq + 32) of row n's 128-byte block
+//     with two non-temporal 16-byte loads straight into the A operands of two
+//     v_mfma_f32_16x16x32_bf16 (a weight byte is used once: no LDS round trip for w).  K inside a
+//     block is thereby permuted; x fragments are read from LDS with the same permutation;
+//   * two register sets of SG_U blocks each are software-pipelined over the flattened
+//     (slab, batch) stream, so a wave always has one batch of loads in flight while it multiplies
+//     the other, across slab boundaries too.
+#include <stdlib.h>
+
+#include "psg_common.h"
+
+typedef __bf16 gbf16x8_t __attribute__((ext_vector_type(8)));
+typedef float gf32x4_t __attribute__((ext_vector_type(4)));
+
+#define SG_ROWS 64      // weight rows per workgroup (4 waves x 16)
+#define SG_U 4          // K blocks per register set
+
+struct SgFrag {
+  gbf16x8_t v[SG_U][2];
+};
+
+__device__ __forceinline__ void sg_load(SgFrag& f, const uint16_t* __restrict__ wp, int kb) {
+#pragma unroll
+  for (int u = 0; u < SG_U; ++u) {
+    f.v[u][0] = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)(kb + u) * 64));
+    f.v[u][1] = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)(kb + u) * 64 + 8));
+  }
+}
+
+__device__ __forceinline__ void sg_mma(const SgFrag& f, const unsigned char* xs0, const unsigned char* xs1, int kbl,
+                                       gf32x4_t& acc0, gf32x4_t& acc1) {
+#pragma unroll
+  for (int u = 0; u < SG_U; ++u) {
+    const int o = (kbl + u) * 128;
+    const gbf16x8_t b00 = *reinterpret_cast<const gbf16x8_t*>(xs0 + o);
+    const gbf16x8_t b01 = *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16);
+    const gbf16x8_t b10 = *reinterpret_cast<const gbf16x8_t*>(xs1 + o);
+    const gbf16x8_t b11 = *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[u][0], b00, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[u][0], b10, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[u][1], b01, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[u][1], b11, acc1, 0, 0, 0);
+  }
+}
+
+__global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __restrict__ x,
+                                                          const uint16_t* __restrict__ w, float* __restrict__ part,
+                                                          int M, int N, int K, int xstride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs[];   // [M][xstride bytes]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int S = gridDim.y, by = blockIdx.y, G = gridDim.x, gx = blockIdx.x;
+  const int KB = K >> 6;
+  const int kbA = (int)(((int64_t)KB * by) / S), kbB = (int)(((int64_t)KB * (by + 1)) / S);
+  const int nkb = kbB - kbA;
+  const int nb = nkb / SG_U;                                        // full batches per slab
+  const int nslab_all = (N + SG_ROWS - 1) / SG_ROWS;
+  const int nslab = gx < nslab_all ? (nslab_all - gx + G - 1) / G : 0;   // slabs gx, gx+G, ... (persistent)
+  // weight pointer of this lane for slab t (rows beyond N are clamped; their results are dropped)
+  auto wrow = [&](int t) -> const uint16_t* {
+    int r = (gx + t * G) * SG_ROWS + wid * 16 + n;
+    r = r < N ? r : N - 1;
+    return w + (int64_t)r * K + (int64_t)kbA * 64 + kq * 16;
+  };
+  const int total = nslab * nb;                                     // flattened (slab, batch) stream
+  SgFrag fa, fb;
+  int lt = 0, lb = 0;                                               // load cursor
+  auto load_next = [&](SgFrag& f) {
+    sg_load(f, wrow(lt), lb * SG_U);
+    if (++lb == nb) { lb = 0; ++lt; }
+  };
+  if (total > 0) load_next(fa);                                     // in flight during the x staging
+
+  // stage x[0..M)[kbA*64 .. kbB*64) once per workgroup: 16-byte pieces, coalesced along K
+  const int pieces = nkb * 8;
+  for (int e = tid; e < M * pieces; e += 256) {
+    const int r = e / pieces, c = e - r * pieces;
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (int64_t)r * K + (int64_t)kbA * 64 + c * 8);
+    *reinterpret_cast<uint4*>(xs + r * xstride + c * 16) = v;
+  }
+  __syncthreads();
+
+  // x rows >= M are clamped: they only feed output columns >= M, which are never stored
+  const unsigned char* xs0 = xs + min(n, M - 1) * xstride + kq * 32;
+  const unsigned char* xs1 = xs + min(16 + n, M - 1) * xstride + kq * 32;
+  gf32x4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  int ct = 0, cb = 0;                                               // compute cursor
+  auto finish_slab = [&]() {
+    const uint16_t* wp = wrow(ct);
+    for (int kb = nb * SG_U; kb < nkb; ++kb) {                      // remainder K blocks of this slab
+      const gbf16x8_t a0 = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)kb * 64));
+      const gbf16x8_t a1 = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)kb * 64 + 8));
+      const int o = kb * 128;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, *reinterpret_cast<const gbf16x8_t*>(xs0 + o), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, *reinterpret_cast<const gbf16x8_t*>(xs1 + o), acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16), acc0, 0, 0,
+                                                     0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16), acc1, 0, 0,
+                                                     0);
+    }
+    // D[row = weight row 4 kq + r][col = x row lane&15] -> part[by][m][n0 + 4 kq + r], 16-byte stores
+    const int n0 = (gx + ct * G) * SG_ROWS + wid * 16;
+    if (n0 + 16 <= N) {
+      float* pp = part + ((int64_t)by * M) * N + n0 + 4 * kq;
+      if (n < M) *reinterpret_cast<float4*>(pp + (int64_t)n * N) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+      if (16 + n < M)
+        *reinterpret_cast<float4*>(pp + (int64_t)(16 + n) * N) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+    }
+    acc0 = (gf32x4_t){0, 0, 0, 0};
+    acc1 = (gf32x4_t){0, 0, 0, 0};
+    cb = 0;
+    ++ct;
+  };
+  if (nb == 0) {                                                    // K range shorter than one batch
+    for (int t = 0; t < nslab; ++t) finish_slab();
+    return;
+  }
+  for (int j = 0; j < total; j += 2) {
+    if (j + 1 < total) load_next(fb);
+    sg_mma(fa, xs0, xs1, cb * SG_U, acc0, acc1);
+    if (++cb == nb) finish_slab();
+    if (j + 1 >= total) break;
+    if (j + 2 < total) load_next(fa);
+    sg_mma(fb, xs0, xs1, cb * SG_U, acc0, acc1);
+    if (++cb == nb) finish_slab();
+  }
+}
+
+// split count: K range per workgroup ~1024 elements (x slice <= 64 KiB of LDS at M = 32), and
+// enough workgroups to give every CU several waves.
+static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("PSG_SKINNY_SPLITS");
+    forced = e ? atoi(e) : 0;
+  }
+  const int KB = K >> 6;
+  int S = forced > 0 ? forced : (K + 512) / 1024;
+  if (S < 1) S = 1;
+  const int blocks_n = (N + SG_ROWS - 1) / SG_ROWS;
+  if (forced <= 0)
+    while (S < KB / 4 && (int64_t)blocks_n * S < 2 * ctx->num_cu) S *= 2;   // small N: split deeper
+  if (S > KB) S = KB;
+  if (S > PSG_MAX_SPLITS && forced <= 0) S = PSG_MAX_SPLITS;
+  if (S < 1) S = 1;
+  // LDS bound: M * (ceil(KB/S)*128 + 16) <= 96 KiB
+  while ((int64_t)M * (((KB + S - 1) / S) * 128 + 16) > 96 * 1024 && S < KB) ++S;
+  return S;
+}
+
+extern "C" int psg_skinny_gemm_plan(psg_ctx* ctx, int M, int N, int K, int* splits) {
+  PSG_REQUIRE(ctx && splits, PSG_ERR_INVALID, "psg_skinny_gemm_plan: NULL argument");
+  PSG_REQUIRE(M >= 1 && M <= 32, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm: M=%d (1..32 rows)", M);
+  PSG_REQUIRE(N > 0 && N % 16 == 0 && K >= 64 && K % 64 == 0, PSG_ERR_UNSUPPORTED,
+              "psg_skinny_gemm: N=%d must be a multiple of 16, K=%d a multiple of 64", N, K);
+  *splits = sg_plan(ctx, M, N, K);
+  return PSG_OK;
+}
+
+extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K,
+                               int splits, void* stream) {
+  PSG_REQUIRE(ctx && x && w && part, PSG_ERR_INVALID, "psg_skinny_gemm: NULL argument");
+  PSG_REQUIRE(M >= 1 && M <= 32, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm: M=%d (1..32 rows)", M);
+  PSG_REQUIRE(N > 0 && N % 16 == 0 && K >= 64 && K % 64 == 0, PSG_ERR_UNSUPPORTED,
+              "psg_skinny_gemm: N=%d must be a multiple of 16, K=%d a multiple of 64", N, K);
+  const int KB = K >> 6;
+  PSG_REQUIRE(splits >= 1 && splits <= KB, PSG_ERR_INVALID, "psg_skinny_gemm: splits=%d (1..%d)", splits, KB);
+  const int nkb_max = (KB + splits - 1) / splits;
+  const int xstride = nkb_max * 128 + 16;
+  const size_t lds = (size_t)M * xstride;
+  PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm: x slice needs %zu B of LDS; use more splits",
+              lds);
+  static size_t configured = 0;
+  if (lds > configured && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)skinny_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) {
+      psg_set_error("psg_skinny_gemm: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+      return PSG_ERR_HIP;
+    }
+    configured = lds;
+  }
+  // persistent over row slabs: ~3 workgroups per CU in total, every workgroup keeps its x slice in LDS
+  const int nslab = (N + SG_ROWS - 1) / SG_ROWS;
+  static int wg_per_cu = -1;
+  if (wg_per_cu < 0) {
+    const char* e = getenv("PSG_SKINNY_WG_PER_CU");
+    wg_per_cu = e ? atoi(e) : 3;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+  }
+  int G = (wg_per_cu * ctx->num_cu + splits - 1) / splits;
+  if (G > nslab) G = nslab;
+  if (G < 1) G = 1;
+  dim3 grid(G, splits);
+  skinny_gemm_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const uint16_t*)x, (const uint16_t*)w, part, M, N, K,
+                                                              xstride);
+  PSG_CHECK_LAUNCH("psg_skinny_gemm");
+  return PSG_OK;
+}
+
+// y[i] = sum_s part[s][i] in split order, converted to the activation dtype (tests, generic consumers)
+template <typename T>
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int S, int64_t n4, T* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = *reinterpret_cast<const float4*>(part + i * 4);
+    for (int s = 1; s < S; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(part + ((int64_t)s * n4 + i) * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    Act<T>::st4(y, i * 4, v);
+  }
+}
+
+extern "C" int psg_reduce_partials(psg_ctx* ctx, const float* part, int splits, int64_t n, void* y, int dtype,
+                                   void* stream) {
+  PSG_REQUIRE(ctx && part && y, PSG_ERR_INVALID, "psg_reduce_partials: NULL argument");
+  PSG_REQUIRE(splits >= 1 && n > 0 && n % 4 == 0, PSG_ERR_INVALID, "psg_reduce_partials: splits=%d n=%lld", splits,
+              (long long)n);
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  PSG_DISPATCH_DTYPE(dtype, "psg_reduce_partials",
+                     (reduce_partials_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(part, splits, n / 4,
+                                                                                                 (T*)y)));
+  PSG_CHECK_LAUNCH("psg_reduce_partials");
+  return PSG_OK;
+}

@@ -200,69 +200,133 @@ extern "C" int psg_exist_head(psg_ctx* ctx, const void* x, const float* w, const
   return PSG_OK;
 }
 
+// ---- split-K partial inputs --------------------------------------------------------------------
+// The decode projections (psg_skinny_gemm) leave fp32 partials part[S][rows][cols]; their consumers
+// sum the S slices in split order while loading, then round once to the activation dtype (exactly
+// what a GEMM with an activation-dtype output would have stored).
+template <typename T>
+__device__ __forceinline__ void ld4_in(const void* __restrict__ in, int S, int64_t slice, int64_t i, float (&o)[4]) {
+  if (S > 0) {
+    const float* p = reinterpret_cast<const float*>(in);
+    float4 t[PSG_MAX_SPLITS];
+#pragma unroll
+    for (int s = 0; s < PSG_MAX_SPLITS; ++s)
+      if (s < S) t[s] = *reinterpret_cast<const float4*>(p + (int64_t)s * slice + i);
+    float4 a = t[0];
+#pragma unroll
+    for (int s = 1; s < PSG_MAX_SPLITS; ++s)
+      if (s < S) { a.x += t[s].x; a.y += t[s].y; a.z += t[s].z; a.w += t[s].w; }
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+    if (sizeof(T) == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = bf16_to_f32(f32_to_bf16(o[e]));
+    }
+  } else {
+    Act<T>::ld4(reinterpret_cast<const T*>(in), i, o);
+  }
+}
+template <typename T>
+__device__ __forceinline__ float ld1_in(const void* __restrict__ in, int S, int64_t slice, int64_t i) {
+  if (S > 0) {
+    const float* p = reinterpret_cast<const float*>(in);
+    float t[PSG_MAX_SPLITS];
+#pragma unroll
+    for (int s = 0; s < PSG_MAX_SPLITS; ++s)
+      if (s < S) t[s] = p[(int64_t)s * slice + i];
+    float a = t[0];
+#pragma unroll
+    for (int s = 1; s < PSG_MAX_SPLITS; ++s)
+      if (s < S) a += t[s];
+    return sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(a)) : a;
+  }
+  return Act<T>::ld(reinterpret_cast<const T*>(in), i);
+}
+
 // ---- K12 RMSNorm (+ residual add) -------------------------------------------------------------
+// One 256-thread workgroup per row (decode has only K ~ 20 rows of 4096: a single wave walking a
+// row serialises ~16 dependent HBM round trips).  Thread t owns the 4-element chunks t, t+256, ...;
+// every load is issued before the first store; the sum of squares is reduced wave -> LDS -> block.
 template <typename T, int NCH>
-__global__ void rmsnorm_kernel(T* __restrict__ resid, const T* __restrict__ delta, const float* __restrict__ w,
-                               float eps, int64_t rows, int hidden, T* __restrict__ out) {
-  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  float v[NCH][4];
+__global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, const void* __restrict__ delta,
+                                                      int dsplits, int64_t dslice, const float* __restrict__ w,
+                                                      float eps, int hidden, T* __restrict__ out) {
+  __shared__ float s_part[16];
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthr = blockDim.x;
+  float v[NCH][4], d[NCH][4];
+  float4 g[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden) {
+      Act<T>::ld4(resid, row * hidden + col, v[c]);
+      if (delta) ld4_in<T>(delta, dsplits, dslice, row * hidden + col, d[c]);
+      g[c] = *reinterpret_cast<const float4*>(w + col);
+    }
+  }
   float ss = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int col = c * 256 + lane * 4;
-    Act<T>::ld4(resid, row * hidden + col, v[c]);
-    if (delta) {
-      float d[4];
-      Act<T>::ld4(delta, row * hidden + col, d);
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden) {
+      if (delta) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[c][e] += d[e];
-      // the residual stream is stored in the activation dtype, as HF does (x = residual + attn)
-      Act<T>::st4(resid, row * hidden + col, v[c]);
-      if (sizeof(T) == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[c][e] = bf16_to_f32(f32_to_bf16(v[c][e]));
+        for (int e = 0; e < 4; ++e) {
+          v[c][e] += d[c][e];
+          // the residual stream is stored in the activation dtype, as HF does (x = residual + attn)
+          if (sizeof(T) == 2) v[c][e] = bf16_to_f32(f32_to_bf16(v[c][e]));
+        }
       }
-    }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ss += v[c][e] * v[c][e];
+      for (int e = 0; e < 4; ++e) ss += v[c][e] * v[c][e];
+    }
   }
-  const float inv = 1.0f / sqrtf(wave_sum(ss) / (float)hidden + eps);
+  ss = wave_sum(ss);
+  if (lane == 0) s_part[wid] = ss;
+  __syncthreads();
+  ss = 0.f;
+  for (int i = 0; i < (nthr >> 6); ++i) ss += s_part[i];
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int col = c * 256 + lane * 4;
-    const float4 g = *reinterpret_cast<const float4*>(w + col);
-    float o[4] = {g.x * (v[c][0] * inv), g.y * (v[c][1] * inv), g.z * (v[c][2] * inv), g.w * (v[c][3] * inv)};
-    Act<T>::st4(out, row * hidden + col, o);
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden) {
+      if (delta) Act<T>::st4(resid, row * hidden + col, v[c]);
+      float o[4] = {g[c].x * (v[c][0] * inv), g[c].y * (v[c][1] * inv), g[c].z * (v[c][2] * inv),
+                    g[c].w * (v[c][3] * inv)};
+      Act<T>::st4(out, row * hidden + col, o);
+    }
   }
 }
 
-extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, const float* w, float eps, int64_t rows,
-                           int hidden, void* out, int dtype, void* stream) {
+extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int delta_splits, const float* w, float eps,
+                           int64_t rows, int hidden, void* out, int dtype, void* stream) {
   PSG_REQUIRE(ctx && resid && w && out, PSG_ERR_INVALID, "psg_rmsnorm: NULL argument");
-  PSG_REQUIRE(hidden % 256 == 0 && hidden <= 8192, PSG_ERR_UNSUPPORTED,
-              "psg_rmsnorm: hidden=%d must be a multiple of 256 and <= 8192", hidden);
+  PSG_REQUIRE(delta_splits >= 0 && (delta || delta_splits == 0), PSG_ERR_INVALID, "psg_rmsnorm: delta_splits=%d",
+              delta_splits);
+  PSG_REQUIRE(hidden % 4 == 0 && hidden > 0 && hidden <= 8192, PSG_ERR_UNSUPPORTED,
+              "psg_rmsnorm: hidden=%d must be a multiple of 4 and <= 8192", hidden);
   if (rows == 0) return PSG_OK;
-  dim3 grid((unsigned)((rows + 3) / 4));
+  PSG_REQUIRE(delta_splits <= PSG_MAX_SPLITS, PSG_ERR_UNSUPPORTED, "psg_rmsnorm: delta_splits=%d > %d", delta_splits,
+              PSG_MAX_SPLITS);
+  dim3 grid((unsigned)rows);
   hipStream_t st = (hipStream_t)stream;
-  const int nch = hidden / 256;
-#define RN(N)                                                                                                    \
-  PSG_DISPATCH_DTYPE(dtype, "psg_rmsnorm",                                                                       \
-                     (rmsnorm_kernel<T, N><<<grid, 256, 0, st>>>((T*)resid, (const T*)delta, w, eps, rows, hidden, \
-                                                                 (T*)out)))
+  // decode-sized launches (a handful of rows) are latency bound: spread each row over 16 waves
+  const int nthr = (rows <= 64 && hidden >= 4096) ? 1024 : 256;
+  const int nch = (hidden + 4 * nthr - 1) / (4 * nthr);
+#define RN(N)                                                                                                        \
+  PSG_DISPATCH_DTYPE(dtype, "psg_rmsnorm",                                                                           \
+                     (rmsnorm_kernel<T, N><<<grid, nthr, 0, st>>>((T*)resid, delta, delta_splits, rows * hidden, w, eps, \
+                                                                 hidden, (T*)out)))
   switch (nch) {
     case 1: RN(1); break;
     case 2: RN(2); break;
     case 3: RN(3); break;
     case 4: RN(4); break;
-    case 8: RN(8); break;
-    case 16: RN(16); break;
-    case 20: RN(20); break;
-    case 32: RN(32); break;
-    default:
-      psg_set_error("psg_rmsnorm: hidden=%d not instantiated (256,512,768,1024,2048,4096,5120,8192)", hidden);
-      return PSG_ERR_UNSUPPORTED;
+    case 5: RN(5); break;
+    case 6: RN(6); break;
+    case 7: RN(7); break;
+    default: RN(8); break;
   }
 #undef RN
   PSG_CHECK_LAUNCH("psg_rmsnorm");
@@ -272,7 +336,7 @@ extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, const f
 // ---- K13 rotary (half-split) + KV-cache write -------------------------------------------------
 // One wave per (row, head); head_dim = 128: lane l holds dims l and l + 64 (the rotate_half pair).
 template <typename T>
-__global__ void rope_kvwrite_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ tok_pair,
+__global__ void rope_kvwrite_kernel(const void* __restrict__ qkv, int qs, const int32_t* __restrict__ tok_pair,
                                     const int32_t* __restrict__ tok_pos, const float* __restrict__ inv_freq,
                                     int64_t rows, int heads, int ctx, T* __restrict__ q_out, T* __restrict__ kc,
                                     T* __restrict__ vc) {
@@ -287,9 +351,11 @@ __global__ void rope_kvwrite_kernel(const T* __restrict__ qkv, const int32_t* __
   const int64_t base = row * 3 * hidden + h * 128;
   const float ang = (float)pos * inv_freq[lane];  // HF: freqs = inv_freq @ position (fp32)
   const float cs = cosf(ang), sn = sinf(ang);
-  const float q1 = Act<T>::ld(qkv, base + lane), q2 = Act<T>::ld(qkv, base + lane + 64);
-  const float k1 = Act<T>::ld(qkv, base + hidden + lane), k2 = Act<T>::ld(qkv, base + hidden + lane + 64);
-  const float v1 = Act<T>::ld(qkv, base + 2 * hidden + lane), v2 = Act<T>::ld(qkv, base + 2 * hidden + lane + 64);
+  const int64_t sl = rows * 3 * hidden;  // split-K slice stride
+  const float q1 = ld1_in<T>(qkv, qs, sl, base + lane), q2 = ld1_in<T>(qkv, qs, sl, base + lane + 64);
+  const float k1 = ld1_in<T>(qkv, qs, sl, base + hidden + lane), k2 = ld1_in<T>(qkv, qs, sl, base + hidden + lane + 64);
+  const float v1 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane);
+  const float v2 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane + 64);
   // q*cos + rotate_half(q)*sin, rotate_half(x) = cat(-x2, x1)   (HF-LL:130-160)
   Act<T>::st(q_out, row * hidden + h * 128 + lane, q1 * cs - q2 * sn);
   Act<T>::st(q_out, row * hidden + h * 128 + lane + 64, q2 * cs + q1 * sn);
@@ -300,7 +366,8 @@ __global__ void rope_kvwrite_kernel(const T* __restrict__ qkv, const int32_t* __
   Act<T>::st(vc, cbase + lane + 64, v2);
 }
 
-extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, const int32_t* tok_pair, const int32_t* tok_pos,
+extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
+                                const int32_t* tok_pos,
                                 const float* inv_freq, int64_t rows, int heads, int head_dim, int ctx, void* q_out,
                                 void* k_cache, void* v_cache, int dtype, void* stream) {
   PSG_REQUIRE(ctx_ && qkv && tok_pair && tok_pos && inv_freq && q_out && k_cache && v_cache, PSG_ERR_INVALID,
@@ -311,7 +378,7 @@ extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, const int32_t* t
   int64_t waves = rows * heads;
   PSG_DISPATCH_DTYPE(dtype, "psg_rope_kvwrite",
                      (rope_kvwrite_kernel<T><<<(unsigned)((waves + 3) / 4), 256, 0, (hipStream_t)stream>>>(
-                         (const T*)qkv, tok_pair, tok_pos, inv_freq, rows, heads, ctx, (T*)q_out, (T*)k_cache,
+                         qkv, qkv_splits, tok_pair, tok_pos, inv_freq, rows, heads, ctx, (T*)q_out, (T*)k_cache,
                          (T*)v_cache)));
   PSG_CHECK_LAUNCH("psg_rope_kvwrite");
   return PSG_OK;
@@ -319,15 +386,15 @@ extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, const int32_t* t
 
 // ---- SwiGLU gate ------------------------------------------------------------------------------
 template <typename T>
-__global__ void silu_mul_kernel(const T* __restrict__ gu, int64_t rows, int inter, T* __restrict__ out) {
+__global__ void silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows, int inter, T* __restrict__ out) {
   const int64_t n4 = rows * inter / 4;
   const int i4 = inter / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / i4;
     const int c = (int)(i % i4) * 4;
     float g[4], u[4], o[4];
-    Act<T>::ld4(gu, r * 2 * inter + c, g);
-    Act<T>::ld4(gu, r * 2 * inter + inter + c, u);
+    ld4_in<T>(gu, S, rows * 2 * inter, r * 2 * inter + c, g);
+    ld4_in<T>(gu, S, rows * 2 * inter, r * 2 * inter + inter + c, u);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float s = g[e] / (1.0f + expf(-g[e]));
@@ -338,15 +405,15 @@ __global__ void silu_mul_kernel(const T* __restrict__ gu, int64_t rows, int inte
   }
 }
 
-extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int64_t rows, int inter, void* out, int dtype,
-                            void* stream) {
+extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int splits, int64_t rows, int inter, void* out,
+                            int dtype, void* stream) {
   PSG_REQUIRE(ctx && gate_up && out, PSG_ERR_INVALID, "psg_silu_mul: NULL argument");
   PSG_REQUIRE(inter > 0 && inter % 4 == 0, PSG_ERR_INVALID, "psg_silu_mul: inter=%d must be a multiple of 4", inter);
   if (rows == 0) return PSG_OK;
   int64_t blocks = (rows * inter / 4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   PSG_DISPATCH_DTYPE(dtype, "psg_silu_mul",
-                     (silu_mul_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const T*)gate_up, rows,
+                     (silu_mul_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(gate_up, splits, rows,
                                                                                           inter, (T*)out)));
   PSG_CHECK_LAUNCH("psg_silu_mul");
   return PSG_OK;
@@ -354,7 +421,7 @@ extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int64_t rows, int
 
 // ---- K16 greedy step: argmax over the vocabulary + per-pair bookkeeping -------------------------
 template <typename T>
-__global__ void __launch_bounds__(1024) greedy_step_kernel(const T* __restrict__ logits, int vocab, int step,
+__global__ void __launch_bounds__(1024) greedy_step_kernel(const void* __restrict__ logits, int S, int vocab, int step,
                                                            int max_new, int eos, int suppress,
                                                            int32_t* __restrict__ tokens, int32_t* __restrict__ done,
                                                            int32_t* __restrict__ next_ids,
@@ -362,11 +429,11 @@ __global__ void __launch_bounds__(1024) greedy_step_kernel(const T* __restrict__
   __shared__ float s_val[16];
   __shared__ int s_idx[16];
   const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const T* row = logits + (int64_t)k * vocab;
+  const int64_t slice = (int64_t)gridDim.x * vocab;
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = tid; i < vocab; i += blockDim.x) {
-    float v = Act<T>::ld(row, i);
+    float v = ld1_in<T>(logits, S, slice, (int64_t)k * vocab + i);
     if (i == suppress) v = -INFINITY;
     if (v > best || (v == best && i < bi)) {  // first maximal index, like torch.argmax
       best = v;
@@ -401,7 +468,7 @@ __global__ void __launch_bounds__(1024) greedy_step_kernel(const T* __restrict__
   }
 }
 
-extern "C" int psg_greedy_step(psg_ctx* ctx, const void* logits, int K, int vocab, int step, int max_new, int eos,
+extern "C" int psg_greedy_step(psg_ctx* ctx, const void* logits, int splits, int K, int vocab, int step, int max_new, int eos,
                                int suppress_token, int32_t* tokens, int32_t* done, int32_t* next_ids, int32_t* tok_pos,
                                int dtype, void* stream) {
   PSG_REQUIRE(ctx && logits && tokens && done && next_ids && tok_pos, PSG_ERR_INVALID,
@@ -409,7 +476,7 @@ extern "C" int psg_greedy_step(psg_ctx* ctx, const void* logits, int K, int voca
   PSG_REQUIRE(K > 0 && vocab > 0 && step >= 0 && step < max_new, PSG_ERR_INVALID,
               "psg_greedy_step: K=%d vocab=%d step=%d max_new=%d", K, vocab, step, max_new);
   PSG_DISPATCH_DTYPE(dtype, "psg_greedy_step",
-                     (greedy_step_kernel<T><<<K, 1024, 0, (hipStream_t)stream>>>((const T*)logits, vocab, step, max_new,
+                     (greedy_step_kernel<T><<<K, 1024, 0, (hipStream_t)stream>>>(logits, splits, vocab, step, max_new,
                                                                                eos, suppress_token, tokens, done,
                                                                                next_ids, tok_pos)));
   PSG_CHECK_LAUNCH("psg_greedy_step");

@@ -53,10 +53,18 @@ class LlamaDecodeEngine:
                 wgu=act(torch.cat([weights[p + "mlp.gate_proj.weight"], weights[p + "mlp.up_proj.weight"]], 0)),
                 wdown=act(weights[p + "mlp.down_proj.weight"]),
                 ln1=f32(p + "input_layernorm.weight"), ln2=f32(p + "post_attention_layernorm.weight")))
+        self.use_skinny = True
+        self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
+        self._graphs = {}
         hd = m.head_dim
         self.inv_freq = (1.0 / (m.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.device)
 
     def linear(self, x, w):
+        """Bias-free projection.  Decode-step shapes (<= 32 rows, bf16) use the hand-written
+        weight-streaming kernel; prefill and the fp32 verification mode go through hipBLASLt."""
+        if (self.use_skinny and x.dtype == torch.bfloat16 and x.shape[0] <= 32 and w.shape[0] % 16 == 0
+                and w.shape[1] % 64 == 0 and w.shape[1] >= 256):
+            return ops.skinny_gemm(x, w)          # fp32 split-K partials, reduced by the consumer kernel
         return F.linear(x, w)
 
     # ---- one pass over `rows` token rows -------------------------------------------------------
@@ -101,9 +109,41 @@ class LlamaDecodeEngine:
     def generate(self, X, prompt_len, max_new_tokens=None, suppress_eos=False, return_first_logits=False):
         """Batched greedy decode.  X [K, 32+Tp, D]; prompt_len int32 [K] (# of prompt tokens).
         Returns tokens int32 [K, max_new] (device; -1 after a pair's EOS) and optionally the
-        first-step logits [K, vocab]."""
-        m = self.cfg.llm
+        first-step logits [K, vocab].
+
+        The whole decode (1 prefill + max_new-1 steps, ~5000 launches for Llama-2-7B) is captured
+        once per shape in a HIP graph and replayed: nothing in it depends on the host (selection,
+        argmax, EOS flags and positions all live on the device), so a replay is a single launch."""
         max_new = self.cfg.max_new_tokens if max_new_tokens is None else max_new_tokens
+        if not self.use_graph:
+            return self._finish(self._generate_eager(X, prompt_len, max_new, suppress_eos, return_first_logits),
+                                return_first_logits)
+        key = (tuple(X.shape), max_new, bool(suppress_eos), bool(return_first_logits))
+        ent = self._graphs.get(key)
+        if ent is None:
+            Xs, ps = X.clone(), prompt_len.to(torch.int32).clone()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):                      # warm-up: lazy library init must not be captured
+                self._generate_eager(Xs, ps, max_new, suppress_eos, return_first_logits)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = self._generate_eager(Xs, ps, max_new, suppress_eos, return_first_logits)
+            ent = self._graphs[key] = (g, Xs, ps, outs)
+        g, Xs, ps, outs = ent
+        Xs.copy_(X)
+        ps.copy_(prompt_len)
+        g.replay()
+        return self._finish(outs, return_first_logits)
+
+    @staticmethod
+    def _finish(outs, want_first):
+        return outs if want_first else outs[0]
+
+    def _generate_eager(self, X, prompt_len, max_new, suppress_eos, return_first_logits):
+        m = self.cfg.llm
         K, maxlen, D = X.shape
         nv = self.cfg.qformer.num_query
         ctx_len = maxlen + max_new
@@ -120,20 +160,20 @@ class LlamaDecodeEngine:
         h_last = torch.empty((K, D), device=dev, dtype=self.dtype)
         ops.gather_rows(h, last_rows, h_last)
         logits = self.linear(h_last, self.lm_head)
-        first_logits = logits.clone() if return_first_logits else None
+        first_logits = None
+        if return_first_logits:
+            first_logits = logits.reduce(self.dtype) if isinstance(logits, ops.Partials) else logits.clone()
         tokens = torch.full((K, max_new), -1, device=dev, dtype=torch.int32)
         done = torch.zeros(K, device=dev, dtype=torch.int32)
         next_ids = torch.zeros(K, device=dev, dtype=torch.int32)
         dec_pos = (seq_len - 1).contiguous()                                           # greedy_step does += 1
         dec_pair = torch.arange(K, device=dev, dtype=torch.int32)
         sup = m.eos if suppress_eos else -1
-        ops.greedy_step(logits, 0, max_new, m.eos, sup, tokens, done, next_ids, dec_pos)
+        ops.greedy_step(logits, 0, max_new, m.eos, sup, tokens, done, next_ids, dec_pos, dtype=self.dtype)
         x = torch.empty((K, D), device=dev, dtype=self.dtype)
         for step in range(1, max_new):
             ops.gather_rows(self.embed, next_ids, x)
             h = self._forward(x, dec_pair, dec_pos, kc, vc, ctx_len)
             logits = self.linear(h, self.lm_head)
-            ops.greedy_step(logits, step, max_new, m.eos, sup, tokens, done, next_ids, dec_pos)
-        if return_first_logits:
-            return tokens, first_logits
-        return tokens
+            ops.greedy_step(logits, step, max_new, m.eos, sup, tokens, done, next_ids, dec_pos, dtype=self.dtype)
+        return tokens, first_logits

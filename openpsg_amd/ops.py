@@ -150,21 +150,54 @@ def gather_rows(src, idx, dst):
     return dst
 
 
+class Partials:
+    """fp32 split-K slices [S, rows, cols] written by `skinny_gemm`; the consumer kernels
+    (rmsnorm, rope_kvwrite, silu_mul, greedy_step) sum them while loading."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        assert t.dim() == 3 and t.dtype == torch.float32 and t.is_contiguous()
+        self.t = t
+
+    @property
+    def splits(self):
+        return self.t.shape[0]
+
+    @property
+    def shape(self):
+        return self.t.shape[1:]
+
+    def reduce(self, dtype=torch.bfloat16):
+        lib, ctx, st = _env(self.t)
+        y = torch.empty(self.shape, device=self.t.device, dtype=dtype)
+        check(lib.psg_reduce_partials(ctx, _p(self.t), self.splits, y.numel(), _p(y), _DT[dtype], st),
+              "psg_reduce_partials")
+        return y
+
+
+def _in(x, dtype):
+    """(pointer, splits) of a kernel input that is either an activation tensor or split-K partials."""
+    if isinstance(x, Partials):
+        return _p(x.t, torch.float32), x.splits
+    return _p(x, dtype), 0
+
+
 def rmsnorm(resid, delta, w, eps, out):
     lib, ctx, st = _env(resid)
     rows, hidden = resid.shape
-    check(lib.psg_rmsnorm(ctx, _p(resid), _p(delta, resid.dtype) if delta is not None else None,
-                          _p(w, torch.float32), float(eps), rows, hidden, _p(out, resid.dtype), _dt(resid), st),
-          "psg_rmsnorm")
+    dp, ds = (None, 0) if delta is None else _in(delta, resid.dtype)
+    check(lib.psg_rmsnorm(ctx, _p(resid), dp, ds, _p(w, torch.float32), float(eps), rows, hidden,
+                          _p(out, resid.dtype), _dt(resid), st), "psg_rmsnorm")
     return out
 
 
 def rope_kvwrite(qkv, tok_pair, tok_pos, inv_freq, heads, head_dim, ctx_len, q_out, k_cache, v_cache):
-    lib, ctx, st = _env(qkv)
-    rows = qkv.shape[0]
-    check(lib.psg_rope_kvwrite(ctx, _p(qkv), _p(tok_pair, torch.int32), _p(tok_pos, torch.int32),
-                               _p(inv_freq, torch.float32), rows, heads, head_dim, ctx_len, _p(q_out, qkv.dtype),
-                               _p(k_cache, qkv.dtype), _p(v_cache, qkv.dtype), _dt(qkv), st), "psg_rope_kvwrite")
+    lib, ctx, st = _env(q_out)
+    rows = q_out.shape[0]
+    qp, qs = _in(qkv, q_out.dtype)
+    check(lib.psg_rope_kvwrite(ctx, qp, qs, _p(tok_pair, torch.int32), _p(tok_pos, torch.int32),
+                               _p(inv_freq, torch.float32), rows, heads, head_dim, ctx_len, _p(q_out),
+                               _p(k_cache, q_out.dtype), _p(v_cache, q_out.dtype), _dt(q_out), st), "psg_rope_kvwrite")
     return q_out
 
 
@@ -177,16 +210,38 @@ def llm_attn(q, k_cache, v_cache, tok_pair, tok_pos, heads, head_dim, ctx_len, o
 
 
 def silu_mul(gate_up, out):
-    lib, ctx, st = _env(gate_up)
-    rows, two_inter = gate_up.shape
-    check(lib.psg_silu_mul(ctx, _p(gate_up), rows, two_inter // 2, _p(out, gate_up.dtype), _dt(gate_up), st),
-          "psg_silu_mul")
+    lib, ctx, st = _env(out)
+    rows, inter = out.shape
+    gp, gs = _in(gate_up, out.dtype)
+    check(lib.psg_silu_mul(ctx, gp, gs, rows, inter, _p(out), _dt(out), st), "psg_silu_mul")
     return out
 
 
-def greedy_step(logits, step, max_new, eos, suppress_token, tokens, done, next_ids, tok_pos):
-    lib, ctx, st = _env(logits)
+def greedy_step(logits, step, max_new, eos, suppress_token, tokens, done, next_ids, tok_pos, dtype=None):
+    lib, ctx, st = _env(tokens)
     K, vocab = logits.shape
-    check(lib.psg_greedy_step(ctx, _p(logits), K, vocab, int(step), int(max_new), int(eos), int(suppress_token),
+    if isinstance(logits, Partials):
+        lp, ls, dt = _p(logits.t), logits.splits, _DT[dtype or torch.bfloat16]
+    else:
+        lp, ls, dt = _p(logits), 0, _dt(logits)
+    check(lib.psg_greedy_step(ctx, lp, ls, K, vocab, int(step), int(max_new), int(eos), int(suppress_token),
                               _p(tokens, torch.int32), _p(done, torch.int32), _p(next_ids, torch.int32),
-                              _p(tok_pos, torch.int32), _dt(logits), st), "psg_greedy_step")
+                              _p(tok_pos, torch.int32), dt, st), "psg_greedy_step")
+
+
+def skinny_gemm(x, w, splits=None) -> Partials:
+    """Decode-step projection: fp32 split-K partials of x @ w.T (x: <= 32 rows of bf16); every
+    weight byte streams from HBM once.  Hand the result to a consumer kernel or call .reduce()."""
+    lib, ctx, st = _env(x)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if splits is None:
+        import ctypes
+        s = ctypes.c_int(0)
+        check(lib.psg_skinny_gemm_plan(ctx, M, N, K, ctypes.byref(s)), "psg_skinny_gemm_plan")
+        splits = s.value
+    part = torch.empty((splits, M, N), device=x.device, dtype=torch.float32)
+    check(lib.psg_skinny_gemm(ctx, _p(x, torch.bfloat16, "x"), _p(w, torch.bfloat16, "w"), _p(part), M, N, K, splits,
+                              st), "psg_skinny_gemm")
+    return Partials(part)

@@ -1,0 +1,91 @@
+"""Kernel micro-benchmarks on one MI355X (development aid): achieved GB/s / TFLOP/s per kernel."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openpsg_amd import ops, _lib  # noqa: E402
+
+
+def timeit(fn, iters=30, warm=5, flush=None):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        if flush is not None:
+            flush.add_(1.0)                      # evict L2/MALL (512 MiB touch)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def skinny(M):
+    dev = torch.device("cuda:0")
+    shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008),
+              ("lm_head", 32000, 4096)]
+    tot_b, tot_s, tot_l = 0, 0.0, 0.0
+    for name, N, K in shapes:
+        x = torch.randn(M, K, device=dev).bfloat16()
+        ncopy = max(2, int(800e6 / (N * K * 2)) + 1)       # rotate > MALL-size of weights: always cold
+        ws = [(torch.randn(N, K, device=dev) / K ** 0.5).bfloat16() for _ in range(ncopy)]
+        it = [0]
+
+        REP = 16                                            # back-to-back launches per timing sample
+
+        def run_s():
+            for _ in range(REP):
+                it[0] += 1
+                ops.skinny_gemm(x, ws[it[0] % ncopy])
+
+        def run_l():
+            for _ in range(REP):
+                it[0] += 1
+                torch.nn.functional.linear(x, ws[it[0] % ncopy])
+        ts, _ = timeit(run_s, iters=12, warm=2)
+        tl, _ = timeit(run_l, iters=12, warm=2)
+        ts, tl = ts / REP, tl / REP
+        gb = N * K * 2 / 1e9
+        print(f"skinny M={M} {name:8s} N={N:6d} K={K:6d}: {ts:8.1f} us = {gb / ts * 1e6:7.0f} GB/s | "
+              f"hipBLASLt {tl:8.1f} us = {gb / tl * 1e6:7.0f} GB/s", flush=True)
+        mult = 1 if name == "lm_head" else 32
+        tot_b += gb * mult
+        tot_s += ts * mult
+        tot_l += tl * mult
+    print(f"  one decode step (32 layers + lm_head): {tot_b:.2f} GB, skinny {tot_s / 1e3:.2f} ms "
+          f"({tot_b / tot_s * 1e6:.0f} GB/s), hipBLASLt {tot_l / 1e3:.2f} ms ({tot_b / tot_l * 1e6:.0f} GB/s)")
+
+
+def xattn(N=50, L=256):
+    dev = torch.device("cuda:0")
+    P = N * N
+    q = torch.randn(P * 33, 768, device=dev).bfloat16()
+    k = torch.randn(L, 768, device=dev).bfloat16()
+    v = torch.randn(L, 768, device=dev).bfloat16()
+    bits = torch.randint(0, 2**62, (N, (L + 63) // 64), device=dev, dtype=torch.int64) & \
+        torch.randint(0, 2**62, (N, (L + 63) // 64), device=dev, dtype=torch.int64)
+    pidx = torch.arange(P, device=dev, dtype=torch.int32)
+    out = torch.empty_like(q)
+    t, tmin = timeit(lambda: ops.qformer_cross_attn(q, k, v, bits, pidx, N, 33, 12, out=out,
+                                                    variant=_lib.PSG_XATTN_MFMA))
+    flops = 4.0 * P * 33 * L * 768
+    print(f"cross_attn_mfma N={N} L={L}: {t:.1f} us (min {tmin:.1f}) = {flops / t / 1e6:.1f} TFLOP/s "
+          f"({flops / t / 1e6 / 2500 * 100:.1f}% of 2.5 PF dense bf16)")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["skinny", "xattn"])
+    a = ap.parse_args()
+    if "skinny" in a.what:
+        skinny(20)
+    if "xattn" in a.what:
+        xattn(50, 256)
+        xattn(100, 256)
