@@ -1,0 +1,242 @@
+"""Headline benchmark: object-pairs/sec of the relation-query + LMM-decode path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the hot path over one synthetic image per rank: BASELINE.json config C3
+(1024x1024, 50 masks = 2450 ordered pairs, relation Q-Former + existence head + top-20 selection +
+batched greedy Llama-2-7B-shaped decode of 16 tokens), bf16, random-init weights, inputs already
+resident in HBM.  `--workload rq` times config C2 (relation-query only).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling.  The job is N
+images; EVERY image's pairs are sharded over all N ranks, existence logits are all-gathered,
+every rank runs the same deterministic top-K, the selected pair features are reduce-scattered to
+the image's decoding rank (openpsg_amd/dist.py).  Per-rank work is that of one image.
+
+The JSON line also carries
+  roofline     - the dominant kernel (skinny_gemm_kernel: HBM stream of the LLM weights in the decode
+                 steps), timed with HIP events on the launch stream right after the timed region with the
+                 same weights and shapes (inside the region the decode is ONE graph replay, which has no
+                 per-kernel events); profiles/ holds the rocprofv3 summary of the same command;
+  cpu_baseline - the CPU oracle (oracle/psg_oracle.py, a restatement of the reference's PyTorch path)
+                 timed on this box's host cores on a bounded sample, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+METRIC = "object-pairs/sec (relation-query + LMM decode), 1024² img × 50 masks"
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["full", "rq"], default="full")
+    ap.add_argument("--objects", type=int, default=50)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--llm-layers", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def setup_head(a, dev):
+    from openpsg_amd.config import LlamaConfig, PSGConfig, QFormerConfig
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.weights import make_weights_device
+    cfg = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=a.llm_layers), max_object_num=a.objects)
+    w = make_weights_device(cfg, 0, dev, llm_dtype=torch.bfloat16, with_llm=a.workload == "full")
+    head = RelationTransformerHeadV4(dtype="bf16", device=str(dev), tokenizers="word", max_object_num=a.objects,
+                                     llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True)
+    head.load_weights(w)
+    del w
+    torch.cuda.empty_cache()
+    return head
+
+
+def measure_decode_gemm(head, K):
+    """Dominant kernel: one decode step's 129 weight-streaming launches (4 per layer + lm_head) with the
+    engine's real weights; HIP events on the launch stream.  Returns (bytes/launch, seconds/launch, n)."""
+    from openpsg_amd import ops
+    eng = head.llm_engine
+    m = head.cfg.llm
+    dev = eng.device
+    x_d = torch.randn(K, m.hidden, device=dev).bfloat16()
+    x_i = torch.randn(K, m.inter, device=dev).bfloat16()
+    mats = []
+    for L in eng.layers:
+        mats += [(x_d, L["wqkv"]), (x_d, L["wo"]), (x_d, L["wgu"]), (x_i, L["wdown"])]
+    mats.append((x_d, eng.lm_head))
+    nbytes = sum(w.numel() * 2 for _, w in mats)
+
+    def run():
+        for x, w in mats:
+            ops.skinny_gemm(x, w)
+    run()
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(5):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        run()
+        e.record()
+        torch.cuda.synchronize()
+        t = s.elapsed_time(e) / 1e3
+        best = t if best is None else min(best, t)
+    return nbytes / len(mats), best / len(mats), len(mats)
+
+
+def cpu_baseline(a, scene_cpu):
+    """The CPU oracle on a bounded sample of the same workload (about 20 s of host work)."""
+    from openpsg_amd.config import LlamaConfig, PSGConfig, QFormerConfig
+    from openpsg_amd.weights import make_weights_numpy
+    from oracle import psg_oracle as O
+    from tests import helpers as H
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    N = a.objects
+    B = N * N
+    cfg = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=2), max_object_num=N)
+    w = make_weights_numpy(cfg, seed=1, with_llm=a.workload == "full")
+    ids, tmask = H.qformer_prompts(scene_cpu)
+    n_rq = min(B, 192)
+    with torch.no_grad():
+        t0 = time.time()
+        patches = O.patch_embed(w, scene_cpu["mask_features"], 16)[0]
+        fh, fw = scene_cpu["mask_features"].shape[-2:]
+        grid = O.mask_grid(scene_cpu["pan_results"], scene_cpu["img_meta"]["img_shape"],
+                           scene_cpu["img_meta"]["pad_shape"], (fh // 16, fw // 16))
+        pm = O.pair_masks(O.object_masks(grid, [int(i) for i in scene_cpu["object_id_list"]]))
+        t_prep = time.time() - t0
+        t0 = time.time()
+        out = O.qformer_forward(w, cfg, ids[:n_rq], tmask[:n_rq], patches, pm[:n_rq], chunk=64)
+        O.existence_head(w, out)
+        t_rq = time.time() - t0
+        rq_rate = n_rq / t_rq
+        t_image = t_prep + B / rq_rate
+        sample = f"relation-query: patch-embed + {n_rq} of {B} pairs through the fp32 oracle ({rq_rate:.0f} pairs/s)"
+        if a.workload == "full":
+            pids, pmask = H.llm_prompts(scene_cpu, [1])
+            x, mask = O.llm_inputs(w, out[1, 1:], pids[0], pmask[0])
+            ts = {}
+            for nl in (1, 2):
+                t0 = time.time()
+                O.llm_generate(w, cfg, x, mask, n_layers=nl, suppress_eos=True)
+                ts[nl] = time.time() - t0
+            per_layer = max(ts[2] - ts[1], 1e-6)
+            t_pair = ts[1] + (a.llm_layers - 1) * per_layer
+            t_image += 20 * t_pair
+            sample += (f"; LMM decode: 1 of 20 selected pairs, 16 new tokens, 1 and 2 full-width fp32 layers timed "
+                       f"({ts[1]:.2f}s, {ts[2]:.2f}s) and extrapolated linearly to {a.llm_layers} layers "
+                       f"({t_pair:.1f}s per pair, serial batch-1 as V4:293-312)")
+    return dict(value=round(N * (N - 1) / t_image, 3), unit="pairs/s", cores=cores, kind="port", sample=sample)
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    from openpsg_amd.synthetic import make_scene
+    head = setup_head(a, dev)
+    N = a.objects
+    pairs_per_image = N * (N - 1)
+
+    if world == 1:
+        scene = make_scene((a.size, a.size), N, seed=0, device=str(dev))
+        inputs = dict(mask_features=scene["mask_features"], img_metas=[scene["img_meta"]],
+                      object_info=[dict(object_id_list=scene["object_id_list"], pan_results=scene["pan_results"])])
+        if a.workload == "full":
+            def step():
+                return head(inputs)
+        else:
+            from openpsg_amd.categories import INSTANCE_OFFSET, object_categories
+            obj_ids = [int(i) for i in scene["object_id_list"]]
+            names = [object_categories[i % INSTANCE_OFFSET] for i in obj_ids]
+
+            def step():
+                rq = head.run_relation_query(scene["mask_features"], scene["img_meta"], obj_ids, names,
+                                             scene["pan_results"])
+                return rq["selected"].cpu()
+        barrier = lambda: None  # noqa: E731
+    else:
+        import torch.distributed as dist
+        from openpsg_amd.dist import PairShardedPipeline
+        scenes = [make_scene((a.size, a.size), N, seed=m, device=str(dev)) for m in range(world)]
+        pipe = PairShardedPipeline(head, dist.group.WORLD, decode=a.workload == "full")
+
+        def step():
+            return pipe.step(scenes)
+        barrier = dist.barrier
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        images = world * a.steps
+        wl = ("C3: 1024x1024, 50 masks, full path incl. LMM autoregressive relation decode (Llama-2-7B shape, top-20 "
+              "pairs, 16 new tokens each, EOS suppressed)") if a.workload == "full" else \
+             "C2: 1024x1024, 50 masks, relation-query transformer only"
+        if (a.size, a.objects) != (1024, 50):
+            wl = f"custom: {a.size}x{a.size}, {a.objects} masks, {a.workload}"
+        line = {
+            "metric": METRIC, "value": round(images * pairs_per_image / elapsed, 1), "unit": "pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": wl, "objects": N, "pairs_per_image": pairs_per_image, "images_per_step": world,
+                       "patches": (a.size // 64) ** 2, "llm_layers": a.llm_layers if a.workload == "full" else 0,
+                       "parallelism": "single GPU" if world == 1 else f"pairs of every image sharded over {world} ranks"},
+        }
+        if not a.no_roofline and a.workload == "full":
+            bpl, spl, n = measure_decode_gemm(head, min(20, N * N))
+            ach = bpl / spl / 1e9
+            traffic = None
+            pmc = os.path.join(REPO, "profiles", "pmc_skinny_gemm.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            line["roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_kernel", "achieved": round(ach, 1),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                "traffic": traffic, "bytes_per_launch": int(bpl),
+                                "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n}
+        if not a.no_cpu_baseline and world == 1:
+            scene_cpu = make_scene((a.size, a.size), N, seed=0)
+            line["cpu_baseline"] = cpu_baseline(a, scene_cpu)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

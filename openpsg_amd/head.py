@@ -116,6 +116,7 @@ class RelationTransformerHeadV4(nn.Module):
         self._rq_engine = None
         self._llm_engine = None
         self._prompt_cache = {"q": {}, "l": {}}
+        self._table_cache = {}
         # tokenizers (V4:85-86, 104-105)
         if tokenizers == "word":
             self.relation_qformer_tokenizer = WordTokenizer("bert")
@@ -236,28 +237,35 @@ class RelationTransformerHeadV4(nn.Module):
         rel_pred, rel_score = self.parse(out["tokens_host"], out["selected_host"], N) if is_generation else ([], [])
         return dict(rel_pred=rel_pred, rel_score=rel_score)
 
-    def run_relation_query(self, feat, meta, obj_ids, names, pan, pair_range=None):
-        """A4-A8 on the GPU.  pair_range=(p0,p1) restricts the Q-Former to a shard of the pairs."""
+    def run_relation_query(self, feat, meta, obj_ids, names, pan, pair_range=None, patches=None):
+        """A4-A8 on the GPU.  pair_range=(p0,p1) restricts the Q-Former to a shard of the pairs;
+        `patches` [L,C] fp32 skips the patch embedding (pair sharding: another rank computed it)."""
         eng = self.rq_engine
         dev = self.device
         N = len(obj_ids)
         B = N * N
-        patches = eng.patch_embed(feat.to(torch.float32))
+        if patches is None:
+            patches = eng.patch_embed(feat.to(torch.float32))
         kv = eng.cross_kv(patches)
         ids_dev = torch.tensor(obj_ids, dtype=torch.int32, device=dev)
         pan_dev = pan.to(device=dev, dtype=torch.int32).contiguous()
         bits = eng.object_bitmasks(pan_dev, meta, ids_dev, feat.shape[-2:])
-        # BERT prompts: [U*U, T] table gathered per pair on the device
-        uidx, U, rows = self._prompt_table("q", names)
-        used = {uidx[i] * U + uidx[j] for i in range(N) for j in range(N)}
-        T = max(len(rows[r]) for r in used)                                                 # padding=True
-        tbl = np.zeros((U * U, T), dtype=np.int32)
-        msk = np.zeros((U * U, T), dtype=np.uint8)
-        for r in used:
-            tbl[r, :len(rows[r])] = rows[r]
-            msk[r, :len(rows[r])] = 1
-        tbl_d, msk_d = torch.from_numpy(tbl).to(dev), torch.from_numpy(msk).to(dev)
-        u_d = torch.tensor(uidx, dtype=torch.int64, device=dev)
+        # BERT prompts: [U*U, T] table gathered per pair on the device (cached per set of names)
+        ck = ("q", tuple(names))
+        if ck not in self._table_cache:
+            uidx, U, rows = self._prompt_table("q", names)
+            used = {uidx[i] * U + uidx[j] for i in range(N) for j in range(N)}
+            T = max(len(rows[r]) for r in used)                                             # padding=True
+            tbl = np.zeros((U * U, T), dtype=np.int32)
+            msk = np.zeros((U * U, T), dtype=np.uint8)
+            for r in used:
+                tbl[r, :len(rows[r])] = rows[r]
+                msk[r, :len(rows[r])] = 1
+            if len(self._table_cache) > 64:
+                self._table_cache.clear()
+            self._table_cache[ck] = (uidx, U, torch.from_numpy(tbl).to(dev), torch.from_numpy(msk).to(dev),
+                                     torch.tensor(uidx, dtype=torch.int64, device=dev))
+        uidx, U, tbl_d, msk_d, u_d = self._table_cache[ck]
         p0, p1 = (0, B) if pair_range is None else pair_range
         q = self.cfg.qformer
         hidden = torch.empty(((p1 - p0) * q.q_rows, q.hidden), device=dev, dtype=self.act_dtype)
@@ -279,37 +287,48 @@ class RelationTransformerHeadV4(nn.Module):
             out["selected"] = eng.select(prob, K)
         return out
 
-    def decode_selected(self, rq, names, selected=None):
-        """A9: batched greedy decode of the selected pairs."""
+    def decode_selected(self, rq, names, selected=None, pair_features=None, to_host=True):
+        """A9: batched greedy decode of the selected pairs.  `pair_features` [K*32, 768] replaces the
+        gather from rq["hidden"] (pair sharding: the features arrive by reduce-scatter)."""
         dev = self.device
         N = rq["num_objects"]
         sel = rq["selected"] if selected is None else selected
         K = sel.numel()
         q = self.cfg.qformer
         nv = q.num_query
-        # pair_feature = hidden[:, 1:] (V4:215) rows of the selected pairs
-        rows = (sel.to(torch.int64)[:, None] * q.q_rows + 1 +
-                torch.arange(nv, device=dev)[None, :]).reshape(-1).to(torch.int32)
-        pf = torch.empty((K * nv, q.hidden), device=dev, dtype=self.act_dtype)
-        ops.gather_rows(rq["hidden"], rows, pf)
-        # Llama prompts, compacted (left padding of V4:262 removed; see llm.py)
-        uidx, U, prow = self._prompt_table("l", names)
-        Tp = max(len(r) for r in prow)
-        tbl = np.full((U * U, Tp), -1, dtype=np.int32)
-        lens = np.zeros(U * U, dtype=np.int32)
-        for r, ids in enumerate(prow):
-            tbl[r, :len(ids)] = ids
-            lens[r] = len(ids)
-        tbl_d, lens_d = torch.from_numpy(tbl).to(dev), torch.from_numpy(lens).to(dev)
-        u_d = torch.tensor(uidx, dtype=torch.int64, device=dev)
+        if pair_features is None:
+            # pair_feature = hidden[:, 1:] (V4:215) rows of the selected pairs
+            rows = (sel.to(torch.int64)[:, None] * q.q_rows + 1 +
+                    torch.arange(nv, device=dev)[None, :]).reshape(-1).to(torch.int32)
+            pf = torch.empty((K * nv, q.hidden), device=dev, dtype=self.act_dtype)
+            ops.gather_rows(rq["hidden"], rows, pf)
+        else:
+            pf = pair_features
+        # Llama prompts, compacted (left padding of V4:262 removed; see llm.py); cached per set of names
+        ck = ("l", tuple(names))
+        if ck not in self._table_cache:
+            uidx, U, prow = self._prompt_table("l", names)
+            Tp = max(len(r) for r in prow)
+            tbl = np.full((U * U, Tp), -1, dtype=np.int32)
+            lens = np.zeros(U * U, dtype=np.int32)
+            for r, ids in enumerate(prow):
+                tbl[r, :len(ids)] = ids
+                lens[r] = len(ids)
+            if len(self._table_cache) > 64:
+                self._table_cache.clear()
+            self._table_cache[ck] = (uidx, U, torch.from_numpy(tbl).to(dev), torch.from_numpy(lens).to(dev),
+                                     torch.tensor(uidx, dtype=torch.int64, device=dev))
+        uidx, U, tbl_d, lens_d, u_d = self._table_cache[ck]
         s64 = sel.to(torch.int64)
         trow = u_d[s64 // N] * U + u_d[s64 % N]
         pids, plen = tbl_d[trow].contiguous(), lens_d[trow].contiguous()
         eng = self.llm_engine
         X = eng.build_inputs(pf, pids, plen)
         tokens, first_logits = eng.generate(X, plen, suppress_eos=self.suppress_eos, return_first_logits=True)
-        return dict(tokens=tokens, first_logits=first_logits, llm_inputs=X, prompt_len=plen,
-                    tokens_host=tokens.cpu().numpy(), selected_host=sel.cpu().numpy())
+        out = dict(tokens=tokens, first_logits=first_logits, llm_inputs=X, prompt_len=plen)
+        if to_host:
+            out["tokens_host"], out["selected_host"] = tokens.cpu().numpy(), sel.cpu().numpy()
+        return out
 
     def parse(self, tokens_host, selected_host, object_num):
         """A10 (V4:313-326): decode -> text between '<s>' and '</s>' -> names split on two spaces."""

@@ -1,0 +1,121 @@
+"""World-size-2 `gloo` test (CPU) of the pair-sharding pipeline: the collectives, shard arithmetic,
+padding of uneven shards, feature routing by reduce-scatter and the deterministic selection.  The
+compute backend here is the CPU oracle (test infrastructure); on a GPU node the same pipeline
+drives the HIP head (`HipBackend`)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    """Implements the five compute calls of PairShardedPipeline with oracle/psg_oracle.py."""
+
+    def __init__(self, cfg, w, k=5, max_new=4):
+        self.cfg, self.w, self.k, self.max_new = cfg, w, k, max_new
+        self.q_rows, self.hidden = cfg.qformer.q_rows, cfg.qformer.hidden
+        self.calls = []
+
+    def num_objects(self, scene):
+        return len(scene["object_id_list"])
+
+    def patch_embed(self, scene):
+        from oracle import psg_oracle as O
+        return O.patch_embed(self.w, scene["mask_features"], 16)[0].contiguous()
+
+    def query_shard(self, scene, patches, p0, p1):
+        from oracle import psg_oracle as O
+        from tests import helpers as H
+        ids, tmask = H.qformer_prompts(scene)
+        fh, fw = scene["mask_features"].shape[-2:]
+        grid = O.mask_grid(scene["pan_results"], scene["img_meta"]["img_shape"], scene["img_meta"]["pad_shape"],
+                           (fh // 16, fw // 16))
+        pm = O.pair_masks(O.object_masks(grid, [int(i) for i in scene["object_id_list"]]))
+        self.calls.append((p0, p1))
+        if p1 <= p0:
+            return torch.zeros(0, self.hidden), torch.zeros(0)
+        out = O.qformer_forward(self.w, self.cfg, ids[p0:p1], tmask[p0:p1], patches, pm[p0:p1])
+        _, prob = O.existence_head(self.w, out)
+        return out.reshape(-1, self.hidden).contiguous(), prob
+
+    def topk(self, prob, k):
+        from oracle import psg_oracle as O
+        return torch.tensor(O.select_topk(prob, k), dtype=torch.int32)
+
+    def gather_features(self, hidden, rows):
+        out = torch.zeros(rows.numel(), self.hidden)
+        ok = rows >= 0
+        if ok.any():
+            out[ok] = hidden[rows[ok].long()]
+        return out
+
+    def decode(self, scene, selected, features):
+        # stand-in for the LMM: keeps what the reduce-scatter delivered (checked by the test) and
+        # returns tokens derived from the selection (checks the token all-gather)
+        self.received = features.clone()
+        return (selected.long()[:, None] * 10 + torch.arange(self.max_new)[None, :]).to(torch.int32)
+
+
+def _worker(rank, world, port, n_obj, ret):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.dist import PairShardedPipeline, shard_range
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_numpy
+    from oracle import psg_oracle as O
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 1, 512, 512))
+    w = make_weights_numpy(cfg, seed=3, with_llm=False)
+    scenes = [make_scene((256, 256), n_obj, seed=40 + m, tiny_object=True) for m in range(world)]
+    be = OracleBackend(cfg, w)
+    with torch.no_grad():
+        out = PairShardedPipeline(be, dist.group.WORLD, decode=True).step(scenes)
+        # single-process reference: the whole pair range of every image on one rank
+        B = n_obj * n_obj
+        ok = True
+        for m in range(world):
+            be1 = OracleBackend(cfg, w)
+            h, prob = be1.query_shard(scenes[m], be1.patch_embed(scenes[m]), 0, B)
+            # shard-wise BLAS calls round differently from one big call: compare with a tolerance
+            ok &= torch.allclose(out["exist_prob"][m], prob, atol=1e-5)
+            sel = O.select_topk(out["exist_prob"][m], be.k)
+            ok &= out["selected"][m].tolist() == sel
+            want_tok = be1.decode(scenes[m], torch.tensor(sel), h[:1])
+            ok &= torch.equal(out["tokens"][m], want_tok)
+            if m == rank:
+                # features routed through the reduce-scatter == rows of the single-rank hidden state
+                rows = (torch.tensor(sel)[:, None] * 33 + 1 + torch.arange(32)[None, :]).reshape(-1)
+                ok &= torch.allclose(be.received, h[rows], atol=1e-4)
+        p0, p1, shard = shard_range(B, world, rank)
+        ok &= all(c == (p0, p1) for c in be.calls)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_obj", [4, 3])          # 16 pairs (even shards) and 9 pairs (uneven: 5 + 4)
+def test_pair_sharding_world2_gloo(n_obj):
+    world = 2
+    port = 29500 + os.getpid() % 2000 + n_obj
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n_obj, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_shard_range_covers_all_pairs():
+    from openpsg_amd.dist import shard_range
+    for B in (1, 9, 16, 100, 2500, 10000):
+        for R in (1, 2, 4, 8):
+            seen = []
+            for r in range(R):
+                p0, p1, shard = shard_range(B, R, r)
+                assert p1 - p0 <= shard
+                seen += list(range(p0, p1))
+            assert seen == list(range(B))
