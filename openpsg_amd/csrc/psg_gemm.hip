@@ -154,6 +154,148 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant: the weight stream goes HBM -> LDS with global_load_lds_dwordx4 in FULL 128-byte
+// lines (one instruction = 8 rows x 128 B; tools/membench measured 6.0-6.6 TB/s for this pattern vs
+// 5.1-5.4 TB/s for the 16-rows-x-64-B pattern the MFMA A layout forces on direct-to-register loads).
+// The LDS image of a DMA is lane-linear, so the bank-conflict swizzle is applied to the SOURCE:
+// lane (r = lane>>3, p = lane&7) fetches piece p ^ r of row r, and the MFMA fragment read of
+// (row n, piece c) looks at slot c ^ (n & 7).  Each wave owns a private 3-slot ring of
+// UD-K-block batches; the only synchronisation is the issuing wave's own counted vmcnt.
+// ---------------------------------------------------------------------------------------------
+template <int N_>
+__device__ __forceinline__ void sgd_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+// wait until at most `newer` batches (2*UD DMA instructions each) issued after the wanted one are outstanding
+template <int UD, int MAXN>
+struct SgdWait {
+  static __device__ __forceinline__ void go(int newer) {
+    if (newer >= MAXN) sgd_wait<(MAXN * 2 * UD < 63 ? MAXN * 2 * UD : 63)>();
+    else SgdWait<UD, MAXN - 1>::go(newer);
+  }
+};
+template <int UD>
+struct SgdWait<UD, 0> {
+  static __device__ __forceinline__ void go(int) { sgd_wait<0>(); }
+};
+
+template <int WAVES, int UD, int SGD_SLOTS>
+__global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint16_t* __restrict__ x,
+                                                                     const uint16_t* __restrict__ w,
+                                                                     float* __restrict__ part, int M, int N, int K,
+                                                                     int xstride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROWS = WAVES * 16;
+  constexpr int BATCH_BYTES = UD * 2048;
+  constexpr int RING_BYTES = SGD_SLOTS * BATCH_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int S = gridDim.y, by = blockIdx.y, G = gridDim.x, gx = blockIdx.x;
+  const int KB = K >> 6;
+  const int kbA = (int)(((int64_t)KB * by) / S), kbB = (int)(((int64_t)KB * (by + 1)) / S);
+  const int nkb = kbB - kbA;
+  const int nb = nkb / UD;
+  const int nslab_all = (N + ROWS - 1) / ROWS;
+  const int nslab = gx < nslab_all ? (nslab_all - gx + G - 1) / G : 0;
+  unsigned char* ring = smem + wid * RING_BYTES;                    // this wave's private ring
+  unsigned char* xs = smem + WAVES * RING_BYTES;                    // shared x slice [M][xstride]
+  const int total = nslab * nb;
+
+  // DMA source of this lane: row (lane>>3) of an 8-row group, piece (lane&7) ^ (lane>>3)
+  const int dr = lane >> 3, dp = (lane & 7) ^ (lane >> 3);
+  auto dma_src = [&](int t) -> const uint16_t* {
+    int r = (gx + t * G) * ROWS + wid * 16 + dr;
+    r = r + 8 < N ? r : (N - 9 > 0 ? N - 9 : 0);                    // keep rows r and r+8 in range (results dropped)
+    return w + (int64_t)r * K + (int64_t)kbA * 64 + dp * 8;
+  };
+  int lt = 0, lb = 0, lj = 0;
+  auto issue = [&]() {
+    const uint16_t* src = dma_src(lt) + (int64_t)lb * UD * 64;
+    unsigned char* dst = ring + (lj % SGD_SLOTS) * BATCH_BYTES;
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 64),
+                                       (__attribute__((address_space(3))) void*)(dst + u * 2048), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 64 + (int64_t)8 * K),
+                                       (__attribute__((address_space(3))) void*)(dst + u * 2048 + 1024), 16, 0, 0);
+    }
+    ++lj;
+    if (++lb == nb) { lb = 0; ++lt; }
+  };
+  for (int i = 0; i < SGD_SLOTS - 1; ++i)
+    if (i < total) issue();
+
+  // stage x once per workgroup (plain loads -> ds_write); the DMAs above are already in flight
+  const int pieces = nkb * 8;
+  for (int e = tid; e < M * pieces; e += WAVES * 64) {
+    const int r = e / pieces, c = e - r * pieces;
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (int64_t)r * K + (int64_t)kbA * 64 + c * 8);
+    *reinterpret_cast<uint4*>(xs + r * xstride + c * 16) = v;
+  }
+  __syncthreads();
+
+  const unsigned char* xs0 = xs + min(n, M - 1) * xstride + kq * 32;
+  const unsigned char* xs1 = xs + min(16 + n, M - 1) * xstride + kq * 32;
+  // fragment (row n, piece c = 2 kq + j) sits at slot c ^ (n & 7) of row n
+  const int arow = (n >> 3) * 1024 + (n & 7) * 128;
+  const int a0off = arow + (((2 * kq) ^ (n & 7)) * 16), a1off = arow + (((2 * kq + 1) ^ (n & 7)) * 16);
+  gf32x4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  int ct = 0, cb = 0;
+  auto finish_slab = [&]() {
+    int r = (gx + ct * G) * ROWS + wid * 16 + n;
+    r = r < N ? r : N - 1;
+    const uint16_t* wp = w + (int64_t)r * K + (int64_t)kbA * 64 + kq * 16;
+    for (int kb = nb * UD; kb < nkb; ++kb) {                        // remainder K blocks: direct loads
+      const gbf16x8_t a0 = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)kb * 64));
+      const gbf16x8_t a1 = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)kb * 64 + 8));
+      const int o = kb * 128;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, *reinterpret_cast<const gbf16x8_t*>(xs0 + o), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, *reinterpret_cast<const gbf16x8_t*>(xs1 + o), acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16), acc0, 0, 0,
+                                                     0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16), acc1, 0, 0,
+                                                     0);
+    }
+    const int n0 = (gx + ct * G) * ROWS + wid * 16;
+    if (n0 + 16 <= N) {
+      float* pp = part + ((int64_t)by * M) * N + n0 + 4 * kq;
+      if (n < M) *reinterpret_cast<float4*>(pp + (int64_t)n * N) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+      if (16 + n < M)
+        *reinterpret_cast<float4*>(pp + (int64_t)(16 + n) * N) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+    }
+    acc0 = (gf32x4_t){0, 0, 0, 0};
+    acc1 = (gf32x4_t){0, 0, 0, 0};
+    cb = 0;
+    ++ct;
+  };
+  if (nb == 0) {
+    for (int t = 0; t < nslab; ++t) finish_slab();
+    return;
+  }
+  for (int j = 0; j < total; ++j) {
+    if (j + SGD_SLOTS - 1 < total) issue();                         // refills the slot consumed at j - 1
+    SgdWait<UD, SGD_SLOTS - 1>::go(total - 1 - j);                  // batches issued after batch j may stay in flight
+    const unsigned char* slot = ring + (j % SGD_SLOTS) * BATCH_BYTES;
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      const gbf16x8_t a0 = *reinterpret_cast<const gbf16x8_t*>(slot + u * 2048 + a0off);
+      const gbf16x8_t a1 = *reinterpret_cast<const gbf16x8_t*>(slot + u * 2048 + a1off);
+      const int o = (cb * UD + u) * 128;
+      const gbf16x8_t b00 = *reinterpret_cast<const gbf16x8_t*>(xs0 + o);
+      const gbf16x8_t b01 = *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16);
+      const gbf16x8_t b10 = *reinterpret_cast<const gbf16x8_t*>(xs1 + o);
+      const gbf16x8_t b11 = *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b00, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b10, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b01, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b11, acc1, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // ring reads retired before the slot is refilled
+    if (++cb == nb) finish_slab();
+  }
+}
+
 // split count: K range per workgroup ~1024 elements (x slice <= 64 KiB of LDS at M = 32), and
 // enough workgroups to give every CU several waves.
 static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
@@ -219,6 +361,50 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
   int G = (wg_per_cu * ctx->num_cu + splits - 1) / splits;
   if (G > nslab) G = nslab;
   if (G < 1) G = 1;
+  static int dma_cfg = -1;                       // PSG_SKINNY_DMA="<waves>x<ud>" selects the LDS-DMA variant
+  if (dma_cfg < 0) {
+    const char* e = getenv("PSG_SKINNY_DMA");
+    int wv = 0, ud = 0;
+    int sl = 3;
+    // default: 8 waves x 1 K-block batches x 3-slot ring (sweep in tools/bench_kernels.py); "0" = register path
+    dma_cfg = e ? ((sscanf(e, "%dx%dx%d", &wv, &ud, &sl) >= 2) ? wv * 100 + ud * 10 + sl : 0) : 813;
+  }
+  if (dma_cfg > 0 && N >= 1024 && K >= 1024) {
+    const int wv = dma_cfg / 100, ud = (dma_cfg / 10) % 10, sl = dma_cfg % 10;
+    const int rows = wv * 16;
+    const int nslab_d = (N + rows - 1) / rows;
+    const size_t ldsd = (size_t)wv * sl * ud * 2048 + lds;
+    PSG_REQUIRE(ldsd <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm(dma): %zu B of LDS", ldsd);
+    int per_cu = (int)((160 * 1024) / ldsd);              // workgroups per CU that LDS admits
+    if (per_cu * wv > 16) per_cu = 16 / wv;               // and at most 16 waves per CU
+    if (per_cu < 1) per_cu = 1;
+    int Gd = (per_cu * ctx->num_cu + splits - 1) / splits;
+    if (Gd > nslab_d) Gd = nslab_d;
+    if (Gd < 1) Gd = 1;
+    dim3 gridd(Gd, splits);
+    hipStream_t st = (hipStream_t)stream;
+#define SGD(WV, UD, SL)                                                                                             \
+  do {                                                                                                              \
+    hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<WV, UD, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        160 * 1024);                                                                                \
+    skinny_gemm_dma_kernel<WV, UD, SL><<<gridd, WV * 64, ldsd, st>>>((const uint16_t*)x, (const uint16_t*)w, part, \
+                                                                     M, N, K, xstride);                             \
+  } while (0)
+    if (wv == 8 && ud == 1 && sl == 3) SGD(8, 1, 3);
+    else if (wv == 8 && ud == 1 && sl == 5) SGD(8, 1, 5);
+    else if (wv == 8 && ud == 2 && sl == 3) SGD(8, 2, 3);
+    else if (wv == 4 && ud == 1 && sl == 4) SGD(4, 1, 4);
+    else if (wv == 4 && ud == 1 && sl == 6) SGD(4, 1, 6);
+    else if (wv == 4 && ud == 2 && sl == 3) SGD(4, 2, 3);
+    else if (wv == 4 && ud == 2 && sl == 4) SGD(4, 2, 4);
+    else {
+      psg_set_error("psg_skinny_gemm: unknown PSG_SKINNY_DMA config %d", dma_cfg);
+      return PSG_ERR_INVALID;
+    }
+#undef SGD
+    PSG_CHECK_LAUNCH("psg_skinny_gemm(dma)");
+    return PSG_OK;
+  }
   dim3 grid(G, splits);
   skinny_gemm_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const uint16_t*)x, (const uint16_t*)w, part, M, N, K,
                                                               xstride);
