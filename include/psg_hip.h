@@ -56,6 +56,16 @@ int psg_destroy(psg_ctx* ctx);
 /* number of compute units / arch name of the context's device (diagnostics, roofline) */
 int psg_device_info(psg_ctx* ctx, int* num_cu, char* arch, int arch_len);
 
+/* ---- A4 / K1: patch embedding, V4:410 (timm PatchEmbed = Conv2d(C, Cout, 16, 16) + flatten(2).transpose(1,2)):
+ * out[l][o] = bias[o] + sum_{c,dy,dx} feat[c][16 py+dy][16 px+dx] * weight[o][c][dy][dx], l = py*(Wf/16)+px.
+ * Exact fp32 (f32 matrix cores), split-K over the chip with a deterministic second-pass reduction.
+ * feat [C][Hf][Wf] fp32, weight [Cout][C*256] fp32, out [L][Cout] fp32; the caller provides the
+ * workspace (size from psg_patch_embed_workspace). */
+int psg_patch_embed_workspace(psg_ctx*, int C, int Hf, int Wf, int Cout, int patch, int64_t* bytes);
+int psg_patch_embed(psg_ctx*, const float* feat, int C, int Hf, int Wf, const float* weight,
+                    const float* bias, int Cout, int patch, float* out, float* workspace,
+                    int64_t workspace_bytes, void* stream);
+
 /* ---- A4 / K2: panoptic id map -> patch grid.  Replaces V4:416-423
  * (F.interpolate nearest -> F.pad zero -> F.interpolate nearest).  grid[gh*gw] float32 ids. */
 int psg_mask_grid(psg_ctx*, const int32_t* pan, int H0, int W0, int img_h, int img_w,
@@ -123,9 +133,10 @@ int psg_rmsnorm(psg_ctx*, void* resid, const void* delta, int delta_splits, cons
  * qkv [rows][3*hidden]; tok_pair / tok_pos int32 [rows] give the cache row (pair) and the
  * position (= cache slot = cumsum(mask)-1, V4 left-padding removed by compaction); tok_pos < 0
  * marks a padding row (skipped).  q_out [rows][hidden]; caches [pairs][heads][ctx][head_dim].
+ * rope_cos / rope_sin: fp32 tables [ctx][head_dim/2] = cos/sin(position * inv_freq), HF-LL:115-128.
  * qkv_splits > 0: qkv is fp32 split-K partials [qkv_splits][rows][3*hidden]. */
 int psg_rope_kvwrite(psg_ctx*, const void* qkv, int qkv_splits, const int32_t* tok_pair, const int32_t* tok_pos,
-                     const float* inv_freq, int64_t rows, int heads, int head_dim, int ctx,
+                     const float* rope_cos, const float* rope_sin, int64_t rows, int heads, int head_dim, int ctx,
                      void* q_out, void* k_cache, void* v_cache, int dtype, void* stream);
 
 /* ---- K14: Llama attention over the KV cache (prefill and decode), HF-LL:191-214: query at
@@ -133,6 +144,14 @@ int psg_rope_kvwrite(psg_ctx*, const void* qkv, int qkv_splits, const int32_t* t
 int psg_llm_attn(psg_ctx*, const void* q, const void* k_cache, const void* v_cache,
                  const int32_t* tok_pair, const int32_t* tok_pos, int64_t rows, int heads,
                  int head_dim, int ctx, void* out, int dtype, void* stream);
+
+/* ---- K13 + K14 fused for the decode step (one new token per pair): rotary + KV-cache append +
+ * attention over the cache in one launch.  qkv [rows][3*hidden] (activation dtype, or fp32 split-K
+ * partials when qkv_splits > 0); out [rows][hidden].  Equivalent to psg_rope_kvwrite followed by
+ * psg_llm_attn for rows that each hold the newest token of their pair. */
+int psg_decode_attn(psg_ctx*, const void* qkv, int qkv_splits, const int32_t* tok_pair, const int32_t* tok_pos,
+                    const float* rope_cos, const float* rope_sin, int rows, int heads, int head_dim, int ctx, void* k_cache,
+                    void* v_cache, void* out, int dtype, void* stream);
 
 /* ---- SwiGLU gate, HF-LL:163-177: out = silu(gate_up[:, :inter]) * gate_up[:, inter:].
  * splits > 0: gate_up is fp32 split-K partials [splits][rows][2*inter]. */

@@ -29,6 +29,8 @@ SIGNATURES = {
     "psg_create": [_i, C.POINTER(_vp)],
     "psg_destroy": [_vp],
     "psg_device_info": [_vp, C.POINTER(_i), C.c_char_p, _i],
+    "psg_patch_embed_workspace": [_vp, _i, _i, _i, _i, _i, C.POINTER(_i64)],
+    "psg_patch_embed": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp],
     "psg_mask_grid": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "psg_object_bitmasks": [_vp, _vp, _i, _vp, _i, _vp, _i, _vp],
     "psg_qformer_embed": [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _vp],
@@ -40,8 +42,9 @@ SIGNATURES = {
     "psg_topk": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "psg_gather_rows": [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _i, _i64, _vp],
     "psg_rmsnorm": [_vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _i, _vp],
-    "psg_rope_kvwrite": [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "psg_rope_kvwrite": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "psg_llm_attn": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp],
+    "psg_decode_attn": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "psg_silu_mul": [_vp, _vp, _i, _i64, _i, _vp, _i, _vp],
     "psg_skinny_gemm_plan": [_vp, _i, _i, _i, C.POINTER(_i)],
     "psg_skinny_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

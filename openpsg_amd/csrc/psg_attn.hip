@@ -2,7 +2,12 @@
 //   K5  Q-Former self-attention (S = 33 + T <= 64 keys, 12 heads x 64)      HF-IB:471-515
 //   K6' scalar fp32 cross-attention (checker / fp32 verification variant)     HF-IB:487-496
 //   K14 Llama attention over the KV cache, prefill + decode (head_dim 128)    HF-LL:191-214
+#include <stdlib.h>
+
 #include "psg_common.h"
+
+int psg_self_attn_mfma_launch(const void* qkv, const uint8_t* text_mask, int B, int T_, int nq, int heads,
+                              int query_rows_only, void* out, hipStream_t st);
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -78,6 +83,12 @@ extern "C" int psg_qformer_self_attn(psg_ctx* ctx, const void* qkv, const uint8_
               T_, nq);
   PSG_REQUIRE(nq + T_ <= 64, PSG_ERR_UNSUPPORTED,
               "psg_qformer_self_attn: %d query rows + %d prompt tokens > 64 keys (one wavefront)", nq, T_);
+  // bf16 activations with the standard geometry run on the matrix cores (psg_selfattn_mfma.hip);
+  // PSG_SELFATTN_SCALAR=1 forces the scalar kernel (on-device cross-check)
+  static int force_scalar = -1;
+  if (force_scalar < 0) force_scalar = getenv("PSG_SELFATTN_SCALAR") ? 1 : 0;
+  if (dtype == PSG_BF16 && nq >= 32 && nq + T_ <= 64 && !force_scalar)
+    return psg_self_attn_mfma_launch(qkv, text_mask, B, T_, nq, heads, query_rows_only, out, (hipStream_t)stream);
   int64_t units = (int64_t)B * heads;
   PSG_DISPATCH_DTYPE(dtype, "psg_qformer_self_attn",
                      (qformer_self_attn_kernel<T><<<(unsigned)((units + 3) / 4), 256, 0, (hipStream_t)stream>>>(
@@ -261,5 +272,145 @@ extern "C" int psg_llm_attn(psg_ctx* ctx_, const void* q, const void* k_cache, c
                          (const T*)q, (const T*)k_cache, (const T*)v_cache, tok_pair, tok_pos, rows, heads, ctx,
                          (T*)out)));
   PSG_CHECK_LAUNCH("psg_llm_attn");
+  return PSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K13 + K14 fused for the decode step: rotary (HF-LL:130-160) + KV-cache append + attention over
+// the cache (HF-LL:191-214) in ONE launch.  One wave per (pair, head); the new token's q/k/v come
+// from the qkv projection (activation tensor or split-K partials), the new key/value are written
+// to slot `pos` and used from registers (no read-after-write through memory); the cached keys
+// [0, pos) are handled lane-per-key, P.V runs 4 keys per iteration with independent loads.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) decode_attn_kernel(const void* __restrict__ qkv, int qs,
+                                                          const int32_t* __restrict__ tok_pair,
+                                                          const int32_t* __restrict__ tok_pos,
+                                                          const float* __restrict__ cos_tab,
+                                                          const float* __restrict__ sin_tab, int rows, int heads,
+                                                          int ctx, T* __restrict__ kc, T* __restrict__ vc,
+                                                          T* __restrict__ out) {
+  __shared__ float s_q[4][128];
+  __shared__ float s_p[4][64];
+  const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (wave >= rows * heads) return;
+  const int row = wave / heads, h = wave % heads;
+  const int pos = tok_pos[row];
+  const int hidden = heads * 128;
+  if (pos < 0) return;
+  const int64_t base = (int64_t)row * 3 * hidden + h * 128;
+  const int64_t sl = (int64_t)rows * 3 * hidden;
+  const float q1 = ld1_in<T>(qkv, qs, sl, base + lane), q2 = ld1_in<T>(qkv, qs, sl, base + lane + 64);
+  const float k1 = ld1_in<T>(qkv, qs, sl, base + hidden + lane), k2 = ld1_in<T>(qkv, qs, sl, base + hidden + lane + 64);
+  const float v1 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane);
+  const float v2 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane + 64);
+  const float cs = cos_tab[pos * 64 + lane], sn = sin_tab[pos * 64 + lane];   // cos/sin(pos * inv_freq), HF-LL:115-128
+  auto rnd = [](float f) { return sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(f)) : f; };
+  const float qa = rnd(q1 * cs - q2 * sn), qb = rnd(q2 * cs + q1 * sn);      // stored dtype, as the unfused path
+  const float ka = rnd(k1 * cs - k2 * sn), kb = rnd(k2 * cs + k1 * sn);
+  const int64_t cbase = ((int64_t)tok_pair[row] * heads + h) * ctx * 128;
+  Act<T>::st(kc, cbase + (int64_t)pos * 128 + lane, ka);
+  Act<T>::st(kc, cbase + (int64_t)pos * 128 + lane + 64, kb);
+  Act<T>::st(vc, cbase + (int64_t)pos * 128 + lane, v1);
+  Act<T>::st(vc, cbase + (int64_t)pos * 128 + lane + 64, v2);
+  s_q[wid][lane] = qa;
+  s_q[wid][lane + 64] = qb;
+  __builtin_amdgcn_wave_barrier();
+  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+  const float s_new = wave_sum(qa * ka + qb * kb) * scale;     // the new key, from registers
+  float m_run = s_new, l_run = 1.0f;                           // exp(s_new - m) = 1
+  float o1 = rnd(v1), o2 = rnd(v2);
+  for (int b0 = 0; b0 < pos; b0 += 64) {
+    const int j = b0 + lane;
+    float s = -INFINITY;
+    if (j < pos) {
+      // the lane's whole key row (128 elements) is requested before the first use: one round trip
+      const T* kp = kc + cbase + (int64_t)j * 128;
+      float t[32][4];
+#pragma unroll
+      for (int d = 0; d < 32; ++d) Act<T>::ld4(kp, d * 4, t[d]);
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+      for (int d = 0; d < 32; d += 2) {
+        acc0 = fmaf(s_q[wid][4 * d], t[d][0], acc0);
+        acc0 = fmaf(s_q[wid][4 * d + 1], t[d][1], acc0);
+        acc0 = fmaf(s_q[wid][4 * d + 2], t[d][2], acc0);
+        acc0 = fmaf(s_q[wid][4 * d + 3], t[d][3], acc0);
+        acc1 = fmaf(s_q[wid][4 * d + 4], t[d + 1][0], acc1);
+        acc1 = fmaf(s_q[wid][4 * d + 5], t[d + 1][1], acc1);
+        acc1 = fmaf(s_q[wid][4 * d + 6], t[d + 1][2], acc1);
+        acc1 = fmaf(s_q[wid][4 * d + 7], t[d + 1][3], acc1);
+      }
+      s = (acc0 + acc1) * scale;
+    }
+    const float m_new = fmaxf(m_run, wave_max(s));
+    const float alpha = expf(m_run - m_new);
+    const float pj = expf(s - m_new);
+    l_run = l_run * alpha + wave_sum(pj);
+    o1 *= alpha;
+    o2 *= alpha;
+    s_p[wid][lane] = pj;
+    __builtin_amdgcn_wave_barrier();
+    const int nk = min(64, pos - b0);
+    const T* vp = vc + cbase + (int64_t)b0 * 128;
+    int jj = 0;
+    for (; jj + 32 <= nk; jj += 32) {                  // 64 loads in flight per lane
+      float a[32], c[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        a[u] = Act<T>::ld(vp, (int64_t)(jj + u) * 128 + lane);
+        c[u] = Act<T>::ld(vp, (int64_t)(jj + u) * 128 + lane + 64);
+      }
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const float pv = s_p[wid][jj + u];
+        o1 = fmaf(pv, a[u], o1);
+        o2 = fmaf(pv, c[u], o2);
+      }
+    }
+    for (; jj + 8 <= nk; jj += 8) {
+      float a[8], c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = Act<T>::ld(vp, (int64_t)(jj + u) * 128 + lane);
+        c[u] = Act<T>::ld(vp, (int64_t)(jj + u) * 128 + lane + 64);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float pv = s_p[wid][jj + u];
+        o1 = fmaf(pv, a[u], o1);
+        o2 = fmaf(pv, c[u], o2);
+      }
+    }
+    for (; jj < nk; ++jj) {
+      const float pv = s_p[wid][jj];
+      o1 = fmaf(pv, Act<T>::ld(vp, (int64_t)jj * 128 + lane), o1);
+      o2 = fmaf(pv, Act<T>::ld(vp, (int64_t)jj * 128 + lane + 64), o2);
+    }
+    __builtin_amdgcn_wave_barrier();
+    m_run = m_new;
+  }
+  const float inv = 1.0f / l_run;
+  Act<T>::st(out, (int64_t)row * hidden + h * 128 + lane, o1 * inv);
+  Act<T>::st(out, (int64_t)row * hidden + h * 128 + lane + 64, o2 * inv);
+}
+
+extern "C" int psg_decode_attn(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
+                               const int32_t* tok_pos, const float* rope_cos, const float* rope_sin, int rows,
+                               int heads, int head_dim, int ctx, void* k_cache, void* v_cache, void* out, int dtype,
+                               void* stream) {
+  PSG_REQUIRE(ctx_ && qkv && tok_pair && tok_pos && rope_cos && rope_sin && k_cache && v_cache && out, PSG_ERR_INVALID,
+              "psg_decode_attn: NULL argument");
+  PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_decode_attn: head_dim=%d (kernel is built for 128)", head_dim);
+  PSG_REQUIRE(qkv_splits >= 0 && qkv_splits <= PSG_MAX_SPLITS, PSG_ERR_INVALID, "psg_decode_attn: qkv_splits=%d",
+              qkv_splits);
+  if (rows == 0) return PSG_OK;
+  const int waves = rows * heads;
+  PSG_DISPATCH_DTYPE(dtype, "psg_decode_attn",
+                     (decode_attn_kernel<T><<<(waves + 3) / 4, 256, 0, (hipStream_t)stream>>>(
+                         qkv, qkv_splits, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, (T*)k_cache,
+                         (T*)v_cache, (T*)out)));
+  PSG_CHECK_LAUNCH("psg_decode_attn");
   return PSG_OK;
 }

@@ -91,6 +91,48 @@ __device__ __forceinline__ float wave_max(float v) {
 
 #define PSG_FMIN (-3.402823466e+38f)  // torch.finfo(float32).min, the legacy additive mask value
 
+// ---- split-K partial inputs --------------------------------------------------------------------
+// The decode projections (psg_skinny_gemm) leave fp32 partials part[S][rows][cols]; their consumers
+// sum the S slices in split order while loading, then round once to the activation dtype (exactly
+// what a GEMM with an activation-dtype output would have stored).
+template <typename T>
+__device__ __forceinline__ void ld4_in(const void* __restrict__ in, int S, int64_t slice, int64_t i, float (&o)[4]) {
+  if (S > 0) {
+    const float* p = reinterpret_cast<const float*>(in);
+    float4 t[PSG_MAX_SPLITS];
+#pragma unroll
+    for (int s = 0; s < PSG_MAX_SPLITS; ++s)
+      if (s < S) t[s] = *reinterpret_cast<const float4*>(p + (int64_t)s * slice + i);
+    float4 a = t[0];
+#pragma unroll
+    for (int s = 1; s < PSG_MAX_SPLITS; ++s)
+      if (s < S) { a.x += t[s].x; a.y += t[s].y; a.z += t[s].z; a.w += t[s].w; }
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+    if (sizeof(T) == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = bf16_to_f32(f32_to_bf16(o[e]));
+    }
+  } else {
+    Act<T>::ld4(reinterpret_cast<const T*>(in), i, o);
+  }
+}
+template <typename T>
+__device__ __forceinline__ float ld1_in(const void* __restrict__ in, int S, int64_t slice, int64_t i) {
+  if (S > 0) {
+    const float* p = reinterpret_cast<const float*>(in);
+    float t[PSG_MAX_SPLITS];
+#pragma unroll
+    for (int s = 0; s < PSG_MAX_SPLITS; ++s)
+      if (s < S) t[s] = p[(int64_t)s * slice + i];
+    float a = t[0];
+#pragma unroll
+    for (int s = 1; s < PSG_MAX_SPLITS; ++s)
+      if (s < S) a += t[s];
+    return sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(a)) : a;
+  }
+  return Act<T>::ld(reinterpret_cast<const T*>(in), i);
+}
+
 // dispatch on the activation dtype enum
 #define PSG_DISPATCH_DTYPE(dtype, NAME, ...)                       \
   do {                                                             \

@@ -200,48 +200,6 @@ extern "C" int psg_exist_head(psg_ctx* ctx, const void* x, const float* w, const
   return PSG_OK;
 }
 
-// ---- split-K partial inputs --------------------------------------------------------------------
-// The decode projections (psg_skinny_gemm) leave fp32 partials part[S][rows][cols]; their consumers
-// sum the S slices in split order while loading, then round once to the activation dtype (exactly
-// what a GEMM with an activation-dtype output would have stored).
-template <typename T>
-__device__ __forceinline__ void ld4_in(const void* __restrict__ in, int S, int64_t slice, int64_t i, float (&o)[4]) {
-  if (S > 0) {
-    const float* p = reinterpret_cast<const float*>(in);
-    float4 t[PSG_MAX_SPLITS];
-#pragma unroll
-    for (int s = 0; s < PSG_MAX_SPLITS; ++s)
-      if (s < S) t[s] = *reinterpret_cast<const float4*>(p + (int64_t)s * slice + i);
-    float4 a = t[0];
-#pragma unroll
-    for (int s = 1; s < PSG_MAX_SPLITS; ++s)
-      if (s < S) { a.x += t[s].x; a.y += t[s].y; a.z += t[s].z; a.w += t[s].w; }
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
-    if (sizeof(T) == 2) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = bf16_to_f32(f32_to_bf16(o[e]));
-    }
-  } else {
-    Act<T>::ld4(reinterpret_cast<const T*>(in), i, o);
-  }
-}
-template <typename T>
-__device__ __forceinline__ float ld1_in(const void* __restrict__ in, int S, int64_t slice, int64_t i) {
-  if (S > 0) {
-    const float* p = reinterpret_cast<const float*>(in);
-    float t[PSG_MAX_SPLITS];
-#pragma unroll
-    for (int s = 0; s < PSG_MAX_SPLITS; ++s)
-      if (s < S) t[s] = p[(int64_t)s * slice + i];
-    float a = t[0];
-#pragma unroll
-    for (int s = 1; s < PSG_MAX_SPLITS; ++s)
-      if (s < S) a += t[s];
-    return sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(a)) : a;
-  }
-  return Act<T>::ld(reinterpret_cast<const T*>(in), i);
-}
-
 // ---- K12 RMSNorm (+ residual add) -------------------------------------------------------------
 // One 256-thread workgroup per row (decode has only K ~ 20 rows of 4096: a single wave walking a
 // row serialises ~16 dependent HBM round trips).  Thread t owns the 4-element chunks t, t+256, ...;
@@ -337,9 +295,9 @@ extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int del
 // One wave per (row, head); head_dim = 128: lane l holds dims l and l + 64 (the rotate_half pair).
 template <typename T>
 __global__ void rope_kvwrite_kernel(const void* __restrict__ qkv, int qs, const int32_t* __restrict__ tok_pair,
-                                    const int32_t* __restrict__ tok_pos, const float* __restrict__ inv_freq,
-                                    int64_t rows, int heads, int ctx, T* __restrict__ q_out, T* __restrict__ kc,
-                                    T* __restrict__ vc) {
+                                    const int32_t* __restrict__ tok_pos, const float* __restrict__ cos_tab,
+                                    const float* __restrict__ sin_tab, int64_t rows, int heads, int ctx,
+                                    T* __restrict__ q_out, T* __restrict__ kc, T* __restrict__ vc) {
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= rows * heads) return;
@@ -349,8 +307,9 @@ __global__ void rope_kvwrite_kernel(const void* __restrict__ qkv, int qs, const 
   if (pos < 0) return;  // padding row
   const int hidden = heads * 128;
   const int64_t base = row * 3 * hidden + h * 128;
-  const float ang = (float)pos * inv_freq[lane];  // HF: freqs = inv_freq @ position (fp32)
-  const float cs = cosf(ang), sn = sinf(ang);
+  // cos/sin(pos * inv_freq) from the caller's table: a precise cosf/sinf per wave cost ~9 us of
+  // large-argument range reduction, more than the rest of the kernel
+  const float cs = cos_tab[pos * 64 + lane], sn = sin_tab[pos * 64 + lane];
   const int64_t sl = rows * 3 * hidden;  // split-K slice stride
   const float q1 = ld1_in<T>(qkv, qs, sl, base + lane), q2 = ld1_in<T>(qkv, qs, sl, base + lane + 64);
   const float k1 = ld1_in<T>(qkv, qs, sl, base + hidden + lane), k2 = ld1_in<T>(qkv, qs, sl, base + hidden + lane + 64);
@@ -367,10 +326,10 @@ __global__ void rope_kvwrite_kernel(const void* __restrict__ qkv, int qs, const 
 }
 
 extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
-                                const int32_t* tok_pos,
-                                const float* inv_freq, int64_t rows, int heads, int head_dim, int ctx, void* q_out,
-                                void* k_cache, void* v_cache, int dtype, void* stream) {
-  PSG_REQUIRE(ctx_ && qkv && tok_pair && tok_pos && inv_freq && q_out && k_cache && v_cache, PSG_ERR_INVALID,
+                                const int32_t* tok_pos, const float* rope_cos, const float* rope_sin,
+                                int64_t rows, int heads, int head_dim, int ctx, void* q_out, void* k_cache,
+                                void* v_cache, int dtype, void* stream) {
+  PSG_REQUIRE(ctx_ && qkv && tok_pair && tok_pos && rope_cos && rope_sin && q_out && k_cache && v_cache, PSG_ERR_INVALID,
               "psg_rope_kvwrite: NULL argument");
   PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_rope_kvwrite: head_dim=%d (kernel is built for 128)",
               head_dim);
@@ -378,7 +337,7 @@ extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, int qkv_splits, 
   int64_t waves = rows * heads;
   PSG_DISPATCH_DTYPE(dtype, "psg_rope_kvwrite",
                      (rope_kvwrite_kernel<T><<<(unsigned)((waves + 3) / 4), 256, 0, (hipStream_t)stream>>>(
-                         qkv, qkv_splits, tok_pair, tok_pos, inv_freq, rows, heads, ctx, (T*)q_out, (T*)k_cache,
+                         qkv, qkv_splits, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, (T*)q_out, (T*)k_cache,
                          (T*)v_cache)));
   PSG_CHECK_LAUNCH("psg_rope_kvwrite");
   return PSG_OK;

@@ -57,7 +57,11 @@ class LlamaDecodeEngine:
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
         self._graphs = {}
         hd = m.head_dim
-        self.inv_freq = (1.0 / (m.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.device)
+        # rotary tables as HF builds them (HF-LL:115-128): inv_freq and the outer product in fp32 on the
+        # host, cos/sin per position; the kernels index them by position
+        inv_freq = 1.0 / (m.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+        ang = torch.arange(4096, dtype=torch.float32)[:, None] * inv_freq[None, :]
+        self.rope = (ang.cos().contiguous().to(self.device), ang.sin().contiguous().to(self.device))
 
     def linear(self, x, w):
         """Bias-free projection.  Decode-step shapes (<= 32 rows, bf16) use the hand-written
@@ -68,8 +72,9 @@ class LlamaDecodeEngine:
         return F.linear(x, w)
 
     # ---- one pass over `rows` token rows -------------------------------------------------------
-    def _forward(self, resid, tok_pair, tok_pos, kc, vc, ctx_len):
-        """resid [rows, D] is updated in place (residual stream); returns final-norm hidden [rows, D]."""
+    def _forward(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, decode=False):
+        """resid [rows, D] is updated in place (residual stream); returns final-norm hidden [rows, D].
+        decode=True: every row is the newest token of its pair -> fused rotary + KV append + attention."""
         m = self.cfg.llm
         rows, D = resid.shape
         n = torch.empty_like(resid)
@@ -79,8 +84,11 @@ class LlamaDecodeEngine:
         act = torch.empty((rows, m.inter), device=self.device, dtype=self.dtype)
         for l, L in enumerate(self.layers):
             qkv = self.linear(n, L["wqkv"])
-            ops.rope_kvwrite(qkv, tok_pair, tok_pos, self.inv_freq, m.heads, m.head_dim, ctx_len, q, kc[l], vc[l])
-            ops.llm_attn(q, kc[l], vc[l], tok_pair, tok_pos, m.heads, m.head_dim, ctx_len, att)
+            if decode:
+                ops.decode_attn(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, kc[l], vc[l], att)
+            else:
+                ops.rope_kvwrite(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, q, kc[l], vc[l])
+                ops.llm_attn(q, kc[l], vc[l], tok_pair, tok_pos, m.heads, m.head_dim, ctx_len, att)
             o = self.linear(att, L["wo"])
             ops.rmsnorm(resid, o, L["ln2"], m.rms_eps, n)                      # resid += o ; n = norm(resid)
             gu = self.linear(n, L["wgu"])
@@ -173,7 +181,7 @@ class LlamaDecodeEngine:
         x = torch.empty((K, D), device=dev, dtype=self.dtype)
         for step in range(1, max_new):
             ops.gather_rows(self.embed, next_ids, x)
-            h = self._forward(x, dec_pair, dec_pos, kc, vc, ctx_len)
+            h = self._forward(x, dec_pair, dec_pos, kc, vc, ctx_len, decode=True)
             logits = self.linear(h, self.lm_head)
             ops.greedy_step(logits, step, max_new, m.eos, sup, tokens, done, next_ids, dec_pos, dtype=self.dtype)
         return tokens, first_logits

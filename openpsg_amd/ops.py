@@ -41,6 +41,23 @@ def _env(t: torch.Tensor):
     return _lib.load(), _lib.ctx(t.device.index or 0), torch.cuda.current_stream(t.device).cuda_stream
 
 
+def patch_embed(feat: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, patch: int = 16) -> torch.Tensor:
+    """feat [1,C,Hf,Wf] fp32, weight [Cout,C,16,16] fp32 -> patches [L, Cout] fp32 (V4:410)."""
+    import ctypes
+    lib, ctx, st = _env(feat)
+    _, Cc, Hf, Wf = feat.shape
+    Cout = weight.shape[0]
+    nbytes = ctypes.c_int64(0)
+    check(lib.psg_patch_embed_workspace(ctx, Cc, Hf, Wf, Cout, patch, ctypes.byref(nbytes)),
+          "psg_patch_embed_workspace")
+    ws = torch.empty(nbytes.value // 4, device=feat.device, dtype=torch.float32)
+    out = torch.empty(((Hf // patch) * (Wf // patch), Cout), device=feat.device, dtype=torch.float32)
+    check(lib.psg_patch_embed(ctx, _p(feat, torch.float32, "mask_features"), Cc, Hf, Wf,
+                              _p(weight, torch.float32, "patch_embed.weight"), _p(bias, torch.float32), Cout, patch,
+                              _p(out), _p(ws), nbytes.value, st), "psg_patch_embed")
+    return out
+
+
 def mask_grid(pan: torch.Tensor, img_hw, pad_hw, grid_hw) -> torch.Tensor:
     lib, ctx, st = _env(pan)
     gh, gw = int(grid_hw[0]), int(grid_hw[1])
@@ -191,12 +208,14 @@ def rmsnorm(resid, delta, w, eps, out):
     return out
 
 
-def rope_kvwrite(qkv, tok_pair, tok_pos, inv_freq, heads, head_dim, ctx_len, q_out, k_cache, v_cache):
+def rope_kvwrite(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, q_out, k_cache, v_cache):
+    """rope = (cos, sin) fp32 tables [>= ctx_len, head_dim/2]."""
     lib, ctx, st = _env(q_out)
     rows = q_out.shape[0]
     qp, qs = _in(qkv, q_out.dtype)
+    assert rope[0].shape[0] >= ctx_len and rope[0].shape[1] == head_dim // 2
     check(lib.psg_rope_kvwrite(ctx, qp, qs, _p(tok_pair, torch.int32), _p(tok_pos, torch.int32),
-                               _p(inv_freq, torch.float32), rows, heads, head_dim, ctx_len, _p(q_out),
+                               _p(rope[0], torch.float32), _p(rope[1], torch.float32), rows, heads, head_dim, ctx_len, _p(q_out),
                                _p(k_cache, q_out.dtype), _p(v_cache, q_out.dtype), _dt(q_out), st), "psg_rope_kvwrite")
     return q_out
 
@@ -206,6 +225,17 @@ def llm_attn(q, k_cache, v_cache, tok_pair, tok_pos, heads, head_dim, ctx_len, o
     check(lib.psg_llm_attn(ctx, _p(q), _p(k_cache, q.dtype), _p(v_cache, q.dtype), _p(tok_pair, torch.int32),
                            _p(tok_pos, torch.int32), q.shape[0], heads, head_dim, ctx_len, _p(out, q.dtype), _dt(q),
                            st), "psg_llm_attn")
+    return out
+
+
+def decode_attn(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, k_cache, v_cache, out):
+    """Fused rotary + KV append + attention for rows that each hold the newest token of their pair."""
+    lib, ctx, st = _env(out)
+    qp, qs = _in(qkv, out.dtype)
+    assert rope[0].shape[0] >= ctx_len and rope[0].shape[1] == head_dim // 2
+    check(lib.psg_decode_attn(ctx, qp, qs, _p(tok_pair, torch.int32), _p(tok_pos, torch.int32),
+                              _p(rope[0], torch.float32), _p(rope[1], torch.float32), out.shape[0], heads, head_dim, ctx_len,
+                              _p(k_cache, out.dtype), _p(v_cache, out.dtype), _p(out), _dt(out), st), "psg_decode_attn")
     return out
 
 

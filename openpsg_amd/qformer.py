@@ -40,7 +40,7 @@ class RelationQueryEngine:
         self.pos_emb = f32(pre + "position_embeddings.weight")
         self.emb_ln = (f32(pre + "layernorm.weight"), f32(pre + "layernorm.bias"))
         self.query_rows = torch.cat([f32("rel_cls_query")[0], f32("relation_query")[0]], dim=0).contiguous()
-        # patch embedding stays fp32: it is one 8.6 GFLOP GEMM per image over fp32 mask_features
+        # patch embedding stays fp32 (exact f32 MFMA kernel): one 8.6 GFLOP GEMM per image over fp32 mask_features
         self.patch_w = f32("patch_embed.proj.weight")
         self.patch_b = f32("patch_embed.proj.bias")
         self.exist_w = f32("binary_rel_cls_pred.weight").reshape(-1).contiguous()
@@ -72,7 +72,9 @@ class RelationQueryEngine:
     # ---- A4: prepare_inference (V4:408-435) ----------------------------------------------------
     def patch_embed(self, mask_features: torch.Tensor) -> torch.Tensor:
         """[1,C,h,w] fp32 -> patches [L, C] fp32 (timm PatchEmbed: conv k=16 s=16, flatten, transpose)."""
-        x = F.conv2d(mask_features, self.patch_w, self.patch_b, stride=self.cfg.patch_size)
+        if self.cfg.patch_size == 16 and mask_features.shape[-1] % 4 == 0 and self.patch_w.shape[0] % 128 == 0:
+            return ops.patch_embed(mask_features.contiguous(), self.patch_w, self.patch_b, 16)
+        x = F.conv2d(mask_features, self.patch_w, self.patch_b, stride=self.cfg.patch_size)   # odd geometries
         return x.flatten(2).transpose(1, 2)[0].contiguous()
 
     def object_bitmasks(self, pan: torch.Tensor, img_meta: dict, object_ids: torch.Tensor, feat_hw) -> torch.Tensor:

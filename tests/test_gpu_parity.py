@@ -254,3 +254,48 @@ def test_skinny_gemm_vs_fp32_reference(M, N, K):
         want = torch.empty_like(out)
         ops.silu_mul(y, want)
         assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("hw,C", [((256, 256), 256), ((128, 128), 256), ((192, 256), 256), ((256, 336), 256), ((64, 48), 32)])
+def test_patch_embed_vs_conv2d(hw, C):
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(hw[0] + hw[1])
+    feat = torch.randn(1, C, hw[0], hw[1], generator=g).to(dev)
+    w = (torch.randn(256, C, 16, 16, generator=g) / (C * 256) ** 0.5).to(dev)
+    b = torch.randn(256, generator=g).to(dev)
+    got = ops.patch_embed(feat, w, b)
+    want = torch.nn.functional.conv2d(feat.double(), w.double(), b.double(), stride=16).flatten(2).transpose(1, 2)[0]
+    err = (got.double() - want).abs().max().item()
+    print(f"patch_embed {hw} C={C}: max err vs fp64 conv {err:.2e}")
+    assert got.shape == want.shape and err < 2e-5
+
+
+@pytest.mark.parametrize("B,T,q_only", [(7, 14, False), (5, 17, True), (3, 31, False), (4, 9, True)])
+def test_self_attn_mfma_vs_fp32_reference(B, T, q_only):
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 100 + T)
+    nq, heads, H = 33, 12, 768
+    R = B * (nq + T)
+    qkv = (torch.randn(R, 3 * H, generator=g) * 1.2).to(dev).bfloat16()
+    tmask = (torch.rand(B, T, generator=g) < 0.8).to(torch.uint8)
+    tmask[:, 0] = 1
+    tmask = tmask.to(dev)
+    out = torch.zeros(R, H, device=dev, dtype=torch.bfloat16)
+    ops.qformer_self_attn(qkv, tmask, B, T, nq, heads, q_only, out)
+    # fp32 torch restatement on the same bf16 inputs
+    f = qkv.float()
+    worst = 0.0
+    for p in range(B):
+        rows = list(range(p * nq, (p + 1) * nq)) + list(range(B * nq + p * T, B * nq + (p + 1) * T))
+        x = f[rows]
+        q_, k_, v_ = [x[:, i * H:(i + 1) * H].view(-1, heads, 64).permute(1, 0, 2) for i in range(3)]
+        valid = torch.cat([torch.ones(nq, device=dev), tmask[p].float()])
+        s = q_ @ k_.transpose(1, 2) * 0.125 + ((1 - valid) * torch.finfo(torch.float32).min)[None, None, :]
+        o = (torch.softmax(s, -1) @ v_).permute(1, 0, 2).reshape(-1, H)
+        n = nq if q_only else nq + T
+        got = out[rows][:n].float()
+        worst = max(worst, (got - o[:n]).abs().max().item())
+    print(f"self_attn mfma B={B} T={T} q_only={q_only}: max err {worst:.3e}")
+    assert worst < 3e-2

@@ -89,3 +89,31 @@ if __name__ == "__main__":
     if "xattn" in a.what:
         xattn(50, 256)
         xattn(100, 256)
+
+
+def decode_attn():
+    dev = torch.device("cuda:0")
+    K, heads, ctx, D = 20, 32, 68, 4096
+    kc = torch.randn(K, heads, ctx, 128, device=dev).bfloat16()
+    vc = torch.randn(K, heads, ctx, 128, device=dev).bfloat16()
+    out = torch.empty(K, D, device=dev, dtype=torch.bfloat16)
+    pair = torch.arange(K, device=dev, dtype=torch.int32)
+    ang = torch.arange(128, dtype=torch.float32)[:, None] / (10000.0 ** (torch.arange(0, 128, 2) / 128))[None, :]
+    inv = (ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous())
+    for pos_v in (1, 50, 64):
+        pos = torch.full((K,), pos_v, device=dev, dtype=torch.int32)
+        for splits in (0, 4):
+            if splits:
+                qkv = ops.Partials(torch.randn(splits, K, 3 * D, device=dev))
+            else:
+                qkv = torch.randn(K, 3 * D, device=dev).bfloat16()
+
+            def run():
+                for _ in range(32):
+                    ops.decode_attn(qkv, pair, pos, inv, heads, 128, ctx, kc, vc, out)
+            t, _ = timeit(run, iters=8, warm=2)
+            print(f"decode_attn pos={pos_v} splits={splits}: {t / 32:.2f} us")
+
+
+if __name__ == "__main__" and "decode_attn" in sys.argv:
+    decode_attn()
