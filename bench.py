@@ -160,7 +160,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # PSG_BENCH_FORCE_DIST=1: run the pair-sharded pipeline (RCCL collectives included) even at world size 1
+    force_dist = os.environ.get("PSG_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -172,7 +174,7 @@ def main():
     N = a.objects
     pairs_per_image = N * (N - 1)
 
-    if world == 1:
+    if world == 1 and not force_dist:
         scene = make_scene((a.size, a.size), N, seed=0, device=str(dev))
         inputs = dict(mask_features=scene["mask_features"], img_metas=[scene["img_meta"]],
                       object_info=[dict(object_id_list=scene["object_id_list"], pan_results=scene["pan_results"])])
@@ -209,7 +211,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -237,15 +239,15 @@ def main():
             pmc = os.path.join(REPO, "profiles", "pmc_skinny_gemm.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            line["roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_kernel", "achieved": round(ach, 1),
+            line["roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_dma_kernel<8,1,3> (psg_skinny_gemm)", "achieved": round(ach, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                 "traffic": traffic, "bytes_per_launch": int(bpl),
                                 "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n}
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and not force_dist:
             scene_cpu = make_scene((a.size, a.size), N, seed=0)
             line["cpu_baseline"] = cpu_baseline(a, scene_cpu)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 
