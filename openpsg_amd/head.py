@@ -81,6 +81,9 @@ class RelationTransformerHeadV4(nn.Module):
                  suppress_eos=False,
                  pair_chunk=4096,
                  xattn_variant=None,
+                 pair_selector="topk",         # 'topk' (V4:235-237) | 'threshold' (the commented V4:230-234 logic)
+                 exclude_diagonal=False,       # the reference never excludes the i == j pairs
+                 max_selected=32,              # cap of the threshold selector (one decode batch)
                  **kwargs):
         super().__init__()
         if rel_cls_type != 'binary':
@@ -99,6 +102,11 @@ class RelationTransformerHeadV4(nn.Module):
         self.suppress_eos = suppress_eos
         self.pair_chunk = int(pair_chunk)
         self.xattn_variant = xattn_variant
+        assert pair_selector in ("topk", "threshold")
+        self.pair_selector = pair_selector
+        self.exclude_diagonal = bool(exclude_diagonal)
+        self.max_llm_forward_num = max_llm_forward_num
+        self.max_selected = int(max_selected)
         self.act_dtype = _DTYPES[dtype]
         self.device = torch.device(device)
         llm = llm_config if llm_config is not None else LlamaConfig(hidden=llm_feature_size,
@@ -283,9 +291,26 @@ class RelationTransformerHeadV4(nn.Module):
         out = dict(patches=patches, bits=bits, hidden=hidden, exist_logit=logit, exist_prob=prob,
                    num_objects=N, pair_range=(p0, p1), uidx=uidx)
         if pair_range is None:
-            K = min(self.cfg.num_selected, B)
-            out["selected"] = eng.select(prob, K)
+            out["selected"] = self.select_pairs(prob, N)
         return out
+
+    def select_pairs(self, prob, N):
+        """A8.  'topk': first num_selected of the full descending order (V4:235-237).  'threshold'
+        (V4:230-234, commented out in the reference): every pair with p > pair_selector_threshold,
+        topped up to at least max_llm_forward_num by score, capped at max_selected; the count is
+        data dependent, so this costs one scalar device->host read."""
+        eng = self.rq_engine
+        B = N * N
+        if self.exclude_diagonal:
+            prob = prob.clone()
+            prob[torch.arange(N, device=prob.device) * (N + 1)] = -1.0
+        if self.pair_selector == "topk":
+            return eng.select(prob, min(self.cfg.num_selected, B))
+        cap = min(self.max_selected, B)
+        order = eng.select(prob, cap)
+        n_hit = int((prob > self.pair_selector_threshold).sum().item())
+        k = max(1, min(cap, max(n_hit, min(self.max_llm_forward_num, B))))
+        return order[:k].contiguous()
 
     def decode_selected(self, rq, names, selected=None, pair_features=None, to_host=True):
         """A9: batched greedy decode of the selected pairs.  `pair_features` [K*32, 768] replaces the
