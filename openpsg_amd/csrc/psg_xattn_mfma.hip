@@ -35,6 +35,17 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 #define XA_KSTRIDE 144  // bytes per K row in LDS: 64 bf16 + 16 B pad
 #define XA_CT 4         // S^T tiles (of 32 keys) per online-softmax chunk
+#define XA_GRAB 4       // row tiles a wave takes from the work counter per atomic
+
+// value of the partner lane (lane ^ 32) via v_permlane32_swap (VALU, no LDS round trip)
+__device__ __forceinline__ float xchg32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xchg32_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   f32x2_t f = {lo, hi};
@@ -42,10 +53,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, b);
 }
 
+template <int NC>   // NC = key chunks of 128 (L <= 128 NC): unrolled so the prefetched mask words index statically
 __global__ void __launch_bounds__(256, 2)
 cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                        const uint64_t* __restrict__ bits, int words, const int32_t* __restrict__ pair_index, int N,
-                       int64_t R, int L, int nq, int heads, int policy, int tiles_per_head_block,
+                       int64_t R, int L, int nq, int heads, int policy, int* __restrict__ counters,
                        uint16_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Lpad = (L + 31) & ~31;
@@ -79,48 +91,115 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
 
   const int lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int64_t ntile = (R + 31) >> 5;
+  // Row tiles.  nq == 33: tile t < P = rows 1..32 of pair t (the 32 relation queries share ONE pair
+  // mask, so most 32-key tiles are masked for the whole tile and are skipped below); tiles >= P batch
+  // the cls rows (row 0) of 32 consecutive pairs.  Other nq: flat 32-row tiles.
+  const bool aligned = nq == 33;
+  const int64_t P = R / nq;
+  const int64_t ntile = aligned ? P + ((P + 31) >> 5) : (R + 31) >> 5;
   const float C = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
   const uint32_t bias_bits = policy == PSG_EMPTY_UNIFORM ? 0xff7fffffu /* finfo.min */
                                                          : __float_as_uint(-10000.0f * 1.4426950408889634f);
   const unsigned char* kfrag_base = k_lds + l31 * XA_KSTRIDE + hi * 16;
   const unsigned char* vfrag_base = vt_lds + l31 * VS + hi * 16;
 
-  for (int64_t tile = (int64_t)g * 4 + wid; tile < ntile; tile += (int64_t)G * 4) {
-    const int64_t row = tile * 32 + l31;
-    const bool rvalid = row < R;
-    const int64_t rowc = rvalid ? row : R - 1;
-    // Q fragments: B operand of S^T = K.Q^T; lane (q = lane&31, hi) holds Q[q][16 s + 8 hi .. +7]
+  // One unit of work = (row tile, head h).  Its operands (Q fragments, the rows' pair-mask words) sit
+  // behind a chain of dependent global loads (pair_index -> bits -> words); with most key tiles skipped
+  // a unit is short, so the NEXT unit's operands are fetched while the current one is computed.
+  struct XUnit {
     bf16x8_t qf[4];
-    {
-      const uint16_t* qp = q + rowc * hidden + h * 64 + hi * 8;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16);
+    uint64_t mw[2 * NC];
+    int64_t row;
+    bool rvalid;
+  };
+  auto fetch = [&](int64_t tile, XUnit& u) {
+    if (aligned) {
+      if (tile < P) {
+        u.row = tile * 33 + 1 + l31;
+        u.rvalid = true;
+      } else {
+        const int64_t pr = (tile - P) * 32 + l31;
+        u.rvalid = pr < P;
+        u.row = (u.rvalid ? pr : P - 1) * 33;
+      }
+    } else {
+      u.row = tile * 32 + l31;
+      u.rvalid = u.row < R;
+      if (!u.rvalid) u.row = R - 1;
     }
-    const int pidx = pair_index[rowc / nq];
+    // Q fragments: B operand of S^T = K.Q^T; lane (q = lane&31, hi) holds Q[q][16 s + 8 hi .. +7]
+    const uint16_t* qp = q + u.row * hidden + h * 64 + hi * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) u.qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16);
+    const int pidx = pair_index[u.row / nq];
     const uint64_t* bi = bits + (int64_t)(pidx / N) * words;
     const uint64_t* bj = bits + (int64_t)(pidx % N) * words;
+#pragma unroll
+    for (int w = 0; w < 2 * NC; ++w) u.mw[w] = w < words ? (bi[w] | bj[w]) : 0ull;
+  };
+  // Dynamic distribution: unit costs differ by 5x (a pair with an empty mask union needs every key
+  // tile, most pairs need one or two), and a static split left the slowest wave at 2x the mean.
+  // Waves of the workgroups that own head h pull batches of XA_GRAB tiles from counters[h]
+  // (zeroed by the launcher on the same stream); one returning atomic per batch.
+  int64_t qbase = 0;
+  int qk = XA_GRAB;
+  auto next_tile = [&]() -> int64_t {
+    if (qk == XA_GRAB) {
+      int b = 0;
+      if (lane == 0) b = atomicAdd(counters + h, XA_GRAB);
+      qbase = __builtin_amdgcn_readfirstlane(b);
+      qk = 0;
+    }
+    return qbase + qk++;
+  };
+  XUnit cur, nxt;
+  int64_t tile = next_tile();
+  if (tile < ntile) fetch(tile, cur);
+  while (tile < ntile) {
+    const int64_t tile_next = next_tile();
+    if (tile_next < ntile) fetch(tile_next, nxt);
+    const int64_t row = cur.row;
+    const bool rvalid = cur.rvalid;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = cur.qf[s];
+
+    // a row whose pair mask is empty attends to every key (uniform softmax): it needs all tiles
+    uint64_t anybits = 0;
+#pragma unroll
+    for (int w = 0; w < 2 * NC; ++w) anybits |= cur.mw[w];
+    const bool any_empty_row = __any(anybits == 0ull);
 
     f32x16_t o0 = {0}, o1 = {0};
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int c0 = 0; c0 < NT; c0 += XA_CT) {
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      const int c0 = cc * XA_CT;
+      if (c0 >= NT) break;
       // inverted mask words (1 = masked), pre-shifted by 4*hi so the bit index is a constant per register
       uint32_t inv[XA_CT];
+      bool need[XA_CT];
       {
-        const int w0 = c0 >> 1;
-        const uint64_t m0 = w0 < words ? (bi[w0] | bj[w0]) : 0ull;
-        const uint64_t m1 = (w0 + 1) < words ? (bi[w0 + 1] | bj[w0 + 1]) : 0ull;
+        const uint64_t m0 = cur.mw[2 * cc], m1 = cur.mw[2 * cc + 1];
         inv[0] = ~(uint32_t)m0 >> (4 * hi);
         inv[1] = ~(uint32_t)(m0 >> 32) >> (4 * hi);
         inv[2] = ~(uint32_t)m1 >> (4 * hi);
         inv[3] = ~(uint32_t)(m1 >> 32) >> (4 * hi);
+        // a 32-key tile no row of this row tile attends to contributes exactly 0: skip it (wave-uniform)
+        need[0] = any_empty_row || __any((uint32_t)m0 != 0u);
+        need[1] = any_empty_row || __any((uint32_t)(m0 >> 32) != 0u);
+        need[2] = any_empty_row || __any((uint32_t)m1 != 0u);
+        need[3] = any_empty_row || __any((uint32_t)(m1 >> 32) != 0u);
       }
+#pragma unroll
+      for (int t = 0; t < XA_CT; ++t) need[t] = need[t] && (c0 + t < NT);
+      if (!(need[0] || need[1] || need[2] || need[3])) continue;
       f32x16_t acc[XA_CT];
 #pragma unroll
       for (int t = 0; t < XA_CT; ++t) {
         acc[t] = (f32x16_t){0};
-        if (c0 + t < NT) {
+        if (need[t]) {
           const unsigned char* kp = kfrag_base + (c0 + t) * 32 * XA_KSTRIDE;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
@@ -133,7 +212,7 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
       float cmax = -INFINITY;
 #pragma unroll
       for (int t = 0; t < XA_CT; ++t) {
-        if (c0 + t < NT) {
+        if (need[t]) {
           const bool has_pad = (c0 + t + 1) * 32 > L;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -146,13 +225,13 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
           }
         }
       }
-      cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+      cmax = xchg32_max(cmax);
       const float m_new = fmaxf(m_run, cmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float csum = 0.f;
 #pragma unroll
       for (int t = 0; t < XA_CT; ++t)
-        if (c0 + t < NT) {
+        if (need[t]) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float pv = __builtin_amdgcn_exp2f(acc[t][r] - m_new);
@@ -160,7 +239,7 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
             csum += pv;
           }
         }
-      csum += __shfl_xor(csum, 32, 64);
+      csum = xchg32_sum(csum);
       l_run = l_run * alpha + csum;
       m_run = m_new;
 #pragma unroll
@@ -171,7 +250,7 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
       // O^T += V^T . P^T : A = V^T fragment (LDS), B = this lane's P values packed to bf16
 #pragma unroll
       for (int t = 0; t < XA_CT; ++t)
-        if (c0 + t < NT) {
+        if (need[t]) {
 #pragma unroll
           for (int gg = 0; gg < 2; ++gg) {
             union {
@@ -203,6 +282,8 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
         *reinterpret_cast<uint2*>(op + 32 + 8 * rr) = w1;
       }
     }
+    cur = nxt;
+    tile = tile_next;
   }
 }
 
@@ -212,7 +293,8 @@ int psg_cross_attn_simple_launch(const void* q, const void* k, const void* v, co
 
 extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
                                       int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads,
-                                      int empty_policy, int variant, void* out, int dtype, void* stream) {
+                                      int empty_policy, int variant, void* out, int32_t* work_counters, int dtype,
+                                      void* stream) {
   PSG_REQUIRE(ctx && q && k && v && bits && pair_index && out, PSG_ERR_INVALID, "psg_qformer_cross_attn: NULL argument");
   PSG_REQUIRE(N > 0 && P >= 0 && L > 0 && nq > 0 && heads > 0 && words * 64 >= L, PSG_ERR_INVALID,
               "psg_qformer_cross_attn: N=%d P=%d L=%d nq=%d heads=%d words=%d", N, P, L, nq, heads, words);
@@ -226,31 +308,48 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
   PSG_REQUIRE(variant == PSG_XATTN_MFMA, PSG_ERR_INVALID, "psg_qformer_cross_attn: variant=%d", variant);
   PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED,
               "psg_qformer_cross_attn: the MFMA variant computes in bf16; use PSG_XATTN_SIMPLE for fp32");
+  PSG_REQUIRE(work_counters != nullptr, PSG_ERR_INVALID,
+              "psg_qformer_cross_attn: the MFMA variant needs work_counters (int32[heads] of caller memory)");
   const int Lpad = (L + 31) & ~31;
   const size_t lds = (size_t)Lpad * XA_KSTRIDE + (size_t)64 * (Lpad * 2 + 16);
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn: L=%d needs %zu B of LDS (> 160 KiB)", L,
               lds);
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)cross_attn_mfma_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int NC = (Lpad / 32 + XA_CT - 1) / XA_CT;
+  PSG_REQUIRE(NC >= 1 && NC <= 4, PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn: L=%d (MFMA variant handles L <= 512)", L);
+  const void* kfn = NC == 1 ? (const void*)cross_attn_mfma_kernel<1>
+                  : NC == 2 ? (const void*)cross_attn_mfma_kernel<2>
+                  : NC == 3 ? (const void*)cross_attn_mfma_kernel<3> : (const void*)cross_attn_mfma_kernel<4>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       psg_set_error("psg_qformer_cross_attn: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
       return PSG_ERR_HIP;
     }
-    configured = lds;
   }
   const int64_t R = (int64_t)P * nq;
-  const int64_t ntile = (R + 31) / 32;
+  const int64_t ntile = nq == 33 ? (int64_t)P + (P + 31) / 32 : (R + 31) / 32;
   // persistent grid: ~2 workgroups per CU, at least one tile per wave
   int blocks_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   int64_t G = ((int64_t)ctx->num_cu * blocks_per_cu + heads - 1) / heads;
   const int64_t maxG = (ntile + 3) / 4;
   if (G > maxG) G = maxG;
   if (G < 1) G = 1;
-  cross_attn_mfma_kernel<<<(unsigned)(G * heads), 256, lds, st>>>(
-      (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads,
-      empty_policy, 0, (uint16_t*)out);
+  {
+    hipError_t e = hipMemsetAsync(work_counters, 0, sizeof(int32_t) * heads, st);   // a memset node under capture
+    if (e != hipSuccess) {
+      psg_set_error("psg_qformer_cross_attn: hipMemsetAsync: %s", hipGetErrorString(e));
+      return PSG_ERR_HIP;
+    }
+  }
+#define XLAUNCH(NC_)                                                                                           \
+  cross_attn_mfma_kernel<NC_><<<(unsigned)(G * heads), 256, lds, st>>>(                                        \
+      (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads, \
+      empty_policy, work_counters, (uint16_t*)out)
+  if (NC == 1) XLAUNCH(1);
+  else if (NC == 2) XLAUNCH(2);
+  else if (NC == 3) XLAUNCH(3);
+  else XLAUNCH(4);
+#undef XLAUNCH
   PSG_CHECK_LAUNCH("psg_qformer_cross_attn");
   return PSG_OK;
 }
