@@ -396,6 +396,135 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const void* __restrict
   Act<T>::st(out, (int64_t)row * hidden + h * 128 + lane + 64, o2 * inv);
 }
 
+// Latency-oriented variant used for the decode step: one WORKGROUP (4 waves) per (pair, head).
+// The single-wave kernel above spends its time in dependent round trips (keys, then values); here
+// wave w owns keys {64 b + 16 w .. + 15}, four lanes share a key (32 dims each, quad shuffle
+// reduce), so the key pass and the value pass of a <= 64-token context are one round trip each;
+// the four partial (m, l, o) states and the new token's own term are merged through LDS.
+template <typename T>
+__global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restrict__ qkv, int qs,
+                                                           const int32_t* __restrict__ tok_pair,
+                                                           const int32_t* __restrict__ tok_pos,
+                                                           const float* __restrict__ cos_tab,
+                                                           const float* __restrict__ sin_tab, int rows, int heads,
+                                                           int ctx, T* __restrict__ kc, T* __restrict__ vc,
+                                                           T* __restrict__ out) {
+  __shared__ float s_q[128];
+  __shared__ float s_p[4][16];
+  __shared__ float s_o[4][128];
+  __shared__ float s_ml[4][2];
+  __shared__ float s_new[3];                                  // s_new, and nothing else shared; v stays in wave 0
+  const int unit = blockIdx.x;
+  const int row = unit / heads, h = unit % heads;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int pos = tok_pos[row];
+  const int hidden = heads * 128;
+  if (pos < 0) return;                                        // whole workgroup (uniform)
+  const int64_t cbase = ((int64_t)tok_pair[row] * heads + h) * ctx * 128;
+  const float scale = 0.08838834764831845f;                   // 1/sqrt(128)
+  auto rnd = [](float f) { return sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(f)) : f; };
+  float vn1 = 0.f, vn2 = 0.f;
+  if (wid == 0) {                                             // new token: rotary, cache append, own score
+    const int64_t base = (int64_t)row * 3 * hidden + h * 128;
+    const int64_t sl = (int64_t)rows * 3 * hidden;
+    const float q1 = ld1_in<T>(qkv, qs, sl, base + lane), q2 = ld1_in<T>(qkv, qs, sl, base + lane + 64);
+    const float k1 = ld1_in<T>(qkv, qs, sl, base + hidden + lane), k2 = ld1_in<T>(qkv, qs, sl, base + hidden + lane + 64);
+    const float v1 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane);
+    const float v2 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane + 64);
+    const float cs = cos_tab[pos * 64 + lane], sn = sin_tab[pos * 64 + lane];
+    const float qa = rnd(q1 * cs - q2 * sn), qb = rnd(q2 * cs + q1 * sn);
+    const float ka = rnd(k1 * cs - k2 * sn), kb = rnd(k2 * cs + k1 * sn);
+    Act<T>::st(kc, cbase + (int64_t)pos * 128 + lane, ka);
+    Act<T>::st(kc, cbase + (int64_t)pos * 128 + lane + 64, kb);
+    Act<T>::st(vc, cbase + (int64_t)pos * 128 + lane, v1);
+    Act<T>::st(vc, cbase + (int64_t)pos * 128 + lane + 64, v2);
+    s_q[lane] = qa;
+    s_q[lane + 64] = qb;
+    const float sn_ = wave_sum(qa * ka + qb * kb) * scale;
+    if (lane == 0) s_new[0] = sn_;
+    vn1 = rnd(v1);
+    vn2 = rnd(v2);
+  }
+  __syncthreads();
+  const int kl = lane >> 2, part = lane & 3;
+  float m_run = -INFINITY, l_run = 0.f, o1 = 0.f, o2 = 0.f;
+  for (int b0 = 0; b0 < pos; b0 += 64) {
+    const int j = b0 + 16 * wid + kl;
+    float s = -INFINITY;
+    {
+      const bool ok = j < pos;
+      const T* kp = kc + cbase + (int64_t)(ok ? j : 0) * 128 + part * 32;
+      float t[8][4];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) Act<T>::ld4(kp, d * 4, t[d]);
+      float acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const float* qq = s_q + part * 32 + d * 4;
+        acc = fmaf(qq[0], t[d][0], acc);
+        acc = fmaf(qq[1], t[d][1], acc);
+        acc = fmaf(qq[2], t[d][2], acc);
+        acc = fmaf(qq[3], t[d][3], acc);
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (ok) s = acc * scale;
+    }
+    const float m_new = fmaxf(m_run, wave_max(s));
+    if (m_new == -INFINITY) continue;                          // this wave has no key in this pass (uniform)
+    const float alpha = expf(m_run - m_new);
+    const float pj = expf(s - m_new);                          // replicated over the 4 lanes of a key
+    l_run = l_run * alpha + wave_sum(pj) * 0.25f;
+    o1 *= alpha;
+    o2 *= alpha;
+    if (part == 0) s_p[wid][kl] = pj;
+    __builtin_amdgcn_wave_barrier();
+    const int kbase = b0 + 16 * wid;
+    const int nk = min(16, pos - kbase);                       // > 0 here
+    const T* vp = vc + cbase + (int64_t)kbase * 128;
+    float a[16], c[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int uu = u < nk ? u : 0;
+      a[u] = Act<T>::ld(vp, (int64_t)uu * 128 + lane);
+      c[u] = Act<T>::ld(vp, (int64_t)uu * 128 + lane + 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float pv = u < nk ? s_p[wid][u] : 0.f;
+      o1 = fmaf(pv, a[u], o1);
+      o2 = fmaf(pv, c[u], o2);
+    }
+    __builtin_amdgcn_wave_barrier();
+    m_run = m_new;
+  }
+  s_o[wid][lane] = o1;
+  s_o[wid][lane + 64] = o2;
+  if (lane == 0) {
+    s_ml[wid][0] = m_run;
+    s_ml[wid][1] = l_run;
+  }
+  __syncthreads();
+  if (wid == 0) {
+    const float sn_ = s_new[0];
+    float m = sn_;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) m = fmaxf(m, s_ml[w][0]);
+    float e_new = expf(sn_ - m);
+    float l = e_new, r1 = e_new * vn1, r2 = e_new * vn2;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = expf(s_ml[w][0] - m);                    // exp(-inf) = 0 for a wave without keys
+      l += f * s_ml[w][1];
+      r1 = fmaf(f, s_o[w][lane], r1);
+      r2 = fmaf(f, s_o[w][lane + 64], r2);
+    }
+    const float inv = 1.0f / l;
+    Act<T>::st(out, (int64_t)row * hidden + h * 128 + lane, r1 * inv);
+    Act<T>::st(out, (int64_t)row * hidden + h * 128 + lane + 64, r2 * inv);
+  }
+}
+
 extern "C" int psg_decode_attn(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
                                const int32_t* tok_pos, const float* rope_cos, const float* rope_sin, int rows,
                                int heads, int head_dim, int ctx, void* k_cache, void* v_cache, void* out, int dtype,
@@ -407,6 +536,16 @@ extern "C" int psg_decode_attn(psg_ctx* ctx_, const void* qkv, int qkv_splits, c
               qkv_splits);
   if (rows == 0) return PSG_OK;
   const int waves = rows * heads;
+  static int single = -1;                          // PSG_DECODE_ATTN_1WAVE=1: the one-wave-per-head kernel
+  if (single < 0) single = getenv("PSG_DECODE_ATTN_1WAVE") ? 1 : 0;
+  if (!single) {
+    PSG_DISPATCH_DTYPE(dtype, "psg_decode_attn",
+                       (decode_attn4_kernel<T><<<waves, 256, 0, (hipStream_t)stream>>>(
+                           qkv, qkv_splits, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, (T*)k_cache,
+                           (T*)v_cache, (T*)out)));
+    PSG_CHECK_LAUNCH("psg_decode_attn");
+    return PSG_OK;
+  }
   PSG_DISPATCH_DTYPE(dtype, "psg_decode_attn",
                      (decode_attn_kernel<T><<<(waves + 3) / 4, 256, 0, (hipStream_t)stream>>>(
                          qkv, qkv_splits, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, (T*)k_cache,

@@ -307,6 +307,7 @@ static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
   const int KB = K >> 6;
   int S = forced > 0 ? forced : (K + 512) / 1024;
   if (S < 1) S = 1;
+  if (forced <= 0 && S > 8) S = 8;       // K = 11008: 8 slices measured faster than 11 (fewer partial bytes)
   const int blocks_n = (N + SG_ROWS - 1) / SG_ROWS;
   if (forced <= 0)
     while (S < KB / 4 && (int64_t)blocks_n * S < 2 * ctx->num_cu) S *= 2;   // small N: split deeper
