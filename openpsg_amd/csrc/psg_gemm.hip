@@ -198,8 +198,10 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
   const int nb = nkb / UD;
   const int nslab_all = (N + ROWS - 1) / ROWS;
   const int nslab = gx < nslab_all ? (nslab_all - gx + G - 1) / G : 0;
+  constexpr int OT_PITCH = ROWS + 4;                                // output tile pitch (floats)
   unsigned char* ring = smem + wid * RING_BYTES;                    // this wave's private ring
-  unsigned char* xs = smem + WAVES * RING_BYTES;                    // shared x slice [M][xstride]
+  float* otile = reinterpret_cast<float*>(smem + WAVES * RING_BYTES);           // [32][OT_PITCH] partial tile
+  unsigned char* xs = smem + WAVES * RING_BYTES + 32 * OT_PITCH * 4;            // shared x slice [M][xstride]
   const int total = nslab * nb;
 
   // DMA source of this lane: row (lane>>3) of an 8-row group, piece (lane&7) ^ (lane>>3)
@@ -257,12 +259,25 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
       acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16), acc1, 0, 0,
                                                      0);
     }
-    const int n0 = (gx + ct * G) * ROWS + wid * 16;
-    if (n0 + 16 <= N) {
-      float* pp = part + ((int64_t)by * M) * N + n0 + 4 * kq;
-      if (n < M) *reinterpret_cast<float4*>(pp + (int64_t)n * N) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+    // partial tile of the workgroup: [M][ROWS] fp32 through LDS, then full 512-byte rows to HBM
+    // (per-wave 64-byte segments cost ~8 % of the kernel: half-line writes at a 4*N-byte stride)
+    __syncthreads();                                                // previous slab's tile fully stored
+    {
+      float* tp = otile + wid * 16 + 4 * kq;
+      if (n < M) *reinterpret_cast<float4*>(tp + n * OT_PITCH) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
       if (16 + n < M)
-        *reinterpret_cast<float4*>(pp + (int64_t)(16 + n) * N) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+        *reinterpret_cast<float4*>(tp + (16 + n) * OT_PITCH) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+    }
+    __syncthreads();
+    {
+      const int nblk = (gx + ct * G) * ROWS;
+      constexpr int C4 = ROWS / 4;                                  // float4 columns per row
+      for (int e = tid; e < M * C4; e += WAVES * 64) {
+        const int m = e / C4, c4 = e - m * C4;
+        if (nblk + c4 * 4 + 4 <= N)
+          *reinterpret_cast<float4*>(part + ((int64_t)by * M + m) * N + nblk + c4 * 4) =
+              *reinterpret_cast<const float4*>(otile + m * OT_PITCH + c4 * 4);
+      }
     }
     acc0 = (gf32x4_t){0, 0, 0, 0};
     acc1 = (gf32x4_t){0, 0, 0, 0};
@@ -374,7 +389,7 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
     const int wv = dma_cfg / 100, ud = (dma_cfg / 10) % 10, sl = dma_cfg % 10;
     const int rows = wv * 16;
     const int nslab_d = (N + rows - 1) / rows;
-    const size_t ldsd = (size_t)wv * sl * ud * 2048 + lds;
+    const size_t ldsd = (size_t)wv * sl * ud * 2048 + (size_t)32 * (rows + 4) * 4 + lds;
     PSG_REQUIRE(ldsd <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm(dma): %zu B of LDS", ldsd);
     int per_cu = (int)((160 * 1024) / ldsd);              // workgroups per CU that LDS admits
     if (per_cu * wv > 16) per_cu = 16 / wv;               // and at most 16 waves per CU
