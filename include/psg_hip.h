@@ -184,6 +184,17 @@ int psg_greedy_step(psg_ctx*, const void* logits, int splits, int K, int vocab, 
                     int eos, int suppress_token, int32_t* tokens, int32_t* done, int32_t* next_ids,
                     int32_t* tok_pos, int dtype, void* stream);
 
+/* ---- masked-mean object pooling of the v1-v3 detectors
+ * (kings_sgg/models/detectors/openseed_relation.py:453-468):
+ * out[n][c] = sum feat[c][y][x] * m_n[y][x] / (sum m_n + 1e-8), m_n = mask of object_ids[n] in the id
+ * map `pan`, resampled nearest(ori->img) -> zero pad -> nearest(pad->feature resolution) as
+ * :456-461 do (padding belongs to no object).  For disjoint (panoptic) masks every feature element
+ * is read exactly once; deterministic.  workspace: int32, size from psg_masked_mean_pool_workspace. */
+int psg_masked_mean_pool_workspace(psg_ctx*, int C, int Hf, int Wf, int N, int64_t* bytes);
+int psg_masked_mean_pool(psg_ctx*, const float* feat, int C, int Hf, int Wf, const int32_t* pan, int H0,
+                         int W0, int img_h, int img_w, int pad_h, int pad_w, const int32_t* object_ids,
+                         int N, float* out, int32_t* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

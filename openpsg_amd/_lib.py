@@ -49,6 +49,8 @@ SIGNATURES = {
     "psg_skinny_gemm_plan": [_vp, _i, _i, _i, C.POINTER(_i)],
     "psg_skinny_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "psg_reduce_partials": [_vp, _vp, _i, _i64, _vp, _i, _vp],
+    "psg_masked_mean_pool_workspace": [_vp, _i, _i, _i, _i, C.POINTER(_i64)],
+    "psg_masked_mean_pool": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i64, _vp],
     "psg_greedy_step": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
 }
 

@@ -276,3 +276,22 @@ def skinny_gemm(x, w, splits=None) -> Partials:
     check(lib.psg_skinny_gemm(ctx, _p(x, torch.bfloat16, "x"), _p(w, torch.bfloat16, "w"), _p(part), M, N, K, splits,
                               st), "psg_skinny_gemm")
     return Partials(part)
+
+
+def masked_mean_pool(feat, pan, img_hw, pad_hw, object_ids):
+    """Masked-mean object embeddings of the v1-v3 detectors (openseed_relation.py:453-468).
+    feat [1,C,Hf,Wf] fp32, pan [H0,W0] int32 id map, object_ids int32 [N] -> [N, C] fp32."""
+    import ctypes
+    lib, ctx, st = _env(feat)
+    _, Cc, Hf, Wf = feat.shape
+    N = object_ids.numel()
+    nbytes = ctypes.c_int64(0)
+    check(lib.psg_masked_mean_pool_workspace(ctx, Cc, Hf, Wf, N, ctypes.byref(nbytes)),
+          "psg_masked_mean_pool_workspace")
+    ws = torch.empty(nbytes.value // 4, device=feat.device, dtype=torch.int32)
+    out = torch.empty((N, Cc), device=feat.device, dtype=torch.float32)
+    check(lib.psg_masked_mean_pool(ctx, _p(feat, torch.float32), Cc, Hf, Wf, _p(pan, torch.int32, "pan_results"),
+                                   pan.shape[0], pan.shape[1], int(img_hw[0]), int(img_hw[1]), int(pad_hw[0]),
+                                   int(pad_hw[1]), _p(object_ids, torch.int32), N, _p(out), _p(ws), nbytes.value, st),
+          "psg_masked_mean_pool")
+    return out

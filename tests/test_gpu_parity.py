@@ -299,3 +299,28 @@ def test_self_attn_mfma_vs_fp32_reference(B, T, q_only):
         worst = max(worst, (got - o[:n]).abs().max().item())
     print(f"self_attn mfma B={B} T={T} q_only={q_only}: max err {worst:.3e}")
     assert worst < 3e-2
+
+
+@pytest.mark.parametrize("geo", [((1024, 1024), None, None, 50), ((768, 1024), (720, 960), (750, 1000), 12)])
+def test_masked_mean_pool_vs_reference_formula(geo):
+    """SURVEY 8f rank 4 (openseed_relation.py:453-468): (feat*m).sum/(m.sum+1e-8) per object."""
+    import torch.nn.functional as F
+    from openpsg_amd import ops
+    from openpsg_amd.synthetic import make_scene
+    pad, ori, img, N = geo
+    sc = make_scene(pad, N, seed=9, ori_hw=ori, img_hw=img, void_id=0, force_id0=True, tiny_object=True, device="cuda:0")
+    feat, pan, meta = sc["mask_features"], sc["pan_results"], sc["img_meta"]
+    ids = torch.tensor([int(i) for i in sc["object_id_list"]], dtype=torch.int32, device="cuda:0")
+    got = ops.masked_mean_pool(feat, pan, meta["img_shape"][:2], meta["pad_shape"][:2], ids)
+    # the reference's chain on the GPU in fp64: per-object masks -> interpolate(img) -> pad -> interpolate(feat)
+    # (float32 masks, as the reference's `.to(dtype)`: ATen derives the nearest-neighbour scale in the tensor's precision)
+    masks = torch.stack([(pan == i) for i in ids.tolist()]).float()[None]
+    m = F.interpolate(masks, size=meta["img_shape"][:2])
+    m = F.pad(m, (0, meta["pad_shape"][1] - meta["img_shape"][1], 0, meta["pad_shape"][0] - meta["img_shape"][0]))
+    m = F.interpolate(m, size=feat.shape[-2:])[0][:, None].double()
+    want = (feat.double() * m).sum(dim=[2, 3]) / (m.sum(dim=[2, 3]) + 1e-8)
+    err = (got.double() - want).abs().max().item()
+    print(f"masked_mean_pool {pad} N={N}: max err {err:.2e}; empty objects: {int((m.sum(dim=[2,3]) == 0).sum())}")
+    assert err < 1e-4
+    again = ops.masked_mean_pool(feat, pan, meta["img_shape"][:2], meta["pad_shape"][:2], ids)
+    assert torch.equal(got, again)                                  # deterministic

@@ -123,3 +123,19 @@ def decode_attn():
 
 if __name__ == "__main__" and "decode_attn" in sys.argv:
     decode_attn()
+
+
+def pool():
+    from openpsg_amd.synthetic import make_scene
+    dev = torch.device("cuda:0")
+    sc = make_scene((1024, 1024), 50, seed=0, device="cuda:0", void_id=0, force_id0=True)
+    ids = torch.tensor([int(i) for i in sc["object_id_list"]], dtype=torch.int32, device=dev)
+    feat, pan = sc["mask_features"], sc["pan_results"]
+    t, tmin = timeit(lambda: ops.masked_mean_pool(feat, pan, (1024, 1024), (1024, 1024), ids), iters=20)
+    nbytes = feat.numel() * 4
+    print(f"masked_mean_pool 1024^2 N=50: {t:.1f} us (min {tmin:.1f}) incl. mask_grid + index passes; feature map "
+          f"{nbytes / 1e6:.0f} MB -> {nbytes / tmin / 1e3:.0f} GB/s (read-once upper bound on algorithmic bytes)")
+
+
+if __name__ == "__main__" and "pool" in sys.argv:
+    pool()
