@@ -14,7 +14,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6"]
+CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6", "G5_c5geo_1024x1344_n8"]
 
 
 def _dev():
@@ -324,3 +324,23 @@ def test_masked_mean_pool_vs_reference_formula(geo):
     assert err < 1e-4
     again = ops.masked_mean_pool(feat, pan, meta["img_shape"][:2], meta["pad_shape"][:2], ids)
     assert torch.equal(got, again)                                  # deterministic
+
+
+def test_head_state_dict_matches_reference_and_loads_partial_checkpoint():
+    """Drop-in checkpoint contract: same parameter names/shapes as the reference module; a partial
+    checkpoint (no language_model.*, part_checkpoint_hook.py:96-116) loads with strict=False."""
+    import json
+    from openpsg_amd.head import RelationTransformerHeadV4
+    ref = json.load(open(H.GOLDEN + "/reference_state_dict_keys.json"))
+    head = RelationTransformerHeadV4(device="cuda:0", tokenizers="word")          # reference default sizes
+    sd = head.state_dict()
+    assert set(sd) == set(ref)
+    for k, shape in ref.items():
+        assert list(sd[k].shape) == shape, k
+    ckpt = {k: torch.full(tuple(shape), 0.5) for k, shape in ref.items() if not k.startswith("language_projection")}
+    ckpt["some_other.module.weight"] = torch.zeros(3)                              # unexpected keys are ignored
+    res = head.load_state_dict(ckpt, strict=False)
+    assert "language_projection.weight" in res.missing_keys
+    assert float(head.binary_rel_cls_pred.weight[0, 0]) == 0.5
+    with pytest.raises(Exception):
+        head.llm_engine                                                            # LLM weights were never provided

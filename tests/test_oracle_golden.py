@@ -7,7 +7,7 @@ import torch
 from oracle import psg_oracle as O
 from tests import helpers as H
 
-CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6"]
+CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6", "G5_c5geo_1024x1344_n8"]
 
 
 def test_mask_grid_goldens():
@@ -75,3 +75,16 @@ def test_parse_relations():
     assert O.parse_relations("<s> not-a-relation </s>", 13, 10, relation_categories, seen) == []
     with pytest.raises(IndexError):                        # V4:315-316 when no '<s>' was generated
         O.parse_relations("over </s>", 13, 10, relation_categories, seen)
+
+
+def test_schema_matches_reference_state_dict():
+    """The weight schema (openpsg_amd/weights.py) names exactly the tensors the REAL reference module's
+    state_dict() holds (captured by oracle/capture_reference.py), with the same shapes."""
+    import json
+    from openpsg_amd.config import PSGConfig
+    from openpsg_amd.weights import head_shapes
+    ref = json.load(open(H.GOLDEN + "/reference_state_dict_keys.json"))
+    mine = {k: list(v) for k, v in head_shapes(PSGConfig()).items()}
+    assert set(mine) == set(ref), (sorted(set(mine) ^ set(ref)))
+    for k in ref:
+        assert mine[k] == ref[k], (k, mine[k], ref[k])
