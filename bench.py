@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--objects", type=int, default=50)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--llm-layers", type=int, default=32)
+    ap.add_argument("--images-per-step", type=int, default=1,
+                    help="single-GPU throughput mode: images per step whose selected pairs are decoded together")
+    ap.add_argument("--no-batched", action="store_true", help="skip the secondary 3-images-per-step measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -155,6 +158,22 @@ def cpu_baseline(a, scene_cpu):
     return dict(value=round(N * (N - 1) / t_image, 3), unit="pairs/s", cores=cores, kind="port", sample=sample)
 
 
+def scene_inputs(scene):
+    return dict(mask_features=scene["mask_features"], img_metas=[scene["img_meta"]],
+                object_info=[dict(object_id_list=scene["object_id_list"], pan_results=scene["pan_results"])])
+
+
+def time_steps(step, warmup, steps):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,9 +195,14 @@ def main():
 
     if world == 1 and not force_dist:
         scene = make_scene((a.size, a.size), N, seed=0, device=str(dev))
-        inputs = dict(mask_features=scene["mask_features"], img_metas=[scene["img_meta"]],
-                      object_info=[dict(object_id_list=scene["object_id_list"], pan_results=scene["pan_results"])])
-        if a.workload == "full":
+        inputs = scene_inputs(scene)
+        if a.workload == "full" and a.images_per_step > 1:
+            batch = [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev)))
+                     for m in range(a.images_per_step)]
+
+            def step():
+                return head.forward_batch(batch)
+        elif a.workload == "full":
             def step():
                 return head(inputs)
         else:
@@ -218,7 +242,8 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        images = world * a.steps
+        ips = a.images_per_step if (world == 1 and not force_dist and a.workload == "full") else world
+        images = ips * a.steps
         wl = ("C3: 1024x1024, 50 masks, full path incl. LMM autoregressive relation decode (Llama-2-7B shape, top-20 "
               "pairs, 16 new tokens each, EOS suppressed)") if a.workload == "full" else \
              "C2: 1024x1024, 50 masks, relation-query transformer only"
@@ -228,7 +253,7 @@ def main():
             "metric": METRIC, "value": round(images * pairs_per_image / elapsed, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": wl, "objects": N, "pairs_per_image": pairs_per_image, "images_per_step": world,
+            "config": {"workload": wl, "objects": N, "pairs_per_image": pairs_per_image, "images_per_step": ips,
                        "patches": (a.size // 64) ** 2, "llm_layers": a.llm_layers if a.workload == "full" else 0,
                        "parallelism": "single GPU" if world == 1 else f"pairs of every image sharded over {world} ranks"},
         }
@@ -243,6 +268,19 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                 "traffic": traffic, "bytes_per_launch": int(bpl),
                                 "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n}
+        if (not a.no_batched and a.workload == "full" and world == 1 and not force_dist
+                and a.images_per_step == 1):
+            # secondary figure, not `value`: the same images, three per step, their 60 selected pairs decoded
+            # together so the Llama weights stream once per decode step for all three (head.forward_batch)
+            try:
+                B3 = 3
+                batch = [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev))) for m in range(B3)]
+                k = max(2, min(a.steps, 5))
+                el = time_steps(lambda: head.forward_batch(batch), 1, k)
+                line["batched_decode"] = {"images_per_step": B3, "value": round(B3 * k * pairs_per_image / el, 1),
+                                          "unit": "pairs/s", "ms_per_step": round(el / k * 1e3, 3), "steps": k}
+            except Exception as exc:                                   # never lose the headline line
+                line["batched_decode"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         if not a.no_cpu_baseline and world == 1 and not force_dist:
             scene_cpu = make_scene((a.size, a.size), N, seed=0)
             line["cpu_baseline"] = cpu_baseline(a, scene_cpu)

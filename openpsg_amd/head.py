@@ -222,21 +222,24 @@ class RelationTransformerHeadV4(nn.Module):
 
     # ---- forward ---------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, inputs, is_generation=None):
-        if self.training:
-            raise NotImplementedError("training branch (V4:114-133, 360-406) is out of scope of this build")
+    def _unpack(self, inputs):
         feat = inputs['mask_features']
         meta = inputs['img_metas'][0]
         assert feat.shape[0] == 1, 'only support batch size 1 for now.'                    # V4:112
         if not feat.is_cuda:
             raise PsgHipError("mask_features must live in HBM; this head has no CPU path")
         info = inputs['object_info'][0]
-        object_id_list = info['object_id_list'][:self.max_object_num]                      # V4:136
-        N = len(object_id_list)
+        obj_ids = [int(x) for x in info['object_id_list'][:self.max_object_num]]           # V4:136
+        names = [object_categories[i % INSTANCE_OFFSET] for i in obj_ids]                  # V4:138-139
+        return feat, meta, info, obj_ids, names
+
+    def forward(self, inputs, is_generation=None):
+        if self.training:
+            raise NotImplementedError("training branch (V4:114-133, 360-406) is out of scope of this build")
+        feat, meta, info, obj_ids, names = self._unpack(inputs)
+        N = len(obj_ids)
         if N == 0:
             return dict(rel_pred=[], rel_score=[])
-        obj_ids = [int(x) for x in object_id_list]
-        names = [object_categories[i % INSTANCE_OFFSET] for i in obj_ids]                  # V4:138-139
         rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
         if is_generation is None:
             is_generation = True
@@ -244,6 +247,45 @@ class RelationTransformerHeadV4(nn.Module):
         self.last = dict(rq, **out)
         rel_pred, rel_score = self.parse(out["tokens_host"], out["selected_host"], N) if is_generation else ([], [])
         return dict(rel_pred=rel_pred, rel_score=rel_score)
+
+    def forward_batch(self, batch):
+        """Throughput mode for several images (the reference handles one image per call, V4:112): the
+        relation query runs per image, then the selected pairs of ALL images are decoded in one batched
+        greedy decode, so the Llama weights stream from HBM once per step for the whole batch instead
+        of once per image.  Per-image results are those of forward() up to the rounding of the
+        projection GEMMs, which see a different row count (library GEMM above 32 rows)."""
+        if self.training:
+            raise NotImplementedError("training branch (V4:114-133, 360-406) is out of scope of this build")
+        items, results = [], [None] * len(batch)
+        for i, inputs in enumerate(batch):
+            feat, meta, info, obj_ids, names = self._unpack(inputs)
+            if not obj_ids:
+                results[i] = dict(rel_pred=[], rel_score=[])
+                continue
+            rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
+            X, plen = self.llm_inputs(rq, names)
+            items.append((i, len(obj_ids), rq["selected"], X, plen))
+        if not items:
+            return results
+        maxlen = max(it[3].shape[1] for it in items)
+        Xs = []
+        for _, _, _, X, _ in items:                                  # rows past a pair's length are never read
+            if X.shape[1] < maxlen:
+                X = torch.cat([X, X.new_zeros((X.shape[0], maxlen - X.shape[1], X.shape[2]))], dim=1)
+            Xs.append(X)
+        tokens = self.llm_engine.generate(torch.cat(Xs), torch.cat([it[4] for it in items]),
+                                          suppress_eos=self.suppress_eos)
+        tokens_host = tokens.cpu().numpy()
+        k0 = 0
+        self.last_batch = []
+        for i, N, sel, X, _ in items:
+            k1 = k0 + X.shape[0]
+            sel_host = sel.cpu().numpy()
+            rel_pred, rel_score = self.parse(tokens_host[k0:k1], sel_host, N)
+            results[i] = dict(rel_pred=rel_pred, rel_score=rel_score)
+            self.last_batch.append(dict(tokens_host=tokens_host[k0:k1], selected_host=sel_host))
+            k0 = k1
+        return results
 
     def run_relation_query(self, feat, meta, obj_ids, names, pan, pair_range=None, patches=None):
         """A4-A8 on the GPU.  pair_range=(p0,p1) restricts the Q-Former to a shard of the pairs;
@@ -312,9 +354,10 @@ class RelationTransformerHeadV4(nn.Module):
         k = max(1, min(cap, max(n_hit, min(self.max_llm_forward_num, B))))
         return order[:k].contiguous()
 
-    def decode_selected(self, rq, names, selected=None, pair_features=None, to_host=True):
-        """A9: batched greedy decode of the selected pairs.  `pair_features` [K*32, 768] replaces the
-        gather from rq["hidden"] (pair sharding: the features arrive by reduce-scatter)."""
+    def llm_inputs(self, rq, names, selected=None, pair_features=None):
+        """V4:240-301: LLM input embeddings X [K, 32+Tp, D] and prompt lengths [K] of the selected pairs.
+        `pair_features` [K*32, 768] replaces the gather from rq["hidden"] (pair sharding: the features
+        arrive by reduce-scatter)."""
         dev = self.device
         N = rq["num_objects"]
         sel = rq["selected"] if selected is None else selected
@@ -347,9 +390,14 @@ class RelationTransformerHeadV4(nn.Module):
         s64 = sel.to(torch.int64)
         trow = u_d[s64 // N] * U + u_d[s64 % N]
         pids, plen = tbl_d[trow].contiguous(), lens_d[trow].contiguous()
-        eng = self.llm_engine
-        X = eng.build_inputs(pf, pids, plen)
-        tokens, first_logits = eng.generate(X, plen, suppress_eos=self.suppress_eos, return_first_logits=True)
+        return self.llm_engine.build_inputs(pf, pids, plen), plen
+
+    def decode_selected(self, rq, names, selected=None, pair_features=None, to_host=True):
+        """A9: batched greedy decode of the selected pairs."""
+        sel = rq["selected"] if selected is None else selected
+        X, plen = self.llm_inputs(rq, names, selected, pair_features)
+        tokens, first_logits = self.llm_engine.generate(X, plen, suppress_eos=self.suppress_eos,
+                                                        return_first_logits=True)
         out = dict(tokens=tokens, first_logits=first_logits, llm_inputs=X, prompt_len=plen)
         if to_host:
             out["tokens_host"], out["selected_host"] = tokens.cpu().numpy(), sel.cpu().numpy()

@@ -66,6 +66,51 @@ def test_object_permutation_equivariance(setup):
     assert err < 5e-2
 
 
+def _inputs(scene):
+    return dict(mask_features=scene["mask_features"], img_metas=[scene["img_meta"]],
+                object_info=[dict(object_id_list=scene["object_id_list"], pan_results=scene["pan_results"])])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_forward_batch_matches_per_image(setup, dtype):
+    """Several images decoded together (60 LLM rows per step) give each image the triplets of its own
+    forward() call; images of different object counts and prompt lengths share one batch."""
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_device
+    if dtype == "bf16":
+        head = setup[0]
+    else:
+        cfg = PSGConfig(qformer=QFormerConfig(vocab=30522), llm=tiny_llm(512, 2, 1024, 512), max_object_num=50)
+        head = RelationTransformerHeadV4(dtype="fp32", device="cuda:0", llm_config=cfg.llm, llm_feature_size=512,
+                                         tokenizers="word", max_object_num=50, on_parse_error="skip",
+                                         suppress_eos=True)
+        head.load_weights(make_weights_device(cfg, 7, torch.device("cuda:0"), llm_dtype=torch.float32))
+    scenes = [make_scene((1024, 1024), 50, seed=3, device="cuda:0", tiny_object=True),
+              make_scene((512, 768), 12, seed=4, device="cuda:0"),
+              make_scene((1024, 1024), 30, seed=5, device="cuda:0")]
+    single, toks = [], []
+    for sc in scenes:
+        single.append(head(_inputs(sc)))
+        toks.append(head.last["tokens_host"].copy())
+    batched = head.forward_batch([_inputs(sc) for sc in scenes] + [dict(
+        mask_features=scenes[0]["mask_features"], img_metas=[scenes[0]["img_meta"]],
+        object_info=[dict(object_id_list=[], pan_results=scenes[0]["pan_results"])])])
+    assert batched[3] == dict(rel_pred=[], rel_score=[])               # an image without objects
+    same = total = 0
+    for i in range(3):
+        got = head.last_batch[i]["tokens_host"]
+        assert got.shape == toks[i].shape
+        same += int((got == toks[i]).sum())
+        total += got.size
+    print(f"{dtype}: {same}/{total} generated tokens identical between forward_batch and forward")
+    if dtype == "fp32":
+        assert same == total and all(batched[i] == single[i] for i in range(3))
+    else:
+        assert same >= 0.9 * total                                     # bf16 GEMM rounding differs with the row count
+
+
 def test_rccl_pipeline_world1_matches_head(setup):
     import torch.distributed as dist
     from openpsg_amd.dist import PairShardedPipeline
