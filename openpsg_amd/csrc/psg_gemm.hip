@@ -180,7 +180,7 @@ struct SgdWait<UD, 0> {
   static __device__ __forceinline__ void go(int) { sgd_wait<0>(); }
 };
 
-template <int WAVES, int UD, int SGD_SLOTS>
+template <int WAVES, int UD, int SGD_SLOTS, int AUX>
 __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint16_t* __restrict__ x,
                                                                      const uint16_t* __restrict__ w,
                                                                      float* __restrict__ part, int M, int N, int K,
@@ -218,9 +218,9 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
 #pragma unroll
     for (int u = 0; u < UD; ++u) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 64),
-                                       (__attribute__((address_space(3))) void*)(dst + u * 2048), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + u * 2048), 16, 0, AUX);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 64 + (int64_t)8 * K),
-                                       (__attribute__((address_space(3))) void*)(dst + u * 2048 + 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + u * 2048 + 1024), 16, 0, AUX);
     }
     ++lj;
     if (++lb == nb) { lb = 0; ++lt; }
@@ -399,12 +399,23 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
     if (Gd < 1) Gd = 1;
     dim3 gridd(Gd, splits);
     hipStream_t st = (hipStream_t)stream;
-#define SGD(WV, UD, SL)                                                                                             \
-  do {                                                                                                              \
-    hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<WV, UD, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        160 * 1024);                                                                                \
-    skinny_gemm_dma_kernel<WV, UD, SL><<<gridd, WV * 64, ldsd, st>>>((const uint16_t*)x, (const uint16_t*)w, part, \
-                                                                     M, N, K, xstride);                             \
+    // weights are read once by one CU: non-temporal (aux = 2) DMA loads; PSG_SKINNY_NT=0 = default policy
+    static int nt = -1;
+    if (nt < 0) {
+      const char* e = getenv("PSG_SKINNY_NT");
+      nt = e ? atoi(e) : 1;
+    }
+#define SGD_L(WV, UD, SL, AUX)                                                                                     \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<WV, UD, SL, AUX>,                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+    skinny_gemm_dma_kernel<WV, UD, SL, AUX><<<gridd, WV * 64, ldsd, st>>>((const uint16_t*)x, (const uint16_t*)w, \
+                                                                          part, M, N, K, xstride);                 \
+  } while (0)
+#define SGD(WV, UD, SL)                                                                                            \
+  do {                                                                                                             \
+    if (nt) SGD_L(WV, UD, SL, 2);                                                                                  \
+    else SGD_L(WV, UD, SL, 0);                                                                                     \
   } while (0)
     if (wv == 8 && ud == 1 && sl == 3) SGD(8, 1, 3);
     else if (wv == 8 && ud == 1 && sl == 5) SGD(8, 1, 5);
@@ -418,6 +429,7 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
       return PSG_ERR_INVALID;
     }
 #undef SGD
+#undef SGD_L
     PSG_CHECK_LAUNCH("psg_skinny_gemm(dma)");
     return PSG_OK;
   }
