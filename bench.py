@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--llm-layers", type=int, default=32)
     ap.add_argument("--images-per-step", type=int, default=1,
                     help="single-GPU throughput mode: images per step whose selected pairs are decoded together")
-    ap.add_argument("--no-batched", action="store_true", help="skip the secondary 3-images-per-step measurement")
+    ap.add_argument("--no-batched", action="store_true", help="skip the secondary 4-images-per-step measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -88,16 +88,27 @@ def measure_decode_gemm(head, K):
             ops.skinny_gemm(x, w)
     run()
     torch.cuda.synchronize()
-    best = None
-    for _ in range(5):
+    ts = []
+    for _ in range(7):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         run()
         e.record()
         torch.cuda.synchronize()
-        t = s.elapsed_time(e) / 1e3
-        best = t if best is None else min(best, t)
-    return nbytes / len(mats), best / len(mats), len(mats)
+        ts.append(s.elapsed_time(e) / 1e3)
+    ts.sort()
+    return nbytes / len(mats), ts[len(ts) // 2] / len(mats), len(mats)      # median pass, averaged over its launches
+
+
+def relation_query_flops(N, L, T):
+    """Algorithmic FLOPs of the relation-query stage for one image, SURVEY 8d's per-layer formula with the
+    work whose result is never read left out (the reference slices the output to the 33 query rows, V4:185:
+    in the last layer the text rows need K/V only).  Plus the per-image patch embedding and shared K/V."""
+    S, H, F = 33 + T, 768, 3072
+    cross = 2 * 33 * H * H + 4 * 33 * L * H + 2 * 33 * H * H
+    first = 2 * S * H * 3 * H + 4 * S * S * H + 2 * S * H * H + cross + 4 * 33 * H * F + 4 * T * H * F
+    last = 2 * S * H * 2 * H + 2 * 33 * H * H + 4 * 33 * S * H + 2 * 33 * H * H + cross + 4 * 33 * H * F
+    return N * N * (first + last) + 2 * L * 65536 * 256 + 2 * 2 * 2 * L * 256 * H
 
 
 def cpu_baseline(a, scene_cpu):
@@ -268,12 +279,35 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                 "traffic": traffic, "bytes_per_launch": int(bpl),
                                 "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n}
+        if a.workload == "rq" and not a.no_roofline and world == 1 and not force_dist:
+            T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
+            fl = relation_query_flops(N, (a.size // 64) ** 2, T)
+            ach = fl / (elapsed / a.steps) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": "relation-query stage (bf16 GEMMs + cross_attn_mfma_kernel + "
+                                "self_attn_mfma_kernel)", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                "frac": round(ach / 2500.0, 4), "traffic": None, "flops_per_step": int(fl)}
+        if world == 1 and not force_dist and a.images_per_step == 1 and a.workload == "full":
+            # stage split (not part of the contract): relation-query stage alone, against the dense bf16 MFMA peak
+            from openpsg_amd.categories import INSTANCE_OFFSET, object_categories
+            ids_ = [int(i) for i in scene["object_id_list"]]
+            names_ = [object_categories[i % INSTANCE_OFFSET] for i in ids_]
+
+            def rq_step():
+                return head.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_,
+                                               scene["pan_results"])["selected"].cpu()
+            el = time_steps(rq_step, 2, 10) / 10
+            T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
+            fl = relation_query_flops(N, (a.size // 64) ** 2, T)
+            line["stages"] = {"relation_query_ms": round(el * 1e3, 3),
+                              "relation_query_pairs_per_s": round(pairs_per_image / el, 1),
+                              "relation_query_tflops": round(fl / el / 1e12, 1),
+                              "relation_query_mfma_frac": round(fl / el / 2.5e15, 4), "prompt_tokens": T}
         if (not a.no_batched and a.workload == "full" and world == 1 and not force_dist
                 and a.images_per_step == 1):
-            # secondary figure, not `value`: the same images, three per step, their 60 selected pairs decoded
-            # together so the Llama weights stream once per decode step for all three (head.forward_batch)
+            # secondary figure, not `value`: four such images per step, their 80 selected pairs decoded together
+            # so the Llama weights stream once per decode step for all of them (head.forward_batch)
             try:
-                B3 = 3
+                B3 = 4
                 batch = [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev))) for m in range(B3)]
                 k = max(2, min(a.steps, 5))
                 el = time_steps(lambda: head.forward_batch(batch), 1, k)

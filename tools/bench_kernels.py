@@ -85,12 +85,42 @@ def xattn(N=50, L=256):
           f"{flops / t / 1e6:.1f} dense-equivalent TFLOP/s ({flops / t / 1e6 / 2500 * 100:.1f}% of 2.5 PF dense bf16)")
 
 
+def mall():
+    """Does the skinny GEMM run faster when part of its weights was pulled into L2 / Infinity Cache just
+    before?  (decides whether the small kernels between the GEMMs should carry prefetch blocks)"""
+    dev = torch.device("cuda:0")
+    M = 20
+    for name, N, K in [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)]:
+        x = torch.randn(M, K, device=dev).bfloat16()
+        ncopy = max(2, int(800e6 / (N * K * 2)) + 1)
+        ws = [(torch.randn(N, K, device=dev) / K ** 0.5).bfloat16() for _ in range(ncopy)]
+        for frac in (0.0, 0.1, 0.25, 0.5, 1.0):
+            ts = []
+            for it in range(40):
+                w = ws[it % ncopy]
+                flat = w.view(-1).view(torch.int32)
+                n = int(flat.numel() * frac)
+                if n:
+                    flat[:n].sum()                                  # touch: reads the first `frac` of the weights
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                ops.skinny_gemm(x, w)
+                e.record()
+                torch.cuda.synchronize()
+                ts.append(s.elapsed_time(e) * 1e3)
+            ts.sort()
+            print(f"mall {name:8s} prefetched {frac:4.2f} ({N * K * 2 * frac / 1e6:6.1f} MB): "
+                  f"gemm {ts[len(ts) // 2]:6.1f} us (min {ts[0]:6.1f})", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["skinny", "xattn"])
     a = ap.parse_args()
     if "skinny" in a.what:
         skinny(20)
+    if "mall" in a.what:
+        mall()
     if "xattn" in a.what:
         xattn(50, 256)
         if "only50" not in a.what:
