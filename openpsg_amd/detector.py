@@ -109,12 +109,26 @@ class OpenSeeDRelationV2(nn.Module):
         """DET2:170-190."""
         results, mask_features = self.forward_openseed(imgs, img_metas, mode='test')
         head_out = self.relation_head(dict(mask_features=mask_features, img_metas=img_metas, object_info=results))
-        res = results[0]
+        return [self._pack(results[0], head_out)]
+
+    @staticmethod
+    def _pack(res, head_out):
+        """DET2:183-188."""
         res['pan_results'] = res['pan_results'].detach().cpu().numpy()
         res['rel_results'] = dict(object_id_list=[oid.item() for oid in res['object_id_list']],
                                   relation=head_out['rel_pred'])
         res['rel_scores'] = head_out['rel_score']
-        return [res]
+        return res
+
+    @torch.no_grad()
+    def simple_test_batch(self, imgs_list, img_metas_list, **kwargs):
+        """Throughput mode: simple_test for several images whose selected pairs are decoded together
+        (RelationTransformerHeadV4.forward_batch).  One entry per image, each as simple_test takes it."""
+        segs = [self.forward_openseed(imgs, metas, mode='test') for imgs, metas in zip(imgs_list, img_metas_list)]
+        outs = self.relation_head.forward_batch(
+            [dict(mask_features=feat, img_metas=metas, object_info=results)
+             for (results, feat), metas in zip(segs, img_metas_list)])
+        return [[self._pack(results[0], out)] for (results, _), out in zip(segs, outs)]
 
     def forward(self, img=None, img_metas=None, return_loss=False, **kwargs):
         if return_loss:

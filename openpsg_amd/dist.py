@@ -32,6 +32,33 @@ def shard_range(num_pairs: int, world: int, rank: int):
     return p0, min(num_pairs, p0 + shard), shard
 
 
+def shard_images(num_images: int, world: int, rank: int):
+    """SURVEY 8e "replicas-only parts": whole images are dealt round-robin to ranks (C5)."""
+    return list(range(rank, num_images, world))
+
+
+def gather_image_results(indexed_results, num_images: int, group=None):
+    """Every rank hands in [(image index, result)] for its share; every rank gets the full list in
+    image order.  Results are host objects (numpy maps, python lists), so this is an object gather."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        parts = [indexed_results]
+    else:
+        parts = [None] * world
+        dist.all_gather_object(parts, indexed_results, group=group)
+    out = [None] * num_images
+    for part in parts:
+        for idx, res in part:
+            if out[idx] is not None:
+                raise RuntimeError(f"image {idx} was processed by two ranks")
+            out[idx] = res
+    missing = [i for i, r in enumerate(out) if r is None]
+    if missing:
+        raise RuntimeError(f"images {missing} were processed by no rank")
+    return out
+
+
 class HipBackend:
     """Adapter from the pipeline's five compute calls to `RelationTransformerHeadV4` on one GPU."""
 

@@ -119,3 +119,40 @@ def test_shard_range_covers_all_pairs():
                 assert p1 - p0 <= shard
                 seen += list(range(p0, p1))
             assert seen == list(range(B))
+
+
+def _image_worker(rank, world, port, n_img, ret):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from openpsg_amd.dist import gather_image_results, shard_images
+    mine = shard_images(n_img, world, rank)
+    local = [(i, dict(pan_results=np.full((2, 2), i), rel_results=dict(relation=[[i, i + 1, rank]]))) for i in mine]
+    full = gather_image_results(local, n_img)
+    ok = len(full) == n_img
+    for i, r in enumerate(full):
+        ok &= int(r["pan_results"][0, 0]) == i and r["rel_results"]["relation"] == [[i, i + 1, i % world]]
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_img", [8, 5, 1])       # even deal, uneven deal, fewer images than ranks
+def test_image_sharding_world2_gloo(n_img):
+    """C5: whole images dealt round-robin to the ranks; every rank gets all results back in image order."""
+    world = 2
+    port = 31500 + os.getpid() % 2000 + n_img
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_image_worker, args=(world, port, n_img, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_gather_image_results_rejects_gaps_and_duplicates():
+    from openpsg_amd.dist import gather_image_results, shard_images
+    assert shard_images(5, 2, 0) == [0, 2, 4] and shard_images(5, 2, 1) == [1, 3] and shard_images(1, 2, 1) == []
+    assert gather_image_results([(1, "b"), (0, "a")], 2) == ["a", "b"]
+    with pytest.raises(RuntimeError):
+        gather_image_results([(0, "a")], 2)
+    with pytest.raises(RuntimeError):
+        gather_image_results([(0, "a"), (0, "b")], 1)

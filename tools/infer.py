@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--llm-layers", type=int, default=2)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--selector", choices=["topk", "threshold"], default="topk")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="images per head call; > 1 decodes their selected pairs together (throughput mode)")
     ap.add_argument("--checkpoint", help="reference-style partial checkpoint (state_dict with relation_head.* keys)")
     a = ap.parse_args()
 
@@ -39,10 +41,18 @@ def main():
     from openpsg_amd.head import RelationTransformerHeadV4
     from openpsg_amd.results import write_submission
     from openpsg_amd.weights import make_weights_device
-    dev = torch.device("cuda:0")
+    # one process per GPU (torch.distributed.run): whole images are dealt round-robin to the ranks
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")                       # host objects only; no device collective on this path
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
     llm = LlamaConfig(layers=a.llm_layers)
     cfg = PSGConfig(qformer=QFormerConfig(), llm=llm, max_object_num=a.objects)
-    head = RelationTransformerHeadV4(dtype=a.dtype, device="cuda:0", tokenizers="word", max_object_num=a.objects,
+    head = RelationTransformerHeadV4(dtype=a.dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
                                      llm_config=llm, on_parse_error="skip", pair_selector=a.selector)
     head.load_weights(make_weights_device(cfg, 0, dev))
     if a.checkpoint:
@@ -58,15 +68,27 @@ def main():
         names = [l.strip() for l in open(a.list) if l.strip()]
     pad = tuple(a.size)
     ori = tuple(a.ori_size) if a.ori_size else pad
-    results, t0 = [], time.time()
-    for name in names:
-        meta = dict(filename=name, ori_shape=ori + (3,), img_shape=pad + (3,), pad_shape=pad + (3,))
-        results.append(det.simple_test(None, [meta])[0])
+    from openpsg_amd.dist import gather_image_results, shard_images
+    mine = shard_images(len(names), world, rank)
+    metas = {i: dict(filename=names[i], ori_shape=ori + (3,), img_shape=pad + (3,), pad_shape=pad + (3,)) for i in mine}
+    local_results, t0 = [], time.time()
+    for b0 in range(0, len(mine), a.batch):
+        idx = mine[b0:b0 + a.batch]
+        if a.batch == 1:
+            outs = [det.simple_test(None, [metas[idx[0]]])]
+        else:
+            outs = det.simple_test_batch([None] * len(idx), [[metas[i]] for i in idx])
+        local_results += [(i, o[0]) for i, o in zip(idx, outs)]
     torch.cuda.synchronize()
     dt = time.time() - t0
-    path = write_submission(results, a.out)
-    n_rel = sum(len(r["rel_results"]["relation"]) for r in results)
-    print(f"{len(names)} images in {dt:.2f}s ({len(names) / dt:.2f} img/s), {n_rel} relations -> {path}")
+    results = gather_image_results(local_results, len(names))
+    if rank == 0:
+        path = write_submission(results, a.out)
+        n_rel = sum(len(r["rel_results"]["relation"]) for r in results)
+        print(f"{len(names)} images on {world} GPU(s) in {dt:.2f}s ({len(names) / dt:.2f} img/s), {n_rel} relations "
+              f"-> {path}")
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
