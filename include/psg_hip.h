@@ -105,8 +105,7 @@ int psg_qformer_self_attn(psg_ctx*, const void* qkv, const uint8_t* text_mask, i
  * V4:168-170 expand removed: K/V [L][hidden] are projected ONCE per image and shared by every
  * pair; the pair mask is bits[i] | bits[j] (pair_index[p] = i*N + j) applied on the fly.
  * q / out [P*nq][hidden]; scores = q.k/sqrt(64) + mask; fp32 softmax; all-masked => uniform.
- * work_counters: int32[heads] of caller memory (MFMA variant: per-head work queue, zeroed by the
- * library on `stream` before the launch); may be NULL for PSG_XATTN_SIMPLE. */
+ * work_counters: reserved (an earlier revision kept a per-head work queue there); may be NULL. */
 int psg_qformer_cross_attn(psg_ctx*, const void* q, const void* k, const void* v,
                            const uint64_t* bits, int words, const int32_t* pair_index, int N, int P,
                            int L, int nq, int heads, int empty_policy, int variant, void* out,

@@ -26,6 +26,11 @@
 // Mask semantics: masked key => score + finfo.min (== finfo.min in
 // fp32) so an all-masked row is a UNIFORM softmax over the L real keys; keys in [L, Lpad) are
 // padding and get -inf (weight exactly 0 in every case).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
 #include "psg_common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -58,36 +63,24 @@ __global__ void __launch_bounds__(256, 2)
 cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                        const uint64_t* __restrict__ bits, int words, const int32_t* __restrict__ pair_index, int N,
                        int64_t R, int L, int nq, int heads, int policy, int* __restrict__ counters,
-                       uint16_t* __restrict__ out) {
+                       uint16_t* __restrict__ out, long long* __restrict__ trace) {
+  // trace != nullptr (PSG_XATTN_TRACE=<file>, debugging only): 32 timestamps per wave
+  long long* tr = trace ? trace + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 : nullptr;
+  if (tr && (threadIdx.x & 63) == 0) tr[0] = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Lpad = (L + 31) & ~31;
   const int NT = Lpad >> 5;
   const int VS = Lpad * 2 + 16;  // bytes per V^T row in LDS
   unsigned char* k_lds = smem;
   unsigned char* vt_lds = smem + (size_t)Lpad * XA_KSTRIDE;
+  unsigned char* mean_lds = vt_lds + (size_t)64 * VS;   // 64 floats: mean of V_h over the L keys
+  uint64_t* bits_lds = reinterpret_cast<uint64_t*>(mean_lds + 256);   // object bit rows [N][words]
   const int h = blockIdx.x % heads;
   const int g = blockIdx.x / heads;
   const int G = gridDim.x / heads;
   const int hidden = heads * 64;
   const int tid = threadIdx.x;
 
-  // ---- stage K_h and V_h^T (once per workgroup) ----
-  for (int e = tid; e < Lpad * 8; e += 256) {
-    const int key = e >> 3, c = e & 7;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-    if (key < L) {
-      kv = *reinterpret_cast<const uint4*>(k + (int64_t)key * hidden + h * 64 + c * 8);
-      vv = *reinterpret_cast<const uint4*>(v + (int64_t)key * hidden + h * 64 + c * 8);
-    }
-    *reinterpret_cast<uint4*>(k_lds + key * XA_KSTRIDE + c * 16) = kv;
-    const int o = key & 15;
-    const int pos = (o & 3) | ((o & 8) >> 1) | ((o & 4) << 1);  // swap bits 2 <-> 3
-    const int kcol = ((key & ~15) | pos) * 2;
-    const uint16_t* ve = reinterpret_cast<const uint16_t*>(&vv);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) *reinterpret_cast<uint16_t*>(vt_lds + (c * 8 + d) * VS + kcol) = ve[d];
-  }
-  __syncthreads();
 
   const int lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -96,149 +89,219 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
   // the cls rows (row 0) of 32 consecutive pairs.  Other nq: flat 32-row tiles.
   const bool aligned = nq == 33;
   const int64_t P = R / nq;
-  const int64_t ntile = aligned ? P + ((P + 31) >> 5) : (R + 31) >> 5;
-  const float C = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
-  const uint32_t bias_bits = policy == PSG_EMPTY_UNIFORM ? 0xff7fffffu /* finfo.min */
-                                                         : __float_as_uint(-10000.0f * 1.4426950408889634f);
+  const int64_t NCLS = aligned ? (P + 31) >> 5 : 0;
+  const int64_t ntile = aligned ? P + NCLS : (R + 31) >> 5;
   const unsigned char* kfrag_base = k_lds + l31 * XA_KSTRIDE + hi * 16;
   const unsigned char* vfrag_base = vt_lds + l31 * VS + hi * 16;
 
-  // One unit of work = (row tile, head h).  Its operands (Q fragments, the rows' pair-mask words) sit
-  // behind a chain of dependent global loads (pair_index -> bits -> words); with most key tiles skipped
-  // a unit is short, so the NEXT unit's operands are fetched while the current one is computed.
+  // One unit of work = (row tile, head h).  Its operands sit behind a chain of dependent global loads
+  // (pair_index -> object bit rows -> mask words); most key tiles are skipped, so a unit is short (~1 us)
+  // and that chain must be off the critical path.  Three units are in flight: unit A is computed while
+  // the Q fragments and mask words of unit B are loading (its pair id arrived during the previous unit)
+  // and the pair id of unit C is loading.  Nothing in a fetch waits on a load issued in the same step.
   struct XUnit {
     bf16x8_t qf[4];
-    uint64_t mw[2 * NC];
+    int pidx;                          // pair id p = i * N + j of this lane's row
     int64_t row;
     bool rvalid;
   };
-  auto fetch = [&](int64_t tile, XUnit& u) {
+  // Queue order (nq == 33): the NCLS tiles that batch the cls rows (row 0) of 32 consecutive pairs come
+  // FIRST - they carry per-row masks and need most key tiles, ~5x the cost of a pair tile; then tile
+  // NCLS + p = rows 1..32 of pair p.
+  auto unit_rows = [&](int64_t tile, int64_t& row, bool& rvalid, int64_t& pair) {
     if (aligned) {
-      if (tile < P) {
-        u.row = tile * 33 + 1 + l31;
-        u.rvalid = true;
+      if (tile >= NCLS) {
+        pair = tile - NCLS;
+        row = pair * 33 + 1 + l31;
+        rvalid = true;
       } else {
-        const int64_t pr = (tile - P) * 32 + l31;
-        u.rvalid = pr < P;
-        u.row = (u.rvalid ? pr : P - 1) * 33;
+        const int64_t pr = tile * 32 + l31;
+        rvalid = pr < P;
+        pair = rvalid ? pr : P - 1;
+        row = pair * 33;
       }
     } else {
-      u.row = tile * 32 + l31;
-      u.rvalid = u.row < R;
-      if (!u.rvalid) u.row = R - 1;
+      row = tile * 32 + l31;
+      rvalid = row < R;
+      if (!rvalid) row = R - 1;
+      pair = row / nq;
     }
+  };
+  // A fetch only ISSUES loads (Q fragments and the pair id); the object bit rows live in LDS, so nothing
+  // in the unit's operand chain depends on another global load.
+  auto fetch = [&](int64_t tile, XUnit& u) {
+    int64_t pair;
+    unit_rows(tile, u.row, u.rvalid, pair);
     // Q fragments: B operand of S^T = K.Q^T; lane (q = lane&31, hi) holds Q[q][16 s + 8 hi .. +7]
     const uint16_t* qp = q + u.row * hidden + h * 64 + hi * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) u.qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16);
-    const int pidx = pair_index[u.row / nq];
-    const uint64_t* bi = bits + (int64_t)(pidx / N) * words;
-    const uint64_t* bj = bits + (int64_t)(pidx % N) * words;
-#pragma unroll
-    for (int w = 0; w < 2 * NC; ++w) u.mw[w] = w < words ? (bi[w] | bj[w]) : 0ull;
+    u.pidx = pair_index[pair];
   };
-  // Dynamic distribution: unit costs differ by 5x (a pair with an empty mask union needs every key
-  // tile, most pairs need one or two), and a static split left the slowest wave at 2x the mean.
-  // Waves of the workgroups that own head h pull batches of XA_GRAB tiles from counters[h]
-  // (zeroed by the launcher on the same stream); one returning atomic per batch.
-  int64_t qbase = 0;
-  int qk = XA_GRAB;
+  const float rcpN = 1.0f / (float)N;
+  // Static round-robin distribution over the waves that own head h (wave w of G*4 takes tiles w, w + 4G, ...).
+  // The expensive cls tiles come first in the order, so every wave gets at most one or two of them, and a
+  // pair with an empty mask union costs less than an average pair (mean-of-V shortcut), so the remaining
+  // cost spread averages out over the ~15 units of a wave.  (A global atomic work queue was measured here:
+  // 2048 waves x 2 returning atomics on 12 words cost 44 us of start-up plus a round trip every 4 units.)
+  const int64_t wstride = (int64_t)G * 4;
+  int64_t wnext = (int64_t)g * 4 + wid;
   auto next_tile = [&]() -> int64_t {
-    if (qk == XA_GRAB) {
-      int b = 0;
-      if (lane == 0) b = atomicAdd(counters + h, XA_GRAB);
-      qbase = __builtin_amdgcn_readfirstlane(b);
-      qk = 0;
-    }
-    return qbase + qk++;
+    const int64_t t = wnext;
+    wnext += wstride;
+    return t;
   };
-  XUnit cur, nxt;
-  int64_t tile = next_tile();
-  if (tile < ntile) fetch(tile, cur);
-  while (tile < ntile) {
-    const int64_t tile_next = next_tile();
-    if (tile_next < ntile) fetch(tile_next, nxt);
+  // B operand of the mask-bias MFMA: B'[k = 0][row] = 1 for every row, all other k-slots 0
+  union {
+    uint32_t u[4];
+    bf16x8_t v;
+  } b_one;
+  b_one.u[0] = hi ? 0u : 0x3f80u;
+  b_one.u[1] = b_one.u[2] = b_one.u[3] = 0u;
+  const float C8 = 0.125f * 1.4426950408889634f;
+  const float bias_raw = policy == PSG_EMPTY_UNIFORM ? -3.4028234663852886e38f : -80000.0f;  // generic path, pre-scale
+
+  // One unit = (row tile, head).  Two code paths:
+  //  AL (nq == 33, tile < P): the 32 rows are rows 1..32 of ONE pair and share its mask, so the mask words
+  //     are wave-uniform (scalar tile skipping) and the additive mask is applied by the matrix core: one
+  //     extra MFMA per key tile adds A'[key][0] * B'[0][row] = bias(key) * 1 to S^T, which replaces three
+  //     VALU instructions per score.  A pair with an empty union under the "uniform" policy is the mean of
+  //     V over the L keys (precomputed per workgroup): no bias has to absorb the scores, so a moderate
+  //     bias (-2^15, exact in bf16) and the fused exp2(fma(s, C, -m C)) are safe.
+  //  generic (cls-row tiles, other nq): per-row masks in VALU, absorbing finfo.min bias as in the reference
+  //     (HF additive mask), exp2((s - m) * C) so that equal scores give exactly 2^0.
+  auto run_unit = [&](const XUnit& cur, auto al_tag) {
+    constexpr bool AL = decltype(al_tag)::value;
     const int64_t row = cur.row;
     const bool rvalid = cur.rvalid;
     bf16x8_t qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = cur.qf[s];
 
-    // a row whose pair mask is empty attends to every key (uniform softmax): it needs all tiles
-    uint64_t anybits = 0;
+    // i = pidx / N, j = pidx % N; exact in fp32 for pidx < 2^24 and N <= 1024
+    int oi, oj;
+    if (N <= 1024) {
+      oi = (int)(((float)cur.pidx + 0.5f) * rcpN);
+      oj = cur.pidx - oi * N;
+    } else {
+      oi = cur.pidx / N;
+      oj = cur.pidx % N;
+    }
+    // object bit rows as 32-bit words: word t = keys [32 t, 32 t + 32), 1 = attend
+    const uint32_t* wi = reinterpret_cast<const uint32_t*>(bits_lds + (int64_t)oi * words);
+    const uint32_t* wj = reinterpret_cast<const uint32_t*>(bits_lds + (int64_t)oj * words);
+    // which 32-key tiles does this row tile need?  A tile no row attends to contributes exactly 0: skipped.
+    uint32_t needmask = 0;      // wave-uniform
+    bool force_all = false;     // AL + "unmasked" policy + empty union: plain attention over the L real keys
+    if constexpr (AL) {
+      for (int t = 0; t < NT; ++t)
+        needmask |= ((__builtin_amdgcn_readfirstlane(wi[t] | wj[t]) != 0u) ? 1u : 0u) << t;
+      if (needmask == 0u) {
+        if (policy == PSG_EMPTY_UNIFORM) {
+          // uniform softmax over the L real keys: out = mean_k V[k]
+          const float* mean = reinterpret_cast<const float*>(mean_lds);
+          uint16_t* op = out + row * hidden + h * 64 + 4 * hi;
 #pragma unroll
-    for (int w = 0; w < 2 * NC; ++w) anybits |= cur.mw[w];
-    const bool any_empty_row = __any(anybits == 0ull);
+          for (int rr = 0; rr < 4; ++rr) {
+            const float4 m0 = *reinterpret_cast<const float4*>(mean + 8 * rr + 4 * hi);
+            const float4 m1 = *reinterpret_cast<const float4*>(mean + 32 + 8 * rr + 4 * hi);
+            uint2 w0, w1;
+            w0.x = pack_bf16x2(m0.x, m0.y);
+            w0.y = pack_bf16x2(m0.z, m0.w);
+            w1.x = pack_bf16x2(m1.x, m1.y);
+            w1.y = pack_bf16x2(m1.z, m1.w);
+            *reinterpret_cast<uint2*>(op + 8 * rr) = w0;
+            *reinterpret_cast<uint2*>(op + 32 + 8 * rr) = w1;
+          }
+          return;
+        }
+        force_all = true;
+        needmask = NT >= 32 ? 0xffffffffu : (1u << NT) - 1u;
+      }
+    } else {
+      bool any_empty = false, row_empty = true;
+      for (int t = 0; t < NT; ++t) {
+        const uint32_t w = wi[t] | wj[t];
+        row_empty = row_empty && (w == 0u);
+        needmask |= (__any(w != 0u) ? 1u : 0u) << t;
+      }
+      // a row whose pair mask is empty attends to every key (uniform softmax): it needs all tiles
+      any_empty = __any(row_empty);
+      if (any_empty) needmask = NT >= 32 ? 0xffffffffu : (1u << NT) - 1u;
+    }
 
     f32x16_t o0 = {0}, o1 = {0};
     float m_run = -INFINITY, l_run = 0.f;
 
+    while (needmask != 0u) {
+      const int t = __builtin_ctz(needmask);
+      needmask &= needmask - 1u;
+      uint32_t word = wi[t] | wj[t];
+      const int left = L - 32 * t;                       // real keys in this tile (>= 1)
+      f32x16_t acc;
+      const unsigned char* kp = kfrag_base + t * 32 * XA_KSTRIDE;
+      if constexpr (AL) {
+        if (force_all) word = left >= 32 ? 0xffffffffu : (1u << left) - 1u;
+        // A'[key = lane&31][k = 0] = 0 if the pair attends to this key, else -2^15 (bf16 0xc700)
+        union {
+          uint32_t u[4];
+          bf16x8_t v;
+        } a_bias;
+        a_bias.u[0] = (((word >> l31) & 1u) | (uint32_t)hi) ? 0u : 0xc700u;
+        a_bias.u[1] = a_bias.u[2] = a_bias.u[3] = 0u;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_bias.v, b_one.v, (f32x16_t){0}, 0, 0, 0);
 #pragma unroll
-    for (int cc = 0; cc < NC; ++cc) {
-      const int c0 = cc * XA_CT;
-      if (c0 >= NT) break;
-      // inverted mask words (1 = masked), pre-shifted by 4*hi so the bit index is a constant per register
-      uint32_t inv[XA_CT];
-      bool need[XA_CT];
-      {
-        const uint64_t m0 = cur.mw[2 * cc], m1 = cur.mw[2 * cc + 1];
-        inv[0] = ~(uint32_t)m0 >> (4 * hi);
-        inv[1] = ~(uint32_t)(m0 >> 32) >> (4 * hi);
-        inv[2] = ~(uint32_t)m1 >> (4 * hi);
-        inv[3] = ~(uint32_t)(m1 >> 32) >> (4 * hi);
-        // a 32-key tile no row of this row tile attends to contributes exactly 0: skip it (wave-uniform)
-        need[0] = any_empty_row || __any((uint32_t)m0 != 0u);
-        need[1] = any_empty_row || __any((uint32_t)(m0 >> 32) != 0u);
-        need[2] = any_empty_row || __any((uint32_t)m1 != 0u);
-        need[3] = any_empty_row || __any((uint32_t)(m1 >> 32) != 0u);
-      }
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(kp + s * 32);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
+        }
+      } else {
+        {
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(kp);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0], (f32x16_t){0}, 0, 0, 0);
+        }
 #pragma unroll
-      for (int t = 0; t < XA_CT; ++t) need[t] = need[t] && (c0 + t < NT);
-      if (!(need[0] || need[1] || need[2] || need[3])) continue;
-      f32x16_t acc[XA_CT];
+        for (int s = 1; s < 4; ++s) {
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(kp + s * 32);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
+        }
+        // additive mask per (row, key): register r of a lane is key (r&3) + 8 (r>>2) + 4 hi of the tile
+        const uint32_t inv = ~word >> (4 * hi);
+        const bool has_pad = left < 32;
 #pragma unroll
-      for (int t = 0; t < XA_CT; ++t) {
-        acc[t] = (f32x16_t){0};
-        if (need[t]) {
-          const unsigned char* kp = kfrag_base + (c0 + t) * 32 * XA_KSTRIDE;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(kp + s * 32);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc[t], 0, 0, 0);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int koff = (r & 3) + 8 * (r >> 2);
+          const int mb = __builtin_amdgcn_sbfe((int)inv, koff, 1);  // -1 if masked
+          float y = acc[r] + __uint_as_float((uint32_t)mb & __float_as_uint(bias_raw));
+          if (has_pad && (koff + 4 * hi >= left)) y = -INFINITY;
+          acc[r] = y;
         }
       }
-      // scaled + masked scores in the log2 domain, chunk max
-      float cmax = -INFINITY;
+      // online softmax over the raw scores (the scale is positive)
+      float cmax = acc[0];
 #pragma unroll
-      for (int t = 0; t < XA_CT; ++t) {
-        if (need[t]) {
-          const bool has_pad = (c0 + t + 1) * 32 > L;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int koff = (r & 3) + 8 * (r >> 2);
-            const int mb = __builtin_amdgcn_sbfe((int)inv[t], koff, 1);  // -1 if masked
-            float y = fmaf(acc[t][r], C, __uint_as_float((uint32_t)mb & bias_bits));
-            if (has_pad && ((c0 + t) * 32 + koff + 4 * hi >= L)) y = -INFINITY;
-            acc[t][r] = y;
-            cmax = fmaxf(cmax, y);
-          }
-        }
-      }
+      for (int r = 1; r < 16; ++r) cmax = fmaxf(cmax, acc[r]);
       cmax = xchg32_max(cmax);
       const float m_new = fmaxf(m_run, cmax);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      float csum = 0.f;
+      float alpha, csum = 0.f;
+      if constexpr (AL) {
+        const float mc = m_new * C8;
+        alpha = __builtin_amdgcn_exp2f(fmaf(m_run, C8, -mc));
 #pragma unroll
-      for (int t = 0; t < XA_CT; ++t)
-        if (need[t]) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(acc[t][r] - m_new);
-            acc[t][r] = pv;
-            csum += pv;
-          }
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(acc[r], C8, -mc));
+          acc[r] = pv;
+          csum += pv;
         }
+      } else {
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f((acc[r] - m_new) * C8);
+          acc[r] = pv;
+          csum += pv;
+        }
+      }
       csum = xchg32_sum(csum);
       l_run = l_run * alpha + csum;
       m_run = m_new;
@@ -249,26 +312,22 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
       }
       // O^T += V^T . P^T : A = V^T fragment (LDS), B = this lane's P values packed to bf16
 #pragma unroll
-      for (int t = 0; t < XA_CT; ++t)
-        if (need[t]) {
+      for (int gg = 0; gg < 2; ++gg) {
+        union {
+          uint32_t u[4];
+          bf16x8_t v;
+        } pf;
 #pragma unroll
-          for (int gg = 0; gg < 2; ++gg) {
-            union {
-              uint32_t u[4];
-              bf16x8_t v;
-            } pf;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(acc[t][8 * gg + 2 * e], acc[t][8 * gg + 2 * e + 1]);
-            const unsigned char* vp = vfrag_base + ((c0 + t) * 32 + 16 * gg) * 2;
-            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(vp);
-            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(vp + 32 * VS);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pf.v, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pf.v, o1, 0, 0, 0);
-          }
-        }
+        for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(acc[8 * gg + 2 * e], acc[8 * gg + 2 * e + 1]);
+        const unsigned char* vp = vfrag_base + (t * 32 + 16 * gg) * 2;
+        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(vp);
+        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(vp + 32 * VS);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pf.v, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pf.v, o1, 0, 0, 0);
+      }
     }
     // epilogue: lane (q, hi) holds O[q][32 dt + (r&3) + 8 (r>>2) + 4 hi]
-    if (rvalid) {
+    if (AL || rvalid) {
       const float inv_l = 1.0f / l_run;
       uint16_t* op = out + row * hidden + h * 64 + 4 * hi;
 #pragma unroll
@@ -282,9 +341,129 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
         *reinterpret_cast<uint2*>(op + 32 + 8 * rr) = w1;
       }
     }
-    cur = nxt;
-    tile = tile_next;
+  };
+
+  int nun = 0;
+  auto stamp = [&]() {
+    if (tr && lane == 0) {
+      if (nun < 28) tr[3 + nun] = __builtin_readcyclecounter();
+      ++nun;
+      tr[31] = nun;
+    }
+  };
+  // The first units' operands are requested BEFORE the K/V staging: the first touch of Q by 2048 waves at
+  // once takes 15-25 us, which now overlaps the staging and the cls unit instead of following them.
+  const int64_t tlast = ntile - 1;
+  int64_t t = next_tile();
+  int64_t tal = t;                     // first pair tile of this wave
+  if (aligned) {
+    while (tal < NCLS) tal += wstride;
+  } else {
+    tal = ntile;
   }
+  XUnit uf, u0, u1, u2;
+  fetch(t < tlast ? t : tlast, uf);
+  fetch(tal < tlast ? tal : tlast, u0);
+  fetch(tal + wstride < tlast ? tal + wstride : tlast, u1);
+
+  for (int e = threadIdx.x; e < N * words; e += 256) bits_lds[e] = bits[e];
+  // ---- stage K_h and V_h^T (once per workgroup) ----
+  // All global loads of a thread are issued before the first LDS write (a load -> write loop paid one
+  // L2 round trip per iteration: 20 us of prologue).  A thread owns the key PAIR (2m, 2m+1) of one 8-dim
+  // chunk c: the two keys are neighbours in the V^T row, so the transposed writes are 32-bit.
+  {
+    constexpr int IT = 2 * NC;                           // (Lpad/2 key pairs * 8 chunks) / 256 threads <= 2 NC
+    uint4 kv[IT][2], vv[IT][2];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256;
+      const int m = e >> 3, c = e & 7;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int key = 2 * m + u;
+        kv[it][u] = make_uint4(0, 0, 0, 0);
+        vv[it][u] = make_uint4(0, 0, 0, 0);
+        if (key < L) {
+          kv[it][u] = *reinterpret_cast<const uint4*>(k + (int64_t)key * hidden + h * 64 + c * 8);
+          vv[it][u] = *reinterpret_cast<const uint4*>(v + (int64_t)key * hidden + h * 64 + c * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256;
+      const int m = e >> 3, c = e & 7;
+      if (2 * m < Lpad) {
+        *reinterpret_cast<uint4*>(k_lds + (2 * m) * XA_KSTRIDE + c * 16) = kv[it][0];
+        *reinterpret_cast<uint4*>(k_lds + (2 * m + 1) * XA_KSTRIDE + c * 16) = kv[it][1];
+        const int o = (2 * m) & 15;
+        const int pos = (o & 3) | ((o & 8) >> 1) | ((o & 4) << 1);  // swap bits 2 <-> 3 (bit 0 stays: pair adjacent)
+        const int kcol = (((2 * m) & ~15) | pos) * 2;
+        const uint32_t a[4] = {vv[it][0].x, vv[it][0].y, vv[it][0].z, vv[it][0].w};
+        const uint32_t bq[4] = {vv[it][1].x, vv[it][1].y, vv[it][1].z, vv[it][1].w};
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2) {
+          const uint32_t lo = (a[d2] & 0xffffu) | (bq[d2] << 16);            // dim 2 d2    of keys 2m, 2m+1
+          const uint32_t hi2 = (a[d2] >> 16) | (bq[d2] & 0xffff0000u);      // dim 2 d2 + 1
+          *reinterpret_cast<uint32_t*>(vt_lds + (c * 8 + 2 * d2) * VS + kcol) = lo;
+          *reinterpret_cast<uint32_t*>(vt_lds + (c * 8 + 2 * d2 + 1) * VS + kcol) = hi2;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {                                       // pad keys hold zeros: sum over all Lpad slots
+    float sum = 0.f;
+    const uint16_t* vr = reinterpret_cast<const uint16_t*>(vt_lds + tid * VS);
+    for (int kk = 0; kk < Lpad; kk += 8) {
+      const uint4 x = *reinterpret_cast<const uint4*>(vr + kk);
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += __uint_as_float(xs[e] << 16) + __uint_as_float(xs[e] & 0xffff0000u);
+    }
+    reinterpret_cast<float*>(mean_lds)[tid] = sum / (float)L;
+  }
+  __syncthreads();
+  if (tr && lane == 0) tr[1] = __builtin_readcyclecounter();
+  if (tr && lane == 0) tr[2] = __builtin_readcyclecounter();
+  // Phase 1: tiles with per-row masks (the cls tiles at the head of the order: at most one or two per wave;
+  // every tile when nq != 33).
+  {
+    bool first = true;
+    while (t < ntile && t < tal) {
+      if (!first) fetch(t, uf);
+      first = false;
+      run_unit(uf, std::false_type{});
+      stamp();
+      t = next_tile();
+    }
+  }
+  if (t >= ntile) return;
+  // Phase 2: pair tiles.  Three units in flight - one is computed, the operands of the next have been
+  // loading for one unit time, the loads of the third are issued now.  The three register sets rotate by
+  // unrolling (a copy `a = b` would have to wait for b's loads); fetches are unconditional (tile clamped to
+  // the last one) because a branch around them makes the compiler wait for the fresh loads at the join.
+  // The compiler's s_waitcnt counts at the loop header are the minimum over the entry edge and the back edge
+  // of "memory operations issued after the load".  In steady state 8 output stores sit between two fetches;
+  // with fewer operations on the entry edge every unit would wait for the previous unit's stores to be
+  // acknowledged.  Volatile (harmless) loads stand in for them.
+#pragma unroll
+  for (int e = 0; e < 16; ++e) (void)*reinterpret_cast<const volatile int*>(pair_index);
+#define XA_STEP(COMPUTE, FILL)                                                  \
+  {                                                                             \
+    const int64_t t2 = t + 2 * wstride;                                         \
+    fetch(t2 < tlast ? t2 : tlast, FILL);                                       \
+    run_unit(COMPUTE, std::true_type{});                                        \
+    stamp();                                                                    \
+    t += wstride;                                                               \
+    if (t >= ntile) break;                                                      \
+  }
+  for (;;) {
+    XA_STEP(u0, u2)
+    XA_STEP(u1, u0)
+    XA_STEP(u2, u1)
+  }
+#undef XA_STEP
 }
 
 int psg_cross_attn_simple_launch(const void* q, const void* k, const void* v, const uint64_t* bits, int words,
@@ -308,10 +487,9 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
   PSG_REQUIRE(variant == PSG_XATTN_MFMA, PSG_ERR_INVALID, "psg_qformer_cross_attn: variant=%d", variant);
   PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED,
               "psg_qformer_cross_attn: the MFMA variant computes in bf16; use PSG_XATTN_SIMPLE for fp32");
-  PSG_REQUIRE(work_counters != nullptr, PSG_ERR_INVALID,
-              "psg_qformer_cross_attn: the MFMA variant needs work_counters (int32[heads] of caller memory)");
+  (void)work_counters;   // kept in the ABI: an earlier version distributed tiles through an atomic work queue
   const int Lpad = (L + 31) & ~31;
-  const size_t lds = (size_t)Lpad * XA_KSTRIDE + (size_t)64 * (Lpad * 2 + 16);
+  const size_t lds = (size_t)Lpad * XA_KSTRIDE + (size_t)64 * (Lpad * 2 + 16) + 256 + (((size_t)N * words * 8 + 15) & ~(size_t)15);
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn: L=%d needs %zu B of LDS (> 160 KiB)", L,
               lds);
   const int NC = (Lpad / 32 + XA_CT - 1) / XA_CT;
@@ -334,22 +512,30 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
   const int64_t maxG = (ntile + 3) / 4;
   if (G > maxG) G = maxG;
   if (G < 1) G = 1;
-  {
-    hipError_t e = hipMemsetAsync(work_counters, 0, sizeof(int32_t) * heads, st);   // a memset node under capture
-    if (e != hipSuccess) {
-      psg_set_error("psg_qformer_cross_attn: hipMemsetAsync: %s", hipGetErrorString(e));
-      return PSG_ERR_HIP;
-    }
-  }
+  long long* trace = nullptr;
+  const char* trace_path = getenv("PSG_XATTN_TRACE");
+  const size_t trace_n = (size_t)G * heads * 4 * 32;
+  if (trace_path && hipMalloc(&trace, trace_n * sizeof(long long)) == hipSuccess)
+    (void)hipMemset(trace, 0, trace_n * sizeof(long long));
 #define XLAUNCH(NC_)                                                                                           \
   cross_attn_mfma_kernel<NC_><<<(unsigned)(G * heads), 256, lds, st>>>(                                        \
       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads, \
-      empty_policy, work_counters, (uint16_t*)out)
+      empty_policy, work_counters, (uint16_t*)out, trace)
   if (NC == 1) XLAUNCH(1);
   else if (NC == 2) XLAUNCH(2);
   else if (NC == 3) XLAUNCH(3);
   else XLAUNCH(4);
 #undef XLAUNCH
+  if (trace) {                                           // debugging aid: synchronous dump of the per-wave timestamps
+    (void)hipStreamSynchronize(st);
+    std::vector<long long> hbuf(trace_n);
+    (void)hipMemcpy(hbuf.data(), trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(trace_path, "wb")) {
+      fwrite(hbuf.data(), sizeof(long long), trace_n, f);
+      fclose(f);
+    }
+    (void)hipFree(trace);
+  }
   PSG_CHECK_LAUNCH("psg_qformer_cross_attn");
   return PSG_OK;
 }

@@ -129,10 +129,9 @@ def qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, out=None, empty_
     if variant is None:
         variant = PSG_XATTN_MFMA if q.dtype == torch.bfloat16 else PSG_XATTN_SIMPLE
     out = torch.empty_like(q) if out is None else out
-    counters = torch.empty(heads, device=q.device, dtype=torch.int32)      # per-head work queue (zeroed by the library)
     check(lib.psg_qformer_cross_attn(ctx, _p(q), _p(k), _p(v), _p(bits, torch.int64, "bits"), bits.shape[1],
                                      _p(pair_index, torch.int32, "pair_index"), int(N), P, L, nq, heads,
-                                     int(empty_policy), int(variant), _p(out, q.dtype), _p(counters), _dt(q), st),
+                                     int(empty_policy), int(variant), _p(out, q.dtype), None, _dt(q), st),
           "psg_qformer_cross_attn")
     return out
 

@@ -169,3 +169,8 @@ def pool():
 
 if __name__ == "__main__" and "pool" in sys.argv:
     pool()
+
+
+if __name__ == "__main__" and "xattn_scale" in sys.argv:
+    for n in (4, 12, 25, 50, 71, 100):
+        xattn(n, 256)
