@@ -35,6 +35,10 @@
 //     the other, across slab boundaries too.
 #include <stdlib.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "psg_common.h"
 
 typedef __bf16 gbf16x8_t __attribute__((ext_vector_type(8)));
@@ -184,8 +188,12 @@ template <int WAVES, int UD, int SGD_SLOTS, int AUX>
 __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint16_t* __restrict__ x,
                                                                      const uint16_t* __restrict__ w,
                                                                      float* __restrict__ part, int M, int N, int K,
-                                                                     int xstride) {
+                                                                     int xstride, long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // trace != nullptr (PSG_SKINNY_TRACE=<file>, debugging only): 8 cycle-counter stamps per wave
+  long long* tr = trace ? trace + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 8
+                        : nullptr;
+  if (tr && (threadIdx.x & 63) == 0) tr[0] = __builtin_readcyclecounter();
   constexpr int ROWS = WAVES * 16;
   constexpr int BATCH_BYTES = UD * 2048;
   constexpr int RING_BYTES = SGD_SLOTS * BATCH_BYTES;
@@ -193,7 +201,7 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
   const int n = lane & 15, kq = lane >> 4;
   const int S = gridDim.y, by = blockIdx.y, G = gridDim.x, gx = blockIdx.x;
   const int KB = K >> 6;
-  const int kbA = (int)(((int64_t)KB * by) / S), kbB = (int)(((int64_t)KB * (by + 1)) / S);
+  const int kbA = (int)((unsigned)(KB * by) / (unsigned)S), kbB = (int)((unsigned)(KB * (by + 1)) / (unsigned)S);   // K <= 2^20
   const int nkb = kbB - kbA;
   const int nb = nkb / UD;
   const int nslab_all = (N + ROWS - 1) / ROWS;
@@ -227,15 +235,36 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
   };
   for (int i = 0; i < SGD_SLOTS - 1; ++i)
     if (i < total) issue();
+  if (tr && lane == 0) tr[1] = __builtin_readcyclecounter();
 
   // stage x once per workgroup (plain loads -> ds_write); the DMAs above are already in flight
+  // (issuing all of a thread's x loads at once, with or without a division-free row/piece mapping, was
+  // measured SLOWER, 3.42 vs 2.97 ms per decode step: 256 workgroups then hit the same 160 KB of x in L2 in one
+  // burst; this loop spreads them)
   const int pieces = nkb * 8;
-  for (int e = tid; e < M * pieces; e += WAVES * 64) {
-    const int r = e / pieces, c = e - r * pieces;
-    const uint4 v = *reinterpret_cast<const uint4*>(x + (int64_t)r * K + (int64_t)kbA * 64 + c * 8);
-    *reinterpret_cast<uint4*>(xs + r * xstride + c * 16) = v;
+  {
+    constexpr int XU = 1;                                           // x loads in flight per thread: 2 measured slower (3.11 vs 2.97 ms/step), 8 slower still (3.42): they queue in front of the weight stream
+    const int total_x = M * pieces;
+    for (int e0 = tid; e0 < total_x; e0 += XU * WAVES * 64) {
+      uint4 v[XU];
+      int off[XU];
+#pragma unroll
+      for (int u = 0; u < XU; ++u) {
+        const int e = e0 + u * WAVES * 64;
+        off[u] = -1;
+        if (e < total_x) {
+          const int r = e / pieces, c = e - r * pieces;
+          v[u] = *reinterpret_cast<const uint4*>(x + (int64_t)r * K + (int64_t)kbA * 64 + c * 8);
+          off[u] = r * xstride + c * 16;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < XU; ++u)
+        if (off[u] >= 0) *reinterpret_cast<uint4*>(xs + off[u]) = v[u];
+    }
   }
   __syncthreads();
+  if (tr && lane == 0) tr[2] = __builtin_readcyclecounter();
 
   const unsigned char* xs0 = xs + min(n, M - 1) * xstride + kq * 32;
   const unsigned char* xs1 = xs + min(16 + n, M - 1) * xstride + kq * 32;
@@ -291,6 +320,7 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
   for (int j = 0; j < total; ++j) {
     if (j + SGD_SLOTS - 1 < total) issue();                         // refills the slot consumed at j - 1
     SgdWait<UD, SGD_SLOTS - 1>::go(total - 1 - j);                  // batches issued after batch j may stay in flight
+    if (tr && lane == 0 && j == 0) tr[3] = __builtin_readcyclecounter();
     const unsigned char* slot = ring + (j % SGD_SLOTS) * BATCH_BYTES;
 #pragma unroll
     for (int u = 0; u < UD; ++u) {
@@ -307,7 +337,16 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
       acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b11, acc1, 0, 0, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // ring reads retired before the slot is refilled
-    if (++cb == nb) finish_slab();
+    if (++cb == nb) {
+      if (tr && lane == 0 && ct == nslab - 1) tr[4] = __builtin_readcyclecounter();
+      finish_slab();
+    }
+  }
+  if (tr && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tr[5] = __builtin_readcyclecounter();
+    tr[6] = nslab;
+    tr[7] = nkb;
   }
 }
 
@@ -399,6 +438,11 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
     if (Gd < 1) Gd = 1;
     dim3 gridd(Gd, splits);
     hipStream_t st = (hipStream_t)stream;
+    long long* trace = nullptr;
+    const char* trace_path = getenv("PSG_SKINNY_TRACE");
+    const size_t trace_n = (size_t)Gd * splits * wv * 8;
+    if (trace_path && hipMalloc(&trace, trace_n * sizeof(long long)) == hipSuccess)
+      (void)hipMemset(trace, 0, trace_n * sizeof(long long));
     // weights are read once by one CU: non-temporal (aux = 2) DMA loads; PSG_SKINNY_NT=0 = default policy
     static int nt = -1;
     if (nt < 0) {
@@ -410,7 +454,7 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
     (void)hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<WV, UD, SL, AUX>,                                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
     skinny_gemm_dma_kernel<WV, UD, SL, AUX><<<gridd, WV * 64, ldsd, st>>>((const uint16_t*)x, (const uint16_t*)w, \
-                                                                          part, M, N, K, xstride);                 \
+                                                                          part, M, N, K, xstride, trace);          \
   } while (0)
 #define SGD(WV, UD, SL)                                                                                            \
   do {                                                                                                             \
@@ -430,6 +474,16 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
     }
 #undef SGD
 #undef SGD_L
+    if (trace) {                                         // debugging aid: synchronous dump of the per-wave stamps
+      (void)hipStreamSynchronize(st);
+      std::vector<long long> hbuf(trace_n);
+      (void)hipMemcpy(hbuf.data(), trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost);
+      if (FILE* f = fopen(trace_path, "wb")) {
+        fwrite(hbuf.data(), sizeof(long long), trace_n, f);
+        fclose(f);
+      }
+      (void)hipFree(trace);
+    }
     PSG_CHECK_LAUNCH("psg_skinny_gemm(dma)");
     return PSG_OK;
   }
