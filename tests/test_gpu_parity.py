@@ -165,6 +165,41 @@ def test_cross_attn_mfma_vs_fp32_reference(L, N, P):
     assert (out_f - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("L,N,nq,policy", [(256, 50, 33, "uniform"), (256, 50, 33, "unmasked"), (96, 9, 33, "unmasked"),
+                                           (128, 6, 16, "uniform"), (336, 7, 40, "unmasked")])
+def test_cross_attn_mfma_matches_scalar_kernel(L, N, nq, policy):
+    """The matrix-core kernel against the scalar checker kernel on what the goldens do not reach: both
+    empty-row policies, row counts other than 33 (generic row tiles), a shuffled subset of the pairs (pair
+    sharding hands the kernel arbitrary pair lists) and 2500 pairs (many row tiles per wave)."""
+    from openpsg_amd import ops, _lib
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(L + 7 * N + nq)
+    heads = 12
+    perm = torch.randperm(N * N, generator=g)
+    pair_index = perm[: max(1, (N * N * 3) // 4)].to(torch.int32).to(dev)
+    P = pair_index.numel()
+    q = (torch.randn(P * nq, 768, generator=g) * 1.5).to(dev).bfloat16()
+    k = (torch.randn(L, 768, generator=g) * 1.5).to(dev).bfloat16()
+    v = torch.randn(L, 768, generator=g).to(dev).bfloat16()
+    om = torch.rand(N, L, generator=g) < 0.06
+    om[0] = False
+    om[N - 1] = False                                              # pairs among {0, N-1} have an empty union
+    words = (L + 63) // 64
+    bits_np = np.zeros((N, words * 64), dtype=np.uint8)
+    bits_np[:, :L] = om.numpy()
+    bits = torch.from_numpy(np.packbits(bits_np, axis=-1, bitorder="little").view(np.int64).reshape(N, words)).to(dev)
+    pol = _lib.PSG_EMPTY_UNIFORM if policy == "uniform" else _lib.PSG_EMPTY_UNMASKED
+    out_m = ops.qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, empty_policy=pol,
+                                   variant=_lib.PSG_XATTN_MFMA)
+    out_s = ops.qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, empty_policy=pol,
+                                   variant=_lib.PSG_XATTN_SIMPLE)
+    torch.cuda.synchronize()
+    a, b = out_m.float(), out_s.float()
+    err = ((a - b).abs() / (1.0 + b.abs())).max().item()          # both outputs are bf16: one ulp is 2^-8 relative
+    print(f"L={L} N={N} nq={nq} {policy}: P={P}, max |mfma - scalar| / (1 + |scalar|) = {err:.3e}")
+    assert torch.isfinite(a).all() and err < 1.2e-2
+
+
 def test_topk_ties_and_order():
     from openpsg_amd import ops
     dev = _dev()
