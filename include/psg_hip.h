@@ -146,6 +146,15 @@ int psg_llm_attn(psg_ctx*, const void* q, const void* k_cache, const void* v_cac
                  const int32_t* tok_pair, const int32_t* tok_pos, int64_t rows, int heads,
                  int head_dim, int ctx, void* out, int dtype, void* stream);
 
+/* ---- K14 (prefill) on the matrix cores, bf16: the same attention for a pair-major prompt batch.
+ * Pair p owns rows [p*rows_per_pair, (p+1)*rows_per_pair) of q / out and cache rows 0.. of its own
+ * (pair, head) slab; tok_pos[row] is the token's position, equal to its row index inside the pair, or
+ * -1 for the padding rows at the end of a pair (output rows of zeros).  rows_per_pair <= 64;
+ * longer prompts and fp32 go through psg_llm_attn. */
+int psg_prefill_attn(psg_ctx*, const void* q, const void* k_cache, const void* v_cache,
+                     const int32_t* tok_pos, int pairs, int rows_per_pair, int heads, int head_dim,
+                     int ctx, void* out, int dtype, void* stream);
+
 /* ---- K13 + K14 fused for the decode step (one new token per pair): rotary + KV-cache append +
  * attention over the cache in one launch.  qkv [rows][3*hidden] (activation dtype, or fp32 split-K
  * partials when qkv_splits > 0); out [rows][hidden].  Equivalent to psg_rope_kvwrite followed by

@@ -1,0 +1,177 @@
+// K14 (prefill) on the matrix cores: causal self-attention of the LLM prompt pass (HF-LL:191-214, eager
+// attention: scores = q.k / sqrt(128), causal + padding mask, fp32 softmax, probabilities cast to the value
+// dtype, p.v) for bf16 activations.
+//
+// The prefill batch is pair-major: pair p owns rows [p*S, (p+1)*S), S = 32 visual tokens + the longest
+// prompt (<= 64 here); tok_pos[row] = position of the token in its compacted sequence (== row index inside
+// the pair for real tokens) or -1 for the padding rows at the end.  One wave per (pair, head):
+//   * S^T = K . Q^T with v_mfma_f32_32x32x16_bf16, 2 key tiles x 2 query tiles x 8 k-steps (head_dim 128);
+//     Q comes from the rotated query matrix, K from the cache rows the rotary kernel has just written,
+//     both as 16-byte loads of a row's 8 consecutive head dims - no LDS;
+//   * a lane owns one query row per query tile and 16 keys per key tile: the causal / padding mask is
+//     index arithmetic in registers, the softmax needs one lane^32 exchange;
+//   * O^T = V^T . P^T over 4 tiles of 32 head dims; the V^T fragment of a lane (one head dim, 8 keys) is
+//     gathered with 2-byte loads from the cache (64 B coalesced per half-wave).
+// The scalar kernel (psg_llm_attn, one wave per (row, head): 51 us per layer at 920 rows) stays for fp32 and
+// for prompts longer than 64 rows.
+#include "psg_common.h"
+
+typedef __bf16 pa_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pa_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pa_f32x16 __attribute__((ext_vector_type(16)));
+typedef float pa_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pa_pack(float lo, float hi) {
+  pa_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, pa_bf16x2));
+}
+
+__global__ void __launch_bounds__(64)
+prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
+                         const uint16_t* __restrict__ vc, const int32_t* __restrict__ tok_pos, int pairs, int S,
+                         int heads, int ctx, uint16_t* __restrict__ out) {
+  const int unit = blockIdx.x;
+  const int p = unit / heads, h = unit % heads;
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int hidden = heads * 128;
+  const int64_t row0 = (int64_t)p * S;
+  const int64_t cbase = ((int64_t)p * heads + h) * ctx * 128;
+  // position of token `lane` of this pair (-1: padding row, also for lane >= S)
+  const int mypos = lane < S ? tok_pos[row0 + lane] : -1;
+  const unsigned long long valid64 = __ballot(mypos >= 0);
+  auto rclamp = [&](int j) { return j < S ? j : S - 1; };
+
+  pa_f32x16 sc[2][2];                                           // [key tile][query tile]
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) sc[kt][qt] = (pa_f32x16){0};
+  // fragments: lane (idx = lane&31, hi) holds row (32 tile + idx), head dims 16 s + 8 hi .. +7
+  const uint16_t* qp[2];
+  const uint16_t* kp[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int r = rclamp(32 * t + l31);
+    qp[t] = q + (row0 + r) * hidden + h * 128 + hi * 8;
+    kp[t] = kc + cbase + (int64_t)r * 128 + hi * 8;           // key j of the pair lives in cache row j (positions are compact)
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    pa_bf16x8 qf[2], kf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      qf[t] = *reinterpret_cast<const pa_bf16x8*>(qp[t] + s * 16);
+      kf[t] = *reinterpret_cast<const pa_bf16x8*>(kp[t] + s * 16);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+        sc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt], qf[qt], sc[kt][qt], 0, 0, 0);
+  }
+  // mask: key j is visible to query row i iff j <= i and key j is a real token (HF-LL causal + padding mask)
+  const float C = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
+  float inv_l[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qi = 32 * qt + l31;
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool vis = key <= qi && ((valid64 >> key) & 1ull);
+        const float y = vis ? sc[kt][qt][r] * C : -INFINITY;
+        sc[kt][qt][r] = y;
+        m = fmaxf(m, y);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (m == -INFINITY) m = 0.f;                                // padding query row: every exp below is 0
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sc[kt][qt][r] - m);
+        sc[kt][qt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const bool qvalid = qi < 64 && ((valid64 >> qi) & 1ull);   // padding rows: zeros (defined, never consumed)
+    inv_l[qt] = (qvalid && sum > 0.f) ? 1.0f / sum : 0.f;
+  }
+  // O^T[d][q] += V^T[d][keys] . P^T[keys][q]; key slice (kt, g): slot (hi, m) <-> key 32 kt + 16 g + (m&3) + 8 (m>>2) + 4 hi
+  pa_f32x16 o[4][2];                                            // [d tile][query tile]
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) o[dt][qt] = (pa_f32x16){0};
+  const uint16_t* vbase = vc + cbase + l31;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      union {
+        uint32_t u[4];
+        pa_bf16x8 v;
+      } pf[2], vf[4];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          pf[qt].u[e] = pa_pack(sc[kt][qt][8 * g + 2 * e], sc[kt][qt][8 * g + 2 * e + 1]);
+      uint16_t ve[4][8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int key = rclamp(32 * kt + 16 * g + (m & 3) + 8 * (m >> 2) + 4 * hi);
+        const uint16_t* vp = vbase + (int64_t)key * 128;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ve[dt][m] = vp[32 * dt];
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vf[dt].u[e] = (uint32_t)ve[dt][2 * e] | ((uint32_t)ve[dt][2 * e + 1] << 16);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          o[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt].v, pf[qt].v, o[dt][qt], 0, 0, 0);
+    }
+  // lane (q = lane&31, hi) holds O[q][32 dt + (r&3) + 8 (r>>2) + 4 hi] for its row of each query tile;
+  // padding rows get zeros (defined output, never consumed: same as the scalar kernel)
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qi = 32 * qt + l31;
+    if (qi < S) {
+      uint16_t* op = out + (row0 + qi) * hidden + h * 128 + 4 * hi;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          uint2 wv;
+          wv.x = pa_pack(o[dt][qt][4 * rr] * inv_l[qt], o[dt][qt][4 * rr + 1] * inv_l[qt]);
+          wv.y = pa_pack(o[dt][qt][4 * rr + 2] * inv_l[qt], o[dt][qt][4 * rr + 3] * inv_l[qt]);
+          *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rr) = wv;
+        }
+    }
+  }
+}
+
+extern "C" int psg_prefill_attn(psg_ctx* ctx_, const void* q, const void* k_cache, const void* v_cache,
+                                const int32_t* tok_pos, int pairs, int rows_per_pair, int heads, int head_dim, int ctx,
+                                void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx_ && q && k_cache && v_cache && tok_pos && out, PSG_ERR_INVALID, "psg_prefill_attn: NULL argument");
+  PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED, "psg_prefill_attn: bf16 only (fp32: psg_llm_attn)");
+  PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_prefill_attn: head_dim=%d (kernel is built for 128)", head_dim);
+  PSG_REQUIRE(rows_per_pair >= 1 && rows_per_pair <= 64 && rows_per_pair <= ctx, PSG_ERR_UNSUPPORTED,
+              "psg_prefill_attn: rows_per_pair=%d (1..64, <= ctx=%d); longer prompts: psg_llm_attn", rows_per_pair, ctx);
+  PSG_REQUIRE(pairs >= 0 && heads > 0, PSG_ERR_INVALID, "psg_prefill_attn: pairs=%d heads=%d", pairs, heads);
+  if (pairs == 0) return PSG_OK;
+  prefill_attn_mfma_kernel<<<(unsigned)(pairs * heads), 64, 0, (hipStream_t)stream>>>(
+      (const uint16_t*)q, (const uint16_t*)k_cache, (const uint16_t*)v_cache, tok_pos, pairs, rows_per_pair, heads, ctx,
+      (uint16_t*)out);
+  PSG_CHECK_LAUNCH("psg_prefill_attn");
+  return PSG_OK;
+}

@@ -20,6 +20,8 @@ gate and the greedy step are HIP kernels.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -72,9 +74,11 @@ class LlamaDecodeEngine:
         return F.linear(x, w)
 
     # ---- one pass over `rows` token rows -------------------------------------------------------
-    def _forward(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, decode=False):
+    def _forward(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, decode=False, prefill_shape=None):
         """resid [rows, D] is updated in place (residual stream); returns final-norm hidden [rows, D].
-        decode=True: every row is the newest token of its pair -> fused rotary + KV append + attention."""
+        decode=True: every row is the newest token of its pair -> fused rotary + KV append + attention.
+        prefill_shape=(pairs, rows_per_pair): the rows are a pair-major prompt batch -> matrix-core attention
+        (bf16, <= 64 rows per pair); otherwise the scalar cache-attention kernel."""
         m = self.cfg.llm
         rows, D = resid.shape
         n = torch.empty_like(resid)
@@ -82,13 +86,19 @@ class LlamaDecodeEngine:
         q = torch.empty_like(resid)
         att = torch.empty_like(resid)
         act = torch.empty((rows, m.inter), device=self.device, dtype=self.dtype)
+        mfma_prefill = (prefill_shape is not None and self.dtype == torch.bfloat16 and m.head_dim == 128
+                        and prefill_shape[1] <= 64 and os.environ.get("PSG_PREFILL_ATTN_SCALAR") != "1")
         for l, L in enumerate(self.layers):
             qkv = self.linear(n, L["wqkv"])
             if decode:
                 ops.decode_attn(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, kc[l], vc[l], att)
             else:
                 ops.rope_kvwrite(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, q, kc[l], vc[l])
-                ops.llm_attn(q, kc[l], vc[l], tok_pair, tok_pos, m.heads, m.head_dim, ctx_len, att)
+                if mfma_prefill:
+                    ops.prefill_attn(q, kc[l], vc[l], tok_pos, prefill_shape[0], prefill_shape[1], m.heads, m.head_dim,
+                                     ctx_len, att)
+                else:
+                    ops.llm_attn(q, kc[l], vc[l], tok_pair, tok_pos, m.heads, m.head_dim, ctx_len, att)
             o = self.linear(att, L["wo"])
             ops.rmsnorm(resid, o, L["ln2"], m.rms_eps, n)                      # resid += o ; n = norm(resid)
             gu = self.linear(n, L["wgu"])
@@ -163,7 +173,7 @@ class LlamaDecodeEngine:
         kc = [torch.zeros((K, m.heads, ctx_len, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
         vc = [torch.zeros((K, m.heads, ctx_len, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
         resid = X.reshape(K * maxlen, D).clone()
-        h = self._forward(resid, tok_pair, tok_pos, kc, vc, ctx_len)
+        h = self._forward(resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape=(K, maxlen))
         last_rows = (torch.arange(K, device=dev, dtype=torch.int32) * maxlen + seq_len - 1).contiguous()
         h_last = torch.empty((K, D), device=dev, dtype=self.dtype)
         ops.gather_rows(h, last_rows, h_last)

@@ -228,6 +228,16 @@ def llm_attn(q, k_cache, v_cache, tok_pair, tok_pos, heads, head_dim, ctx_len, o
     return out
 
 
+def prefill_attn(q, k_cache, v_cache, tok_pos, pairs, rows_per_pair, heads, head_dim, ctx_len, out):
+    """Causal attention of a pair-major prompt batch on the matrix cores (bf16, rows_per_pair <= 64)."""
+    lib, ctx, st = _env(q)
+    assert q.shape[0] == pairs * rows_per_pair
+    check(lib.psg_prefill_attn(ctx, _p(q, torch.bfloat16, "q"), _p(k_cache, q.dtype), _p(v_cache, q.dtype),
+                               _p(tok_pos, torch.int32), pairs, rows_per_pair, heads, head_dim, ctx_len,
+                               _p(out, q.dtype), _dt(q), st), "psg_prefill_attn")
+    return out
+
+
 def decode_attn(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, k_cache, v_cache, out):
     """Fused rotary + KV append + attention for rows that each hold the newest token of their pair."""
     lib, ctx, st = _env(out)

@@ -200,6 +200,43 @@ def test_cross_attn_mfma_matches_scalar_kernel(L, N, nq, policy):
     assert torch.isfinite(a).all() and err < 1.2e-2
 
 
+@pytest.mark.parametrize("K,S,heads", [(20, 46, 32), (3, 64, 4), (5, 33, 2), (1, 7, 1)])
+def test_prefill_attn_mfma_vs_scalar_kernel_and_fp32(K, S, heads):
+    """psg_prefill_attn (matrix cores) against psg_llm_attn (scalar) and an fp32 torch causal attention on a
+    pair-major prompt batch with ragged lengths (padding rows at the end of every pair)."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(K * 100 + S)
+    D, ctx = heads * 128, S + 16
+    lens = torch.randint(max(1, S - 12), S + 1, (K,), generator=g)
+    lens[0] = S
+    q = torch.randn(K * S, D, generator=g).to(dev).bfloat16()
+    kc = torch.zeros(K, heads, ctx, 128, device=dev, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    kc[:, :, :S] = torch.randn(K, heads, S, 128, generator=g).to(dev).bfloat16()
+    vc[:, :, :S] = torch.randn(K, heads, S, 128, generator=g).to(dev).bfloat16()
+    t = torch.arange(S)[None, :].expand(K, -1)
+    pos = torch.where(t < lens[:, None], t, torch.full_like(t, -1)).reshape(-1).to(torch.int32).to(dev)
+    pair = torch.arange(K, dtype=torch.int32)[:, None].expand(-1, S).reshape(-1).contiguous().to(dev)
+    out_m = torch.full((K * S, D), 7.0, device=dev, dtype=torch.bfloat16)
+    out_s = torch.empty_like(out_m)
+    ops.prefill_attn(q, kc, vc, pos, K, S, heads, 128, ctx, out_m)
+    ops.llm_attn(q, kc, vc, pair, pos, heads, 128, ctx, out_s)
+    # fp32 reference
+    qh = q.float().view(K, S, heads, 128).permute(0, 2, 1, 3)
+    sc = torch.einsum("khqd,khjd->khqj", qh, kc[:, :, :S].float()) / 128 ** 0.5
+    causal = torch.ones(S, S, dtype=torch.bool, device=dev).tril()
+    keyok = (t < lens[:, None]).to(dev)
+    sc = sc.masked_fill(~(causal[None, None] & keyok[:, None, None, :]), float("-inf"))
+    ref = torch.einsum("khqj,khjd->khqd", torch.softmax(sc, -1), vc[:, :, :S].float()).permute(0, 2, 1, 3).reshape(K * S, D)
+    ok = (pos >= 0)
+    e_m = (out_m.float() - ref)[ok].abs().max().item()
+    e_s = (out_s.float() - ref)[ok].abs().max().item()
+    print(f"K={K} S={S}: mfma err {e_m:.3e}, scalar err {e_s:.3e}")
+    assert e_m < 3e-2 and e_s < 3e-2
+    assert (out_m[~ok] == 0).all()                                  # padding rows: zeros, like the scalar kernel
+
+
 def test_topk_ties_and_order():
     from openpsg_amd import ops
     dev = _dev()
