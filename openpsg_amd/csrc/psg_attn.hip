@@ -423,26 +423,6 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
   const int64_t cbase = ((int64_t)tok_pair[row] * heads + h) * ctx * 128;
   const float scale = 0.08838834764831845f;                   // 1/sqrt(128)
   auto rnd = [](float f) { return sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(f)) : f; };
-  // K and V of the cached keys do not depend on the new token: every wave requests its 16 keys of the first
-  // pass BEFORE wave 0 walks the qkv -> rotary -> LDS chain, so the two L2 round trips overlap.
-  const int kl = lane >> 2, part = lane & 3;
-  float t[8][4], a[16], c[16];
-  auto load_pass = [&](int b0) {
-    const int j = b0 + 16 * wid + kl;
-    const T* kp = kc + cbase + (int64_t)(j < pos ? j : 0) * 128 + part * 32;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) Act<T>::ld4(kp, d * 4, t[d]);
-    const int kbase = b0 + 16 * wid;
-    const int nk = min(16, pos - kbase);
-    const T* vp = vc + cbase + (int64_t)(nk > 0 ? kbase : 0) * 128;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int uu = u < nk ? u : 0;
-      a[u] = Act<T>::ld(vp, (int64_t)uu * 128 + lane);
-      c[u] = Act<T>::ld(vp, (int64_t)uu * 128 + lane + 64);
-    }
-  };
-  load_pass(0);
   float vn1 = 0.f, vn2 = 0.f;
   if (wid == 0) {                                             // new token: rotary, cache append, own score
     const int64_t base = (int64_t)row * 3 * hidden + h * 128;
@@ -466,12 +446,17 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
     vn2 = rnd(v2);
   }
   __syncthreads();
+  const int kl = lane >> 2, part = lane & 3;
   float m_run = -INFINITY, l_run = 0.f, o1 = 0.f, o2 = 0.f;
   for (int b0 = 0; b0 < pos; b0 += 64) {
-    if (b0 > 0) load_pass(b0);
     const int j = b0 + 16 * wid + kl;
     float s = -INFINITY;
     {
+      const bool ok = j < pos;
+      const T* kp = kc + cbase + (int64_t)(ok ? j : 0) * 128 + part * 32;
+      float t[8][4];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) Act<T>::ld4(kp, d * 4, t[d]);
       float acc = 0.f;
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
@@ -483,7 +468,7 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
       }
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
-      if (j < pos) s = acc * scale;
+      if (ok) s = acc * scale;
     }
     const float m_new = fmaxf(m_run, wave_max(s));
     if (m_new == -INFINITY) continue;                          // this wave has no key in this pass (uniform)
@@ -494,7 +479,16 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
     o2 *= alpha;
     if (part == 0) s_p[wid][kl] = pj;
     __builtin_amdgcn_wave_barrier();
-    const int nk = min(16, pos - (b0 + 16 * wid));             // > 0 here
+    const int kbase = b0 + 16 * wid;
+    const int nk = min(16, pos - kbase);                       // > 0 here
+    const T* vp = vc + cbase + (int64_t)kbase * 128;
+    float a[16], c[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int uu = u < nk ? u : 0;
+      a[u] = Act<T>::ld(vp, (int64_t)uu * 128 + lane);
+      c[u] = Act<T>::ld(vp, (int64_t)uu * 128 + lane + 64);
+    }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const float pv = u < nk ? s_p[wid][u] : 0.f;
