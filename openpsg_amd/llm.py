@@ -57,6 +57,8 @@ class LlamaDecodeEngine:
                 ln1=f32(p + "input_layernorm.weight"), ln2=f32(p + "post_attention_layernorm.weight")))
         self.use_skinny = True
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
+        self.early_exit_chunk = 4        # natural-EOS decode: steps per graph between "all pairs done?" checks
+        self.last_replays = 0
         self._graphs = {}
         hd = m.head_dim
         # rotary tables as HF builds them (HF-LL:115-128): inv_freq and the outer product in fp32 on the
@@ -129,14 +131,18 @@ class LlamaDecodeEngine:
         Returns tokens int32 [K, max_new] (device; -1 after a pair's EOS) and optionally the
         first-step logits [K, vocab].
 
-        The whole decode (1 prefill + max_new-1 steps, ~5000 launches for Llama-2-7B) is captured
-        once per shape in a HIP graph and replayed: nothing in it depends on the host (selection,
-        argmax, EOS flags and positions all live on the device), so a replay is a single launch."""
+        The decode is captured in HIP graphs per input shape and replayed: nothing in it depends on
+        the host (selection, argmax, EOS flags and positions all live on the device).
+          * suppress_eos (benchmark worst case): ONE graph = prefill + max_new-1 steps (~5000 launches);
+          * natural EOS: the reference's per-pair `generate` stops at EOS (V4:305-312), and a relation string
+            is a handful of tokens, so the steps are cut into graphs of `early_exit_chunk` steps and the
+            replay stops as soon as every pair has emitted EOS (one 4-byte read-back per chunk)."""
         max_new = self.cfg.max_new_tokens if max_new_tokens is None else max_new_tokens
         if not self.use_graph:
             return self._finish(self._generate_eager(X, prompt_len, max_new, suppress_eos, return_first_logits),
                                 return_first_logits)
-        key = (tuple(X.shape), max_new, bool(suppress_eos), bool(return_first_logits))
+        chunk = 0 if suppress_eos else int(self.early_exit_chunk)
+        key = (tuple(X.shape), max_new, bool(suppress_eos), bool(return_first_logits), chunk)
         ent = self._graphs.get(key)
         if ent is None:
             Xs, ps = X.clone(), prompt_len.to(torch.int32).clone()
@@ -146,21 +152,43 @@ class LlamaDecodeEngine:
                 self._generate_eager(Xs, ps, max_new, suppress_eos, return_first_logits)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                outs = self._generate_eager(Xs, ps, max_new, suppress_eos, return_first_logits)
-            ent = self._graphs[key] = (g, Xs, ps, outs)
-        g, Xs, ps, outs = ent
+            bounds = [max_new] if chunk <= 0 else sorted(set(list(range(chunk, max_new, chunk)) + [max_new]))
+            graphs, st, lo = [], None, 0
+            for hi in bounds:                                  # graph i runs steps [lo, hi); step 0 includes the prefill
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=graphs[0][0].pool() if graphs else None):
+                    if st is None:
+                        st = self._prefill(Xs, ps, max_new, suppress_eos, return_first_logits)
+                        self._steps(st, 1, hi)
+                        all_done = st["done"].min() if chunk > 0 else None
+                    else:
+                        self._steps(st, lo, hi)
+                        all_done = st["done"].min()
+                graphs.append((g, hi, all_done))
+                lo = hi
+            ent = self._graphs[key] = (graphs, Xs, ps, st)
+        graphs, Xs, ps, st = ent
         Xs.copy_(X)
         ps.copy_(prompt_len)
-        g.replay()
-        return self._finish(outs, return_first_logits)
+        self.last_replays = 0
+        for g, hi, all_done in graphs:
+            g.replay()
+            self.last_replays += 1
+            if hi < max_new and int(all_done.item()) != 0:     # every pair has emitted EOS: the rest would be -1
+                break
+        return self._finish((st["tokens"], st["first_logits"]), return_first_logits)
 
     @staticmethod
     def _finish(outs, want_first):
         return outs if want_first else outs[0]
 
     def _generate_eager(self, X, prompt_len, max_new, suppress_eos, return_first_logits):
+        st = self._prefill(X, prompt_len, max_new, suppress_eos, return_first_logits)
+        self._steps(st, 1, max_new)
+        return st["tokens"], st["first_logits"]
+
+    def _prefill(self, X, prompt_len, max_new, suppress_eos, return_first_logits):
+        """Prompt pass + first greedy token.  Returns the decode state (KV caches, token / flag buffers)."""
         m = self.cfg.llm
         K, maxlen, D = X.shape
         nv = self.cfg.qformer.num_query
@@ -189,9 +217,15 @@ class LlamaDecodeEngine:
         sup = m.eos if suppress_eos else -1
         ops.greedy_step(logits, 0, max_new, m.eos, sup, tokens, done, next_ids, dec_pos, dtype=self.dtype)
         x = torch.empty((K, D), device=dev, dtype=self.dtype)
-        for step in range(1, max_new):
-            ops.gather_rows(self.embed, next_ids, x)
-            h = self._forward(x, dec_pair, dec_pos, kc, vc, ctx_len, decode=True)
+        return dict(kc=kc, vc=vc, ctx_len=ctx_len, tokens=tokens, done=done, next_ids=next_ids, dec_pos=dec_pos,
+                    dec_pair=dec_pair, sup=sup, x=x, max_new=max_new, first_logits=first_logits)
+
+    def _steps(self, st, lo, hi):
+        """Decode steps lo .. hi-1 (step s writes tokens[:, s])."""
+        m = self.cfg.llm
+        for step in range(lo, hi):
+            ops.gather_rows(self.embed, st["next_ids"], st["x"])
+            h = self._forward(st["x"], st["dec_pair"], st["dec_pos"], st["kc"], st["vc"], st["ctx_len"], decode=True)
             logits = self.linear(h, self.lm_head)
-            ops.greedy_step(logits, step, max_new, m.eos, sup, tokens, done, next_ids, dec_pos, dtype=self.dtype)
-        return tokens, first_logits
+            ops.greedy_step(logits, step, st["max_new"], m.eos, st["sup"], st["tokens"], st["done"], st["next_ids"],
+                            st["dec_pos"], dtype=self.dtype)

@@ -237,6 +237,49 @@ def test_prefill_attn_mfma_vs_scalar_kernel_and_fp32(K, S, heads):
     assert (out_m[~ok] == 0).all()                                  # padding rows: zeros, like the scalar kernel
 
 
+@pytest.mark.parametrize("dtype,competitors,seed", [("fp32", 0, 5), ("fp32", 1, 2), ("fp32", 1, 1), ("bf16", 1, 2),
+                                                    ("bf16", 2, 0)])
+def test_natural_eos_early_exit_matches_eager(dtype, competitors, seed):
+    """Natural-EOS decoding replays graphs of 4 steps and stops once every pair has emitted EOS (the
+    reference's per-pair generate stops at EOS, V4:305-312).  Tokens must equal the un-chunked eager decode,
+    and the replay must really stop early when the pairs finish early."""
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.llm import LlamaDecodeEngine
+    from openpsg_amd.weights import make_weights_device
+    dev = _dev()
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(512, 2, 1024, 512), max_new_tokens=16)
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    w = make_weights_device(cfg, 11, dev, llm_dtype=tdt)
+    # lm_head: every row zero except EOS and `competitors` other rows: the more competitors, the later the
+    # slowest of the six pairs emits EOS (or never); the (competitors, seed) cases were picked to cover 1, 3 and 4
+    # replayed graphs
+    key = [k for k in w if k.endswith("lm_head.weight")][0]
+    head_w = torch.zeros_like(w[key])
+    for r in (cfg.llm.eos, 40, 41, 42)[:1 + competitors]:
+        head_w[r] = w[key][r]
+    w[key] = head_w
+    eng = LlamaDecodeEngine(w, cfg, dev, tdt)
+    g = torch.Generator().manual_seed(seed)
+    K, Tp = 6, 9
+    X = (torch.randn(K, 32 + Tp, cfg.llm.hidden, generator=g) * 0.5).to(dev).to(tdt)
+    plen = torch.tensor([9, 7, 9, 5, 8, 9], dtype=torch.int32, device=dev)
+    eng.use_graph = False
+    want = eng.generate(X, plen, suppress_eos=False).clone()
+    eng.use_graph = True
+    for _ in range(2):                                            # capture, then pure replay
+        got = eng.generate(X, plen, suppress_eos=False)
+        assert torch.equal(got, want)
+    is_eos = want == cfg.llm.eos
+    first = torch.where(is_eos.any(dim=1), is_eos.int().argmax(dim=1), torch.full((K,), 15, device=dev))
+    last_eos = int(first.max().item())                            # step at which the slowest pair ends (15: never)
+    expect_replays = min(4, last_eos // 4 + 1)
+    print(f"{dtype}/{competitors}: slowest pair emits EOS at step {last_eos}; graphs replayed {eng.last_replays} of 4")
+    assert eng.last_replays == expect_replays
+    # the worst-case (suppressed EOS) path is still one graph
+    eng.generate(X, plen, suppress_eos=True)
+    assert eng.last_replays == 1
+
+
 def test_topk_ties_and_order():
     from openpsg_amd import ops
     dev = _dev()
