@@ -395,9 +395,17 @@ class RelationTransformerHeadV4(nn.Module):
     def decode_selected(self, rq, names, selected=None, pair_features=None, to_host=True):
         """A9: batched greedy decode of the selected pairs."""
         sel = rq["selected"] if selected is None else selected
-        X, plen = self.llm_inputs(rq, names, selected, pair_features)
+        K = sel.numel()
+        sel_in = sel
+        if self.pair_selector == "threshold" and pair_features is None and K % 4:
+            # the pair count is data dependent here: round it up to a multiple of 4 with copies of the last pair
+            # (decode is weight-streaming-bound, extra rows are almost free) so that the engine keeps a few
+            # decode graphs instead of one per count
+            sel_in = torch.cat([sel, sel[-1:].expand(4 - K % 4)]).contiguous()
+        X, plen = self.llm_inputs(rq, names, sel_in, pair_features)
         tokens, first_logits = self.llm_engine.generate(X, plen, suppress_eos=self.suppress_eos,
                                                         return_first_logits=True)
+        tokens, first_logits, X, plen = tokens[:K], first_logits[:K], X[:K], plen[:K]
         out = dict(tokens=tokens, first_logits=first_logits, llm_inputs=X, prompt_len=plen)
         if to_host:
             out["tokens_host"], out["selected_host"] = tokens.cpu().numpy(), sel.cpu().numpy()

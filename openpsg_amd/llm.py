@@ -20,6 +20,7 @@ gate and the greedy step are HIP kernels.
 """
 from __future__ import annotations
 
+import collections
 import os
 
 import torch
@@ -59,7 +60,8 @@ class LlamaDecodeEngine:
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
         self.early_exit_chunk = 4        # natural-EOS decode: steps per graph between "all pairs done?" checks
         self.last_replays = 0
-        self._graphs = {}
+        self._graphs = collections.OrderedDict()   # input shape -> captured decode graphs (LRU, at most max_graphs)
+        self.max_graphs = 6              # a graph owns its KV caches (~0.7 GB at K = 20 for Llama-2-7B)
         hd = m.head_dim
         # rotary tables as HF builds them (HF-LL:115-128): inv_freq and the outer product in fp32 on the
         # host, cos/sin per position; the kernels index them by position
@@ -144,7 +146,11 @@ class LlamaDecodeEngine:
         chunk = 0 if suppress_eos else int(self.early_exit_chunk)
         key = (tuple(X.shape), max_new, bool(suppress_eos), bool(return_first_logits), chunk)
         ent = self._graphs.get(key)
+        if ent is not None:
+            self._graphs.move_to_end(key)
         if ent is None:
+            while len(self._graphs) >= self.max_graphs:        # least recently used shape: frees its graph pool
+                self._graphs.popitem(last=False)
             Xs, ps = X.clone(), prompt_len.to(torch.int32).clone()
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))

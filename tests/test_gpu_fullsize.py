@@ -111,6 +111,44 @@ def test_forward_batch_matches_per_image(setup, dtype):
         assert same >= 0.9 * total                                     # bf16 GEMM rounding differs with the row count
 
 
+def test_threshold_selector_bucketing_and_graph_cache(setup):
+    """'threshold' selection (the commented V4:230-234 logic): the pair count depends on the data.  The decode
+    batch is rounded up to a multiple of 4 with copies of the last pair; the extra rows must not leak into the
+    result, and the engine keeps at most `max_graphs` captured shapes."""
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_device
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=30522), llm=tiny_llm(512, 2, 1024, 512), max_object_num=50)
+    w = make_weights_device(cfg, 7, torch.device("cuda:0"), llm_dtype=torch.float32)
+    kw = dict(dtype="fp32", device="cuda:0", llm_config=cfg.llm, llm_feature_size=512, tokenizers="word",
+              max_object_num=50, on_parse_error="skip", suppress_eos=True)
+    scene = make_scene((512, 768), 12, seed=4, device="cuda:0")
+    plain = RelationTransformerHeadV4(**kw)
+    plain.load_weights(w)
+    plain(_inputs(scene))
+    prob = plain.last["exist_prob"]
+    order = torch.argsort(prob, descending=True, stable=True)
+    thr_head = RelationTransformerHeadV4(pair_selector="threshold", max_llm_forward_num=1, max_selected=32, **kw)
+    thr_head.load_weights(w)
+    thr_head.llm_engine.max_graphs = 2
+    for want_k in (5, 6, 8, 13, 3):                                # 5, 6 -> 8 rows; 13 -> 16; 3 -> 4
+        thr = 0.5 * (prob[order[want_k - 1]] + prob[order[want_k]]).item()
+        thr_head.pair_selector_threshold = thr
+        out = thr_head(_inputs(scene))
+        sel = thr_head.last["selected"]
+        assert sel.numel() == want_k and torch.equal(sel.long(), order[:want_k])
+        assert thr_head.last["tokens_host"].shape == (want_k, 16)
+        # the same pairs decoded without padding rows
+        rq = plain.last
+        from openpsg_amd.categories import INSTANCE_OFFSET, object_categories
+        names = [object_categories[int(i) % INSTANCE_OFFSET] for i in scene["object_id_list"]]
+        ref = plain.decode_selected(rq, names, selected=sel)
+        assert np.array_equal(ref["tokens_host"], thr_head.last["tokens_host"]), want_k
+        assert len(thr_head.llm_engine._graphs) <= 2
+        assert isinstance(out["rel_pred"], list)
+
+
 def test_rccl_pipeline_world1_matches_head(setup):
     import torch.distributed as dist
     from openpsg_amd.dist import PairShardedPipeline
