@@ -280,6 +280,40 @@ def test_natural_eos_early_exit_matches_eager(dtype, competitors, seed):
     assert eng.last_replays == 1
 
 
+def test_mask_kernels_bit_exact_on_random_geometries():
+    """psg_mask_grid / psg_object_bitmasks against the torch interpolate -> pad -> interpolate chain of the
+    reference (V4:416-433, via the oracle) on 40 seeded random geometries: odd sizes, non-square images,
+    down- and up-scaling, padding, id 0 (void aliasing person #0), objects that vanish on the grid."""
+    from openpsg_amd import ops
+    from oracle import psg_oracle as O
+    dev = _dev()
+    rng = np.random.default_rng(1234)
+    for case in range(40):
+        H0, W0 = int(rng.integers(17, 700)), int(rng.integers(17, 900))
+        scale = float(rng.uniform(0.4, 2.2))
+        img_h, img_w = max(16, int(round(H0 * scale))), max(16, int(round(W0 * scale)))
+        pad_h, pad_w = -(-img_h // 64) * 64, -(-img_w // 64) * 64        # feature map = pad / 4, patch 16
+        if rng.random() < 0.3:
+            pad_h += 64
+        gh, gw = pad_h // 64, pad_w // 64
+        n = int(rng.integers(1, 14))
+        ids = [int(rng.integers(0, 133)) + 1000 * int(rng.integers(0, 3)) for _ in range(n)]
+        ids = list(dict.fromkeys(ids))
+        pan = np.full((H0, W0), 0 if rng.random() < 0.3 else 133, dtype=np.int32)
+        for oid in ids:
+            y0, x0 = int(rng.integers(0, H0)), int(rng.integers(0, W0))
+            hh, ww = int(rng.integers(1, max(2, H0 // 2))), int(rng.integers(1, max(2, W0 // 2)))
+            pan[y0:y0 + hh, x0:x0 + ww] = oid
+        pan_t = torch.from_numpy(pan)
+        want_grid = O.mask_grid(pan_t, (img_h, img_w), (pad_h, pad_w), (gh, gw))
+        want = O.object_masks(want_grid, ids).numpy()
+        grid = ops.mask_grid(pan_t.to(dev), (img_h, img_w), (pad_h, pad_w), (gh, gw))
+        assert torch.equal(grid.cpu().reshape(gh, gw), want_grid), (case, H0, W0, img_h, img_w, pad_h, pad_w)
+        bits = ops.object_bitmasks(grid, torch.tensor(ids, dtype=torch.int32, device=dev)).cpu().numpy().view(np.uint64)
+        got = np.unpackbits(bits.view(np.uint8), axis=-1, bitorder="little")[:, :gh * gw].astype(bool)
+        assert np.array_equal(got, want), (case, ids)
+
+
 def test_topk_ties_and_order():
     from openpsg_amd import ops
     dev = _dev()
