@@ -155,6 +155,13 @@ int psg_prefill_attn(psg_ctx*, const void* q, const void* k_cache, const void* v
                      const int32_t* tok_pos, int pairs, int rows_per_pair, int heads, int head_dim,
                      int ctx, void* out, int dtype, void* stream);
 
+/* ---- K13 + K14 (prefill) fused: psg_rope_kvwrite + psg_prefill_attn in one launch.  qkv is the dense
+ * bf16 projection output [pairs*rows_per_pair][3*hidden]; the rotated K and the V rows of the real
+ * tokens are written to the cache (positions == row index inside the pair), Q is never stored. */
+int psg_prefill_attn_rope(psg_ctx*, const void* qkv, const int32_t* tok_pos, const float* rope_cos,
+                          const float* rope_sin, int pairs, int rows_per_pair, int heads, int head_dim,
+                          int ctx, void* k_cache, void* v_cache, void* out, int dtype, void* stream);
+
 /* ---- K13 + K14 fused for the decode step (one new token per pair): rotary + KV-cache append +
  * attention over the cache in one launch.  qkv [rows][3*hidden] (activation dtype, or fp32 split-K
  * partials when qkv_splits > 0); out [rows][hidden].  Equivalent to psg_rope_kvwrite followed by

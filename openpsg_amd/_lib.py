@@ -45,6 +45,7 @@ SIGNATURES = {
     "psg_rope_kvwrite": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "psg_llm_attn": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp],
     "psg_prefill_attn": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "psg_prefill_attn_rope": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "psg_decode_attn": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "psg_silu_mul": [_vp, _vp, _i, _i64, _i, _vp, _i, _vp],
     "psg_skinny_gemm_plan": [_vp, _i, _i, _i, C.POINTER(_i)],

@@ -159,6 +159,204 @@ prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restr
   }
 }
 
+// The same attention with the rotary embedding and the KV-cache write folded in (HF-LL:130-160 + 191-214):
+// reads the fused projection output qkv [rows][3*hidden] directly, rotates Q and K in registers (a lane's
+// fragment for k-step s holds dims 16 s + 8 hi .. +7; the partner dims + 64 are k-step s + 4 of the same lane),
+// writes the rotated K and the V rows to the cache for the decode steps, and never materialises Q.
+__global__ void __launch_bounds__(64)
+prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ tok_pos,
+                              const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, int pairs, int S,
+                              int heads, int ctx, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
+                              uint16_t* __restrict__ out) {
+  const int unit = blockIdx.x;
+  const int p = unit / heads, h = unit % heads;
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int hidden = heads * 128;
+  const int64_t ld = 3 * (int64_t)hidden;
+  const int64_t row0 = (int64_t)p * S;
+  const int64_t cbase = ((int64_t)p * heads + h) * ctx * 128;
+  const int mypos = lane < S ? tok_pos[row0 + lane] : -1;
+  const unsigned long long valid64 = __ballot(mypos >= 0);
+  auto rclamp = [&](int j) { return j < S ? j : S - 1; };
+
+  // V rows of the real tokens -> cache (16-byte pieces, 16 per row)
+  for (int i = lane; i < S * 16; i += 64) {
+    const int r = i >> 4, c = i & 15;
+    if ((valid64 >> r) & 1ull) {
+      const uint4 x = *reinterpret_cast<const uint4*>(qkv + (row0 + r) * ld + 2 * hidden + h * 128 + c * 8);
+      *reinterpret_cast<uint4*>(vc + cbase + (int64_t)r * 128 + c * 8) = x;
+    }
+  }
+
+  pa_f32x16 sc[2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) sc[kt][qt] = (pa_f32x16){0};
+  int rr[2];
+  bool rreal[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    rr[t] = rclamp(32 * t + l31);
+    rreal[t] = (32 * t + l31 < S) && ((valid64 >> rr[t]) & 1ull);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    union F8 {
+      uint4 u;
+      uint16_t h[8];
+      pa_bf16x8 v;
+    };
+    F8 qa[2], qb[2], ka[2], kb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint16_t* rp = qkv + (row0 + rr[t]) * ld + h * 128 + 16 * s + 8 * hi;
+      qa[t].u = *reinterpret_cast<const uint4*>(rp);
+      qb[t].u = *reinterpret_cast<const uint4*>(rp + 64);
+      ka[t].u = *reinterpret_cast<const uint4*>(rp + hidden);
+      kb[t].u = *reinterpret_cast<const uint4*>(rp + hidden + 64);
+      // position of a real token == its row index inside the pair (compact sequences)
+      const float* cp = cos_tab + rr[t] * 64 + 16 * s + 8 * hi;
+      const float* sp = sin_tab + rr[t] * 64 + 16 * s + 8 * hi;
+      float cs[8], sn[8];
+      *reinterpret_cast<float4*>(cs) = *reinterpret_cast<const float4*>(cp);
+      *reinterpret_cast<float4*>(cs + 4) = *reinterpret_cast<const float4*>(cp + 4);
+      *reinterpret_cast<float4*>(sn) = *reinterpret_cast<const float4*>(sp);
+      *reinterpret_cast<float4*>(sn + 4) = *reinterpret_cast<const float4*>(sp + 4);
+      F8 qa2, qb2, ka2, kb2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float q1 = bf16_to_f32(qa[t].h[e]), q2 = bf16_to_f32(qb[t].h[e]);
+        const float k1 = bf16_to_f32(ka[t].h[e]), k2 = bf16_to_f32(kb[t].h[e]);
+        // q*cos + rotate_half(q)*sin, rotate_half(x) = cat(-x2, x1)
+        qa2.h[e] = f32_to_bf16(q1 * cs[e] - q2 * sn[e]);
+        qb2.h[e] = f32_to_bf16(q2 * cs[e] + q1 * sn[e]);
+        ka2.h[e] = f32_to_bf16(k1 * cs[e] - k2 * sn[e]);
+        kb2.h[e] = f32_to_bf16(k2 * cs[e] + k1 * sn[e]);
+      }
+      qa[t] = qa2;
+      qb[t] = qb2;
+      ka[t] = ka2;
+      kb[t] = kb2;
+      if (rreal[t]) {
+        uint16_t* kp = kc + cbase + (int64_t)rr[t] * 128 + 16 * s + 8 * hi;
+        *reinterpret_cast<uint4*>(kp) = ka2.u;
+        *reinterpret_cast<uint4*>(kp + 64) = kb2.u;
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        sc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[kt].v, qa[qt].v, sc[kt][qt], 0, 0, 0);
+        sc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[kt].v, qb[qt].v, sc[kt][qt], 0, 0, 0);
+      }
+  }
+  const float C = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
+  float inv_l[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qi = 32 * qt + l31;
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool vis = key <= qi && ((valid64 >> key) & 1ull);
+        const float y = vis ? sc[kt][qt][r] * C : -INFINITY;
+        sc[kt][qt][r] = y;
+        m = fmaxf(m, y);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (m == -INFINITY) m = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sc[kt][qt][r] - m);
+        sc[kt][qt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const bool qvalid = qi < 64 && ((valid64 >> qi) & 1ull);
+    inv_l[qt] = (qvalid && sum > 0.f) ? 1.0f / sum : 0.f;
+  }
+  pa_f32x16 o[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) o[dt][qt] = (pa_f32x16){0};
+  const uint16_t* vbase = qkv + row0 * ld + 2 * hidden + h * 128 + l31;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      union {
+        uint32_t u[4];
+        pa_bf16x8 v;
+      } pf[2], vf[4];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          pf[qt].u[e] = pa_pack(sc[kt][qt][8 * g + 2 * e], sc[kt][qt][8 * g + 2 * e + 1]);
+      uint16_t ve[4][8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int key = rclamp(32 * kt + 16 * g + (m & 3) + 8 * (m >> 2) + 4 * hi);
+        const uint16_t* vp = vbase + (int64_t)key * ld;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ve[dt][m] = vp[32 * dt];
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vf[dt].u[e] = (uint32_t)ve[dt][2 * e] | ((uint32_t)ve[dt][2 * e + 1] << 16);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          o[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt].v, pf[qt].v, o[dt][qt], 0, 0, 0);
+    }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qi = 32 * qt + l31;
+    if (qi < S) {
+      uint16_t* op = out + (row0 + qi) * hidden + h * 128 + 4 * hi;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          uint2 wv;
+          wv.x = pa_pack(o[dt][qt][4 * r4] * inv_l[qt], o[dt][qt][4 * r4 + 1] * inv_l[qt]);
+          wv.y = pa_pack(o[dt][qt][4 * r4 + 2] * inv_l[qt], o[dt][qt][4 * r4 + 3] * inv_l[qt]);
+          *reinterpret_cast<uint2*>(op + 32 * dt + 8 * r4) = wv;
+        }
+    }
+  }
+}
+
+extern "C" int psg_prefill_attn_rope(psg_ctx* ctx_, const void* qkv, const int32_t* tok_pos, const float* rope_cos,
+                                     const float* rope_sin, int pairs, int rows_per_pair, int heads, int head_dim,
+                                     int ctx, void* k_cache, void* v_cache, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx_ && qkv && tok_pos && rope_cos && rope_sin && k_cache && v_cache && out, PSG_ERR_INVALID,
+              "psg_prefill_attn_rope: NULL argument");
+  PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED, "psg_prefill_attn_rope: bf16 only");
+  PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_prefill_attn_rope: head_dim=%d (kernel is built for 128)",
+              head_dim);
+  PSG_REQUIRE(rows_per_pair >= 1 && rows_per_pair <= 64 && rows_per_pair <= ctx, PSG_ERR_UNSUPPORTED,
+              "psg_prefill_attn_rope: rows_per_pair=%d (1..64, <= ctx=%d)", rows_per_pair, ctx);
+  PSG_REQUIRE(pairs >= 0 && heads > 0, PSG_ERR_INVALID, "psg_prefill_attn_rope: pairs=%d heads=%d", pairs, heads);
+  if (pairs == 0) return PSG_OK;
+  prefill_attn_rope_mfma_kernel<<<(unsigned)(pairs * heads), 64, 0, (hipStream_t)stream>>>(
+      (const uint16_t*)qkv, tok_pos, rope_cos, rope_sin, pairs, rows_per_pair, heads, ctx, (uint16_t*)k_cache,
+      (uint16_t*)v_cache, (uint16_t*)out);
+  PSG_CHECK_LAUNCH("psg_prefill_attn_rope");
+  return PSG_OK;
+}
+
 extern "C" int psg_prefill_attn(psg_ctx* ctx_, const void* q, const void* k_cache, const void* v_cache,
                                 const int32_t* tok_pos, int pairs, int rows_per_pair, int heads, int head_dim, int ctx,
                                 void* out, int dtype, void* stream) {

@@ -96,6 +96,9 @@ class LlamaDecodeEngine:
             qkv = self.linear(n, L["wqkv"])
             if decode:
                 ops.decode_attn(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, kc[l], vc[l], att)
+            elif mfma_prefill and isinstance(qkv, torch.Tensor):
+                ops.prefill_attn_rope(qkv, tok_pos, self.rope, prefill_shape[0], prefill_shape[1], m.heads, m.head_dim,
+                                      ctx_len, kc[l], vc[l], att)
             else:
                 ops.rope_kvwrite(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, q, kc[l], vc[l])
                 if mfma_prefill:

@@ -238,6 +238,18 @@ def prefill_attn(q, k_cache, v_cache, tok_pos, pairs, rows_per_pair, heads, head
     return out
 
 
+def prefill_attn_rope(qkv, tok_pos, rope, pairs, rows_per_pair, heads, head_dim, ctx_len, k_cache, v_cache, out):
+    """Rotary + KV-cache write + causal attention of a pair-major prompt batch in one launch (bf16)."""
+    lib, ctx, st = _env(out)
+    assert qkv.shape == (pairs * rows_per_pair, 3 * heads * head_dim) and rope[0].shape[1] == head_dim // 2
+    assert rope[0].shape[0] >= rows_per_pair
+    check(lib.psg_prefill_attn_rope(ctx, _p(qkv, torch.bfloat16, "qkv"), _p(tok_pos, torch.int32),
+                                    _p(rope[0], torch.float32), _p(rope[1], torch.float32), pairs, rows_per_pair, heads,
+                                    head_dim, ctx_len, _p(k_cache, out.dtype), _p(v_cache, out.dtype), _p(out),
+                                    _dt(out), st), "psg_prefill_attn_rope")
+    return out
+
+
 def decode_attn(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, k_cache, v_cache, out):
     """Fused rotary + KV append + attention for rows that each hold the newest token of their pair."""
     lib, ctx, st = _env(out)

@@ -280,6 +280,41 @@ def test_natural_eos_early_exit_matches_eager(dtype, competitors, seed):
     assert eng.last_replays == 1
 
 
+@pytest.mark.parametrize("K,S,heads", [(20, 46, 32), (3, 64, 4), (4, 21, 2)])
+def test_prefill_attn_rope_fused_matches_two_kernels(K, S, heads):
+    """psg_prefill_attn_rope == psg_rope_kvwrite followed by psg_prefill_attn: attention output, rotated K rows
+    and V rows in the cache (real tokens only; cache rows of padding tokens stay untouched)."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(K * 10 + S)
+    D, ctx = heads * 128, S + 16
+    lens = torch.randint(max(1, S - 9), S + 1, (K,), generator=g)
+    lens[0] = S
+    qkv = torch.randn(K * S, 3 * D, generator=g).to(dev).bfloat16()
+    t = torch.arange(S)[None, :].expand(K, -1)
+    pos = torch.where(t < lens[:, None], t, torch.full_like(t, -1)).reshape(-1).to(torch.int32).to(dev)
+    pair = torch.arange(K, dtype=torch.int32)[:, None].expand(-1, S).reshape(-1).contiguous().to(dev)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128))
+    ang = torch.arange(ctx, dtype=torch.float32)[:, None] * inv_freq[None, :]
+    rope = (ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev))
+    kc1 = torch.zeros(K, heads, ctx, 128, device=dev, dtype=torch.bfloat16)
+    vc1, kc2, vc2 = torch.zeros_like(kc1), torch.zeros_like(kc1), torch.zeros_like(kc1)
+    q = torch.zeros(K * S, D, device=dev, dtype=torch.bfloat16)
+    out1 = torch.empty_like(q)
+    out2 = torch.full_like(q, 3.0)
+    ops.rope_kvwrite(qkv, pair, pos, rope, heads, 128, ctx, q, kc1, vc1)
+    ops.prefill_attn(q, kc1, vc1, pos, K, S, heads, 128, ctx, out1)
+    ops.prefill_attn_rope(qkv, pos, rope, K, S, heads, 128, ctx, kc2, vc2, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(vc1, vc2)
+    dk = ((kc1.float() - kc2.float()).abs() / (1 + kc1.float().abs())).max().item()
+    do = ((out1.float() - out2.float()).abs() / (1 + out1.float().abs())).max().item()
+    print(f"K={K} S={S}: cache K rel diff {dk:.2e}, output rel diff {do:.2e}")
+    assert dk < 8e-3 and do < 1.2e-2                                # one bf16 ulp
+    for k in range(K):                                              # rows past a pair's length: untouched
+        assert (kc2[k, :, int(lens[k]):] == 0).all() and (vc2[k, :, int(lens[k]):] == 0).all()
+
+
 def test_mask_kernels_bit_exact_on_random_geometries():
     """psg_mask_grid / psg_object_bitmasks against the torch interpolate -> pad -> interpolate chain of the
     reference (V4:416-433, via the oracle) on 40 seeded random geometries: odd sizes, non-square images,
