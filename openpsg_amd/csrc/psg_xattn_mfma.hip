@@ -7,25 +7,28 @@
 // bitmask table and tests bits in registers.
 //
 // Work layout (gfx950, wave = 64):
-//   * query rows of all pairs are one flat list of R = P*33 rows, cut into 32-row tiles
-//     (33 = 1 cls row + 32 relation rows, so there is no padding waste beyond the last tile);
-//   * a workgroup (4 waves) owns one head h: it stages K_h [Lpad][64] and V_h^T [64][Lpad] (bf16)
-//     into LDS once (row strides padded by 16 B => conflict-free ds_read_b128) and then walks
-//     row tiles persistently, one tile per wave per iteration;
-//   * S^T = K . Q^T with v_mfma_f32_32x32x16_bf16 (A = K fragment from LDS, B = Q fragment held
-//     in registers), so a lane owns ONE query row (column lane&31 of D) and 16 keys per 32-key
-//     tile: the mask is per lane, the softmax reduction is in-register plus one lane^32 exchange;
-//   * O^T = V^T . P^T the same way (A = V^T fragment from LDS, B = P fragment = this lane's
-//     exponentiated scores packed to bf16), so the online-softmax rescale and the final 1/l are
-//     lane-local.  V^T is stored with key bits 2<->3 swapped inside every 16-key group, which makes
-//     the accumulator registers of the S^T tile line up with the B-operand slots of the P.V MFMA
-//     without any cross-lane shuffle;
-//   * keys are processed in chunks of 128 (4 S^T tiles, 64 accumulator registers) with an fp32
-//     online softmax, so any L works with one instantiation.
+//   * a workgroup (4 waves, 2 per CU) owns one head h: it stages K_h [Lpad][64], V_h^T [64][Lpad] (bf16, row
+//     strides padded by 16 B => conflict-free ds_read_b128), the mean of V_h and the whole object bit table
+//     into LDS once, then its waves walk row tiles in a static round-robin order;
+//   * row tiles (nq == 33): first the tiles that batch the cls rows (row 0) of 32 consecutive pairs - they
+//     carry per-row masks - then one tile per pair = its rows 1..32, which share ONE mask, so the mask words
+//     are wave-uniform, 32-key tiles nobody attends to are skipped (they contribute exactly 0), and an empty
+//     union under the "uniform" policy is just the mean of V;
+//   * S^T = K . Q^T with v_mfma_f32_32x32x16_bf16 (A = K fragment from LDS, B = Q fragment held in
+//     registers), so a lane owns ONE query row (column lane&31 of D) and 16 keys per 32-key tile; for pair
+//     tiles the additive mask is one more MFMA (A'[key][0] = 0 / -2^15, B'[0][row] = 1) instead of three
+//     VALU instructions per score; the softmax reduction is in-register plus one lane^32 exchange;
+//   * O^T = V^T . P^T the same way (A = V^T fragment from LDS, B = this lane's exponentiated scores packed to
+//     bf16), so the online-softmax rescale and the final 1/l are lane-local.  V^T is stored with key bits
+//     2<->3 swapped inside every 16-key group, which makes the accumulator registers of the S^T tile line up
+//     with the B-operand slots of the P.V MFMA without any cross-lane shuffle;
+//   * the active key tiles of a unit are a dynamic loop (per-tile online softmax, 22 KB of code instead of
+//     55 KB unrolled); the Q fragments and pair ids of the next two units are in flight while one is computed.
+// The kernel moves Q in and the context out once each (PMC: 126 MB + 124 MB at N = 50) and is bound by that
+// traffic, 128 bytes per row per head; see DESIGN.md for the timeline that led here.
 //
-// Mask semantics: masked key => score + finfo.min (== finfo.min in
-// fp32) so an all-masked row is a UNIFORM softmax over the L real keys; keys in [L, Lpad) are
-// padding and get -inf (weight exactly 0 in every case).
+// Mask semantics: masked key => score + finfo.min (== finfo.min in fp32) so an
+// all-masked row is a UNIFORM softmax over the L real keys; keys in [L, Lpad) are padding (weight 0).
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -39,8 +42,6 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 #define XA_KSTRIDE 144  // bytes per K row in LDS: 64 bf16 + 16 B pad
-#define XA_CT 4         // S^T tiles (of 32 keys) per online-softmax chunk
-#define XA_GRAB 4       // row tiles a wave takes from the work counter per atomic
 
 // value of the partner lane (lane ^ 32) via v_permlane32_swap (VALU, no LDS round trip)
 __device__ __forceinline__ float xchg32_max(float x) {
@@ -492,7 +493,7 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
   const size_t lds = (size_t)Lpad * XA_KSTRIDE + (size_t)64 * (Lpad * 2 + 16) + 256 + (((size_t)N * words * 8 + 15) & ~(size_t)15);
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn: L=%d needs %zu B of LDS (> 160 KiB)", L,
               lds);
-  const int NC = (Lpad / 32 + XA_CT - 1) / XA_CT;
+  const int NC = (Lpad / 32 + 3) / 4;                     // template parameter: staging passes / 128 keys
   PSG_REQUIRE(NC >= 1 && NC <= 4, PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn: L=%d (MFMA variant handles L <= 512)", L);
   const void* kfn = NC == 1 ? (const void*)cross_attn_mfma_kernel<1>
                   : NC == 2 ? (const void*)cross_attn_mfma_kernel<2>
