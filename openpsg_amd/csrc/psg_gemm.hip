@@ -365,6 +365,18 @@ static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
   const int blocks_n = (N + SG_ROWS - 1) / SG_ROWS;
   if (forced <= 0)
     while (S < KB / 4 && (int64_t)blocks_n * S < 2 * ctx->num_cu) S *= 2;   // small N: split deeper
+  static int balance = -1;
+  if (balance < 0) {
+    const char* e = getenv("PSG_SKINNY_BALANCE");
+    balance = e ? atoi(e) : 1;
+  }
+  if (balance && forced <= 0 && 2 * S <= 8 && 2 * S <= KB / 4) {
+    // balance: one workgroup per CU works through ceil(units / CUs) rounds of (slab, slice) units; if the last
+    // round is mostly empty (q/k/v projection: 96 slabs x 4 slices = 1.5 rounds), twice the slices fill it
+    const double r1 = (double)((N + 127) / 128) * S / ctx->num_cu, r2 = 2.0 * r1;   // 128-row slabs (8-wave DMA variant)
+    const double e1 = r1 / (double)(int64_t)(r1 + 0.999999), e2 = r2 / (double)(int64_t)(r2 + 0.999999);
+    if (e1 < 0.8 && e2 > e1 + 0.15) S *= 2;
+  }
   if (S > KB) S = KB;
   if (S > PSG_MAX_SPLITS && forced <= 0) S = PSG_MAX_SPLITS;
   if (S < 1) S = 1;
