@@ -364,11 +364,42 @@ __global__ void silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows
   }
 }
 
+// prompt pass (hundreds of dense bf16 rows): 8 columns per thread (16-byte loads), one row per blockIdx.y,
+// no index division; the decode step (<= 64 rows, split-K partials) keeps the kernel above
+__global__ void __launch_bounds__(256) silu_mul_rows_bf16_kernel(const uint16_t* __restrict__ gu, int64_t rows,
+                                                                  int inter, uint16_t* __restrict__ out) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= inter) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const uint4 gv = *reinterpret_cast<const uint4*>(gu + r * 2 * inter + c);
+    const uint4 uv = *reinterpret_cast<const uint4*>(gu + r * 2 * inter + inter + c);
+    const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, uw[4] = {uv.x, uv.y, uv.z, uv.w};
+    uint32_t ow[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
+      const float u0 = __uint_as_float(uw[e] << 16), u1 = __uint_as_float(uw[e] & 0xffff0000u);
+      // same arithmetic as silu_mul_kernel<bf16_t>: silu in fp32, rounded to bf16 (HF rounds act_fn(gate)), product
+      const float s0 = bf16_to_f32(f32_to_bf16(g0 / (1.0f + expf(-g0))));
+      const float s1 = bf16_to_f32(f32_to_bf16(g1 / (1.0f + expf(-g1))));
+      ow[e] = (uint32_t)f32_to_bf16(s0 * u0) | ((uint32_t)f32_to_bf16(s1 * u1) << 16);
+    }
+    *reinterpret_cast<uint4*>(out + r * inter + c) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+}
+
 extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int splits, int64_t rows, int inter, void* out,
                             int dtype, void* stream) {
   PSG_REQUIRE(ctx && gate_up && out, PSG_ERR_INVALID, "psg_silu_mul: NULL argument");
   PSG_REQUIRE(inter > 0 && inter % 4 == 0, PSG_ERR_INVALID, "psg_silu_mul: inter=%d must be a multiple of 4", inter);
   if (rows == 0) return PSG_OK;
+  if (dtype == PSG_BF16 && splits == 0 && rows > 64 && inter % 8 == 0) {
+    const dim3 grid((unsigned)((inter / 8 + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+    silu_mul_rows_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t*)gate_up, rows, inter,
+                                                                     (uint16_t*)out);
+    PSG_CHECK_LAUNCH("psg_silu_mul");
+    return PSG_OK;
+  }
   int64_t blocks = (rows * inter / 4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   PSG_DISPATCH_DTYPE(dtype, "psg_silu_mul",

@@ -315,6 +315,24 @@ def test_prefill_attn_rope_fused_matches_two_kernels(K, S, heads):
         assert (kc2[k, :, int(lens[k]):] == 0).all() and (vc2[k, :, int(lens[k]):] == 0).all()
 
 
+def test_silu_mul_prompt_pass_kernel_equals_decode_kernel():
+    """The 16-byte-load SwiGLU kernel used for dense bf16 batches of more than 64 rows computes exactly what the
+    generic kernel computes row by row."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    rows, inter = 333, 2752
+    gu = (torch.randn(rows, 2 * inter, generator=g) * 2).to(dev).bfloat16()
+    big = torch.empty(rows, inter, device=dev, dtype=torch.bfloat16)
+    ops.silu_mul(gu, big)
+    small = torch.empty_like(big)
+    for r0 in range(0, rows, 64):
+        ops.silu_mul(gu[r0:r0 + 64].contiguous(), small[r0:r0 + 64])
+    assert torch.equal(big, small)
+    want = torch.nn.functional.silu(gu[:, :inter].float()).bfloat16().float() * gu[:, inter:].float()
+    assert ((big.float() - want).abs() / (1 + want.abs())).max().item() < 8e-3       # one bf16 ulp
+
+
 def test_mask_kernels_bit_exact_on_random_geometries():
     """psg_mask_grid / psg_object_bitmasks against the torch interpolate -> pad -> interpolate chain of the
     reference (V4:416-433, via the oracle) on 40 seeded random geometries: odd sizes, non-square images,
