@@ -143,6 +143,7 @@ class RelationTransformerHeadV4(nn.Module):
             self.relation_qformer_tokenizer, self.llm_tokenizer = tokenizers
         self.llm_tokenizer.pad_token = self.llm_tokenizer.unk_token        # V4:105
         self.last = {}
+        self._gather_cache = {}
         self.train(False)                                                   # inference-only module
 
     # ---- weights ---------------------------------------------------------------------------------
@@ -318,18 +319,29 @@ class RelationTransformerHeadV4(nn.Module):
         uidx, U, tbl_d, msk_d, u_d = self._table_cache[ck]
         p0, p1 = (0, B) if pair_range is None else pair_range
         q = self.cfg.qformer
-        hidden = torch.empty(((p1 - p0) * q.q_rows, q.hidden), device=dev, dtype=self.act_dtype)
-        logit = torch.empty(p1 - p0, device=dev, dtype=torch.float32)
-        prob = torch.empty(p1 - p0, device=dev, dtype=torch.float32)
+        single = p1 - p0 <= self.pair_chunk                      # one chunk: take the engine's outputs as they are
+        if not single:
+            hidden = torch.empty(((p1 - p0) * q.q_rows, q.hidden), device=dev, dtype=self.act_dtype)
+            logit = torch.empty(p1 - p0, device=dev, dtype=torch.float32)
+            prob = torch.empty(p1 - p0, device=dev, dtype=torch.float32)
         for c0 in range(p0, p1, self.pair_chunk):
             c1 = min(p1, c0 + self.pair_chunk)
-            pidx = torch.arange(c0, c1, device=dev, dtype=torch.int64)
-            trow = u_d[pidx // N] * U + u_d[pidx % N]
-            h, lg, pr = eng.forward_pairs(kv, bits, N, pidx.to(torch.int32), tbl_d[trow].contiguous(),
-                                          msk_d[trow].contiguous())
-            hidden[(c0 - p0) * q.q_rows:(c1 - p0) * q.q_rows] = h
-            logit[c0 - p0:c1 - p0] = lg
-            prob[c0 - p0:c1 - p0] = pr
+            gk = (ck, N, c0, c1)                                  # per-pair prompt ids of a chunk depend on the names only
+            ent = self._gather_cache.get(gk)
+            if ent is None:
+                pidx = torch.arange(c0, c1, device=dev, dtype=torch.int64)
+                trow = u_d[pidx // N] * U + u_d[pidx % N]
+                if len(self._gather_cache) > 64:
+                    self._gather_cache.clear()
+                ent = self._gather_cache[gk] = (pidx.to(torch.int32), tbl_d[trow].contiguous(),
+                                                msk_d[trow].contiguous())
+            if single:
+                hidden, logit, prob = eng.forward_pairs(kv, bits, N, ent[0], ent[1], ent[2])
+            else:                                                 # the last layer writes straight into its slice
+                _, lg, pr = eng.forward_pairs(kv, bits, N, ent[0], ent[1], ent[2],
+                                              hidden_out=hidden[(c0 - p0) * q.q_rows:(c1 - p0) * q.q_rows])
+                logit[c0 - p0:c1 - p0] = lg
+                prob[c0 - p0:c1 - p0] = pr
         out = dict(patches=patches, bits=bits, hidden=hidden, exist_logit=logit, exist_prob=prob,
                    num_objects=N, pair_range=(p0, p1), uidx=uidx)
         if pair_range is None:

@@ -88,9 +88,10 @@ class RelationQueryEngine:
         return [(F.linear(pa, L["wk_x"], L["bk_x"]), F.linear(pa, L["wv_x"], L["bv_x"])) for L in self.layers]
 
     # ---- A6 + A7: Q-Former over a list of pairs ---------------------------------------------------
-    def forward_pairs(self, kv, bits, num_objects, pair_index, ids, text_mask):
+    def forward_pairs(self, kv, bits, num_objects, pair_index, ids, text_mask, hidden_out=None):
         """pair_index int32 [P] (p = i*N + j), ids int32 [P,T], text_mask uint8 [P,T].
-        Returns (hidden [P*33, 768] in the activation dtype, exist_logit [P] fp32, exist_prob [P] fp32)."""
+        Returns (hidden [P*33, 768] in the activation dtype, exist_logit [P] fp32, exist_prob [P] fp32).
+        hidden_out: caller-owned [P*33, 768] buffer the last layer writes into (no copy when pairs are chunked)."""
         q = self.cfg.qformer
         nq, H = q.q_rows, q.hidden
         P, T = ids.shape
@@ -114,7 +115,11 @@ class RelationQueryEngine:
             Cq = F.linear(cx, L["wo_x"])
             ops.add_layernorm(Cq, A[:RQ], L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
             del qx, cx
-            Xn = torch.empty((RQ if last else R, H), device=self.device, dtype=self.dtype)
+            if last and hidden_out is not None:
+                assert hidden_out.shape == (RQ, H) and hidden_out.dtype == self.dtype and hidden_out.is_contiguous()
+                Xn = hidden_out
+            else:
+                Xn = torch.empty((RQ if last else R, H), device=self.device, dtype=self.dtype)
             iq = F.linear(Cq, L["w1q"])
             ops.bias_gelu(iq, L["b1q"])
             hq = F.linear(iq, L["w2q"])
