@@ -40,6 +40,9 @@ prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restr
   const int mypos = lane < S ? tok_pos[row0 + lane] : -1;
   const unsigned long long valid64 = __ballot(mypos >= 0);
   auto rclamp = [&](int j) { return j < S ? j : S - 1; };
+  // cache rows are only defined for the real tokens (a prefix of the pair's rows): never read past them
+  const int nreal = __popcll(valid64);
+  auto kclamp = [&](int j) { return j < nreal ? j : (nreal > 0 ? nreal - 1 : 0); };
 
   pa_f32x16 sc[2][2];                                           // [key tile][query tile]
 #pragma unroll
@@ -53,7 +56,7 @@ prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restr
   for (int t = 0; t < 2; ++t) {
     const int r = rclamp(32 * t + l31);
     qp[t] = q + (row0 + r) * hidden + h * 128 + hi * 8;
-    kp[t] = kc + cbase + (int64_t)r * 128 + hi * 8;           // key j of the pair lives in cache row j (positions are compact)
+    kp[t] = kc + cbase + (int64_t)kclamp(r) * 128 + hi * 8;   // key j of the pair lives in cache row j (positions are compact)
   }
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
@@ -124,7 +127,7 @@ prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restr
       uint16_t ve[4][8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        const int key = rclamp(32 * kt + 16 * g + (m & 3) + 8 * (m >> 2) + 4 * hi);
+        const int key = kclamp(32 * kt + 16 * g + (m & 3) + 8 * (m >> 2) + 4 * hi);
         const uint16_t* vp = vbase + (int64_t)key * 128;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) ve[dt][m] = vp[32 * dt];

@@ -218,17 +218,21 @@ def test_prefill_attn_mfma_vs_scalar_kernel_and_fp32(K, S, heads):
     t = torch.arange(S)[None, :].expand(K, -1)
     pos = torch.where(t < lens[:, None], t, torch.full_like(t, -1)).reshape(-1).to(torch.int32).to(dev)
     pair = torch.arange(K, dtype=torch.int32)[:, None].expand(-1, S).reshape(-1).contiguous().to(dev)
+    kc_clean, vc_clean = kc.clone(), vc.clone()
+    for kk in range(K):                                             # the engine does not zero the cache: rows the
+        kc[kk, :, int(lens[kk]):] = float("nan")                    # rotary kernel never wrote must not be read
+        vc[kk, :, int(lens[kk]):] = float("nan")
     out_m = torch.full((K * S, D), 7.0, device=dev, dtype=torch.bfloat16)
     out_s = torch.empty_like(out_m)
     ops.prefill_attn(q, kc, vc, pos, K, S, heads, 128, ctx, out_m)
     ops.llm_attn(q, kc, vc, pair, pos, heads, 128, ctx, out_s)
     # fp32 reference
     qh = q.float().view(K, S, heads, 128).permute(0, 2, 1, 3)
-    sc = torch.einsum("khqd,khjd->khqj", qh, kc[:, :, :S].float()) / 128 ** 0.5
+    sc = torch.einsum("khqd,khjd->khqj", qh, kc_clean[:, :, :S].float()) / 128 ** 0.5
     causal = torch.ones(S, S, dtype=torch.bool, device=dev).tril()
     keyok = (t < lens[:, None]).to(dev)
     sc = sc.masked_fill(~(causal[None, None] & keyok[:, None, None, :]), float("-inf"))
-    ref = torch.einsum("khqj,khjd->khqd", torch.softmax(sc, -1), vc[:, :, :S].float()).permute(0, 2, 1, 3).reshape(K * S, D)
+    ref = torch.einsum("khqj,khjd->khqd", torch.softmax(sc, -1), vc_clean[:, :, :S].float()).permute(0, 2, 1, 3).reshape(K * S, D)
     ok = (pos >= 0)
     e_m = (out_m.float() - ref)[ok].abs().max().item()
     e_s = (out_s.float() - ref)[ok].abs().max().item()
