@@ -422,10 +422,26 @@ __global__ void __launch_bounds__(1024) greedy_step_kernel(const void* __restric
   const int64_t slice = (int64_t)gridDim.x * vocab;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = tid; i < vocab; i += blockDim.x) {
+  // 4 vocabulary entries per thread and pass (16-byte loads per split-K slice): one workgroup per pair has to
+  // pull 4 slices x 128 KB through a single CU, and scalar 4-byte loads made that 38 us of a decode step
+  const int v4 = (vocab % 4 == 0 && ((int64_t)k * vocab) % 4 == 0) ? vocab / 4 : 0;
+  for (int i4 = tid; i4 < v4; i4 += blockDim.x) {
+    float v[4];
+    ld4_in<T>(logits, S, slice, (int64_t)k * vocab + 4 * i4, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * i4 + e;
+      const float x = i == suppress ? -INFINITY : v[e];
+      if (x > best || (x == best && i < bi)) {  // first maximal index, like torch.argmax
+        best = x;
+        bi = i;
+      }
+    }
+  }
+  for (int i = 4 * v4 + tid; i < vocab; i += blockDim.x) {
     float v = ld1_in<T>(logits, S, slice, (int64_t)k * vocab + i);
     if (i == suppress) v = -INFINITY;
-    if (v > best || (v == best && i < bi)) {  // first maximal index, like torch.argmax
+    if (v > best || (v == best && i < bi)) {
       best = v;
       bi = i;
     }

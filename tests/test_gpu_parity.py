@@ -337,6 +337,54 @@ def test_silu_mul_prompt_pass_kernel_equals_decode_kernel():
     assert ((big.float() - want).abs() / (1 + want.abs())).max().item() < 8e-3       # one bf16 ulp
 
 
+@pytest.mark.parametrize("vocab,splits,dtype", [(32000, 4, "bf16"), (32000, 0, "bf16"), (32003, 0, "fp32"), (515, 3, "bf16"),
+                                                 (32000, 0, "fp32")])
+def test_greedy_step_argmax_ties_suppress_and_bookkeeping(vocab, splits, dtype):
+    """psg_greedy_step against torch.argmax: first maximal index on ties, suppressed token, EOS / done / position
+    bookkeeping; vocabulary sizes with and without the 16-byte fast path, dense logits and split-K partials."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(vocab + splits)
+    K, max_new, eos = 7, 5, 2
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    base = (torch.randn(K, vocab, generator=g) * 2).to(tdt).float()
+    base[0, 100] = base[0, 400] = base[0].max() + 1                # tie: index 100 must win
+    base[1, eos] = base[1].max() + 3                               # pair 1 emits EOS
+    base[2, 7] = base[2].max() + 3                                 # pair 2's maximum is the suppressed token
+    base[3, vocab - 1] = base[3].max() + 2                         # last entry (tail loop when vocab % 4 != 0)
+    if splits:
+        parts = torch.randn(splits, K, vocab, generator=g)
+        parts[-1] = base - parts[:-1].sum(0)
+        logits = ops.Partials(parts.to(dev).contiguous())
+        summed = parts.to(dev)[0].clone()
+        for sidx in range(1, splits):
+            summed += parts.to(dev)[sidx]
+        ref_logits = summed.to(tdt).float() if tdt == torch.bfloat16 else summed
+    else:
+        logits = base.to(dev).to(tdt).contiguous()
+        ref_logits = logits.float()
+    ref = ref_logits.clone()
+    ref[:, 7] = float("-inf")
+    want = ref.argmax(dim=1).to(torch.int32)
+    tokens = torch.full((K, max_new), -1, device=dev, dtype=torch.int32)
+    done = torch.zeros(K, device=dev, dtype=torch.int32)
+    done[4] = 1                                                    # pair 4 finished earlier
+    next_ids = torch.zeros(K, device=dev, dtype=torch.int32)
+    pos = torch.arange(K, device=dev, dtype=torch.int32) + 40
+    ops.greedy_step(logits, 1, max_new, eos, 7, tokens, done, next_ids, pos, dtype=tdt)
+    torch.cuda.synchronize()
+    assert torch.equal(next_ids, want)
+    if not splits:
+        assert int(want[0]) == 100 and int(want[3]) == vocab - 1
+    exp_tok = want.clone()
+    exp_tok[4] = -1
+    assert torch.equal(tokens[:, 1], exp_tok) and (tokens[:, 0] == -1).all()
+    exp_done = (want == eos).to(torch.int32)
+    exp_done[4] = 1
+    assert torch.equal(done, exp_done)
+    assert torch.equal(pos, torch.arange(K, device=dev, dtype=torch.int32) + 41)
+
+
 def test_mask_kernels_bit_exact_on_random_geometries():
     """psg_mask_grid / psg_object_bitmasks against the torch interpolate -> pad -> interpolate chain of the
     reference (V4:416-433, via the oracle) on 40 seeded random geometries: odd sizes, non-square images,
