@@ -85,6 +85,12 @@ class HipBackend:
                                           scene["pan_results"], pair_range=(p0, p1), patches=patches)
         return rq["hidden"], rq["exist_prob"]
 
+    def query_shards(self, scenes, patches, p0, p1):
+        """The shard [p0, p1) of every image in ONE Q-Former pass (per-image cross-attention only)."""
+        items = [(s["mask_features"], s["img_meta"], [int(i) for i in s["object_id_list"]], self._names(s),
+                  s["pan_results"]) for s in scenes]
+        return self.head.run_relation_query_shards(items, (p0, p1), [patches[m] for m in range(len(scenes))])
+
     def topk(self, prob, k):
         return self.head.rq_engine.select(prob, k)
 
@@ -142,8 +148,9 @@ class PairShardedPipeline:
         p0, p1, shard = shard_range(B, R, r)
         prob_pad = torch.full((R, shard), -1.0, device=patches.device, dtype=torch.float32)
         hidden = []
-        for m in range(R):
-            h, prob = be.query_shard(scenes[m], patches[m], p0, p1)
+        shards = be.query_shards(scenes, patches, p0, p1) if hasattr(be, "query_shards") else \
+            [be.query_shard(scenes[m], patches[m], p0, p1) for m in range(R)]
+        for m, (h, prob) in enumerate(shards):
             hidden.append(h)
             prob_pad[m, :p1 - p0] = prob
         gathered = self._all_gather(prob_pad)                                     # [rank, image, shard]

@@ -88,10 +88,12 @@ class RelationQueryEngine:
         return [(F.linear(pa, L["wk_x"], L["bk_x"]), F.linear(pa, L["wv_x"], L["bv_x"])) for L in self.layers]
 
     # ---- A6 + A7: Q-Former over a list of pairs ---------------------------------------------------
-    def forward_pairs(self, kv, bits, num_objects, pair_index, ids, text_mask, hidden_out=None):
+    def forward_pairs(self, kv, bits, num_objects, pair_index, ids, text_mask, hidden_out=None, segments=None):
         """pair_index int32 [P] (p = i*N + j), ids int32 [P,T], text_mask uint8 [P,T].
         Returns (hidden [P*33, 768] in the activation dtype, exist_logit [P] fp32, exist_prob [P] fp32).
-        hidden_out: caller-owned [P*33, 768] buffer the last layer writes into (no copy when pairs are chunked)."""
+        hidden_out: caller-owned [P*33, 768] buffer the last layer writes into (no copy when pairs are chunked).
+        segments: [(first pair, pair count, kv, bits, num_objects)] - the pairs come from several images (pair
+        sharding); everything but the cross-attention runs over all of them at once."""
         q = self.cfg.qformer
         nq, H = q.q_rows, q.hidden
         P, T = ids.shape
@@ -110,8 +112,15 @@ class RelationQueryEngine:
             ops.add_layernorm(A, X[:ra], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
             del ctx
             qx = F.linear(A[:RQ], L["wq_x"], L["bq_x"])
-            cx = ops.qformer_cross_attn(qx, kv[li][0], kv[li][1], bits, pair_index, num_objects, nq, q.heads,
-                                        empty_policy=self.empty_policy, variant=self.xattn_variant)
+            if segments is None:
+                cx = ops.qformer_cross_attn(qx, kv[li][0], kv[li][1], bits, pair_index, num_objects, nq, q.heads,
+                                            empty_policy=self.empty_policy, variant=self.xattn_variant)
+            else:
+                cx = torch.empty_like(qx)
+                for ps, pc, kv_m, bits_m, n_m in segments:
+                    ops.qformer_cross_attn(qx[ps * nq:(ps + pc) * nq], kv_m[li][0], kv_m[li][1], bits_m,
+                                           pair_index[ps:ps + pc], n_m, nq, q.heads, out=cx[ps * nq:(ps + pc) * nq],
+                                           empty_policy=self.empty_policy, variant=self.xattn_variant)
             Cq = F.linear(cx, L["wo_x"])
             ops.add_layernorm(Cq, A[:RQ], L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
             del qx, cx

@@ -149,6 +149,30 @@ def test_threshold_selector_bucketing_and_graph_cache(setup):
         assert isinstance(out["rel_pred"], list)
 
 
+def test_multi_image_shard_query_matches_per_image_calls(setup):
+    """Pair sharding at R ranks: the shard [p0, p1) of all R images in one Q-Former pass (dense projections over
+    R x shard pairs, cross-attention per image) against R separate calls; images with different class names
+    (different prompt lengths) share the pass; an empty shard is legal."""
+    from openpsg_amd.categories import INSTANCE_OFFSET, object_categories
+    from openpsg_amd.synthetic import make_scene
+    head = setup[0]
+    scenes = [make_scene((1024, 1024), 50, seed=20 + m, device="cuda:0") for m in range(4)]
+    items = [(s["mask_features"], s["img_meta"], [int(i) for i in s["object_id_list"]],
+              [object_categories[int(i) % INSTANCE_OFFSET] for i in s["object_id_list"]], s["pan_results"])
+             for s in scenes]
+    patches = [head.rq_engine.patch_embed(s["mask_features"]) for s in scenes]
+    p0, p1 = 625, 1250                                             # rank 1 of 4
+    multi = head.run_relation_query_shards(items, (p0, p1), patches)
+    for m, it in enumerate(items):
+        one = head.run_relation_query(*it, pair_range=(p0, p1), patches=patches[m])
+        dp = (multi[m][1] - one["exist_prob"]).abs().max().item()
+        dh = (multi[m][0].float() - one["hidden"].float()).abs().max().item()
+        print(f"image {m}: max |prob diff| {dp:.2e}, max |hidden diff| {dh:.2e}")
+        assert multi[m][0].shape == one["hidden"].shape and dp < 2e-2 and dh < 0.25   # bf16; GEMM tiles depend on M
+    empty = head.run_relation_query(*items[0], pair_range=(2500, 2500), patches=patches[0])
+    assert empty["hidden"].shape[0] == 0 and empty["exist_prob"].numel() == 0
+
+
 def test_rccl_pipeline_world1_matches_head(setup):
     import torch.distributed as dist
     from openpsg_amd.dist import PairShardedPipeline
