@@ -149,11 +149,62 @@ __global__ void bias_gelu_kernel(const T* __restrict__ x, const float* __restric
   }
 }
 
+// bf16 activations, many rows (the Q-Former FFN: 82.5 k x 3072): the generic kernel above is VALU-bound there
+// (64-bit index modulo per 4 elements, libm erff).  One row per blockIdx.y, 8 columns per thread (16-byte
+// accesses), erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three orders below bf16 resolution; the
+// fp32 verification mode keeps erff).
+__device__ __forceinline__ float gelu_erf_as(float v) {
+  // the reference computes 0.5 v (1 + erf(v / sqrt 2)) in fp32; erf here is Abramowitz-Stegun 7.1.26,
+  // |error| <= 1.5e-7 (about two fp32 ulps of a value near 1).  It differs from erff only where 1 + erf cancels
+  // (v < -5, |gelu| < 1e-5), where the reference's own result is rounding noise of the same size.
+  const float x = v * 0.70710678118654752440f;
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float erf_abs = fmaf(-poly * t, e, 1.0f);
+  return 0.5f * v * (1.0f + copysignf(erf_abs, x));
+}
+
+__global__ void __launch_bounds__(256) bias_gelu_rows_bf16_kernel(const uint16_t* __restrict__ x,
+                                                                   const float* __restrict__ bias, int64_t rows,
+                                                                   int cols, uint16_t* __restrict__ out) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= cols) return;
+  float b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (bias) {
+    *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(bias + c);
+    *reinterpret_cast<float4*>(b + 4) = *reinterpret_cast<const float4*>(bias + c + 4);
+  }
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const uint4 xv = *reinterpret_cast<const uint4*>(x + r * cols + c);
+    const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+    uint32_t ow[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v0 = __uint_as_float(xw[e] << 16) + b[2 * e];
+      const float v1 = __uint_as_float(xw[e] & 0xffff0000u) + b[2 * e + 1];
+      ow[e] = (uint32_t)f32_to_bf16(gelu_erf_as(v0)) | ((uint32_t)f32_to_bf16(gelu_erf_as(v1)) << 16);
+    }
+    *reinterpret_cast<uint4*>(out + r * cols + c) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+}
+
 extern "C" int psg_bias_gelu(psg_ctx* ctx, const void* x, const float* bias, int64_t rows, int cols, void* out,
                              int dtype, void* stream) {
   PSG_REQUIRE(ctx && x && out, PSG_ERR_INVALID, "psg_bias_gelu: NULL argument");
   PSG_REQUIRE(cols > 0 && cols % 4 == 0, PSG_ERR_INVALID, "psg_bias_gelu: cols=%d must be a multiple of 4", cols);
   if (rows == 0) return PSG_OK;
+  if (dtype == PSG_BF16 && rows >= 256 && cols % 8 == 0) {
+    const dim3 grid((unsigned)((cols / 8 + 255) / 256), (unsigned)(rows < 16384 ? rows : 16384));
+    bias_gelu_rows_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t*)x, bias, rows, cols,
+                                                                      (uint16_t*)out);
+    PSG_CHECK_LAUNCH("psg_bias_gelu");
+    return PSG_OK;
+  }
   int64_t n4 = rows * cols / 4;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
