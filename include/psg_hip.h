@@ -101,6 +101,13 @@ int psg_bias_gelu(psg_ctx*, const void* x, const float* bias, int64_t rows, int 
 int psg_qformer_self_attn(psg_ctx*, const void* qkv, const uint8_t* text_mask, int B, int T, int nq,
                           int heads, int query_rows_only, void* out, int dtype, void* stream);
 
+/* First-layer variant (bf16): the nq query rows entering layer 0 are the same for every pair (learned query
+ * tokens through the embedding LayerNorm, HF-IB:728-757), so their fused Q/K/V projection qkv_query
+ * [nq][3*hidden] is computed once; qkv_text [B*T][3*hidden] holds the text rows.  out as above. */
+int psg_qformer_self_attn_shared(psg_ctx*, const void* qkv_query, const void* qkv_text,
+                                 const uint8_t* text_mask, int B, int T, int nq, int heads, void* out,
+                                 int dtype, void* stream);
+
 /* ---- K6: relation-query cross-attention (primary kernel), HF-IB:464-466, 487-496 with the
  * V4:168-170 expand removed: K/V [L][hidden] are projected ONCE per image and shared by every
  * pair; the pair mask is bits[i] | bits[j] (pair_index[p] = i*N + j) applied on the fly.

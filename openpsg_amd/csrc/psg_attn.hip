@@ -6,7 +6,7 @@
 
 #include "psg_common.h"
 
-int psg_self_attn_mfma_launch(const void* qkv, const uint8_t* text_mask, int B, int T_, int nq, int heads,
+int psg_self_attn_mfma_launch(const void* qkv, const void* q_shared, const uint8_t* text_mask, int B, int T_, int nq, int heads,
                               int query_rows_only, void* out, hipStream_t st);
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
@@ -88,13 +88,27 @@ extern "C" int psg_qformer_self_attn(psg_ctx* ctx, const void* qkv, const uint8_
   static int force_scalar = -1;
   if (force_scalar < 0) force_scalar = getenv("PSG_SELFATTN_SCALAR") ? 1 : 0;
   if (dtype == PSG_BF16 && nq >= 32 && nq + T_ <= 64 && !force_scalar)
-    return psg_self_attn_mfma_launch(qkv, text_mask, B, T_, nq, heads, query_rows_only, out, (hipStream_t)stream);
+    return psg_self_attn_mfma_launch(qkv, nullptr, text_mask, B, T_, nq, heads, query_rows_only, out, (hipStream_t)stream);
   int64_t units = (int64_t)B * heads;
   PSG_DISPATCH_DTYPE(dtype, "psg_qformer_self_attn",
                      (qformer_self_attn_kernel<T><<<(unsigned)((units + 3) / 4), 256, 0, (hipStream_t)stream>>>(
                          (const T*)qkv, text_mask, B, T_, nq, heads, query_rows_only, (T*)out)));
   PSG_CHECK_LAUNCH("psg_qformer_self_attn");
   return PSG_OK;
+}
+
+// First-layer variant: the nq query rows entering layer 0 are identical for every pair, so their fused Q/K/V
+// projection is one [nq][3*hidden] block shared by all pairs; qkv_text holds the text rows [B*T][3*hidden].
+extern "C" int psg_qformer_self_attn_shared(psg_ctx* ctx, const void* qkv_query, const void* qkv_text,
+                                            const uint8_t* text_mask, int B, int T_, int nq, int heads, void* out,
+                                            int dtype, void* stream) {
+  PSG_REQUIRE(ctx && qkv_query && out && ((qkv_text && text_mask) || T_ == 0), PSG_ERR_INVALID,
+              "psg_qformer_self_attn_shared: NULL argument");
+  PSG_REQUIRE(B > 0 && T_ >= 0 && nq > 0 && heads > 0 && nq + T_ <= 64, PSG_ERR_INVALID,
+              "psg_qformer_self_attn_shared: B=%d T=%d nq=%d", B, T_, nq);
+  PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED, "psg_qformer_self_attn_shared: bf16 only");
+  return psg_self_attn_mfma_launch(qkv_text ? qkv_text : qkv_query, qkv_query, text_mask, B, T_, nq, heads, 0, out,
+                                   (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,8 +23,9 @@ __device__ __forceinline__ uint32_t sa_pack(float lo, float hi) {
 }
 
 __global__ void __launch_bounds__(256, 2)
-self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint8_t* __restrict__ text_mask, int B, int Tt, int nq,
-                      int heads, int q_only, uint16_t* __restrict__ out) {
+self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ q_shared,
+                      const uint8_t* __restrict__ text_mask, int B, int Tt, int nq, int heads, int q_only,
+                      uint16_t* __restrict__ out) {
   const int unit = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (unit >= B * heads) return;
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -32,9 +33,17 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint8_t* __restric
   const int hidden = heads * 64, ld = 3 * hidden;
   const int S = nq + Tt;
   const int64_t qrow0 = (int64_t)p * nq, trow0 = (int64_t)B * nq + (int64_t)p * Tt;
-  auto row_of = [&](int j) -> int64_t {
+  auto row_of = [&](int j) -> int64_t {                         // output row of token j
     j = j < S ? j : S - 1;                                      // clamp: rows beyond S are masked / dropped
     return j < nq ? qrow0 + j : trow0 + (j - nq);
+  };
+  // input row of token j.  q_shared != nullptr (first layer): the query rows entering the layer are the same
+  // for every pair (learned query tokens through the embedding LayerNorm), so their Q/K/V projection
+  // [nq][3*hidden] is computed once and read from L2, and `qkv` holds the text rows only ([B*Tt][3*hidden]).
+  auto in_row = [&](int j) -> const uint16_t* {
+    j = j < S ? j : S - 1;
+    if (q_shared) return j < nq ? q_shared + (int64_t)j * ld : qkv + ((int64_t)p * Tt + (j - nq)) * ld;
+    return qkv + (j < nq ? qrow0 + j : trow0 + (j - nq)) * ld;
   };
   // validity of key `lane` (query rows are always valid; prompt tokens follow the attention mask)
   bool kvalid = lane < S;
@@ -46,7 +55,7 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint8_t* __restric
   sa_bf16x8 kf[2][4], qf[2][4];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const uint16_t* rp = qkv + row_of(32 * t + l31) * ld + h * 64 + hi * 8;
+    const uint16_t* rp = in_row(32 * t + l31) + h * 64 + hi * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       qf[t][s] = *reinterpret_cast<const sa_bf16x8*>(rp + s * 16);
@@ -100,7 +109,7 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint8_t* __restric
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) o[dt][qt] = (sa_f32x16){0};
-  const uint16_t* vbase = qkv + 2 * hidden + h * 64 + l31;
+  const int voff = 2 * hidden + h * 64 + l31;
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -118,7 +127,7 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint8_t* __restric
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const int key = 32 * kt + 16 * g + (m & 3) + 8 * (m >> 2) + 4 * hi;
-        const uint16_t* vp = vbase + row_of(key) * ld;
+        const uint16_t* vp = in_row(key) + voff;
         ve[0][m] = vp[0];
         ve[1][m] = vp[32];
       }
@@ -152,11 +161,12 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint8_t* __restric
   }
 }
 
-int psg_self_attn_mfma_launch(const void* qkv, const uint8_t* text_mask, int B, int T_, int nq, int heads,
-                              int query_rows_only, void* out, hipStream_t st) {
+int psg_self_attn_mfma_launch(const void* qkv, const void* q_shared, const uint8_t* text_mask, int B, int T_, int nq,
+                              int heads, int query_rows_only, void* out, hipStream_t st) {
   const int64_t units = (int64_t)B * heads;
-  self_attn_mfma_kernel<<<(unsigned)((units + 3) / 4), 256, 0, st>>>((const uint16_t*)qkv, text_mask, B, T_, nq, heads,
-                                                                    query_rows_only, (uint16_t*)out);
+  self_attn_mfma_kernel<<<(unsigned)((units + 3) / 4), 256, 0, st>>>((const uint16_t*)qkv, (const uint16_t*)q_shared,
+                                                                    text_mask, B, T_, nq, heads, query_rows_only,
+                                                                    (uint16_t*)out);
   PSG_CHECK_LAUNCH("psg_qformer_self_attn(mfma)");
   return PSG_OK;
 }

@@ -120,6 +120,18 @@ def qformer_self_attn(qkv, text_mask, B, T, nq, heads, query_rows_only, out):
     return out
 
 
+def qformer_self_attn_shared(qkv_query, qkv_text, text_mask, B, T, nq, heads, out):
+    """Layer-0 self-attention with ONE shared [nq, 3*hidden] projection of the query rows (bf16)."""
+    lib, ctx, st = _env(qkv_query)
+    hidden = qkv_query.shape[1] // 3
+    assert qkv_query.shape == (nq, 3 * hidden) and qkv_text.shape == (B * T, 3 * hidden)
+    assert out.shape == (B * (nq + T), hidden) and out.dtype == qkv_query.dtype == qkv_text.dtype
+    check(lib.psg_qformer_self_attn_shared(ctx, _p(qkv_query, torch.bfloat16, "qkv_query"), _p(qkv_text),
+                                           _p(text_mask, torch.uint8, "text_mask"), B, T, nq, heads, _p(out),
+                                           _dt(qkv_query), st), "psg_qformer_self_attn_shared")
+    return out
+
+
 def qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, out=None, empty_policy=PSG_EMPTY_UNIFORM,
                        variant=None):
     lib, ctx, st = _env(q)

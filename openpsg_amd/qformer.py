@@ -18,6 +18,8 @@ Dense projections go through torch (`F.linear` -> hipBLASLt); everything else is
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -68,6 +70,7 @@ class RelationQueryEngine:
             )
             self.layers.append(L)
         self.empty_policy = PSG_EMPTY_UNIFORM if cfg.empty_row_policy == "uniform" else PSG_EMPTY_UNMASKED
+        self.share_query_qkv = os.environ.get("PSG_SHARE_QUERY_QKV", "1") != "0"
 
     # ---- A4: prepare_inference (V4:408-435) ----------------------------------------------------
     def patch_embed(self, mask_features: torch.Tensor) -> torch.Tensor:
@@ -103,9 +106,15 @@ class RelationQueryEngine:
                           q.ln_eps, X)
         for li, L in enumerate(self.layers):
             last = li == len(self.layers) - 1
-            qkv = F.linear(X, L["wqkv"], L["bqkv"])
             ctx = torch.empty((R, H), device=self.device, dtype=self.dtype)
-            ops.qformer_self_attn(qkv, text_mask, P, T, nq, q.heads, last, ctx)
+            if li == 0 and not last and T > 0 and self.dtype == torch.bfloat16 and self.share_query_qkv:
+                # the query rows entering layer 0 are identical for every pair: project the first pair's 33 rows once
+                qkv_q = F.linear(X[:nq], L["wqkv"], L["bqkv"])
+                qkv = F.linear(X[RQ:], L["wqkv"], L["bqkv"])
+                ops.qformer_self_attn_shared(qkv_q, qkv, text_mask, P, T, nq, q.heads, ctx)
+            else:
+                qkv = F.linear(X, L["wqkv"], L["bqkv"])
+                ops.qformer_self_attn(qkv, text_mask, P, T, nq, q.heads, last, ctx)
             del qkv
             ra = RQ if last else R
             A = F.linear(ctx[:ra], L["wo"])

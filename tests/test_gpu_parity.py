@@ -409,6 +409,27 @@ def test_bias_gelu_many_rows_bf16_kernel():
     assert mism < 2e-2 and excess < 2e-6
 
 
+@pytest.mark.parametrize("B,T", [(7, 14), (33, 9), (4, 31)])
+def test_self_attn_shared_query_rows_equals_full_kernel(B, T):
+    """Layer 0: every pair's 33 query rows carry the same Q/K/V projection.  The shared-block kernel entry must give
+    bit-identical output to the full kernel run on a qkv matrix that repeats that block for every pair."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 10 + T)
+    nq, heads, H = 33, 12, 768
+    qkv_q = torch.randn(nq, 3 * H, generator=g).to(dev).bfloat16()
+    qkv_t = torch.randn(B * T, 3 * H, generator=g).to(dev).bfloat16()
+    mask = (torch.rand(B, T, generator=g) < 0.8).to(torch.uint8)
+    mask[:, 0] = 1
+    mask = mask.to(dev)
+    full = torch.cat([qkv_q.repeat(B, 1), qkv_t]).contiguous()
+    want = torch.empty(B * (nq + T), H, device=dev, dtype=torch.bfloat16)
+    ops.qformer_self_attn(full, mask, B, T, nq, heads, False, want)
+    got = torch.full_like(want, 5.0)
+    ops.qformer_self_attn_shared(qkv_q, qkv_t, mask, B, T, nq, heads, got)
+    assert torch.equal(got, want)
+
+
 def test_mask_kernels_bit_exact_on_random_geometries():
     """psg_mask_grid / psg_object_bitmasks against the torch interpolate -> pad -> interpolate chain of the
     reference (V4:416-433, via the oracle) on 40 seeded random geometries: odd sizes, non-square images,
