@@ -101,14 +101,15 @@ def measure_decode_gemm(head, K):
 
 
 def relation_query_flops(N, L, T):
-    """Algorithmic FLOPs of the relation-query stage for one image, SURVEY 8d's per-layer formula with the
-    work whose result is never read left out (the reference slices the output to the 33 query rows, V4:185:
-    in the last layer the text rows need K/V only).  Plus the per-image patch embedding and shared K/V."""
+    """FLOPs the relation-query stage has to execute for one image: SURVEY 8d's per-layer formula with the work
+    whose result is never read or is identical for every pair left out (V4:185 slices the output to the 33 query
+    rows, so in the last layer the text rows need K/V only; the Q/K/V projection of the 33 query rows entering
+    layer 0 is the same for all pairs and is computed once).  Plus the per-image patch embedding and shared K/V."""
     S, H, F = 33 + T, 768, 3072
     cross = 2 * 33 * H * H + 4 * 33 * L * H + 2 * 33 * H * H
-    first = 2 * S * H * 3 * H + 4 * S * S * H + 2 * S * H * H + cross + 4 * 33 * H * F + 4 * T * H * F
+    first = 2 * T * H * 3 * H + 4 * S * S * H + 2 * S * H * H + cross + 4 * 33 * H * F + 4 * T * H * F
     last = 2 * S * H * 2 * H + 2 * 33 * H * H + 4 * 33 * S * H + 2 * 33 * H * H + cross + 4 * 33 * H * F
-    return N * N * (first + last) + 2 * L * 65536 * 256 + 2 * 2 * 2 * L * 256 * H
+    return N * N * (first + last) + 2 * 33 * H * 3 * H + 2 * L * 65536 * 256 + 2 * 2 * 2 * L * 256 * H
 
 
 def cpu_baseline(a, scene_cpu):
