@@ -89,6 +89,11 @@ int psg_qformer_embed(psg_ctx*, const int32_t* ids, int B, int T, const float* w
 int psg_add_layernorm(psg_ctx*, const void* x, const void* residual, const float* bias,
                       const float* gamma, const float* beta, float eps, int64_t rows, int hidden,
                       void* out, int dtype, void* stream);
+/* residual row of output row r = residual_table[r % table_rows] (layer 0: the embedded query rows are one
+ * [33][hidden] block shared by all pairs, HF-IB:728-757 + 519-527). */
+int psg_add_layernorm_periodic(psg_ctx*, const void* x, const void* residual_table, int table_rows,
+                               const float* bias, const float* gamma, const float* beta, float eps,
+                               int64_t rows, int hidden, void* out, int dtype, void* stream);
 
 /* ---- BertIntermediate activation, HF-IB:563-577: out = gelu_erf(x + bias); bias may be NULL. */
 int psg_bias_gelu(psg_ctx*, const void* x, const float* bias, int64_t rows, int cols, void* out,

@@ -50,7 +50,7 @@ __global__ void qformer_embed_kernel(const int32_t* __restrict__ ids, int B, int
   const int64_t nqrows = (int64_t)B * nq;
   if (row >= nqrows + (int64_t)B * Tt) return;
   float v[NCH][4];
-  if (row < nqrows) {
+  if (row < nqrows) {                                 // (nq == 0 never gets here)
     const int r = (int)(row % nq);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) Act<float>::ld4(query, (int64_t)r * hidden + c * 256 + lane * 4, v[c]);
@@ -78,7 +78,8 @@ extern "C" int psg_qformer_embed(psg_ctx* ctx, const int32_t* ids, int B, int T_
   PSG_REQUIRE(ctx && word_emb && pos_emb && query_rows && ln_w && ln_b && out && (ids || T_ == 0), PSG_ERR_INVALID,
               "psg_qformer_embed: NULL argument");
   PSG_REQUIRE(hidden == 768, PSG_ERR_UNSUPPORTED, "psg_qformer_embed: hidden=%d (kernel is built for 768)", hidden);
-  PSG_REQUIRE(B > 0 && T_ >= 0 && nq > 0, PSG_ERR_INVALID, "psg_qformer_embed: B=%d T=%d nq=%d", B, T_, nq);
+  PSG_REQUIRE(B > 0 && T_ >= 0 && nq >= 0 && nq + T_ > 0, PSG_ERR_INVALID, "psg_qformer_embed: B=%d T=%d nq=%d", B, T_,
+              nq);                                    // nq == 0: text rows only; T == 0: query rows only
   int64_t rows = (int64_t)B * (nq + T_);
   dim3 grid((unsigned)((rows + 3) / 4));
   PSG_DISPATCH_DTYPE(dtype, "psg_qformer_embed",
@@ -92,10 +93,11 @@ extern "C" int psg_qformer_embed(psg_ctx* ctx, const int32_t* ids, int B, int T_
 template <typename T, int NCH>
 __global__ void add_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ bias,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                     int64_t rows, int hidden, T* __restrict__ out) {
+                                     int64_t rows, int hidden, T* __restrict__ out, int res_period) {
   const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
+  const int64_t rrow = res_period > 0 ? row % res_period : row;   // periodic residual: a [res_period][hidden] table
   float v[NCH][4];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -107,7 +109,7 @@ __global__ void add_layernorm_kernel(const T* __restrict__ x, const T* __restric
     }
     if (res) {
       float r[4];
-      Act<T>::ld4(res, row * hidden + col, r);
+      Act<T>::ld4(res, rrow * hidden + col, r);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[c][e] += r[e];
     }
@@ -117,18 +119,35 @@ __global__ void add_layernorm_kernel(const T* __restrict__ x, const T* __restric
   for (int c = 0; c < NCH; ++c) Act<T>::st4(out, row * hidden + c * 256 + lane * 4, v[c]);
 }
 
+static int add_layernorm_launch(const char* who, psg_ctx* ctx, const void* x, const void* residual, int res_period,
+                                const float* bias, const float* gamma, const float* beta, float eps, int64_t rows,
+                                int hidden, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && x && gamma && beta && out, PSG_ERR_INVALID, "%s: NULL argument", who);
+  PSG_REQUIRE(hidden == 768, PSG_ERR_UNSUPPORTED, "%s: hidden=%d (kernel is built for 768)", who, hidden);
+  if (rows == 0) return PSG_OK;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  PSG_DISPATCH_DTYPE(dtype, who,
+                     (add_layernorm_kernel<T, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
+                         (const T*)x, (const T*)residual, bias, gamma, beta, eps, rows, hidden, (T*)out, res_period)));
+  PSG_CHECK_LAUNCH(who);
+  return PSG_OK;
+}
+
 extern "C" int psg_add_layernorm(psg_ctx* ctx, const void* x, const void* residual, const float* bias,
                                  const float* gamma, const float* beta, float eps, int64_t rows, int hidden, void* out,
                                  int dtype, void* stream) {
-  PSG_REQUIRE(ctx && x && gamma && beta && out, PSG_ERR_INVALID, "psg_add_layernorm: NULL argument");
-  PSG_REQUIRE(hidden == 768, PSG_ERR_UNSUPPORTED, "psg_add_layernorm: hidden=%d (kernel is built for 768)", hidden);
-  if (rows == 0) return PSG_OK;
-  dim3 grid((unsigned)((rows + 3) / 4));
-  PSG_DISPATCH_DTYPE(dtype, "psg_add_layernorm",
-                     (add_layernorm_kernel<T, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
-                         (const T*)x, (const T*)residual, bias, gamma, beta, eps, rows, hidden, (T*)out)));
-  PSG_CHECK_LAUNCH("psg_add_layernorm");
-  return PSG_OK;
+  return add_layernorm_launch("psg_add_layernorm", ctx, x, residual, 0, bias, gamma, beta, eps, rows, hidden, out, dtype,
+                              stream);
+}
+
+// residual row of output row r is residual_table[r % table_rows]: the layer-0 query rows of every pair share ONE
+// [33][768] block of embeddings, which therefore never has to be written out per pair
+extern "C" int psg_add_layernorm_periodic(psg_ctx* ctx, const void* x, const void* residual_table, int table_rows,
+                                          const float* bias, const float* gamma, const float* beta, float eps,
+                                          int64_t rows, int hidden, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(residual_table && table_rows > 0, PSG_ERR_INVALID, "psg_add_layernorm_periodic: table_rows=%d", table_rows);
+  return add_layernorm_launch("psg_add_layernorm_periodic", ctx, x, residual_table, table_rows, bias, gamma, beta, eps,
+                              rows, hidden, out, dtype, stream);
 }
 
 // ---- bias + GELU(erf) -------------------------------------------------------------------------

@@ -90,6 +90,21 @@ def qformer_embed(ids, word_emb, pos_emb, query_rows, ln_w, ln_b, eps, out):
     return out
 
 
+def qformer_embed_split(ids, word_emb, pos_emb, query_rows, ln_w, ln_b, eps, out_query, out_text):
+    """The same embedding, written as ONE block of query rows [nq, hidden] (identical for every pair) and the
+    text rows [B*T, hidden]."""
+    lib, ctx, st = _env(out_text)
+    B, T = ids.shape
+    nq, hidden = query_rows.shape
+    assert out_query.shape == (nq, hidden) and out_text.shape == (B * T, hidden)
+    common = (_p(word_emb, torch.float32), _p(pos_emb, torch.float32), _p(query_rows, torch.float32))
+    tail = (_p(ln_w, torch.float32), _p(ln_b, torch.float32), float(eps), hidden)
+    check(lib.psg_qformer_embed(ctx, None, 1, 0, *common, nq, *tail, _p(out_query), _dt(out_query), st),
+          "psg_qformer_embed")
+    check(lib.psg_qformer_embed(ctx, _p(ids, torch.int32, "ids"), B, T, *common, 0, *tail, _p(out_text), _dt(out_text),
+                                st), "psg_qformer_embed")
+
+
 def add_layernorm(x, residual, bias, gamma, beta, eps, out=None):
     lib, ctx, st = _env(x)
     out = x if out is None else out
@@ -99,6 +114,19 @@ def add_layernorm(x, residual, bias, gamma, beta, eps, out=None):
     check(lib.psg_add_layernorm(ctx, _p(x), _p(residual), _p(bias, torch.float32), _p(gamma, torch.float32),
                                 _p(beta, torch.float32), float(eps), rows, hidden, _p(out, x.dtype), _dt(x), st),
           "psg_add_layernorm")
+    return out
+
+
+def add_layernorm_periodic(x, residual_table, bias, gamma, beta, eps, out=None):
+    """LayerNorm(x + bias + residual_table[row % table_rows]); in place unless `out` is given."""
+    lib, ctx, st = _env(x)
+    out = x if out is None else out
+    rows, hidden = x.shape
+    assert residual_table.shape[1] == hidden and residual_table.dtype == x.dtype
+    check(lib.psg_add_layernorm_periodic(ctx, _p(x), _p(residual_table), residual_table.shape[0],
+                                         _p(bias, torch.float32), _p(gamma, torch.float32), _p(beta, torch.float32),
+                                         float(eps), rows, hidden, _p(out, x.dtype), _dt(x), st),
+          "psg_add_layernorm_periodic")
     return out
 
 

@@ -102,12 +102,19 @@ class RelationQueryEngine:
         P, T = ids.shape
         R, RQ = P * (nq + T), P * nq
         X = torch.empty((R, H), device=self.device, dtype=self.dtype)
-        ops.qformer_embed(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
-                          q.ln_eps, X)
+        # bf16 mode: the embedded query rows are ONE [33, 768] block for all pairs (learned tokens through the embedding
+        # LayerNorm); layer 0 projects it once and uses it as a periodic residual, so rows [33, P*33) of X stay unwritten
+        shared0 = (len(self.layers) > 1 and T > 0 and self.dtype == torch.bfloat16 and self.share_query_qkv)
+        if shared0:
+            ops.qformer_embed_split(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
+                                    q.ln_eps, X[:nq], X[RQ:])
+        else:
+            ops.qformer_embed(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
+                              q.ln_eps, X)
         for li, L in enumerate(self.layers):
             last = li == len(self.layers) - 1
             ctx = torch.empty((R, H), device=self.device, dtype=self.dtype)
-            if li == 0 and not last and T > 0 and self.dtype == torch.bfloat16 and self.share_query_qkv:
+            if li == 0 and shared0:
                 # the query rows entering layer 0 are identical for every pair: project the first pair's 33 rows once
                 qkv_q = F.linear(X[:nq], L["wqkv"], L["bqkv"])
                 qkv = F.linear(X[RQ:], L["wqkv"], L["bqkv"])
@@ -118,7 +125,11 @@ class RelationQueryEngine:
             del qkv
             ra = RQ if last else R
             A = F.linear(ctx[:ra], L["wo"])
-            ops.add_layernorm(A, X[:ra], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+            if li == 0 and shared0:
+                ops.add_layernorm_periodic(A[:RQ], X[:nq], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+                ops.add_layernorm(A[RQ:], X[RQ:], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+            else:
+                ops.add_layernorm(A, X[:ra], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
             del ctx
             qx = F.linear(A[:RQ], L["wq_x"], L["bq_x"])
             if segments is None:

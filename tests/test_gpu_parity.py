@@ -430,6 +430,33 @@ def test_self_attn_shared_query_rows_equals_full_kernel(B, T):
     assert torch.equal(got, want)
 
 
+def test_embed_split_and_periodic_residual_equal_the_full_kernels():
+    """Layer-0 redundancy removal: qformer_embed_split writes the query block once + the text rows;
+    add_layernorm_periodic reads the residual from that one block.  Both must be bit-identical to the full kernels
+    fed with the per-pair copies."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(17)
+    B, T, nq, H = 9, 11, 33, 768
+    ids = torch.randint(0, 500, (B, T), generator=g, dtype=torch.int32).to(dev)
+    word = torch.randn(500, H, generator=g).to(dev)
+    posw = torch.randn(64, H, generator=g).to(dev)
+    qrows = torch.randn(nq, H, generator=g).to(dev)
+    lw, lb = torch.rand(H, generator=g).to(dev) + 0.5, torch.randn(H, generator=g).to(dev)
+    full = torch.empty(B * (nq + T), H, device=dev, dtype=torch.bfloat16)
+    ops.qformer_embed(ids, word, posw, qrows, lw, lb, 1e-12, full)
+    part = torch.full_like(full, 9.0)
+    ops.qformer_embed_split(ids, word, posw, qrows, lw, lb, 1e-12, part[:nq], part[B * nq:])
+    assert torch.equal(part[:nq], full[:nq]) and torch.equal(part[B * nq:], full[B * nq:])
+    assert torch.equal(full[:B * nq], full[:nq].repeat(B, 1))       # the premise: every pair has the same query rows
+    assert (part[nq:B * nq] == 9.0).all()                           # rows in between are not touched
+    x = torch.randn(B * nq, H, generator=g).to(dev).bfloat16()
+    bias = torch.randn(H, generator=g).to(dev)
+    want = ops.add_layernorm(x.clone(), full[:B * nq].contiguous(), bias, lw, lb, 1e-12)
+    got = ops.add_layernorm_periodic(x.clone(), full[:nq].contiguous(), bias, lw, lb, 1e-12)
+    assert torch.equal(got, want)
+
+
 def test_mask_kernels_bit_exact_on_random_geometries():
     """psg_mask_grid / psg_object_bitmasks against the torch interpolate -> pad -> interpolate chain of the
     reference (V4:416-433, via the oracle) on 40 seeded random geometries: odd sizes, non-square images,
