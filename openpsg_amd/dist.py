@@ -65,34 +65,40 @@ class HipBackend:
     def __init__(self, head):
         from .categories import INSTANCE_OFFSET, object_categories
         self.head = head
-        self._names = lambda scene: [object_categories[int(i) % INSTANCE_OFFSET] for i in scene["object_id_list"]]
+        # the same object truncation (V4:136) and selector options as head.forward, so sharded == single GPU
+        self._ids = lambda scene: [int(i) for i in scene["object_id_list"][:head.max_object_num]]
+        self._names = lambda scene: [object_categories[i % INSTANCE_OFFSET] for i in self._ids(scene)]
         self.device = head.device
         self.feat_dtype = head.act_dtype
+        if head.pair_selector != "topk":
+            raise NotImplementedError("pair sharding needs a selection size known on every rank before the "
+                                      "exchange: pair_selector='topk' only")
         self.k = head.cfg.num_selected
         self.q_rows = head.cfg.qformer.q_rows
         self.hidden = head.cfg.qformer.hidden
         self.max_new = head.cfg.max_new_tokens
 
     def num_objects(self, scene):
-        return len(scene["object_id_list"])
+        return len(self._ids(scene))
 
     def patch_embed(self, scene):
         return self.head.rq_engine.patch_embed(scene["mask_features"].to(torch.float32))
 
     def query_shard(self, scene, patches, p0, p1):
-        obj_ids = [int(i) for i in scene["object_id_list"]]
-        rq = self.head.run_relation_query(scene["mask_features"], scene["img_meta"], obj_ids, self._names(scene),
+        rq = self.head.run_relation_query(scene["mask_features"], scene["img_meta"], self._ids(scene), self._names(scene),
                                           scene["pan_results"], pair_range=(p0, p1), patches=patches)
         return rq["hidden"], rq["exist_prob"]
 
     def query_shards(self, scenes, patches, p0, p1):
         """The shard [p0, p1) of every image in ONE Q-Former pass (per-image cross-attention only)."""
-        items = [(s["mask_features"], s["img_meta"], [int(i) for i in s["object_id_list"]], self._names(s),
-                  s["pan_results"]) for s in scenes]
+        items = [(s["mask_features"], s["img_meta"], self._ids(s), self._names(s), s["pan_results"]) for s in scenes]
         return self.head.run_relation_query_shards(items, (p0, p1), [patches[m] for m in range(len(scenes))])
 
     def topk(self, prob, k):
-        return self.head.rq_engine.select(prob, k)
+        n = int(round(prob.numel() ** 0.5))
+        sel = self.head.select_pairs(prob, n)          # honours exclude_diagonal (V4 never excludes; SURVEY 0.6)
+        assert sel.numel() == k
+        return sel
 
     def gather_features(self, hidden, rows):
         from . import ops

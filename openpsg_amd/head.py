@@ -45,6 +45,12 @@ def _set_nested(root: nn.Module, dotted: str, tensor: torch.Tensor):
 
 @HEADS.register_module()
 class RelationTransformerHeadV4(nn.Module):
+    # What `tokenizers=None` / `device=None` resolve to.  A config dict such as the reference's
+    # (configs/psg/baseline_v4_ov.py:58-63) carries neither keyword; a deployment without hub access points
+    # these at local tokenizer objects / a device before `build_detector(cfg.model)`.
+    default_tokenizers = "auto"
+    default_device = "cuda"
+
     def __init__(self,
                  # relation qformer (V4:24-32)
                  qformer_model_name='Salesforce/instructblip-vicuna-7b',
@@ -70,20 +76,23 @@ class RelationTransformerHeadV4(nn.Module):
                  max_object_num=30,
                  # ---- build-specific, keyword only --------------------------------------------------
                  dtype="bf16",                 # activation/weight dtype of the GPU path ('fp32' = verification)
-                 device="cuda",
+                 device=None,                  # None -> RelationTransformerHeadV4.default_device
                  qformer_vocab_size=30522,
                  llm_config: LlamaConfig | None = None,
-                 tokenizers="auto",            # 'auto': HF tokenizers from the model names; 'word': WordTokenizer
+                 tokenizers=None,              # None -> default_tokenizers; 'auto': HF tokenizers from the model
+                                               # names; 'word': WordTokenizer; or (qformer_tok, llm_tok) objects
                  num_selected=20,              # V4:237
                  max_new_tokens=16,            # V4:308
                  empty_row_policy="uniform",
                  on_parse_error="raise",       # V4:315-316 raises IndexError when no '<s>' was generated
+                 implicit_bos=True,            # parse the generation as following an implicit '<s>' (see parse())
                  suppress_eos=False,
                  pair_chunk=4096,
                  xattn_variant=None,
                  pair_selector="topk",         # 'topk' (V4:235-237) | 'threshold' (the commented V4:230-234 logic)
                  exclude_diagonal=False,       # the reference never excludes the i == j pairs
                  max_selected=32,              # cap of the threshold selector (one decode batch)
+                 prompt_bucket=8,              # Llama prompt grid rounded up to a multiple of this (graph reuse)
                  **kwargs):
         super().__init__()
         if rel_cls_type != 'binary':
@@ -99,6 +108,7 @@ class RelationTransformerHeadV4(nn.Module):
         self.num_object_classes = num_object_classes
         self.max_object_num = max_object_num
         self.on_parse_error = on_parse_error
+        self.implicit_bos = bool(implicit_bos)
         self.suppress_eos = suppress_eos
         self.pair_chunk = int(pair_chunk)
         self.xattn_variant = xattn_variant
@@ -107,8 +117,11 @@ class RelationTransformerHeadV4(nn.Module):
         self.exclude_diagonal = bool(exclude_diagonal)
         self.max_llm_forward_num = max_llm_forward_num
         self.max_selected = int(max_selected)
+        self.prompt_bucket = int(prompt_bucket)
         self.act_dtype = _DTYPES[dtype]
-        self.device = torch.device(device)
+        self.device = torch.device(self.default_device if device is None else device)
+        if tokenizers is None:
+            tokenizers = self.default_tokenizers
         llm = llm_config if llm_config is not None else LlamaConfig(hidden=llm_feature_size,
                                                                     heads=llm_feature_size // 128)
         assert llm.hidden == llm_feature_size, "llm_feature_size must match llm_config.hidden"
@@ -160,13 +173,23 @@ class RelationTransformerHeadV4(nn.Module):
         return self
 
     def load_state_dict(self, state_dict, strict=False, **kw):  # reference checkpoints are partial
-        llm = {k: v for k, v in state_dict.items() if k.startswith("language_model.")}
-        rest = {k: v for k, v in state_dict.items() if not k.startswith("language_model.")}
-        res = super().load_state_dict(rest, strict=False, **kw)
-        if llm:
-            self.load_llm_weights(llm)
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """Runs in every loading flow: `head.load_state_dict`, a parent's `load_state_dict` (the detector's,
+        keys `relation_head.*`) and mmcv's `load_checkpoint`, which all recurse through this method.  The packed
+        engine copies are dropped (rebuilt lazily from the freshly loaded fp32 masters) and `language_model.*`
+        tensors - absent from reference checkpoints (part_checkpoint_hook.py:96-116), present in full ones - are
+        routed to the decode engine instead of being reported as unexpected."""
+        lm = prefix + "language_model."
+        llm = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(lm)}
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+        unexpected_keys[:] = [k for k in unexpected_keys if not k.startswith(lm)]
         self._rq_engine = None
-        return res
+        if llm:
+            self.load_llm_weights(llm)        # language_projection is re-synchronised when rq_engine is rebuilt
 
     def load_llm_weights(self, weights: dict):
         """`language_model.*` tensors (HF LlamaForCausalLM names); V4:99-103."""
@@ -274,8 +297,12 @@ class RelationTransformerHeadV4(nn.Module):
             if X.shape[1] < maxlen:
                 X = torch.cat([X, X.new_zeros((X.shape[0], maxlen - X.shape[1], X.shape[2]))], dim=1)
             Xs.append(X)
-        tokens = self.llm_engine.generate(torch.cat(Xs), torch.cat([it[4] for it in items]),
-                                          suppress_eos=self.suppress_eos)
+        Xall, pall = torch.cat(Xs), torch.cat([it[4] for it in items])
+        if Xall.shape[0] % 4:                                        # data-dependent pair counts: keep the decode
+            extra = 4 - Xall.shape[0] % 4                            # graphs few (copies of the last pair, cut below)
+            Xall = torch.cat([Xall, Xall[-1:].expand(extra, -1, -1)])
+            pall = torch.cat([pall, pall[-1:].expand(extra)])
+        tokens = self.llm_engine.generate(Xall, pall, suppress_eos=self.suppress_eos)
         tokens_host = tokens.cpu().numpy()
         k0 = 0
         self.last_batch = []
@@ -432,6 +459,11 @@ class RelationTransformerHeadV4(nn.Module):
         if ck not in self._table_cache:
             uidx, U, prow = self._prompt_table("l", names)
             Tp = max(len(r) for r in prow)
+            # the longest prompt changes from image to image (its class names); the prompt grid is rounded up so
+            # that the decode graphs, keyed by input shape, are reused (rows past a pair's length carry pos = -1
+            # and are skipped by every kernel)
+            if self.prompt_bucket > 1:
+                Tp = -(-Tp // self.prompt_bucket) * self.prompt_bucket
             tbl = np.full((U * U, Tp), -1, dtype=np.int32)
             lens = np.zeros(U * U, dtype=np.int32)
             for r, ids in enumerate(prow):
@@ -467,17 +499,31 @@ class RelationTransformerHeadV4(nn.Module):
         return out
 
     def parse(self, tokens_host, selected_host, object_num):
-        """A10 (V4:313-326): decode -> text between '<s>' and '</s>' -> names split on two spaces."""
+        """A10 (V4:313-326): decode -> text between '<s>' and '</s>' -> names split on two spaces.
+
+        `generate(inputs_embeds=...)` returns only the NEW tokens on current transformers, while the
+        reference's `split('<s>')[1]` needs a '<s>' in the decoded text.  Training never teaches the
+        model to emit one (the label's BOS is an INPUT: the loss pairs logits[-Tl:-1] with
+        labels[1:], V4:327-341), so the sequence the reference parses is the generation behind an
+        implicit BOS - which is what the transformers releases that seed `sequences` with a BOS
+        token hand to `batch_decode`.  Default `implicit_bos=True`: a text without '<s>' is parsed
+        as if it followed one.  `implicit_bos=False` keeps the literal V4:315 behaviour
+        (IndexError unless on_parse_error='skip')."""
         rel_pred, rel_score = [], []
         for k, si in enumerate(selected_host.tolist()):
             seq = [int(t) for t in tokens_host[k] if t >= 0]
             text = self.llm_tokenizer.batch_decode([seq])[0]
-            try:
-                pred = text.split('<s>')[1].split('</s>')[0].strip()
-            except IndexError:
-                if self.on_parse_error == "raise":
-                    raise
+            parts = text.split('<s>')
+            if len(parts) > 1:
+                body = parts[1]
+            elif self.implicit_bos:
+                body = parts[0]
+            elif self.on_parse_error == "raise":
+                raise IndexError("no '<s>' in the generated text (V4:315-316); construct the head with "
+                                 "implicit_bos=True or on_parse_error='skip'")
+            else:
                 continue
+            pred = body.split('</s>')[0].strip()
             for name in pred.split('  '):
                 if name in relation_categories:
                     t = [si // object_num, si % object_num, relation_categories.index(name)]

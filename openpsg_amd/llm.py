@@ -185,7 +185,9 @@ class LlamaDecodeEngine:
             self.last_replays += 1
             if hi < max_new and int(all_done.item()) != 0:     # every pair has emitted EOS: the rest would be -1
                 break
-        return self._finish((st["tokens"], st["first_logits"]), return_first_logits)
+        # the graph's static buffers are overwritten by the next replay: hand out copies
+        fl = st["first_logits"]
+        return self._finish((st["tokens"].clone(), None if fl is None else fl.clone()), return_first_logits)
 
     @staticmethod
     def _finish(outs, want_first):

@@ -167,7 +167,9 @@ def qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, out=None, empty_
     L, hidden = k.shape
     assert q.shape == (P * nq, hidden) and v.shape == k.shape and k.dtype == q.dtype == v.dtype
     if variant is None:
-        variant = PSG_XATTN_MFMA if q.dtype == torch.bfloat16 else PSG_XATTN_SIMPLE
+        # the matrix-core kernel keeps all keys of one head in LDS (L <= 512 patches = images up to ~1450 px);
+        # larger inputs take the row kernel (the reference runs them too)
+        variant = PSG_XATTN_MFMA if (q.dtype == torch.bfloat16 and L <= 512) else PSG_XATTN_SIMPLE
     out = torch.empty_like(q) if out is None else out
     check(lib.psg_qformer_cross_attn(ctx, _p(q), _p(k), _p(v), _p(bits, torch.int64, "bits"), bits.shape[1],
                                      _p(pair_index, torch.int32, "pair_index"), int(N), P, L, nq, heads,

@@ -45,8 +45,13 @@ def render_result(res: dict, rng: random.Random):
     return png.astype(np.uint8), segments_info, [[s, o, r + 1] for s, o, r in relation]
 
 
-def write_submission(results, output_dir: str, seed: int = 0) -> str:
-    """results: list of `OpenSeeDRelationV2.simple_test(...)[0]` dicts, in test order."""
+def write_submission(results, output_dir: str, seed: int = 0, keep_scores: bool = False, names=None,
+                     entries=None) -> str:
+    """results: list of `OpenSeeDRelationV2.simple_test(...)[0]` dicts, in test order.
+
+    keep_scores / names / entries give the score-preserving variant of tools/predict.py:60-108: every record
+    also carries `relation_scores` (:97), starts from the dataset entry `entries[i]` (:92) and the panoptic PNG
+    is named after the image (`names[i]`, :84-85) instead of its index (tools/infer.py:168-169)."""
     from PIL import Image
     panseg_dir = os.path.join(output_dir, "submission", "panseg")
     os.makedirs(panseg_dir, exist_ok=True)
@@ -54,8 +59,15 @@ def write_submission(results, output_dir: str, seed: int = 0) -> str:
     all_results = []
     for idx, res in enumerate(results):
         png, segments_info, relations = render_result(res, rng)
-        Image.fromarray(png, mode="RGB").save(os.path.join(panseg_dir, f"{idx}.png"))
-        all_results.append(dict(relations=relations, segments_info=segments_info, pan_seg_file_name=f"{idx}.png"))
+        stem = str(idx) if names is None else os.path.splitext(os.path.basename(str(names[idx])))[0]
+        Image.fromarray(png, mode="RGB").save(os.path.join(panseg_dir, f"{stem}.png"))
+        rec = dict(entries[idx]) if entries is not None else {}
+        rec.update(relations=relations, segments_info=segments_info)
+        if keep_scores:
+            rec["relation_scores"] = list(res.get("rel_scores", []))
+        else:
+            rec["pan_seg_file_name"] = f"{stem}.png"
+        all_results.append(rec)
     path = os.path.join(output_dir, "submission", "relation.json")
     with open(path, "w") as f:
         json.dump(all_results, f, default=str)

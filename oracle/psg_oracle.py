@@ -12,6 +12,11 @@ pinned against OUTPUTS OF THE REFERENCE ITSELF run in the build container:
 (transformers 5.15.0, eager attention) and writes ``tests/golden/*.npz``;
 ``tests/test_oracle_golden.py`` checks every function here against those captures.
 
+The pinned mode is fp32.  The same functions also run with bf16 tensors (weights cast by the caller), following
+HF's own conventions for a model cast to bf16 (masks from finfo(dtype).min, softmax / RMSNorm statistics in fp32
+and cast back, rotary tables cast to the model dtype): tests use that as "PyTorch's bf16 CPU path" next to the HIP
+bf16 kernels.
+
 Reference anchors (file:line; V4 = kings_sgg/models/relation_heads/relation_transformer_head_v4.py,
 HF-IB = transformers/models/instructblip/modeling_instructblip.py, HF-LL = .../llama/modeling_llama.py,
 both third-party and absent from /root/reference; the reference pins no version):
@@ -112,7 +117,7 @@ def _mha(q, k, v, add_mask, heads):
     kh = k.view(k.shape[0], -1, heads, hd).transpose(1, 2)
     vh = v.view(v.shape[0], -1, heads, hd).transpose(1, 2)
     s = torch.matmul(qh, kh.transpose(-1, -2)) * (hd ** -0.5)
-    s = s + add_mask
+    s = s + add_mask.to(s.dtype)
     p = torch.softmax(s, dim=-1)
     o = torch.matmul(p, vh)
     return o.transpose(1, 2).reshape(B, Sq, D)
@@ -147,9 +152,10 @@ def qformer_forward(w, cfg, input_ids, text_mask, patches, pmask, chunk: int = 2
         B = ids.shape[0]
         h = qformer_embeddings(w, cfg, ids)
         self_mask = torch.cat([torch.ones(B, nq), tm.float()], dim=1)            # V4:158-159
-        add_self = ((1.0 - self_mask) * FMIN)[:, None, None, :]
+        fmin = torch.finfo(h.dtype).min                    # == FMIN in fp32, the pinned mode (HF: finfo(dtype).min)
+        add_self = ((1.0 - self_mask) * fmin)[:, None, None, :]
         if cfg.empty_row_policy == "uniform":
-            add_cross = ((1.0 - pm.float()) * FMIN)[:, None, None, :]
+            add_cross = ((1.0 - pm.float()) * fmin)[:, None, None, :]
         else:
             add_cross = ((1.0 - pm.float()) * -10000.0)[:, None, None, :]
         dump = []
@@ -199,7 +205,7 @@ def select_topk(prob: torch.Tensor, k: int = 20):
 
 def relation_query(w, cfg, mask_features, img_meta, object_ids, pan, input_ids, text_mask):
     """The whole relation-query stage (V4:146-215) -> dict of intermediates."""
-    patches = patch_embed(w, mask_features, cfg.patch_size)[0]
+    patches = patch_embed(w, mask_features.to(w["patch_embed.proj.weight"].dtype), cfg.patch_size)[0]
     fh, fw = mask_features.shape[-2:]
     grid = mask_grid(pan, img_meta["img_shape"], img_meta["pad_shape"], (fh // cfg.patch_size, fw // cfg.patch_size))
     om = object_masks(grid, object_ids)
@@ -243,6 +249,7 @@ def llama_forward(w, cfg, x, positions, key_valid, cache, n_layers=None):
     T = x.shape[0]
     hd = m.head_dim
     cos, sin = rope_cos_sin(positions, hd, m.rope_theta)
+    cos, sin = cos.to(x.dtype), sin.to(x.dtype)            # HF-LL:127-128 (tables computed in fp32, cast to the model dtype)
     L = m.layers if n_layers is None else n_layers
     for l in range(L):
         p = f"language_model.model.layers.{l}."
@@ -260,8 +267,8 @@ def llama_forward(w, cfg, x, positions, key_valid, cache, n_layers=None):
         s = torch.matmul(qh, kh.transpose(1, 2)) * (hd ** -0.5)                     # [h,T,ctx]
         qpos = torch.arange(ctx - T, ctx)[:, None]
         allowed = (torch.arange(ctx)[None, :] <= qpos) & key_valid[None, :ctx]
-        s = s + torch.where(allowed, 0.0, FMIN)[None]
-        pr = torch.softmax(s, dim=-1, dtype=torch.float32)
+        s = s + torch.where(allowed, 0.0, torch.finfo(s.dtype).min).to(s.dtype)[None]
+        pr = torch.softmax(s, dim=-1, dtype=torch.float32).to(qh.dtype)              # HF-LL:208
         o = torch.matmul(pr, vh).transpose(0, 1).reshape(T, m.hidden)
         x = x + F.linear(o, w[p + "self_attn.o_proj.weight"])
         n2 = rmsnorm(x, w[p + "post_attention_layernorm.weight"], m.rms_eps)
@@ -297,7 +304,7 @@ def llm_generate(w, cfg, inputs_embeds, attention_mask, max_new_tokens=None, n_l
     tokens, step_logits = [], []
     n_valid = int(mask.sum())
     for step in range(max_new):
-        logits = F.linear(h[-1], w["language_model.lm_head.weight"])
+        logits = F.linear(h[-1], w["language_model.lm_head.weight"]).float()
         if suppress_eos:
             logits = logits.clone()
             logits[m.eos] = -float("inf")

@@ -50,3 +50,45 @@ def llm_prompts(scene, selected):
 
 def unpack_bits(bits, n):
     return torch.from_numpy(np.unpackbits(bits, axis=-1, bitorder="little")[..., :n].astype(bool))
+
+
+# ---- a Llama whose greedy decode is known in advance (product-output tests) -----------------------------------
+class ChainTokenizer(WordTokenizer):
+    """WordTokenizer('llama') + one extra piece ';' that decodes to the empty string, so that joining pieces
+    with single spaces yields the DOUBLE space the reference splits relation names on (V4:317)."""
+
+    def __init__(self):
+        from openpsg_amd.tokenizers import default_words
+        super().__init__("llama", default_words() + [";"])
+
+    def decode(self, ids):
+        return " ".join("" if self.id_to_piece[int(i)] == ";" else self.id_to_piece[int(i)] for i in ids)
+
+
+def rig_llm_chain(w, cfg, tok, chain=("over", ";", "in", "front", "of", "</s>")):
+    """Overwrites the LLM tensors of `w` so that greedy decoding after the prompt's last token ':' emits `chain`:
+    attention and MLP outputs are zeroed (o_proj = down_proj = 0), embeddings are one-hot, norms are 1, and the
+    lm_head maps each token to its successor (everything outside the chain -> '</s>').  Returns the token ids."""
+    m = cfg.llm
+    assert tok.vocab_size <= m.hidden and tok.vocab_size <= m.vocab
+    ids = [tok.piece_to_id[p] for p in chain]
+    emb = torch.zeros(m.vocab, m.hidden)
+    for t in range(min(m.vocab, m.hidden)):
+        emb[t, t] = 1.0
+    head = torch.zeros(m.vocab, m.hidden)
+    head[m.eos, :] = 0.5                                      # default successor: '</s>'
+    prev = tok.piece_to_id[":"]
+    for t in ids:
+        head[:, prev] = 0.0
+        head[t, prev] = 1.0
+        prev = t
+    w["language_model.model.embed_tokens.weight"] = emb
+    w["language_model.lm_head.weight"] = head
+    w["language_model.model.norm.weight"] = torch.ones(m.hidden)
+    for l in range(m.layers):
+        p = f"language_model.model.layers.{l}."
+        w[p + "self_attn.o_proj.weight"] = torch.zeros(m.hidden, m.hidden)
+        w[p + "mlp.down_proj.weight"] = torch.zeros(m.hidden, m.inter)
+        w[p + "input_layernorm.weight"] = torch.ones(m.hidden)
+        w[p + "post_attention_layernorm.weight"] = torch.ones(m.hidden)
+    return ids

@@ -190,3 +190,45 @@ def test_rccl_pipeline_world1_matches_head(setup):
         assert np.array_equal(out["tokens"][0].cpu().numpy(), head.last["tokens_host"])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N", [50, 100])
+def test_fp32_head_vs_oracle_at_full_size(N):
+    """BASELINE C2 (N = 50: 2500 pairs) and C4 (N = 100: 10000 pairs) at 1024x1024 / L = 256: the fp32 verification
+    mode of the HIP head against the CPU oracle on ALL pairs (north_star bar: relation logits within 1e-3), the
+    top-20 selection identical; the bf16 mode's deviation on the same scene is reported."""
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_numpy
+    from oracle import psg_oracle as O
+    from tests import helpers as H
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 1, 256, 256), max_object_num=N)
+    w = make_weights_numpy(cfg, seed=100 + N, with_llm=False)
+    scene = make_scene((1024, 1024), N, seed=N, tiny_object=True)
+    ids = [int(i) for i in scene["object_id_list"]]
+    names = H.object_names(scene)
+    qids, qmask = H.qformer_prompts(scene)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        orq = O.relation_query(w, cfg, scene["mask_features"], scene["img_meta"], ids, scene["pan_results"], qids, qmask)
+    want_sel = O.select_topk(orq["exist_prob"], 20)
+    errs = {}
+    for dtype in ("fp32", "bf16"):
+        head = RelationTransformerHeadV4(dtype=dtype, device="cuda:0", qformer_vocab_size=512, llm_config=cfg.llm,
+                                         llm_feature_size=256, tokenizers="word", max_object_num=N)
+        head.load_weights(w)
+        rq = head.run_relation_query(scene["mask_features"].cuda(), scene["img_meta"], ids, names,
+                                     scene["pan_results"].cuda())
+        errs[dtype] = (rq["exist_logit"].cpu() - orq["exist_logit"]).abs().max().item()
+        if dtype == "fp32":
+            assert rq["exist_logit"].numel() == N * N
+            herr = (rq["hidden"].float().cpu().view(N * N, 33, 768) - orq["qformer_out"]).abs().max().item()
+            assert rq["selected"].cpu().tolist() == want_sel
+        else:
+            overlap = len(set(rq["selected"].cpu().tolist()) & set(want_sel))
+        del head
+    print(f"N={N} ({N * N} pairs): fp32 max |logit - oracle| = {errs['fp32']:.3e}, hidden {herr:.3e}; "
+          f"bf16 {errs['bf16']:.3e}, top-20 overlap {overlap}/20")
+    assert errs["fp32"] < 1e-3 and herr < 1e-3
+    assert errs["bf16"] < 0.35 and overlap >= 14

@@ -1,0 +1,130 @@
+"""Host-side product logic that needs no GPU: token ids -> triples (V4:313-326), result packing (DET2:183-188),
+registry construction from the reference's config dict through the `kings_sgg.*` dotted imports (CFG:7-13, 52-68),
+the test pipeline's shape arithmetic (CFG:109-123, INFER:39-41) and the score-preserving writer
+(tools/predict.py:91-97)."""
+import importlib
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from openpsg_amd.categories import relation_categories
+from oracle import psg_oracle as O
+from tests import helpers as H
+
+
+@pytest.fixture()
+def cpu_head():
+    from openpsg_amd.config import tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    tok = H.ChainTokenizer()
+    return RelationTransformerHeadV4(device="cpu", qformer_vocab_size=512, llm_config=tiny_llm(256, 2, 512, 512),
+                                     llm_feature_size=256, tokenizers=(H.WordTokenizer("bert"), tok)), tok
+
+
+def test_parse_tokens_to_triples_matches_oracle(cpu_head):
+    head, tok = cpu_head
+    enc = lambda s: [tok.piece_to_id[p] for p in s.split()]                       # noqa: E731
+    rows = [enc("over ; in front of </s>"), enc("on </s> beside </s>"), enc("person tree </s>"), enc("over </s>"),
+            enc("holding ; holding ; looking at")]
+    T = max(len(r) for r in rows)
+    toks = np.full((len(rows), T + 2), -1, dtype=np.int32)
+    for i, r in enumerate(rows):
+        toks[i, :len(r)] = r
+    sel = np.array([13, 7, 5, 13, 99], dtype=np.int32)
+    N = 10
+    pred, score = head.parse(toks, sel, N)
+    seen = []
+    for i, r in enumerate(rows):                                   # the reference sees the text behind a BOS
+        O.parse_relations("<s> " + tok.decode(r), int(sel[i]), N, relation_categories, seen)
+    assert pred == seen and score == [1] * len(seen)
+    ri = relation_categories.index
+    assert pred == [[1, 3, ri("over")], [1, 3, ri("in front of")], [0, 7, ri("on")], [9, 9, ri("holding")],
+                    [9, 9, ri("looking at")]]
+
+
+def test_parse_literal_mode_needs_generated_bos(cpu_head):
+    head, tok = cpu_head
+    toks = np.array([[tok.piece_to_id["over"], tok.piece_to_id["</s>"], -1]], dtype=np.int32)
+    head.implicit_bos = False
+    with pytest.raises(IndexError):                                # V4:315-316 as committed
+        head.parse(toks, np.array([3], dtype=np.int32), 4)
+    head.on_parse_error = "skip"
+    assert head.parse(toks, np.array([3], dtype=np.int32), 4) == ([], [])
+    with_bos = np.array([[tok.piece_to_id["<s>"], tok.piece_to_id["over"], tok.piece_to_id["</s>"]]], dtype=np.int32)
+    assert head.parse(with_bos, np.array([3], dtype=np.int32), 4) == ([[0, 3, 0]], [1])
+
+
+def test_detector_pack_contract():
+    from openpsg_amd.detector import OpenSeeDRelationV2, panoptic_to_mmdet
+    seg = torch.tensor([[0, 1, 1], [2, 2, 3]])
+    info = [dict(id=1, category_id=0), dict(id=2, category_id=17), dict(id=3, category_id=0)]
+    pan, ids = panoptic_to_mmdet(seg, info)
+    assert [int(i) for i in ids] == [0, 17, 1000]                  # DET2:117-130: category + 1000 * instance
+    assert pan.tolist() == [[0, 0, 0], [17, 17, 1000]]             # unassigned pixels alias id 0 (DET2:114)
+    res = {'pan_results': pan, 'object_id_list': ids, 'object_score_list': [torch.tensor(1.0)] * 3, 'ins_results': None}
+    out = OpenSeeDRelationV2._pack(res, dict(rel_pred=[[0, 1, 5]], rel_score=[1]))
+    assert isinstance(out['pan_results'], np.ndarray)
+    assert out['rel_results'] == dict(object_id_list=[0, 17, 1000], relation=[[0, 1, 5]])
+    assert out['rel_scores'] == [1]
+
+
+def test_build_detector_from_reference_config_dict():
+    """CFG:52-68 as a dict, resolved by importing the dotted paths of `custom_imports` (CFG:7-13)."""
+    for mod in ("kings_sgg.models.detectors.openseed_relation_v2",
+                "kings_sgg.models.relation_heads.relation_transformer_head_v4"):
+        importlib.import_module(mod)
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.registry import build_detector
+    model = dict(
+        type='OpenSeeDRelationV2',
+        openseed_config_path='./3rdparty/OpenSeeD/configs/openseed/openseed_swint_lang.yaml',
+        openseed_pretrained_path='./work_dirs/checkpoints/openseed/model_state_dict_swint_51.2ap.pt',
+        thing_classes=['person'], stuff_classes=['wall'],
+        relation_head=dict(type='RelationTransformerHeadV4', qformer_model_name='Salesforce/instructblip-vicuna-7b',
+                           llm_model_name='meta-llama/Llama-2-7b-hf', relation_classes=list(relation_categories)),
+        train_cfg=dict(freeze_layers=['openseed', 'relation_head.language_model']), test_cfg=None, init_cfg=None)
+    old = RelationTransformerHeadV4.default_tokenizers, RelationTransformerHeadV4.default_device
+    try:
+        RelationTransformerHeadV4.default_tokenizers, RelationTransformerHeadV4.default_device = "word", "cpu"
+        det = build_detector(model)
+    finally:
+        RelationTransformerHeadV4.default_tokenizers, RelationTransformerHeadV4.default_device = old
+    assert type(det).__name__ == "OpenSeeDRelationV2" and type(det.relation_head).__name__ == "RelationTransformerHeadV4"
+    assert det.freeze_layers == ['openseed', 'relation_head.language_model']
+    keys = set(det.state_dict())
+    ref = json.load(open(H.GOLDEN + "/reference_state_dict_keys.json"))        # schema of the real reference module
+    assert {"relation_head." + k for k in ref if not k.startswith("language_model.")} <= keys
+    # a detector-level load reaches the head's hook: unknown LLM keys are not reported, engines are reset
+    det.relation_head._rq_engine = object()
+    sd = {"relation_head.relation_query": torch.ones(1, 32, 768)}
+    res = det.load_state_dict(sd, strict=False)
+    assert det.relation_head._rq_engine is None and not res.unexpected_keys
+    assert float(det.relation_head.relation_query.mean()) == 1.0
+
+
+def test_pipeline_shape_arithmetic():
+    from openpsg_amd.preprocess import image_meta, preprocess_image
+    m = image_meta((480, 640))                                     # 480x640 -> 1000x1333 -> 1024x1344
+    assert m["img_shape"] == (1000, 1333, 3) and m["pad_shape"] == (1024, 1344, 3) and m["ori_shape"] == (480, 640, 3)
+    assert image_meta((640, 480))["pad_shape"] == (1344, 1024, 3)
+    assert image_meta((1333, 1333))["img_shape"] == (1333, 1333, 3)
+    x, metas = preprocess_image(np.full((30, 40, 3), 255, np.uint8), scale=(80, 80), divisor=32)
+    assert tuple(x.shape) == (1, 3, 64, 96) and metas[0]["img_shape"] == (60, 80, 3)
+    assert float(x[0, 0, 61, 0]) == 0.0 and abs(float(x[0, 0, 0, 0]) - (255 - 123.675) / 58.395) < 1e-5
+
+
+def test_score_preserving_writer(tmp_path):
+    from openpsg_amd.results import write_submission
+    pan = np.full((4, 6), 133, dtype=np.int32)
+    pan[:2, :3] = 0
+    pan[2:, 3:] = 1017
+    res = dict(pan_results=pan, rel_results=dict(object_id_list=[0, 1017], relation=[[0, 1, 4], [1, 0, 0]]),
+               rel_scores=[1, 1])
+    path = write_submission([res], str(tmp_path), keep_scores=True, names=["a/b/img_7.jpg"],
+                            entries=[dict(image_id=7, file_name="a/b/img_7.jpg")])
+    rec = json.load(open(path))[0]
+    assert rec["relations"] == [[0, 1, 5], [1, 0, 1]] and rec["relation_scores"] == [1, 1]      # predict.py:93-97
+    assert rec["image_id"] == 7 and [s["category_id"] for s in rec["segments_info"]] == [1, 18]
+    assert (tmp_path / "submission" / "panseg" / "img_7.png").exists()

@@ -1,12 +1,16 @@
 """mmdet-free work-alike of the reference's tools/infer.py (INFER:65-188) for the MI355X path.
 
     python tools/infer.py --segmenter synthetic --images 8 --objects 50 --out work_dirs/demo
-    python tools/infer.py --segmenter precomputed --seg-dir seg_npz/ --list files.txt --out work_dirs/run
+    python tools/infer.py --segmenter precomputed --seg-dir seg_npz/ --list files.txt --image-dir imgs/ --out work_dirs/run
 
 The segmenter (OpenSeeD in the reference, DET2:92-143) is pluggable: `synthetic` rectangles
- or `.npz` files of precomputed OpenSeeD outputs.  Everything downstream - relation
-head on the GPU, result packing (DET2:183-190), submission files (INFER:149-187) - is this repo's.
-Random-init weights are used unless --checkpoint / --llm are given (no model files exist offline).
+ or `.npz` files of precomputed OpenSeeD outputs.  Everything downstream - image ->
+`img_metas` (CFG:109-123 with INFER:39-41's 1333 scale; openpsg_amd/preprocess.py), relation head on
+the GPU, result packing (DET2:183-190), submission files (INFER:149-187; `--keep-scores` = the
+tools/predict.py:91-97 variant) - is this repo's.  Random-init weights are used unless
+--checkpoint / --llm are given (no model files exist offline).
+
+`run(args, head=None)` is the importable entry (tests inject a head with known weights).
 """
 import argparse
 import os
@@ -18,38 +22,33 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--segmenter", choices=["synthetic", "precomputed"], default="synthetic")
     ap.add_argument("--seg-dir")
     ap.add_argument("--list", help="text file with one image file name per line (precomputed mode)")
+    ap.add_argument("--image-dir", help="directory of the image files: shapes come from the files through the "
+                                        "test pipeline (resize to 1333 keep-ratio, pad to 32)")
     ap.add_argument("--images", type=int, default=4)
     ap.add_argument("--objects", type=int, default=20)
-    ap.add_argument("--size", type=int, nargs=2, default=[1024, 1024], help="pad_shape H W")
-    ap.add_argument("--ori-size", type=int, nargs=2, default=None)
+    ap.add_argument("--size", type=int, nargs=2, default=[1024, 1024], help="pad_shape H W (no --image-dir)")
+    ap.add_argument("--ori-size", type=int, nargs=2, default=None,
+                    help="original H W; with it and without --size the pipeline's shape arithmetic is applied")
     ap.add_argument("--out", default="work_dirs/demo")
     ap.add_argument("--llm-layers", type=int, default=2)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--selector", choices=["topk", "threshold"], default="topk")
     ap.add_argument("--batch", type=int, default=1,
                     help="images per head call; > 1 decodes their selected pairs together (throughput mode)")
+    ap.add_argument("--keep-scores", action="store_true", help="tools/predict.py:91-97 output variant")
     ap.add_argument("--checkpoint", help="reference-style partial checkpoint (state_dict with relation_head.* keys)")
-    a = ap.parse_args()
+    return ap
 
+
+def build_head(a, dev):
     from openpsg_amd.config import LlamaConfig, PSGConfig, QFormerConfig
-    from openpsg_amd.detector import OpenSeeDRelationV2, PrecomputedSegmenter, SyntheticSegmenter
     from openpsg_amd.head import RelationTransformerHeadV4
-    from openpsg_amd.results import write_submission
     from openpsg_amd.weights import make_weights_device
-    # one process per GPU (torch.distributed.run): whole images are dealt round-robin to the ranks
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")                       # host objects only; no device collective on this path
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
     llm = LlamaConfig(layers=a.llm_layers)
     cfg = PSGConfig(qformer=QFormerConfig(), llm=llm, max_object_num=a.objects)
     head = RelationTransformerHeadV4(dtype=a.dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
@@ -60,35 +59,84 @@ def main():
         sd = sd.get("state_dict", sd)
         head.load_state_dict({k[len("relation_head."):]: v for k, v in sd.items() if k.startswith("relation_head.")},
                              strict=False)
-    seg = SyntheticSegmenter(a.objects, seed=0) if a.segmenter == "synthetic" else PrecomputedSegmenter(a.seg_dir)
+    return head
+
+
+def image_metas(a, names):
+    """img_metas per image: from the files (--image-dir), from --ori-size through the pipeline's shape
+    arithmetic, or the fixed --size grid."""
+    from openpsg_amd.preprocess import image_meta, load_image
+    metas = []
+    for n in names:
+        if a.image_dir:
+            img = load_image(os.path.join(a.image_dir, n))
+            metas.append(image_meta(img.shape[:2], filename=n))
+        elif a.ori_size and not a.size_given:
+            metas.append(image_meta(tuple(a.ori_size), filename=n))
+        else:
+            pad = tuple(a.size)
+            ori = tuple(a.ori_size) if a.ori_size else pad
+            metas.append(dict(filename=n, ori_shape=ori + (3,), img_shape=pad + (3,), pad_shape=pad + (3,)))
+    return metas
+
+
+def run(a, head=None):
+    from openpsg_amd.detector import OpenSeeDRelationV2, PrecomputedSegmenter, SyntheticSegmenter
+    from openpsg_amd.dist import gather_image_results, shard_images
+    from openpsg_amd.results import write_submission
+    if not hasattr(a, "size_given"):
+        a.size_given = True
+    # one process per GPU (torch.distributed.run): whole images are dealt round-robin to the ranks
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    own_group = False
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")                   # host objects only; no device collective on this path
+            own_group = True
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if head is None:
+        head = build_head(a, dev)
+    seg = SyntheticSegmenter(a.objects, seed=0, device=str(dev)) if a.segmenter == "synthetic" else \
+        PrecomputedSegmenter(a.seg_dir, device=str(dev))
     det = OpenSeeDRelationV2(relation_head=head, segmenter=seg)
-    if a.segmenter == "synthetic":
+    if a.segmenter == "synthetic" and not a.list:
         names = [f"{i}.jpg" for i in range(a.images)]
     else:
         names = [l.strip() for l in open(a.list) if l.strip()]
-    pad = tuple(a.size)
-    ori = tuple(a.ori_size) if a.ori_size else pad
-    from openpsg_amd.dist import gather_image_results, shard_images
+    all_metas = image_metas(a, names)
     mine = shard_images(len(names), world, rank)
-    metas = {i: dict(filename=names[i], ori_shape=ori + (3,), img_shape=pad + (3,), pad_shape=pad + (3,)) for i in mine}
     local_results, t0 = [], time.time()
     for b0 in range(0, len(mine), a.batch):
         idx = mine[b0:b0 + a.batch]
         if a.batch == 1:
-            outs = [det.simple_test(None, [metas[idx[0]]])]
+            outs = [det.simple_test(None, [all_metas[idx[0]]])]
         else:
-            outs = det.simple_test_batch([None] * len(idx), [[metas[i]] for i in idx])
+            outs = det.simple_test_batch([None] * len(idx), [[all_metas[i]] for i in idx])
         local_results += [(i, o[0]) for i, o in zip(idx, outs)]
     torch.cuda.synchronize()
     dt = time.time() - t0
     results = gather_image_results(local_results, len(names))
+    path = None
     if rank == 0:
-        path = write_submission(results, a.out)
+        path = write_submission(results, a.out, keep_scores=a.keep_scores, names=names if a.keep_scores else None)
         n_rel = sum(len(r["rel_results"]["relation"]) for r in results)
         print(f"{len(names)} images on {world} GPU(s) in {dt:.2f}s ({len(names) / dt:.2f} img/s), {n_rel} relations "
               f"-> {path}")
-    if world > 1:
+    if own_group:
+        import torch.distributed as dist
         dist.destroy_process_group()
+    return results, path
+
+
+def main():
+    ap = parser()
+    a = ap.parse_args()
+    a.size_given = any(x == "--size" for x in sys.argv)
+    run(a)
 
 
 if __name__ == "__main__":
