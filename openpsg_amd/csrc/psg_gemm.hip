@@ -184,7 +184,7 @@ struct SgdWait<UD, 0> {
   static __device__ __forceinline__ void go(int) { sgd_wait<0>(); }
 };
 
-template <int WAVES, int UD, int SGD_SLOTS, int AUX>
+template <int WAVES, int UD, int SGD_SLOTS, int AUX, int XDMA>
 __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint16_t* __restrict__ x,
                                                                      const uint16_t* __restrict__ w,
                                                                      float* __restrict__ part, int M, int N, int K,
@@ -233,6 +233,22 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
     ++lj;
     if (++lb == nb) { lb = 0; ++lt; }
   };
+  const int pieces = nkb * 8;
+  if constexpr (XDMA) {
+    // x slice by LDS-DMA as well: one instruction = up to 64 16-byte pieces of ONE row (lanes past the row's
+    // slice are masked off), issued ahead of the weight stream, no VGPR round trip and no ordinary load next to
+    // the DMAs (hipcc drains the whole DMA queue at every use of a plain load while a DMA is in flight)
+    const int cpr = (pieces + 63) >> 6;                             // 1 KiB chunks per row
+    const int items = M * cpr;
+    for (int it = wid; it < items; it += WAVES) {
+      const int r = it / cpr, j = it - r * cpr;
+      const int c = j * 64 + lane;
+      if (c < pieces)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(x + (int64_t)r * K + (int64_t)kbA * 64 + c * 8),
+            (__attribute__((address_space(3))) void*)(xs + r * xstride + j * 1024), 16, 0, 0);
+    }
+  }
   for (int i = 0; i < SGD_SLOTS - 1; ++i)
     if (i < total) issue();
   if (tr && lane == 0) tr[1] = __builtin_readcyclecounter();
@@ -241,8 +257,7 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
   // (issuing all of a thread's x loads at once, with or without a division-free row/piece mapping, was
   // measured SLOWER, 3.42 vs 2.97 ms per decode step: 256 workgroups then hit the same 160 KB of x in L2 in one
   // burst; this loop spreads them)
-  const int pieces = nkb * 8;
-  {
+  if constexpr (!XDMA) {
     constexpr int XU = 1;                                           // x loads in flight per thread: 2 measured slower (3.11 vs 2.97 ms/step), 8 slower still (3.42): they queue in front of the weight stream
     const int total_x = M * pieces;
     for (int e0 = tid; e0 < total_x; e0 += XU * WAVES * 64) {
@@ -262,6 +277,8 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
       for (int u = 0; u < XU; ++u)
         if (off[u] >= 0) *reinterpret_cast<uint4*>(xs + off[u]) = v[u];
     }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's x rows (and first weight batches) landed
   }
   __syncthreads();
   if (tr && lane == 0) tr[2] = __builtin_readcyclecounter();
@@ -461,17 +478,23 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
       const char* e = getenv("PSG_SKINNY_NT");
       nt = e ? atoi(e) : 1;
     }
-#define SGD_L(WV, UD, SL, AUX)                                                                                     \
+    static int xdma = -1;                                // PSG_SKINNY_XDMA=0: x slice by plain loads + ds_write
+    if (xdma < 0) {
+      const char* e = getenv("PSG_SKINNY_XDMA");
+      xdma = e ? atoi(e) : 1;
+    }
+#define SGD_L(WV, UD, SL, AUX, XD)                                                                                 \
   do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<WV, UD, SL, AUX>,                                \
+    (void)hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<WV, UD, SL, AUX, XD>,                            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
-    skinny_gemm_dma_kernel<WV, UD, SL, AUX><<<gridd, WV * 64, ldsd, st>>>((const uint16_t*)x, (const uint16_t*)w, \
-                                                                          part, M, N, K, xstride, trace);          \
+    skinny_gemm_dma_kernel<WV, UD, SL, AUX, XD><<<gridd, WV * 64, ldsd, st>>>(                                     \
+        (const uint16_t*)x, (const uint16_t*)w, part, M, N, K, xstride, trace);                                    \
   } while (0)
 #define SGD(WV, UD, SL)                                                                                            \
   do {                                                                                                             \
-    if (nt) SGD_L(WV, UD, SL, 2);                                                                                  \
-    else SGD_L(WV, UD, SL, 0);                                                                                     \
+    if (nt && xdma) SGD_L(WV, UD, SL, 2, 1);                                                                       \
+    else if (nt) SGD_L(WV, UD, SL, 2, 0);                                                                          \
+    else SGD_L(WV, UD, SL, 0, 0);                                                                                  \
   } while (0)
     if (wv == 8 && ud == 1 && sl == 3) SGD(8, 1, 3);
     else if (wv == 8 && ud == 1 && sl == 5) SGD(8, 1, 5);

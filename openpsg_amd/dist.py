@@ -14,6 +14,14 @@ shard naturally.  One process per GPU; a job is R images for R ranks (weak scali
      rank m (exactly one non-zero contributor per row, so the sum is exact);
   5. rank m decodes image m's K pairs (LLM weights replicated) and token ids are ALL-GATHERED.
 
+`step_one_image` is the STRONG-scaling form (one image for all ranks, BASELINE C4): rank 0 broadcasts its
+patches, every rank runs its pair shard, probabilities are all-gathered, the selected pair features are
+all-reduced (one non-zero contributor per row) and the K decodes are DEALT round-robin to the ranks (SURVEY 8e
+item 3; LLM weights replicated), token ids all-gathered.  What dealing can and cannot buy: a decode step streams
+all 13.5 GB of Llama weights for 1 row as for 20, so only the compute-bound prompt pass and the relation query
+shrink with the rank count; without tensor parallelism (out of scope) one image's latency is bounded
+below by 16 weight passes.
+
 Messages are <= 1 MB: latency-bound, so each step is one collective on the compute stream.
 The compute is behind a small backend interface so the collective logic can be exercised with
 `gloo` on CPU (tests/test_dist_gloo.py injects the CPU oracle); the product backend is
@@ -115,6 +123,11 @@ class HipBackend:
         return out["tokens"]
 
 
+def deal_indices(k: int, world: int, rank: int):
+    """Positions (into the selection) of the pairs rank `rank` decodes: round-robin."""
+    return list(range(rank, k, world))
+
+
 class PairShardedPipeline:
     def __init__(self, head_or_backend, group=None, decode=True):
         self.be = head_or_backend if hasattr(head_or_backend, "query_shard") else HipBackend(head_or_backend)
@@ -138,6 +151,68 @@ class PairShardedPipeline:
         recv = torch.empty_like(send[0])
         dist.reduce_scatter_tensor(recv.view(-1), send.contiguous().view(-1), op=dist.ReduceOp.SUM, group=self.group)
         return recv
+
+    def step_one_image(self, scene, deal_decodes=True):
+        """Strong scaling: ONE image, its pairs sharded over all ranks; returns dict(exist_prob [B], selected [K],
+        tokens [K, max_new]) identical on every rank."""
+        be, R, r = self.be, self.world, self.rank
+        N = be.num_objects(scene)
+        B = N * N
+        K = min(be.k, B)
+        # 1. patches from the rank that holds the feature map (rank 0) - 256 KB instead of 67 MB
+        patches = be.patch_embed(scene) if r == 0 else None
+        if R > 1:
+            shape = torch.zeros(2, dtype=torch.int64, device=self._device(scene))
+            if r == 0:
+                shape[0], shape[1] = patches.shape
+            dist.broadcast(shape, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)
+            if r != 0:
+                patches = torch.empty((int(shape[0]), int(shape[1])), device=shape.device, dtype=torch.float32)
+            dist.broadcast(patches, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)
+        # 2. my pair shard; 3. probabilities everywhere, identical top-K everywhere
+        p0, p1, shard = shard_range(B, R, r)
+        hidden, prob = be.query_shard(scene, patches, p0, p1)
+        prob_pad = torch.full((shard,), -1.0, device=patches.device, dtype=torch.float32)
+        prob_pad[:p1 - p0] = prob
+        probs = self._all_gather(prob_pad).reshape(-1)[:B].contiguous()
+        sel = be.topk(probs, K)
+        out = dict(exist_prob=probs, selected=sel)
+        if not self.decode:
+            return out
+        # 4. features of the selected pairs to everyone (exactly one rank owns each row -> the sum is exact)
+        nv = be.q_rows - 1
+        s64 = sel.to(torch.int64)
+        mine = (s64 >= p0) & (s64 < p1)
+        rows = (s64 - p0)[:, None] * be.q_rows + 1 + torch.arange(nv, device=patches.device, dtype=torch.int64)[None, :]
+        rows = torch.where(mine[:, None], rows, torch.full_like(rows, -1)).reshape(-1).to(torch.int32)
+        feats = be.gather_features(hidden, rows)                                    # [K*nv, hidden], zeros where not mine
+        if R > 1:
+            dist.all_reduce(feats, op=dist.ReduceOp.SUM, group=self.group)
+        # 5. the K decodes dealt round-robin; 6. token ids to everyone
+        if deal_decodes and R > 1:
+            per = (K + R - 1) // R
+            idx = deal_indices(K, R, r)
+            tok_pad = torch.full((per, be.max_new), -1, device=patches.device, dtype=torch.int32)
+            if idx:
+                it = torch.tensor(idx, device=patches.device, dtype=torch.int64)
+                frow = (it[:, None] * nv + torch.arange(nv, device=patches.device)[None, :]).reshape(-1)
+                tok_pad[:len(idx)] = be.decode(scene, sel[it].contiguous(), feats[frow].contiguous())
+            allt = self._all_gather(tok_pad)                                         # [R, per, max_new]
+            tokens = torch.empty((K, be.max_new), device=patches.device, dtype=torch.int32)
+            for rr in range(R):
+                ii = deal_indices(K, R, rr)
+                if ii:
+                    tokens[torch.tensor(ii, device=patches.device)] = allt[rr, :len(ii)]
+        else:
+            tokens = be.decode(scene, sel, feats)
+        out["tokens"] = tokens
+        return out
+
+    @staticmethod
+    def _device(scene):
+        return scene["mask_features"].device
 
     def step(self, scenes):
         """scenes[m] = inputs of image m, resident on every rank.  Returns dict with the per-image

@@ -109,6 +109,53 @@ def test_pair_sharding_world2_gloo(n_obj):
     assert all(ret.get(r) for r in range(world)), dict(ret)
 
 
+def _one_image_worker(rank, world, port, n_obj, ret):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.dist import PairShardedPipeline, deal_indices
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_numpy
+    from oracle import psg_oracle as O
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 1, 512, 512))
+    w = make_weights_numpy(cfg, seed=3, with_llm=False)
+    scene = make_scene((256, 256), n_obj, seed=77, tiny_object=True)
+    if rank != 0:                               # only rank 0 holds the feature map; the others get the patches
+        scene = dict(scene, mask_features=torch.full_like(scene["mask_features"], float("nan")))
+    be = OracleBackend(cfg, w)
+    real_pe = be.patch_embed
+    be.patch_embed = lambda sc: real_pe(sc) if rank == 0 else (_ for _ in ()).throw(AssertionError("rank > 0"))
+    with torch.no_grad():
+        out = PairShardedPipeline(be, dist.group.WORLD, decode=True).step_one_image(scene)
+        B = n_obj * n_obj
+        full_scene = make_scene((256, 256), n_obj, seed=77, tiny_object=True)
+        be1 = OracleBackend(cfg, w)
+        h, prob = be1.query_shard(full_scene, be1.patch_embed(full_scene), 0, B)
+        ok = torch.allclose(out["exist_prob"], prob, atol=1e-5)
+        sel = O.select_topk(out["exist_prob"], be.k)
+        ok &= out["selected"].tolist() == sel
+        ok &= torch.equal(out["tokens"], be1.decode(full_scene, torch.tensor(sel), h[:1]))
+        mine = deal_indices(len(sel), world, rank)              # this rank decoded exactly its dealt pairs
+        rows = (torch.tensor([sel[i] for i in mine])[:, None] * 33 + 1 + torch.arange(32)[None, :]).reshape(-1)
+        ok &= torch.allclose(be.received, h[rows], atol=1e-4)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_obj", [4, 3])
+def test_one_image_strong_scaling_world2_gloo(n_obj):
+    """SURVEY 8e incl. item 3: one image for both ranks - patches broadcast from rank 0, pair shards, identical
+    top-K, selected features all-reduced, the K decodes dealt round-robin, tokens gathered in selection order."""
+    world = 2
+    port = 33500 + os.getpid() % 2000 + n_obj
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_one_image_worker, args=(world, port, n_obj, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
 def test_shard_range_covers_all_pairs():
     from openpsg_amd.dist import shard_range
     for B in (1, 9, 16, 100, 2500, 10000):
