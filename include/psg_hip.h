@@ -56,6 +56,18 @@ int psg_destroy(psg_ctx* ctx);
 /* number of compute units / arch name of the context's device (diagnostics, roofline) */
 int psg_device_info(psg_ctx* ctx, int* num_cu, char* arch, int arch_len);
 
+/* Tunables of a context (kernel variants, split planner; names in openpsg_amd/csrc/psg_common.h `psg_opts`).
+ * Defaults are the measured-best settings; psg_create also reads PSG_<NAME> from the environment once per
+ * context.  The library keeps no process-global mutable state: every launch consults only its psg_ctx. */
+int psg_set_option(psg_ctx* ctx, const char* name, int value);
+int psg_get_option(psg_ctx* ctx, const char* name, int* value);
+
+/* Debugging aid: per-wave cycle-counter stamps of the next launches of one kernel family are written to a
+ * CALLER-PROVIDED device buffer (the library does not allocate, copy or synchronise; a buffer too small for a
+ * launch is simply not written).  PSG_TRACE_SKINNY_GEMM: 8 int64 per wave; PSG_TRACE_CROSS_ATTN: 32 per wave. */
+enum psg_trace_kind { PSG_TRACE_NONE = 0, PSG_TRACE_SKINNY_GEMM = 1, PSG_TRACE_CROSS_ATTN = 2 };
+int psg_set_trace_buffer(psg_ctx* ctx, int kind, void* device_buffer, int64_t bytes);
+
 /* ---- A4 / K1: patch embedding, V4:410 (timm PatchEmbed = Conv2d(C, Cout, 16, 16) + flatten(2).transpose(1,2)):
  * out[l][o] = bias[o] + sum_{c,dy,dx} feat[c][16 py+dy][16 px+dx] * weight[o][c][dy][dx], l = py*(Wf/16)+px.
  * Exact fp32 (f32 matrix cores), split-K over the chip with a deterministic second-pass reduction.
@@ -117,11 +129,11 @@ int psg_qformer_self_attn_shared(psg_ctx*, const void* qkv_query, const void* qk
  * V4:168-170 expand removed: K/V [L][hidden] are projected ONCE per image and shared by every
  * pair; the pair mask is bits[i] | bits[j] (pair_index[p] = i*N + j) applied on the fly.
  * q / out [P*nq][hidden]; scores = q.k/sqrt(64) + mask; fp32 softmax; all-masked => uniform.
- * work_counters: reserved (an earlier revision kept a per-head work queue there); may be NULL. */
+ */
 int psg_qformer_cross_attn(psg_ctx*, const void* q, const void* k, const void* v,
                            const uint64_t* bits, int words, const int32_t* pair_index, int N, int P,
                            int L, int nq, int heads, int empty_policy, int variant, void* out,
-                           int32_t* work_counters, int dtype, void* stream);
+                           int dtype, void* stream);
 
 /* ---- K8: pair-existence scoring head, V4:206-209: logit = w . x[p*nq] + b, prob = sigmoid. */
 int psg_exist_head(psg_ctx*, const void* x, const float* w, const float* b, int P, int nq, int hidden,

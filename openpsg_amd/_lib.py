@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libpsg_hip.so")
 PSG_F32, PSG_BF16 = 0, 1
 PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED = 0, 1
 PSG_XATTN_MFMA, PSG_XATTN_SIMPLE = 0, 1
+PSG_TRACE_NONE, PSG_TRACE_SKINNY_GEMM, PSG_TRACE_CROSS_ATTN = 0, 1, 2
 
 
 class PsgHipError(RuntimeError):
@@ -29,6 +30,9 @@ SIGNATURES = {
     "psg_create": [_i, C.POINTER(_vp)],
     "psg_destroy": [_vp],
     "psg_device_info": [_vp, C.POINTER(_i), C.c_char_p, _i],
+    "psg_set_option": [_vp, C.c_char_p, _i],
+    "psg_get_option": [_vp, C.c_char_p, C.POINTER(_i)],
+    "psg_set_trace_buffer": [_vp, _i, _vp, _i64],
     "psg_patch_embed_workspace": [_vp, _i, _i, _i, _i, _i, C.POINTER(_i64)],
     "psg_patch_embed": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp],
     "psg_mask_grid": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
@@ -39,7 +43,7 @@ SIGNATURES = {
     "psg_bias_gelu": [_vp, _vp, _vp, _i64, _i, _vp, _i, _vp],
     "psg_qformer_self_attn": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "psg_qformer_self_attn_shared": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp],
-    "psg_qformer_cross_attn": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "psg_qformer_cross_attn": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "psg_exist_head": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "psg_topk": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "psg_gather_rows": [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _i, _i64, _vp],
@@ -112,3 +116,22 @@ def device_info(device_index: int):
     buf = C.create_string_buffer(64)
     check(load().psg_device_info(ctx(device_index), C.byref(n), buf, 64), "psg_device_info")
     return n.value, buf.value.decode()
+
+
+def set_option(device_index: int, name: str, value: int):
+    check(load().psg_set_option(ctx(device_index), name.encode(), int(value)), f"psg_set_option({name})")
+
+
+def get_option(device_index: int, name: str) -> int:
+    v = _i(0)
+    check(load().psg_get_option(ctx(device_index), name.encode(), C.byref(v)), f"psg_get_option({name})")
+    return v.value
+
+
+def set_trace_buffer(device_index: int, kind: int, tensor=None):
+    """Per-wave cycle stamps of the next launches of `kind` go to `tensor` (int64, on the device); None = off."""
+    if tensor is None or kind == PSG_TRACE_NONE:
+        check(load().psg_set_trace_buffer(ctx(device_index), PSG_TRACE_NONE, None, 0), "psg_set_trace_buffer")
+    else:
+        check(load().psg_set_trace_buffer(ctx(device_index), int(kind), tensor.data_ptr(),
+                                          tensor.numel() * tensor.element_size()), "psg_set_trace_buffer")

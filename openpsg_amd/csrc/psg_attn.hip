@@ -84,9 +84,8 @@ extern "C" int psg_qformer_self_attn(psg_ctx* ctx, const void* qkv, const uint8_
   PSG_REQUIRE(nq + T_ <= 64, PSG_ERR_UNSUPPORTED,
               "psg_qformer_self_attn: %d query rows + %d prompt tokens > 64 keys (one wavefront)", nq, T_);
   // bf16 activations with the standard geometry run on the matrix cores (psg_selfattn_mfma.hip);
-  // PSG_SELFATTN_SCALAR=1 forces the scalar kernel (on-device cross-check)
-  static int force_scalar = -1;
-  if (force_scalar < 0) force_scalar = getenv("PSG_SELFATTN_SCALAR") ? 1 : 0;
+  // option selfattn_scalar forces the scalar kernel (on-device cross-check)
+  const int force_scalar = ctx->opt.selfattn_scalar;
   if (dtype == PSG_BF16 && nq >= 32 && nq + T_ <= 64 && !force_scalar)
     return psg_self_attn_mfma_launch(qkv, nullptr, text_mask, B, T_, nq, heads, query_rows_only, out, (hipStream_t)stream);
   int64_t units = (int64_t)B * heads;
@@ -193,7 +192,7 @@ int psg_cross_attn_simple_launch(const void* q, const void* k, const void* v, co
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "cross_attn(simple): L=%d needs %zu B of LDS", L, lds);
   PSG_DISPATCH_DTYPE(dtype, "psg_qformer_cross_attn(simple)", {
     if (lds > 64 * 1024)
-      hipFuncSetAttribute((const void*)cross_attn_simple_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)cross_attn_simple_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds);
     cross_attn_simple_kernel<T><<<P * heads, 256, lds, st>>>((const T*)q, (const T*)k, (const T*)v, bits, words,
                                                             pair_index, N, L, nq, heads, policy, (T*)out);
@@ -550,8 +549,7 @@ extern "C" int psg_decode_attn(psg_ctx* ctx_, const void* qkv, int qkv_splits, c
               qkv_splits);
   if (rows == 0) return PSG_OK;
   const int waves = rows * heads;
-  static int single = -1;                          // PSG_DECODE_ATTN_1WAVE=1: the one-wave-per-head kernel
-  if (single < 0) single = getenv("PSG_DECODE_ATTN_1WAVE") ? 1 : 0;
+  const int single = ctx_->opt.decode_attn_1wave;    // option decode_attn_1wave: the one-wave-per-head kernel
   if (!single) {
     PSG_DISPATCH_DTYPE(dtype, "psg_decode_attn",
                        (decode_attn4_kernel<T><<<waves, 256, 0, (hipStream_t)stream>>>(

@@ -8,10 +8,31 @@
 
 #include "../../include/psg_hip.h"
 
+// Tunables of a context (psg_set_option).  Defaults are the measured-best settings; psg_create reads the PSG_*
+// environment variables of the same names ONCE per context, so an experiment needs no rebuild.  There is no
+// process-global mutable state: everything a launch consults lives here.
+struct psg_opts {
+  int skinny_splits = 0;        // > 0: forced split-K count of psg_skinny_gemm_plan
+  int skinny_balance = 1;       // last-round balance rule of the split planner
+  int skinny_wg_per_cu = 3;     // register variant: persistent workgroups per CU
+  int skinny_dma = 813;         // LDS-DMA variant <waves><K blocks per batch><ring slots>; 0 = register variant
+  int skinny_nt = 1;            // non-temporal weight DMAs
+  int skinny_xdma = 1;          // x slice staged by LDS-DMA as well
+  int selfattn_scalar = 0;      // Q-Former self-attention: scalar checker kernel even in bf16
+  int decode_attn_1wave = 0;    // decode attention: one wave per (pair, head) instead of a workgroup
+};
+
 struct psg_ctx {
   int device;
   int num_cu;
   char arch[64];
+  psg_opts opt;
+  // caller-provided device buffer for per-wave cycle-counter stamps (psg_set_trace_buffer); the library never
+  // allocates, copies or synchronises for it
+  long long* trace = nullptr;
+  int64_t trace_words = 0;
+  int trace_kind = 0;           // PSG_TRACE_*
+  size_t skinny_lds_configured = 0;
 };
 
 void psg_set_error(const char* fmt, ...);

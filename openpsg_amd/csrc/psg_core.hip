@@ -1,6 +1,8 @@
 // Context, error handling and the integer / byte kernels of the path:
 //   K2 mask -> patch grid, K3 object bitmasks, K9 top-k selector, row gather.
+#include <ctype.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "psg_common.h"
 
@@ -15,6 +17,56 @@ void psg_set_error(const char* fmt, ...) {
 
 extern "C" const char* psg_last_error(void) { return g_err; }
 extern "C" int psg_version(void) { return 100; }
+
+struct OptName {
+  const char* name;
+  int psg_opts::*field;
+};
+static const OptName kOpts[] = {
+    {"skinny_splits", &psg_opts::skinny_splits},       {"skinny_balance", &psg_opts::skinny_balance},
+    {"skinny_wg_per_cu", &psg_opts::skinny_wg_per_cu}, {"skinny_dma", &psg_opts::skinny_dma},
+    {"skinny_nt", &psg_opts::skinny_nt},               {"skinny_xdma", &psg_opts::skinny_xdma},
+    {"selfattn_scalar", &psg_opts::selfattn_scalar},   {"decode_attn_1wave", &psg_opts::decode_attn_1wave},
+};
+
+// "8x1x3" (waves x K blocks x ring slots) is accepted for skinny_dma next to a plain integer
+static int parse_opt(const char* name, const char* text) {
+  int a = 0, b = 0, c = 3;
+  if (!strcmp(name, "skinny_dma") && sscanf(text, "%dx%dx%d", &a, &b, &c) >= 2) return a * 100 + b * 10 + c;
+  return atoi(text);
+}
+
+extern "C" int psg_set_option(psg_ctx* ctx, const char* name, int value) {
+  PSG_REQUIRE(ctx && name, PSG_ERR_INVALID, "psg_set_option: NULL argument");
+  for (const OptName& o : kOpts)
+    if (!strcmp(o.name, name)) {
+      ctx->opt.*(o.field) = value;
+      return PSG_OK;
+    }
+  psg_set_error("psg_set_option: unknown option '%s'", name);
+  return PSG_ERR_INVALID;
+}
+
+extern "C" int psg_get_option(psg_ctx* ctx, const char* name, int* value) {
+  PSG_REQUIRE(ctx && name && value, PSG_ERR_INVALID, "psg_get_option: NULL argument");
+  for (const OptName& o : kOpts)
+    if (!strcmp(o.name, name)) {
+      *value = ctx->opt.*(o.field);
+      return PSG_OK;
+    }
+  psg_set_error("psg_get_option: unknown option '%s'", name);
+  return PSG_ERR_INVALID;
+}
+
+extern "C" int psg_set_trace_buffer(psg_ctx* ctx, int kind, void* device_buffer, int64_t bytes) {
+  PSG_REQUIRE(ctx, PSG_ERR_INVALID, "psg_set_trace_buffer: ctx is NULL");
+  PSG_REQUIRE(kind == PSG_TRACE_NONE || (device_buffer && bytes >= 8), PSG_ERR_INVALID,
+              "psg_set_trace_buffer: kind=%d needs a device buffer", kind);
+  ctx->trace_kind = kind;
+  ctx->trace = kind == PSG_TRACE_NONE ? nullptr : (long long*)device_buffer;
+  ctx->trace_words = kind == PSG_TRACE_NONE ? 0 : bytes / 8;
+  return PSG_OK;
+}
 
 extern "C" int psg_create(int device, psg_ctx** out) {
   PSG_REQUIRE(out != nullptr, PSG_ERR_INVALID, "psg_create: out is NULL");
@@ -32,6 +84,11 @@ extern "C" int psg_create(int device, psg_ctx** out) {
     return PSG_ERR_HIP;
   }
   psg_ctx* c = new psg_ctx();
+  for (const OptName& o : kOpts) {                          // environment overrides, read once per context
+    std::string env = "PSG_";
+    for (const char* q = o.name; *q; ++q) env += (char)toupper(*q);
+    if (const char* e = getenv(env.c_str())) c->opt.*(o.field) = parse_opt(o.name, e);
+  }
   c->device = device;
   c->num_cu = prop.multiProcessorCount;
   strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);

@@ -167,6 +167,21 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
 // (row n, piece c) looks at slot c ^ (n & 7).  Each wave owns a private 3-slot ring of
 // UD-K-block batches; the only synchronisation is the issuing wave's own counted vmcnt.
 // ---------------------------------------------------------------------------------------------
+// Workgroup barrier for LDS traffic only.  __syncthreads() would also drain the vector-memory counter whenever an
+// LDS-DMA is in flight (the DMA is a pending LDS write to the compiler): at every slab end the whole prefetch ring
+// would be waited for and the weight stream would stall.  Ordering of the partial tile needs lgkmcnt only.
+__device__ __forceinline__ void sgd_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void sgd_ds_write128(uint32_t lds_addr, gf32x4_t v) {
+  // v holds MFMA results: the matrix-core -> LDS-store wait states are not inserted for an asm consumer
+  asm volatile("s_nop 15\n\tds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ gf32x4_t sgd_ds_read128(uint32_t lds_addr) {
+  gf32x4_t v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr) : "memory");
+  return v;
+}
+
 template <int N_>
 __device__ __forceinline__ void sgd_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
@@ -190,7 +205,7 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
                                                                      float* __restrict__ part, int M, int N, int K,
                                                                      int xstride, long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // trace != nullptr (PSG_SKINNY_TRACE=<file>, debugging only): 8 cycle-counter stamps per wave
+  // trace != nullptr (psg_set_trace_buffer(PSG_TRACE_SKINNY_GEMM), debugging only): 8 cycle-counter stamps per wave
   long long* tr = trace ? trace + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 8
                         : nullptr;
   if (tr && (threadIdx.x & 63) == 0) tr[0] = __builtin_readcyclecounter();
@@ -208,7 +223,9 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
   const int nslab = gx < nslab_all ? (nslab_all - gx + G - 1) / G : 0;
   constexpr int OT_PITCH = ROWS + 4;                                // output tile pitch (floats)
   unsigned char* ring = smem + wid * RING_BYTES;                    // this wave's private ring
-  float* otile = reinterpret_cast<float*>(smem + WAVES * RING_BYTES);           // [32][OT_PITCH] partial tile
+  // [32][OT_PITCH] fp32 partial tile behind the rings, addressed by its LDS byte address (see finish_slab)
+  const uint32_t otile_lds =
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(smem + WAVES * RING_BYTES);
   unsigned char* xs = smem + WAVES * RING_BYTES + 32 * OT_PITCH * 4;            // shared x slice [M][xstride]
   const int total = nslab * nb;
 
@@ -307,22 +324,25 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
     }
     // partial tile of the workgroup: [M][ROWS] fp32 through LDS, then full 512-byte rows to HBM
     // (per-wave 64-byte segments cost ~8 % of the kernel: half-line writes at a 4*N-byte stride)
-    __syncthreads();                                                // previous slab's tile fully stored
+    // The tile's LDS traffic is written as inline asm: to hipcc a pending LDS-DMA is a pending LDS write that may
+    // alias ANY ds access it generates itself, so a compiler-visible ds_write / ds_read here waits vmcnt(0) first
+    // and the prefetched weight batches of the next slab drain at every slab end.
+    sgd_lds_barrier();                                              // previous slab's tile fully read
     {
-      float* tp = otile + wid * 16 + 4 * kq;
-      if (n < M) *reinterpret_cast<float4*>(tp + n * OT_PITCH) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
-      if (16 + n < M)
-        *reinterpret_cast<float4*>(tp + (16 + n) * OT_PITCH) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+      const uint32_t tp = otile_lds + (uint32_t)(wid * 16 + 4 * kq) * 4u;
+      if (n < M) sgd_ds_write128(tp + (uint32_t)(n * OT_PITCH) * 4u, acc0);
+      if (16 + n < M) sgd_ds_write128(tp + (uint32_t)((16 + n) * OT_PITCH) * 4u, acc1);
     }
-    __syncthreads();
+    sgd_lds_barrier();
     {
       const int nblk = (gx + ct * G) * ROWS;
       constexpr int C4 = ROWS / 4;                                  // float4 columns per row
       for (int e = tid; e < M * C4; e += WAVES * 64) {
         const int m = e / C4, c4 = e - m * C4;
-        if (nblk + c4 * 4 + 4 <= N)
-          *reinterpret_cast<float4*>(part + ((int64_t)by * M + m) * N + nblk + c4 * 4) =
-              *reinterpret_cast<const float4*>(otile + m * OT_PITCH + c4 * 4);
+        if (nblk + c4 * 4 + 4 <= N) {
+          const gf32x4_t v = sgd_ds_read128(otile_lds + (uint32_t)(m * OT_PITCH + c4 * 4) * 4u);
+          *reinterpret_cast<float4*>(part + ((int64_t)by * M + m) * N + nblk + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
       }
     }
     acc0 = (gf32x4_t){0, 0, 0, 0};
@@ -370,11 +390,7 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
 // split count: K range per workgroup ~1024 elements (x slice <= 64 KiB of LDS at M = 32), and
 // enough workgroups to give every CU several waves.
 static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("PSG_SKINNY_SPLITS");
-    forced = e ? atoi(e) : 0;
-  }
+  const int forced = ctx->opt.skinny_splits;
   const int KB = K >> 6;
   int S = forced > 0 ? forced : (K + 512) / 1024;
   if (S < 1) S = 1;
@@ -382,11 +398,7 @@ static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
   const int blocks_n = (N + SG_ROWS - 1) / SG_ROWS;
   if (forced <= 0)
     while (S < KB / 4 && (int64_t)blocks_n * S < 2 * ctx->num_cu) S *= 2;   // small N: split deeper
-  static int balance = -1;
-  if (balance < 0) {
-    const char* e = getenv("PSG_SKINNY_BALANCE");
-    balance = e ? atoi(e) : 1;
-  }
+  const int balance = ctx->opt.skinny_balance;
   if (balance && forced <= 0 && 2 * S <= 8 && 2 * S <= KB / 4) {
     // balance: one workgroup per CU works through ceil(units / CUs) rounds of (slab, slice) units; if the last
     // round is mostly empty (q/k/v projection: 96 slabs x 4 slices = 1.5 rounds), twice the slices fill it
@@ -424,35 +436,22 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
   const size_t lds = (size_t)M * xstride;
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm: x slice needs %zu B of LDS; use more splits",
               lds);
-  static size_t configured = 0;
-  if (lds > configured && lds > 64 * 1024) {
+  if (lds > ctx->skinny_lds_configured && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)skinny_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) {
       psg_set_error("psg_skinny_gemm: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
       return PSG_ERR_HIP;
     }
-    configured = lds;
+    ctx->skinny_lds_configured = lds;
   }
   // persistent over row slabs: ~3 workgroups per CU in total, every workgroup keeps its x slice in LDS
   const int nslab = (N + SG_ROWS - 1) / SG_ROWS;
-  static int wg_per_cu = -1;
-  if (wg_per_cu < 0) {
-    const char* e = getenv("PSG_SKINNY_WG_PER_CU");
-    wg_per_cu = e ? atoi(e) : 3;
-    if (wg_per_cu < 1) wg_per_cu = 1;
-  }
+  const int wg_per_cu = ctx->opt.skinny_wg_per_cu < 1 ? 1 : ctx->opt.skinny_wg_per_cu;
   int G = (wg_per_cu * ctx->num_cu + splits - 1) / splits;
   if (G > nslab) G = nslab;
   if (G < 1) G = 1;
-  static int dma_cfg = -1;                       // PSG_SKINNY_DMA="<waves>x<ud>" selects the LDS-DMA variant
-  if (dma_cfg < 0) {
-    const char* e = getenv("PSG_SKINNY_DMA");
-    int wv = 0, ud = 0;
-    int sl = 3;
-    // default: 8 waves x 1 K-block batches x 3-slot ring (sweep in tools/bench_kernels.py); "0" = register path
-    dma_cfg = e ? ((sscanf(e, "%dx%dx%d", &wv, &ud, &sl) >= 2) ? wv * 100 + ud * 10 + sl : 0) : 813;
-  }
+  const int dma_cfg = ctx->opt.skinny_dma;     // <waves><K blocks per batch><ring slots>; 0 = register variant
   if (dma_cfg > 0 && N >= 1024 && K >= 1024) {
     const int wv = dma_cfg / 100, ud = (dma_cfg / 10) % 10, sl = dma_cfg % 10;
     const int rows = wv * 16;
@@ -467,22 +466,11 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
     if (Gd < 1) Gd = 1;
     dim3 gridd(Gd, splits);
     hipStream_t st = (hipStream_t)stream;
-    long long* trace = nullptr;
-    const char* trace_path = getenv("PSG_SKINNY_TRACE");
-    const size_t trace_n = (size_t)Gd * splits * wv * 8;
-    if (trace_path && hipMalloc(&trace, trace_n * sizeof(long long)) == hipSuccess)
-      (void)hipMemset(trace, 0, trace_n * sizeof(long long));
-    // weights are read once by one CU: non-temporal (aux = 2) DMA loads; PSG_SKINNY_NT=0 = default policy
-    static int nt = -1;
-    if (nt < 0) {
-      const char* e = getenv("PSG_SKINNY_NT");
-      nt = e ? atoi(e) : 1;
-    }
-    static int xdma = -1;                                // PSG_SKINNY_XDMA=0: x slice by plain loads + ds_write
-    if (xdma < 0) {
-      const char* e = getenv("PSG_SKINNY_XDMA");
-      xdma = e ? atoi(e) : 1;
-    }
+    // per-wave stamps go to the caller's buffer (psg_set_trace_buffer) when it is large enough
+    const int64_t trace_n = (int64_t)Gd * splits * wv * 8;
+    long long* trace = (ctx->trace_kind == PSG_TRACE_SKINNY_GEMM && ctx->trace_words >= trace_n) ? ctx->trace : nullptr;
+    // weights are read once by one CU: non-temporal (aux = 2) DMA loads
+    const int nt = ctx->opt.skinny_nt, xdma = ctx->opt.skinny_xdma;
 #define SGD_L(WV, UD, SL, AUX, XD)                                                                                 \
   do {                                                                                                             \
     (void)hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<WV, UD, SL, AUX, XD>,                            \
@@ -504,21 +492,11 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
     else if (wv == 4 && ud == 2 && sl == 3) SGD(4, 2, 3);
     else if (wv == 4 && ud == 2 && sl == 4) SGD(4, 2, 4);
     else {
-      psg_set_error("psg_skinny_gemm: unknown PSG_SKINNY_DMA config %d", dma_cfg);
+      psg_set_error("psg_skinny_gemm: unknown skinny_dma option %d", dma_cfg);
       return PSG_ERR_INVALID;
     }
 #undef SGD
 #undef SGD_L
-    if (trace) {                                         // debugging aid: synchronous dump of the per-wave stamps
-      (void)hipStreamSynchronize(st);
-      std::vector<long long> hbuf(trace_n);
-      (void)hipMemcpy(hbuf.data(), trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost);
-      if (FILE* f = fopen(trace_path, "wb")) {
-        fwrite(hbuf.data(), sizeof(long long), trace_n, f);
-        fclose(f);
-      }
-      (void)hipFree(trace);
-    }
     PSG_CHECK_LAUNCH("psg_skinny_gemm(dma)");
     return PSG_OK;
   }

@@ -63,9 +63,9 @@ template <int NC>   // NC = key chunks of 128 (L <= 128 NC): unrolled so the pre
 __global__ void __launch_bounds__(256, 2)
 cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                        const uint64_t* __restrict__ bits, int words, const int32_t* __restrict__ pair_index, int N,
-                       int64_t R, int L, int nq, int heads, int policy, int* __restrict__ counters,
+                       int64_t R, int L, int nq, int heads, int policy,
                        uint16_t* __restrict__ out, long long* __restrict__ trace) {
-  // trace != nullptr (PSG_XATTN_TRACE=<file>, debugging only): 32 timestamps per wave
+  // trace != nullptr (psg_set_trace_buffer(PSG_TRACE_CROSS_ATTN), debugging only): 32 timestamps per wave
   long long* tr = trace ? trace + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 : nullptr;
   if (tr && (threadIdx.x & 63) == 0) tr[0] = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -473,8 +473,7 @@ int psg_cross_attn_simple_launch(const void* q, const void* k, const void* v, co
 
 extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
                                       int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads,
-                                      int empty_policy, int variant, void* out, int32_t* work_counters, int dtype,
-                                      void* stream) {
+                                      int empty_policy, int variant, void* out, int dtype, void* stream) {
   PSG_REQUIRE(ctx && q && k && v && bits && pair_index && out, PSG_ERR_INVALID, "psg_qformer_cross_attn: NULL argument");
   PSG_REQUIRE(N > 0 && P >= 0 && L > 0 && nq > 0 && heads > 0 && words * 64 >= L, PSG_ERR_INVALID,
               "psg_qformer_cross_attn: N=%d P=%d L=%d nq=%d heads=%d words=%d", N, P, L, nq, heads, words);
@@ -488,7 +487,6 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
   PSG_REQUIRE(variant == PSG_XATTN_MFMA, PSG_ERR_INVALID, "psg_qformer_cross_attn: variant=%d", variant);
   PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED,
               "psg_qformer_cross_attn: the MFMA variant computes in bf16; use PSG_XATTN_SIMPLE for fp32");
-  (void)work_counters;   // kept in the ABI: an earlier version distributed tiles through an atomic work queue
   const int Lpad = (L + 31) & ~31;
   const size_t lds = (size_t)Lpad * XA_KSTRIDE + (size_t)64 * (Lpad * 2 + 16) + 256 + (((size_t)N * words * 8 + 15) & ~(size_t)15);
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn: L=%d needs %zu B of LDS (> 160 KiB)", L,
@@ -513,30 +511,17 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
   const int64_t maxG = (ntile + 3) / 4;
   if (G > maxG) G = maxG;
   if (G < 1) G = 1;
-  long long* trace = nullptr;
-  const char* trace_path = getenv("PSG_XATTN_TRACE");
-  const size_t trace_n = (size_t)G * heads * 4 * 32;
-  if (trace_path && hipMalloc(&trace, trace_n * sizeof(long long)) == hipSuccess)
-    (void)hipMemset(trace, 0, trace_n * sizeof(long long));
+  const int64_t trace_n = G * heads * 4 * 32;
+  long long* trace = (ctx->trace_kind == PSG_TRACE_CROSS_ATTN && ctx->trace_words >= trace_n) ? ctx->trace : nullptr;
 #define XLAUNCH(NC_)                                                                                           \
   cross_attn_mfma_kernel<NC_><<<(unsigned)(G * heads), 256, lds, st>>>(                                        \
       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads, \
-      empty_policy, work_counters, (uint16_t*)out, trace)
+      empty_policy, (uint16_t*)out, trace)
   if (NC == 1) XLAUNCH(1);
   else if (NC == 2) XLAUNCH(2);
   else if (NC == 3) XLAUNCH(3);
   else XLAUNCH(4);
 #undef XLAUNCH
-  if (trace) {                                           // debugging aid: synchronous dump of the per-wave timestamps
-    (void)hipStreamSynchronize(st);
-    std::vector<long long> hbuf(trace_n);
-    (void)hipMemcpy(hbuf.data(), trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost);
-    if (FILE* f = fopen(trace_path, "wb")) {
-      fwrite(hbuf.data(), sizeof(long long), trace_n, f);
-      fclose(f);
-    }
-    (void)hipFree(trace);
-  }
   PSG_CHECK_LAUNCH("psg_qformer_cross_attn");
   return PSG_OK;
 }

@@ -173,7 +173,7 @@ def qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, out=None, empty_
     out = torch.empty_like(q) if out is None else out
     check(lib.psg_qformer_cross_attn(ctx, _p(q), _p(k), _p(v), _p(bits, torch.int64, "bits"), bits.shape[1],
                                      _p(pair_index, torch.int32, "pair_index"), int(N), P, L, nq, heads,
-                                     int(empty_policy), int(variant), _p(out, q.dtype), None, _dt(q), st),
+                                     int(empty_policy), int(variant), _p(out, q.dtype), _dt(q), st),
           "psg_qformer_cross_attn")
     return out
 

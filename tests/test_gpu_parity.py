@@ -670,3 +670,40 @@ def test_head_state_dict_matches_reference_and_loads_partial_checkpoint():
     assert float(head.binary_rel_cls_pred.weight[0, 0]) == 0.5
     with pytest.raises(Exception):
         head.llm_engine                                                            # LLM weights were never provided
+
+
+def test_context_options_and_caller_provided_trace_buffer():
+    """Kernel variants are options of the psg_ctx (no process-global state); per-wave stamps go to a buffer the
+    CALLER provides (the library never allocates or synchronises)."""
+    from openpsg_amd import _lib, ops
+    from openpsg_amd._lib import PsgHipError
+    dev = _dev()
+    assert _lib.get_option(0, "skinny_xdma") in (0, 1)
+    with pytest.raises(PsgHipError):
+        _lib.set_option(0, "no_such_option", 1)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(20, 4096, generator=g).to(dev).bfloat16()
+    w = (torch.randn(4096, 4096, generator=g) / 64).to(dev).bfloat16()
+    outs = {}
+    old = _lib.get_option(0, "skinny_xdma")
+    try:
+        for xd in (0, 1):                                           # x slice by plain loads vs by LDS-DMA: same bits
+            _lib.set_option(0, "skinny_xdma", xd)
+            outs[xd] = ops.skinny_gemm(x, w).t.clone()
+    finally:
+        _lib.set_option(0, "skinny_xdma", old)
+    assert torch.equal(outs[0], outs[1])
+    buf = torch.zeros(1 << 18, dtype=torch.int64, device=dev)
+    _lib.set_trace_buffer(0, _lib.PSG_TRACE_SKINNY_GEMM, buf)
+    try:
+        ops.skinny_gemm(x, w)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_trace_buffer(0, _lib.PSG_TRACE_NONE)
+    t = buf.cpu().view(-1, 8)
+    t = t[t[:, 0] > 0]
+    assert t.shape[0] >= 256 and (t[:, 5] >= t[:, 0]).all()        # every wave stamped start <= end
+    buf.zero_()
+    ops.skinny_gemm(x, w)                                           # tracing off again: nothing is written
+    torch.cuda.synchronize()
+    assert int(buf.abs().sum()) == 0

@@ -1,5 +1,5 @@
-"""Per-wave timeline of one weight-streaming GEMM launch (debugging aid; PSG_SKINNY_TRACE makes the library
-dump 8 cycle-counter stamps per wave).  python tools/skinny_trace.py"""
+"""Per-wave timeline of one weight-streaming GEMM launch (debugging aid; psg_set_trace_buffer makes the kernel
+write 8 cycle-counter stamps per wave into a caller-provided buffer).  python tools/skinny_trace.py"""
 import os
 import sys
 
@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from openpsg_amd import ops  # noqa: E402
+from openpsg_amd import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 M = 20
@@ -24,12 +24,12 @@ for name, N, K in [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4
     e_.record()
     torch.cuda.synchronize()
     kus = s_.elapsed_time(e_) * 1e3 / 16
-    path = "/tmp/skinny_trace.bin"
-    os.environ["PSG_SKINNY_TRACE"] = path
+    buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)       # caller-provided stamp buffer
+    _lib.set_trace_buffer(0, _lib.PSG_TRACE_SKINNY_GEMM, buf)
     ops.skinny_gemm(x, ws[1])
     torch.cuda.synchronize()
-    del os.environ["PSG_SKINNY_TRACE"]
-    t = np.fromfile(path, dtype=np.int64).reshape(-1, 8)
+    _lib.set_trace_buffer(0, _lib.PSG_TRACE_NONE)
+    t = buf.cpu().numpy().reshape(-1, 8)
     t = t[t[:, 0] > 0]
     life = t[:, 5] - t[:, 0]
     # calibrate ticks/us on the constant 100 MHz assumption check: longest wave ~ kernel time minus launch ramp

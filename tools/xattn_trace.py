@@ -1,5 +1,5 @@
-"""Per-wave timeline of one cross-attention launch (debugging aid; PSG_XATTN_TRACE makes the library dump
-32 cycle-counter stamps per wave).  python tools/xattn_trace.py [N]"""
+"""Per-wave timeline of one cross-attention launch (debugging aid; psg_set_trace_buffer makes the kernel write
+32 cycle-counter stamps per wave into a caller-provided buffer).  python tools/xattn_trace.py [N]"""
 import os
 import sys
 
@@ -24,11 +24,12 @@ out = torch.empty_like(q)
 for _ in range(3):
     ops.qformer_cross_attn(q, k, v, bits, pidx, N, 33, 12, out=out, variant=_lib.PSG_XATTN_MFMA)
 torch.cuda.synchronize()
-path = "/tmp/xattn_trace.bin"
-os.environ["PSG_XATTN_TRACE"] = path
+buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)           # caller-provided stamp buffer
+_lib.set_trace_buffer(0, _lib.PSG_TRACE_CROSS_ATTN, buf)
 ops.qformer_cross_attn(q, k, v, bits, pidx, N, 33, 12, out=out, variant=_lib.PSG_XATTN_MFMA)
 torch.cuda.synchronize()
-t = np.fromfile(path, dtype=np.int64).reshape(-1, 32)
+_lib.set_trace_buffer(0, _lib.PSG_TRACE_NONE)
+t = buf.cpu().numpy().reshape(-1, 32)
 t = t[t[:, 0] > 0]
 busy = t[t[:, 31] > 0]
 t0 = t[:, 0].min()
@@ -36,7 +37,6 @@ nun = busy[:, 31]
 last = np.array([busy[i, 2 + min(int(nun[i]), 28)] for i in range(len(busy))])
 life = last - busy[:, 0]
 s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-del os.environ["PSG_XATTN_TRACE"]
 s_.record()
 for _ in range(10):
     ops.qformer_cross_attn(q, k, v, bits, pidx, N, 33, 12, out=out, variant=_lib.PSG_XATTN_MFMA)
