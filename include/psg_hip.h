@@ -46,8 +46,9 @@ enum psg_dtype { PSG_F32 = 0, PSG_BF16 = 1 };
 /* cross-attention empty-pair-mask policy: additive finfo.min => uniform softmax */
 enum psg_empty_policy { PSG_EMPTY_UNIFORM = 0, PSG_EMPTY_UNMASKED = 1 };
 
-/* cross-attention implementation: MFMA tiles (default) or the scalar fp32 checker kernel */
-enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1 };
+/* cross-attention implementation: matrix-core kernels (default: the LDS-DMA kernel when its LDS image fits, else
+ * the first-generation kernel), the scalar fp32 checker kernel, or the first-generation matrix-core kernel */
+enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFMA_V1 = 2 };
 
 int psg_version(void);
 const char* psg_last_error(void);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpsg_hip.so")
 
 PSG_F32, PSG_BF16 = 0, 1
 PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED = 0, 1
-PSG_XATTN_MFMA, PSG_XATTN_SIMPLE = 0, 1
+PSG_XATTN_MFMA, PSG_XATTN_SIMPLE, PSG_XATTN_MFMA_V1 = 0, 1, 2
 PSG_TRACE_NONE, PSG_TRACE_SKINNY_GEMM, PSG_TRACE_CROSS_ATTN = 0, 1, 2
 
 

@@ -20,6 +20,8 @@ struct psg_opts {
   int skinny_xdma = 1;          // x slice staged by LDS-DMA as well
   int selfattn_scalar = 0;      // Q-Former self-attention: scalar checker kernel even in bf16
   int decode_attn_1wave = 0;    // decode attention: one wave per (pair, head) instead of a workgroup
+  int xattn_waves = 8;          // LDS-DMA cross-attention: waves per workgroup (8 or 10)
+  int xattn_dma = 1;            // cross-attention: LDS-DMA kernel (psg_xattn_dma.hip) when its LDS image fits
 };
 
 struct psg_ctx {

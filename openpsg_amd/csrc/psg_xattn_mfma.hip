@@ -467,6 +467,11 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
 #undef XA_STEP
 }
 
+int psg_cross_attn_dma_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
+                              int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy,
+                              void* out, hipStream_t st);
+extern "C" int psg_cross_attn_dma_lds_bytes(int N, int words, int L);
+
 int psg_cross_attn_simple_launch(const void* q, const void* k, const void* v, const uint64_t* bits, int words,
                                  const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy,
                                  void* out, int dtype, hipStream_t st);
@@ -484,9 +489,14 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
   if (variant == PSG_XATTN_SIMPLE)
     return psg_cross_attn_simple_launch(q, k, v, bits, words, pair_index, N, P, L, nq, heads, empty_policy, out, dtype,
                                         st);
-  PSG_REQUIRE(variant == PSG_XATTN_MFMA, PSG_ERR_INVALID, "psg_qformer_cross_attn: variant=%d", variant);
+  PSG_REQUIRE(variant == PSG_XATTN_MFMA || variant == PSG_XATTN_MFMA_V1, PSG_ERR_INVALID,
+              "psg_qformer_cross_attn: variant=%d", variant);
   PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED,
-              "psg_qformer_cross_attn: the MFMA variant computes in bf16; use PSG_XATTN_SIMPLE for fp32");
+              "psg_qformer_cross_attn: the MFMA variants compute in bf16; use PSG_XATTN_SIMPLE for fp32");
+  // second-generation kernel (full-line Q / context traffic through LDS-DMA) whenever its LDS image fits
+  if (variant == PSG_XATTN_MFMA && ctx->opt.xattn_dma && psg_cross_attn_dma_lds_bytes(N, words, L) <= 160 * 1024 &&
+      L <= 384)
+    return psg_cross_attn_dma_launch(ctx, q, k, v, bits, words, pair_index, N, P, L, nq, heads, empty_policy, out, st);
   const int Lpad = (L + 31) & ~31;
   const size_t lds = (size_t)Lpad * XA_KSTRIDE + (size_t)64 * (Lpad * 2 + 16) + 256 + (((size_t)N * words * 8 + 15) & ~(size_t)15);
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn: L=%d needs %zu B of LDS (> 160 KiB)", L,

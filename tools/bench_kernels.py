@@ -78,11 +78,14 @@ def xattn(N=50, L=256):
     dens = sum(bin(int(b) & (2**64 - 1)).count("1") for b in bits.cpu().flatten().tolist()) / (N * L)
     pidx = torch.arange(P, device=dev, dtype=torch.int32)
     out = torch.empty_like(q)
-    t, tmin = timeit(lambda: ops.qformer_cross_attn(q, k, v, bits, pidx, N, 33, 12, out=out,
-                                                    variant=_lib.PSG_XATTN_MFMA))
     flops = 4.0 * P * 33 * L * 768
-    print(f"cross_attn_mfma N={N} L={L} (object mask density {dens:.3f}): {t:.1f} us (min {tmin:.1f}) = "
-          f"{flops / t / 1e6:.1f} dense-equivalent TFLOP/s ({flops / t / 1e6 / 2500 * 100:.1f}% of 2.5 PF dense bf16)")
+    nbytes = 2.0 * P * 33 * 768 * 2                                 # Q in + context out
+    for name, var in (("LDS-DMA kernel", _lib.PSG_XATTN_MFMA), ("first-generation kernel", _lib.PSG_XATTN_MFMA_V1)):
+        t, tmin = timeit(lambda: ops.qformer_cross_attn(q, k, v, bits, pidx, N, 33, 12, out=out, variant=var))
+        print(f"cross_attn [{name}] N={N} L={L} (object mask density {dens:.3f}): {t:.1f} us (min {tmin:.1f}) = "
+              f"{flops / t / 1e6:.1f} dense-equivalent TFLOP/s ({flops / t / 1e6 / 2500 * 100:.1f}% of 2.5 PF dense "
+              f"bf16); Q + context traffic {nbytes / 1e6:.0f} MB -> {nbytes / t / 1e6:.2f} TB/s "
+              f"({nbytes / t / 1e6 / 8 * 100:.0f}% of 8 TB/s)")
 
 
 def mall():

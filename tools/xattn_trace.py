@@ -24,7 +24,7 @@ out = torch.empty_like(q)
 for _ in range(3):
     ops.qformer_cross_attn(q, k, v, bits, pidx, N, 33, 12, out=out, variant=_lib.PSG_XATTN_MFMA)
 torch.cuda.synchronize()
-buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)           # caller-provided stamp buffer
+buf = torch.zeros(1 << 21, dtype=torch.int64, device=dev)           # caller-provided stamp buffer
 _lib.set_trace_buffer(0, _lib.PSG_TRACE_CROSS_ATTN, buf)
 ops.qformer_cross_attn(q, k, v, bits, pidx, N, 33, 12, out=out, variant=_lib.PSG_XATTN_MFMA)
 torch.cuda.synchronize()
