@@ -160,10 +160,12 @@ int psg_rmsnorm(psg_ctx*, void* resid, const void* delta, int delta_splits, cons
  * position (= cache slot = cumsum(mask)-1, V4 left-padding removed by compaction); tok_pos < 0
  * marks a padding row (skipped).  q_out [rows][hidden]; caches [pairs][heads][ctx][head_dim].
  * rope_cos / rope_sin: fp32 tables [ctx][head_dim/2] = cos/sin(position * inv_freq), HF-LL:115-128.
- * qkv_splits > 0: qkv is fp32 split-K partials [qkv_splits][rows][3*hidden]. */
+ * qkv_splits > 0: qkv is fp32 split-K partials [qkv_splits][rows][3*hidden].
+ * rope_pos (may be NULL = tok_pos): rotary position per row when it differs from the cache slot - the TRAINING
+ * forward numbers positions over the padded sequence (plain HF forward, V4:327-330), the cache stays compact. */
 int psg_rope_kvwrite(psg_ctx*, const void* qkv, int qkv_splits, const int32_t* tok_pair, const int32_t* tok_pos,
-                     const float* rope_cos, const float* rope_sin, int64_t rows, int heads, int head_dim, int ctx,
-                     void* q_out, void* k_cache, void* v_cache, int dtype, void* stream);
+                     const int32_t* rope_pos, const float* rope_cos, const float* rope_sin, int64_t rows, int heads,
+                     int head_dim, int ctx, void* q_out, void* k_cache, void* v_cache, int dtype, void* stream);
 
 /* ---- K14: Llama attention over the KV cache (prefill and decode), HF-LL:191-214: query at
  * (pair, pos) attends cache slots [0, pos]; fp32 softmax; out [rows][hidden]. head_dim 128. */
@@ -234,6 +236,28 @@ int psg_masked_mean_pool_workspace(psg_ctx*, int C, int Hf, int Wf, int N, int64
 int psg_masked_mean_pool(psg_ctx*, const float* feat, int C, int Hf, int Wf, const int32_t* pan, int H0,
                          int W0, int img_h, int img_w, int pad_h, int pad_w, const int32_t* object_ids,
                          int N, float* out, int32_t* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- 8f rank 3: training branch of the head (forward arithmetic of the losses).
+ * psg_train_object_bitmasks: V4:371-399 prepare_train.  thing_masks uint8 [n_thing][H][W] (padded ground-truth
+ *   masks) resampled to the gh x gw patch grid by bilinear interpolation (align_corners=False) > 0.5; stuff objects:
+ *   nearest-resampled semantic map sem int32 [H][W] == category.  Object n is thing #thing_index[n] when
+ *   is_thing[n].  bits [N][words] uint64 as psg_object_bitmasks.
+ * psg_bce_with_logits: V4:463-482 (binary case): out[0] = weight * mean BCE-with-logits.
+ * psg_cross_entropy_rows: V4:337-341: loss[row] = logsumexp(logits[row]) - logits[row][label]; label < 0 (the
+ *   reference's ignore_index -100) gives 0; the caller averages over the rows that count. */
+int psg_train_object_bitmasks(psg_ctx*, const uint8_t* thing_masks, int n_thing, const int32_t* sem, int H, int W,
+                              const int32_t* is_thing, const int32_t* category, const int32_t* thing_index, int N,
+                              int gh, int gw, uint64_t* bits, int words, void* stream);
+int psg_bce_with_logits(psg_ctx*, const float* logit, const float* label, int n, float weight, float* out,
+                        void* stream);
+int psg_cross_entropy_rows(psg_ctx*, const void* logits, int64_t rows, int vocab, const int32_t* labels, float* loss,
+                           int dtype, void* stream);
+
+/* ---- 8f: bilinear relation scorer of the closed-set heads (relation_transformer_head_v2.py:204-209):
+ * pred[b][r][s][o] = sum_c sub[b][s][r*C + c] * obj[b][o][r*C + c], i.e. einsum('nrsc,nroc->nrso') on the
+ * outputs of the two Linear layers in their natural [B][N][R*C] layout.  Exact fp32 (f32 matrix cores). */
+int psg_bilinear_scores(psg_ctx*, const float* sub, const float* obj, int B, int N, int R, int C, float* pred,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,7 +48,10 @@ SIGNATURES = {
     "psg_topk": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "psg_gather_rows": [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _i, _i64, _vp],
     "psg_rmsnorm": [_vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _i, _vp],
-    "psg_rope_kvwrite": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "psg_rope_kvwrite": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "psg_train_object_bitmasks": [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
+    "psg_bce_with_logits": [_vp, _vp, _vp, _i, _f, _vp, _vp],
+    "psg_cross_entropy_rows": [_vp, _vp, _i64, _i, _vp, _vp, _i, _vp],
     "psg_llm_attn": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp],
     "psg_prefill_attn": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "psg_prefill_attn_rope": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
@@ -59,6 +62,7 @@ SIGNATURES = {
     "psg_reduce_partials": [_vp, _vp, _i, _i64, _vp, _i, _vp],
     "psg_masked_mean_pool_workspace": [_vp, _i, _i, _i, _i, C.POINTER(_i64)],
     "psg_masked_mean_pool": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i64, _vp],
+    "psg_bilinear_scores": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "psg_greedy_step": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
 }
 

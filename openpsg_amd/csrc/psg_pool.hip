@@ -162,3 +162,75 @@ extern "C" int psg_masked_mean_pool(psg_ctx* ctx, const float* feat, int C, int 
   PSG_CHECK_LAUNCH("psg_masked_mean_pool(final)");
   return PSG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// SURVEY 8f rank 4, second half: the bilinear relation scorer of the closed-set heads
+// (kings_sgg/models/relation_heads/relation_transformer_head_v2.py:204-209, same form in v1 / v3):
+//
+//   sub = sub_pred(obj_emb).reshape(B, N, R, C).permute(0, 2, 1, 3)       [B, R, N, C]
+//   obj = obj_pred(obj_emb).reshape(B, N, R, C).permute(0, 2, 1, 3)
+//   pred = einsum('nrsc,nroc->nrso', sub, obj)                            [B, R, N, N]
+//
+// i.e. R independent N x N x C products per image.  The kernel reads the Linear outputs in their natural
+// [B][N][R*C] layout (the permute is index arithmetic) and uses the exact-f32 matrix cores
+// (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain over c), one wave per 32 x 32 output tile, operands staged
+// through LDS in 32-column chunks so that global reads are 128-byte row pieces.
+// ---------------------------------------------------------------------------------------------
+typedef float bl_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(64) bilinear_scores_kernel(const float* __restrict__ sub,
+                                                             const float* __restrict__ obj, int B, int N, int R,
+                                                             int C, float* __restrict__ pred) {
+  __shared__ float s_a[32][33], s_b[32][33];
+  const int lane = threadIdx.x;
+  const int nt = (N + 31) >> 5;
+  int u = blockIdx.x;
+  const int ot = u % nt; u /= nt;
+  const int st = u % nt; u /= nt;
+  const int r = u % R;
+  const int b = u / R;
+  const int64_t ld = (int64_t)R * C;                                // row stride of the [B][N][R*C] inputs
+  const float* sp = sub + ((int64_t)b * N) * ld + (int64_t)r * C;
+  const float* op = obj + ((int64_t)b * N) * ld + (int64_t)r * C;
+  bl_f32x16 acc = {0};
+  const int i = lane & 31, kh = lane >> 5;
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    // stage [32 rows][32 c] of both operands: lane -> (row = lane>>3 + 8 j, 4 floats at c0 + 4 (lane&7))
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lane >> 3) + 8 * j, cc = 4 * (lane & 7);
+      const int s = st * 32 + row, o = ot * 32 + row;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + cc + e;
+        s_a[row][cc + e] = (s < N && c < C) ? sp[(int64_t)s * ld + c] : 0.f;
+        s_b[row][cc + e] = (o < N && c < C) ? op[(int64_t)o * ld + c] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 2)                                  // A[i][k + kh], B[k + kh][j = i]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_a[i][k + kh], s_b[i][k + kh], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  // D: col = lane & 31 (o), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (s)
+  float* pp = pred + (((int64_t)b * R + r) * N) * N;
+  const int o = ot * 32 + i;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int s = st * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+    if (s < N && o < N) pp[(int64_t)s * N + o] = acc[reg];
+  }
+}
+
+extern "C" int psg_bilinear_scores(psg_ctx* ctx, const float* sub, const float* obj, int B, int N, int R, int C,
+                                   float* pred, void* stream) {
+  PSG_REQUIRE(ctx && sub && obj && pred, PSG_ERR_INVALID, "psg_bilinear_scores: NULL argument");
+  PSG_REQUIRE(B > 0 && N > 0 && R > 0 && C > 0, PSG_ERR_INVALID, "psg_bilinear_scores: B=%d N=%d R=%d C=%d", B, N, R, C);
+  const int nt = (N + 31) / 32;
+  const int64_t units = (int64_t)B * R * nt * nt;
+  PSG_REQUIRE(units < (1ll << 31), PSG_ERR_UNSUPPORTED, "psg_bilinear_scores: %lld tiles", (long long)units);
+  bilinear_scores_kernel<<<(unsigned)units, 64, 0, (hipStream_t)stream>>>(sub, obj, B, N, R, C, pred);
+  PSG_CHECK_LAUNCH("psg_bilinear_scores");
+  return PSG_OK;
+}

@@ -365,7 +365,8 @@ extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int del
 // One wave per (row, head); head_dim = 128: lane l holds dims l and l + 64 (the rotate_half pair).
 template <typename T>
 __global__ void rope_kvwrite_kernel(const void* __restrict__ qkv, int qs, const int32_t* __restrict__ tok_pair,
-                                    const int32_t* __restrict__ tok_pos, const float* __restrict__ cos_tab,
+                                    const int32_t* __restrict__ tok_pos, const int32_t* __restrict__ rope_pos,
+                                    const float* __restrict__ cos_tab,
                                     const float* __restrict__ sin_tab, int64_t rows, int heads, int ctx,
                                     T* __restrict__ q_out, T* __restrict__ kc, T* __restrict__ vc) {
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -379,7 +380,10 @@ __global__ void rope_kvwrite_kernel(const void* __restrict__ qkv, int qs, const 
   const int64_t base = row * 3 * hidden + h * 128;
   // cos/sin(pos * inv_freq) from the caller's table: a precise cosf/sinf per wave cost ~9 us of
   // large-argument range reduction, more than the rest of the kernel
-  const float cs = cos_tab[pos * 64 + lane], sn = sin_tab[pos * 64 + lane];
+  // rope_pos (optional): rotary position when it differs from the cache slot (training forward: HF numbers the
+  // positions over the PADDED sequence, V4:327-330, while the cache holds the compacted tokens)
+  const int rp = rope_pos ? rope_pos[row] : pos;
+  const float cs = cos_tab[rp * 64 + lane], sn = sin_tab[rp * 64 + lane];
   const int64_t sl = rows * 3 * hidden;  // split-K slice stride
   const float q1 = ld1_in<T>(qkv, qs, sl, base + lane), q2 = ld1_in<T>(qkv, qs, sl, base + lane + 64);
   const float k1 = ld1_in<T>(qkv, qs, sl, base + hidden + lane), k2 = ld1_in<T>(qkv, qs, sl, base + hidden + lane + 64);
@@ -396,9 +400,9 @@ __global__ void rope_kvwrite_kernel(const void* __restrict__ qkv, int qs, const 
 }
 
 extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
-                                const int32_t* tok_pos, const float* rope_cos, const float* rope_sin,
-                                int64_t rows, int heads, int head_dim, int ctx, void* q_out, void* k_cache,
-                                void* v_cache, int dtype, void* stream) {
+                                const int32_t* tok_pos, const int32_t* rope_pos, const float* rope_cos,
+                                const float* rope_sin, int64_t rows, int heads, int head_dim, int ctx, void* q_out,
+                                void* k_cache, void* v_cache, int dtype, void* stream) {
   PSG_REQUIRE(ctx_ && qkv && tok_pair && tok_pos && rope_cos && rope_sin && q_out && k_cache && v_cache, PSG_ERR_INVALID,
               "psg_rope_kvwrite: NULL argument");
   PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_rope_kvwrite: head_dim=%d (kernel is built for 128)",
@@ -407,8 +411,8 @@ extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, int qkv_splits, 
   int64_t waves = rows * heads;
   PSG_DISPATCH_DTYPE(dtype, "psg_rope_kvwrite",
                      (rope_kvwrite_kernel<T><<<(unsigned)((waves + 3) / 4), 256, 0, (hipStream_t)stream>>>(
-                         qkv, qkv_splits, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, (T*)q_out, (T*)k_cache,
-                         (T*)v_cache)));
+                         qkv, qkv_splits, tok_pair, tok_pos, rope_pos, rope_cos, rope_sin, rows, heads, ctx, (T*)q_out,
+                         (T*)k_cache, (T*)v_cache)));
   PSG_CHECK_LAUNCH("psg_rope_kvwrite");
   return PSG_OK;
 }

@@ -10,7 +10,8 @@ names so a reference checkpoint loads with `strict=False`
 Differences that are deliberate and documented:
   * V4:355-356 raises UnboundLocalError in the default 'binary' mode as committed; this head
     implements the intended contract: rel_pred = LLM triples, rel_score = 1 each (SURVEY 0.3);
-  * only the eval path is built (training: SURVEY 8f "next");
+  * the training branch computes the reference's two losses (forward arithmetic, `forward_train`); gradients are
+    not implemented (SURVEY 8f rank 3);
   * all arithmetic runs in libpsg_hip.so / hipBLASLt on the GPU; there is no CPU path.
 """
 from __future__ import annotations
@@ -99,6 +100,9 @@ class RelationTransformerHeadV4(nn.Module):
             raise NotImplementedError("only rel_cls_type='binary' (the reference default, V4:31) is built; the "
                                       "'multiclass' branch of the reference is broken as committed (SURVEY 0.3)")
         self.qformer_instruction = qformer_instruction
+        self.sampled_qformer_batch_size = int(sampled_qformer_batch_size)
+        self.qformer_neg_over_pos = int(qformer_neg_over_pos)
+        self.rel_cls_loss_weight = float(rel_cls_loss_weight)
         self.llm_instruction = llm_instruction
         self.rel_cls_type = rel_cls_type
         self.llm_truncate_num = llm_truncate_num
@@ -157,7 +161,7 @@ class RelationTransformerHeadV4(nn.Module):
         self.llm_tokenizer.pad_token = self.llm_tokenizer.unk_token        # V4:105
         self.last = {}
         self._gather_cache = {}
-        self.train(False)                                                   # inference-only module
+        self.train(False)                                                   # eval by default, as init_detector leaves it
 
     # ---- weights ---------------------------------------------------------------------------------
     def load_weights(self, weights: dict):
@@ -259,7 +263,7 @@ class RelationTransformerHeadV4(nn.Module):
 
     def forward(self, inputs, is_generation=None):
         if self.training:
-            raise NotImplementedError("training branch (V4:114-133, 360-406) is out of scope of this build")
+            return self.forward_train(inputs)
         feat, meta, info, obj_ids, names = self._unpack(inputs)
         N = len(obj_ids)
         if N == 0:
@@ -271,6 +275,132 @@ class RelationTransformerHeadV4(nn.Module):
         self.last = dict(rq, **out)
         rel_pred, rel_score = self.parse(out["tokens_host"], out["selected_host"], N) if is_generation else ([], [])
         return dict(rel_pred=rel_pred, rel_score=rel_score)
+
+    # ---- training branch: forward arithmetic of the losses -------------------------------------
+    def qformer_sampler(self, relation_target):
+        """V4:437-461: positive pairs + up to qformer_neg_over_pos x as many negatives (torch's CPU generator)."""
+        t = relation_target.reshape(-1, self.num_relation_classes).sum(1)
+        pos = torch.nonzero(t, as_tuple=False)[:, 0]
+        neg = torch.nonzero(t == 0, as_tuple=False)[:, 0]
+        pn, nn_, bs, k = pos.shape[0], neg.shape[0], self.sampled_qformer_batch_size, self.qformer_neg_over_pos
+        if pn < bs:
+            sp = pos
+            sn = neg[torch.randint(0, nn_, (min(bs - pn, pn * k),))]
+        else:
+            sp = pos[torch.randint(0, pn, (bs // (k + 1),))]
+            sn = neg[torch.randint(0, nn_, (bs * k // (k + 1),))]
+        return torch.cat([sp, sn], dim=0)
+
+    @torch.no_grad()
+    def forward_train(self, inputs, sampled=None, selected=None):
+        """V4:114-133, 176-196, 218-228, 260-341, 360-406: the two losses of the training branch, computed by the
+        HIP path - `binary_rel_cls_loss` (BCE-with-logits x rel_cls_loss_weight over the sampled pairs) and
+        `rel_llm_loss` (teacher-forced next-token cross entropy over the label tokens, mean over the selected pairs).
+        This is the FORWARD arithmetic (loss values, e.g. for validation or for checking a checkpoint against the
+        reference); gradients are not implemented - the kernels have no backward.  `sampled` / `selected` replace
+        the random draws (V4:173 `qformer_sampler`, V4:222-228 `random.sample`)."""
+        import random
+        dev = self.device
+        feat = inputs['mask_features']
+        assert feat.shape[0] == 1, 'only support batch size 1 for now.'                     # V4:112
+        meta = inputs['img_metas'][0]
+        info = meta['masks_info']
+        N = len(info)
+        names = [object_categories[x['category']] for x in info]                            # V4:116-117
+        target = torch.zeros((N, N, self.num_relation_classes))
+        for ii, jj, rc in meta['gt_rels'][0]:                                               # V4:122-126
+            target[ii, jj, rc] = 1
+        binary = (target.sum(2) > 0).float().reshape(-1)
+        label_index = torch.nonzero(target, as_tuple=False)
+        eng = self.rq_engine
+        q = self.cfg.qformer
+        # prepare_train (V4:360-406)
+        patches = eng.patch_embed(feat.to(torch.float32))
+        kv = eng.cross_kv(patches)
+        gt_masks = inputs['gt_masks'][0]
+        tm = gt_masks.to_tensor(torch.uint8, dev) if hasattr(gt_masks, "to_tensor") else gt_masks.to(dev, torch.uint8)
+        sem = inputs['gt_semantic_seg'][0].to(dev).reshape(feat.shape[-2] * 4, feat.shape[-1] * 4).to(torch.int32)
+        is_thing = torch.tensor([1 if x['is_thing'] else 0 for x in info], dtype=torch.int32, device=dev)
+        cat = torch.tensor([x['category'] for x in info], dtype=torch.int32, device=dev)
+        tidx = torch.tensor(np.cumsum([1 if x['is_thing'] else 0 for x in info]) - 1, dtype=torch.int32, device=dev)
+        gh, gw = feat.shape[-2] // self.cfg.patch_size, feat.shape[-1] // self.cfg.patch_size
+        bits = ops.train_object_bitmasks(tm.contiguous(), sem.contiguous(), is_thing, cat, tidx.clamp(min=0), (gh, gw))
+        # sampled pairs through the Q-Former (V4:172-186); prompts are padded over ALL pairs (V4:146-150)
+        if sampled is None:
+            sampled = self.qformer_sampler(target)
+        sampled = torch.as_tensor(sampled, dtype=torch.int64)
+        uidx, U, rows = self._prompt_table("q", names)
+        T = max(len(rows[uidx[i] * U + uidx[j]]) for i in range(N) for j in range(N))
+        ids = np.zeros((len(sampled), T), dtype=np.int32)
+        msk = np.zeros((len(sampled), T), dtype=np.uint8)
+        for r, p in enumerate(sampled.tolist()):
+            tok = rows[uidx[p // N] * U + uidx[p % N]]
+            ids[r, :len(tok)] = tok
+            msk[r, :len(tok)] = 1
+        hidden, logit, _ = eng.forward_pairs(kv, bits, N, sampled.to(dev, torch.int32), torch.from_numpy(ids).to(dev),
+                                             torch.from_numpy(msk).to(dev))
+        bce = ops.bce_with_logits(logit, binary[sampled].to(dev), self.rel_cls_loss_weight)  # V4:186-196, 463-482
+        # LLM selection (V4:221-228)
+        if selected is None:
+            selected = [int(x[0]) * N + int(x[1]) for x in label_index.tolist()]
+            selected = random.sample(selected, min(len(selected), self.max_llm_forward_num))
+            if len(selected) == 0:
+                selected = random.sample(list(range(N * N)), min(N * N, self.max_llm_forward_num))
+        selected = [int(x) for x in selected]
+        K = len(selected)
+        # pair features of the selected pairs; pairs the sampler skipped stay zero (V4:177, 186)
+        nv = q.num_query
+        where = {int(p): r for r, p in enumerate(sampled.tolist())}
+        grow = torch.tensor([[where[si] * q.q_rows + 1 + t if si in where else -1 for t in range(nv)] for si in selected],
+                            dtype=torch.int32, device=dev).reshape(-1)
+        pf = torch.empty((K * nv, q.hidden), device=dev, dtype=self.act_dtype)
+        ops.gather_rows(hidden, grow, pf)
+        # prompts (left padded, V4:262) and labels ' {name} </s>' per predicate (right padded, V4:267-281)
+        tl = target.reshape(-1, self.num_relation_classes).tolist()
+        labels = ["".join(" {} </s>".format(self.relation_classes[r]) for r, e in enumerate(tl[si]) if e)
+                  for si in selected]
+        tok = self.llm_tokenizer
+        tok.padding_side = 'left'
+        enc_p = tok([self.llm_instruction.format(names[si // N], names[si % N]) for si in selected],
+                    return_tensors="pt", padding=True, return_attention_mask=True)
+        tok.padding_side = 'right'
+        enc_l = tok(labels, return_tensors="pt", padding=True, return_attention_mask=True)
+        p_ids, p_m = np.asarray(enc_p["input_ids"]), np.asarray(enc_p["attention_mask"]).astype(bool)
+        l_ids, l_m = np.asarray(enc_l["input_ids"]), np.asarray(enc_l["attention_mask"]).astype(bool)
+        Tp = p_ids.shape[1]
+        seqs, rope, want_rows, want_lab, counts = [], [], [], [], []
+        for i in range(K):
+            pv, lv = p_ids[i][p_m[i]], l_ids[i][l_m[i]]
+            seqs.append(np.concatenate([pv, lv]).astype(np.int32))
+            # positions in the reference's padded sequence: a plain HF forward numbers them 0..T-1 over the pads
+            ppos = nv + np.nonzero(p_m[i])[0]
+            lpos = nv + Tp + np.nonzero(l_m[i])[0]
+            rope.append(np.concatenate([np.arange(nv), ppos, lpos]).astype(np.int32))
+            for t in range(len(lv) - 1):                        # logits[-Tl:-1] against labels[1:] (V4:337-339)
+                want_rows.append((i, nv + len(pv) + t))
+                want_lab.append(int(lv[t + 1]))
+            counts.append(max(len(lv) - 1, 0))
+        Tc = max(len(s_) for s_ in seqs)
+        S = nv + Tc
+        cids = np.full((K, Tc), -1, dtype=np.int32)
+        rpos = np.full((K, S), -1, dtype=np.int32)
+        for i in range(K):
+            cids[i, :len(seqs[i])] = seqs[i]
+            rpos[i, :len(rope[i])] = rope[i]
+        llm = self.llm_engine
+        X = llm.build_inputs(pf, torch.from_numpy(cids).to(dev), None)
+        seq_len = torch.tensor([nv + len(s_) for s_ in seqs], dtype=torch.int32, device=dev)
+        flat = torch.tensor([i * S + r for i, r in want_rows], dtype=torch.int32, device=dev)
+        logits = llm.teacher_forcing_logits(X, seq_len, torch.from_numpy(rpos.reshape(-1)).to(dev), flat)
+        rl = ops.cross_entropy_rows(logits.contiguous(), torch.tensor(want_lab, dtype=torch.int32, device=dev))
+        per_pair, o = [], 0
+        for c in counts:                                         # CrossEntropyLoss(reduction='mean') per pair (V4:339)
+            per_pair.append(rl[o:o + c].mean() if c else rl.new_tensor(float("nan")))
+            o += c
+        llm_loss = torch.stack(per_pair).mean()                                              # V4:350-351
+        self.last = dict(sampled=sampled, selected=selected, bits=bits, bce_logit=logit, llm_logits=logits,
+                         llm_row_loss=rl, llm_pair_loss=per_pair)
+        return dict(binary_rel_cls_loss=bce, rel_llm_loss=llm_loss)
 
     def forward_batch(self, batch):
         """Throughput mode for several images (the reference handles one image per call, V4:112): the

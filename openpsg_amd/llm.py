@@ -78,11 +78,12 @@ class LlamaDecodeEngine:
         return F.linear(x, w)
 
     # ---- one pass over `rows` token rows -------------------------------------------------------
-    def _forward(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, decode=False, prefill_shape=None):
+    def _forward(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, decode=False, prefill_shape=None, rope_pos=None):
         """resid [rows, D] is updated in place (residual stream); returns final-norm hidden [rows, D].
         decode=True: every row is the newest token of its pair -> fused rotary + KV append + attention.
         prefill_shape=(pairs, rows_per_pair): the rows are a pair-major prompt batch -> matrix-core attention
-        (bf16, <= 64 rows per pair); otherwise the scalar cache-attention kernel."""
+        (bf16, <= 64 rows per pair); otherwise the scalar cache-attention kernel.
+        rope_pos int32 [rows]: rotary positions when they differ from the cache slots `tok_pos` (training)."""
         m = self.cfg.llm
         rows, D = resid.shape
         n = torch.empty_like(resid)
@@ -96,11 +97,12 @@ class LlamaDecodeEngine:
             qkv = self.linear(n, L["wqkv"])
             if decode:
                 ops.decode_attn(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, kc[l], vc[l], att)
-            elif mfma_prefill and isinstance(qkv, torch.Tensor):
+            elif mfma_prefill and isinstance(qkv, torch.Tensor) and rope_pos is None:
                 ops.prefill_attn_rope(qkv, tok_pos, self.rope, prefill_shape[0], prefill_shape[1], m.heads, m.head_dim,
                                       ctx_len, kc[l], vc[l], att)
             else:
-                ops.rope_kvwrite(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, q, kc[l], vc[l])
+                ops.rope_kvwrite(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, q, kc[l], vc[l],
+                                 rope_pos=rope_pos)
                 if mfma_prefill:
                     ops.prefill_attn(q, kc[l], vc[l], tok_pos, prefill_shape[0], prefill_shape[1], m.heads, m.head_dim,
                                      ctx_len, att)
@@ -129,6 +131,26 @@ class LlamaDecodeEngine:
         ops.gather_rows(self.embed, prompt_ids.reshape(-1).contiguous(), tok)
         X[:, nv:] = tok.view(K, Tp, m.hidden)
         return X
+
+    @torch.no_grad()
+    def teacher_forcing_logits(self, X, seq_len, rope_pos, rows):
+        """Training forward (V4:327-336: a plain `language_model(inputs_embeds, attention_mask)` call).
+        X [K, S, D] COMPACT sequences (pads removed), seq_len int32 [K], rope_pos int32 [K*S] = each row's position
+        in the reference's PADDED sequence (HF numbers positions 0..T-1 over pads in a plain forward), rows int32:
+        flat row indices whose logits are wanted.  Returns logits [len(rows), vocab] in the activation dtype."""
+        m = self.cfg.llm
+        K, S, D = X.shape
+        dev = self.device
+        t = torch.arange(S, device=dev, dtype=torch.int32)[None, :].expand(K, -1)
+        tok_pos = torch.where(t < seq_len[:, None].to(torch.int32), t, torch.full_like(t, -1)).reshape(-1).contiguous()
+        tok_pair = torch.arange(K, device=dev, dtype=torch.int32)[:, None].expand(-1, S).reshape(-1).contiguous()
+        kc = [torch.empty((K, m.heads, S, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
+        vc = [torch.empty((K, m.heads, S, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
+        resid = X.reshape(K * S, D).clone()
+        h = self._forward(resid, tok_pair, tok_pos, kc, vc, S, rope_pos=rope_pos.contiguous())
+        h_rows = torch.empty((rows.numel(), D), device=dev, dtype=self.dtype)
+        ops.gather_rows(h, rows.to(torch.int32).contiguous(), h_rows)
+        return F.linear(h_rows, self.lm_head)
 
     @torch.no_grad()
     def generate(self, X, prompt_len, max_new_tokens=None, suppress_eos=False, return_first_logits=False):

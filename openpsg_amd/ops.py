@@ -250,14 +250,15 @@ def rmsnorm(resid, delta, w, eps, out):
     return out
 
 
-def rope_kvwrite(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, q_out, k_cache, v_cache):
-    """rope = (cos, sin) fp32 tables [>= ctx_len, head_dim/2]."""
+def rope_kvwrite(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, q_out, k_cache, v_cache, rope_pos=None):
+    """rope = (cos, sin) fp32 tables [>= ctx_len, head_dim/2].  rope_pos int32 [rows]: rotary positions when they
+    differ from the cache slots (training forward)."""
     lib, ctx, st = _env(q_out)
     rows = q_out.shape[0]
     qp, qs = _in(qkv, q_out.dtype)
     assert rope[0].shape[0] >= ctx_len and rope[0].shape[1] == head_dim // 2
     check(lib.psg_rope_kvwrite(ctx, qp, qs, _p(tok_pair, torch.int32), _p(tok_pos, torch.int32),
-                               _p(rope[0], torch.float32), _p(rope[1], torch.float32), rows, heads, head_dim, ctx_len, _p(q_out),
+                               _p(rope_pos, torch.int32), _p(rope[0], torch.float32), _p(rope[1], torch.float32), rows, heads, head_dim, ctx_len, _p(q_out),
                                _p(k_cache, q_out.dtype), _p(v_cache, q_out.dtype), _dt(q_out), st), "psg_rope_kvwrite")
     return q_out
 
@@ -358,3 +359,49 @@ def masked_mean_pool(feat, pan, img_hw, pad_hw, object_ids):
                                    int(pad_hw[1]), _p(object_ids, torch.int32), N, _p(out), _p(ws), nbytes.value, st),
           "psg_masked_mean_pool")
     return out
+
+
+def bilinear_scores(sub, obj, num_relations):
+    """einsum('nrsc,nroc->nrso') of the closed-set heads (relation_transformer_head_v2.py:204-209).
+    sub / obj [B, N, R*C] fp32 (the Linear outputs before the reference's reshape + permute) -> [B, R, N, N] fp32."""
+    lib, ctx, st = _env(sub)
+    B, N, RC = sub.shape
+    assert obj.shape == sub.shape and RC % num_relations == 0
+    pred = torch.empty((B, num_relations, N, N), device=sub.device, dtype=torch.float32)
+    check(lib.psg_bilinear_scores(ctx, _p(sub, torch.float32, "sub"), _p(obj, torch.float32, "obj"), B, N,
+                                  num_relations, RC // num_relations, _p(pred), st), "psg_bilinear_scores")
+    return pred
+
+
+def train_object_bitmasks(thing_masks, sem, is_thing, category, thing_index, grid_hw):
+    """V4:371-399.  thing_masks uint8 [n_thing,H,W], sem int32 [H,W], per-object int32 vectors -> int64 bits [N, words]."""
+    lib, ctx, st = _env(sem)
+    H, W = sem.shape
+    N = is_thing.numel()
+    gh, gw = int(grid_hw[0]), int(grid_hw[1])
+    words = (gh * gw + 63) // 64
+    bits = torch.empty((N, words), device=sem.device, dtype=torch.int64)
+    n_thing = 0 if thing_masks is None else thing_masks.shape[0]
+    check(lib.psg_train_object_bitmasks(ctx, _p(thing_masks, torch.uint8, "thing_masks") if n_thing else None, n_thing,
+                                        _p(sem, torch.int32, "sem"), H, W, _p(is_thing, torch.int32),
+                                        _p(category, torch.int32), _p(thing_index, torch.int32), N, gh, gw, _p(bits),
+                                        words, st), "psg_train_object_bitmasks")
+    return bits
+
+
+def bce_with_logits(logit, label, weight=1.0):
+    lib, ctx, st = _env(logit)
+    out = torch.empty(1, device=logit.device, dtype=torch.float32)
+    check(lib.psg_bce_with_logits(ctx, _p(logit, torch.float32, "logit"), _p(label, torch.float32, "label"),
+                                  logit.numel(), float(weight), _p(out), st), "psg_bce_with_logits")
+    return out[0]
+
+
+def cross_entropy_rows(logits, labels):
+    """per-row -log softmax(logits)[label] in fp32; label < 0 -> 0 (ignored)."""
+    lib, ctx, st = _env(logits)
+    rows, vocab = logits.shape
+    loss = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    check(lib.psg_cross_entropy_rows(ctx, _p(logits), rows, vocab, _p(labels, torch.int32, "labels"), _p(loss),
+                                     _dt(logits), st), "psg_cross_entropy_rows")
+    return loss

@@ -56,3 +56,44 @@ def make_scene(pad_hw, num_objects, seed=0, ori_hw=None, img_hw=None, void_id=13
             scene["mask_features"] = torch.randn((1, channels, pad_h // 4, pad_w // 4), generator=g,
                                                  device=device, dtype=torch.float32)
     return scene
+
+
+class BitmapMasksLike:
+    """Stand-in for mmdet's BitmapMasks as the training branch uses it (V4:371: `.to_tensor(dtype, device)`)."""
+
+    def __init__(self, masks: np.ndarray):
+        self.masks = masks
+
+    def to_tensor(self, dtype, device):
+        return torch.from_numpy(self.masks).to(device=device, dtype=dtype)
+
+
+def make_train_scene(pad_hw, categories_, gt_rels, seed=0, channels=256, device="cpu"):
+    """Training-mode inputs of the head (V4:114-133, 360-406): padded ground-truth thing masks
+    [n_thing, pad_h, pad_w] (BitmapMasks), a padded semantic map [1, pad_h, pad_w] holding stuff labels (255 =
+    none), `masks_info` [{category, is_thing}] (things: category < 80, COCO panoptic order) and `gt_rels`
+    [(subject, object, predicate)].  Rectangles are painted in order."""
+    rng = np.random.default_rng(seed)
+    H, W = pad_hw
+    sem = np.full((H, W), 255, dtype=np.int64)
+    thing_masks, info = [], []
+    lo, hi = (96, 384) if max(pad_hw) >= 1024 else (48, 192)
+    for c in categories_:
+        y, x = int(rng.integers(0, H - lo)), int(rng.integers(0, W - lo))
+        h, w = int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))
+        is_thing = c < 80
+        if is_thing:
+            m = np.zeros((H, W), dtype=np.uint8)
+            m[y:y + h, x:x + w] = 1
+            thing_masks.append(m)
+        else:
+            sem[y:y + h, x:x + w] = c
+        info.append(dict(category=int(c), is_thing=bool(is_thing)))
+    feat = rng.standard_normal((1, channels, H // 4, W // 4), dtype=np.float32)
+    masks = np.stack(thing_masks) if thing_masks else np.zeros((0, H, W), dtype=np.uint8)
+    meta = dict(masks_info=info, gt_rels=[[tuple(int(v) for v in r) for r in gt_rels]],
+                img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3))
+    return dict(mask_features=torch.from_numpy(feat).to(device), img_metas=[meta],
+                gt_masks=[BitmapMasksLike(masks)],
+                gt_labels=[torch.tensor([c for c in categories_ if c < 80], dtype=torch.long)],
+                gt_semantic_seg=[torch.from_numpy(sem)[None].to(device)])

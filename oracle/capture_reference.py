@@ -313,6 +313,86 @@ def capture_state_dict_keys(mod):
     print(f"state_dict keys: {len(keys)} -> {path}")
 
 
+TRAIN_CASES = {
+    # name: (pad_hw, categories, gt_rels, scene seed, weight seed, torch/random seed)
+    "T1_train_512_n7": ((512, 512), [0, 17, 0, 100, 95, 56, 120],
+                        [(0, 1, 3), (0, 1, 20), (2, 3, 5), (4, 0, 0), (6, 5, 55)], 7, 31, 5),
+    "T2_train_768x1024_n9": ((768, 1024), [2, 2, 81, 60, 132, 0, 44, 99, 15],
+                             [(0, 1, 1), (5, 3, 16), (5, 3, 21), (8, 2, 14), (6, 3, 3), (1, 4, 47), (7, 0, 54)], 8, 32, 6),
+}
+
+
+def capture_train_case(mod, name):
+    """The reference's TRAINING branch (V4:114-133, 176-196, 218-228, 260-341, 360-406, 437-482) on the CPU with
+    dropout off (the head's `training` flag set, its sub-modules in eval): captures what the random draws were
+    (qformer_sampler's indices, the LLM selection) and every loss term, so that the build can be driven with
+    the same draws."""
+    import random
+    from openpsg_amd.synthetic import make_train_scene
+    pad_hw, cats, gt_rels, scene_seed, weight_seed, draw_seed = TRAIN_CASES[name]
+    llm = tiny_llm(256, 2, 512, 512)
+    cfg = case_config(llm)
+    w = make_weights_numpy(cfg, seed=weight_seed)
+    h = build_reference_head(mod, cfg, w)
+    h.sampled_qformer_batch_size, h.qformer_neg_over_pos, h.rel_cls_loss_weight = 32, 3, 50.0   # V4:29-32
+    h.training = True
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    inputs = make_train_scene(pad_hw, cats, gt_rels, seed=scene_seed)
+    cap = dict(llm=[])
+    real_sampler = h.qformer_sampler
+    h.qformer_sampler = lambda t: cap.setdefault("sampled", real_sampler(t).clone())
+    real_prepare = h.prepare_train
+
+    def prepare(*a, **k):
+        patches, pm = real_prepare(*a, **k)
+        cap["pair_masks"] = pm.detach().clone()
+        return patches, pm
+    h.prepare_train = prepare
+    h.binary_rel_cls_pred.register_forward_hook(lambda m_, i, o: cap.__setitem__("bce_logit", o.detach().clone()))
+    real_lm = h.language_model.forward
+
+    def lm_forward(**kw):
+        out = real_lm(**kw)
+        cap["llm"].append(dict(mask=kw["attention_mask"].detach().clone(), logits=out.logits.detach().clone()))
+        return out
+    h.language_model.forward = lm_forward
+    real_sample = random.sample
+
+    def sample(pop, k):
+        r = real_sample(pop, k)
+        cap.setdefault("selected", list(r))
+        return r
+    mod.random.sample = sample
+    torch.manual_seed(draw_seed)
+    random.seed(draw_seed)
+    try:
+        with torch.no_grad():
+            out = h(inputs)
+    finally:
+        mod.random.sample = real_sample
+    n = len(cats)
+    pm = cap["pair_masks"][:, 0, :]
+    diag = pm[torch.arange(n) * n + torch.arange(n)]
+    res = dict(
+        pad_hw=np.array(pad_hw), categories=np.array(cats, dtype=np.int64), gt_rels=np.array(gt_rels, dtype=np.int64),
+        scene_seed=np.int64(scene_seed), weight_seed=np.int64(weight_seed),
+        llm_hidden=np.int64(llm.hidden), llm_layers=np.int64(llm.layers), llm_inter=np.int64(llm.inter),
+        llm_vocab=np.int64(llm.vocab),
+        sampled=cap["sampled"].numpy().astype(np.int64), selected=np.array(cap["selected"], dtype=np.int64),
+        obj_masks_bits=pack_bits(diag), num_patches=np.int64(pm.shape[1]),
+        bce_logit=cap["bce_logit"].reshape(-1).numpy(),
+        binary_rel_cls_loss=np.float32(out["binary_rel_cls_loss"]), rel_llm_loss=np.float32(out["rel_llm_loss"]),
+        llm_seq_len=np.array([int(c["mask"].shape[1]) for c in cap["llm"]], dtype=np.int64),
+        llm_valid_len=np.array([int(c["mask"].sum()) for c in cap["llm"]], dtype=np.int64),
+        llm_last_logits_sample=np.stack([c["logits"][0, -2, ::7].numpy() for c in cap["llm"]]),
+    )
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **res)
+    print(f"{name}: N={n} sampled={len(res['sampled'])} selected={res['selected'].tolist()} "
+          f"bce={float(res['binary_rel_cls_loss']):.6f} llm={float(res['rel_llm_loss']):.6f} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -338,6 +418,9 @@ def main():
     capture_scene_case(mod, "G4_llm_wide_n6",
                        dict(pad_hw=(512, 512), num_objects=6, seed=4, void_id=133),
                        tiny_llm(1024, 3, 2752, 512), weight_seed=14, keep_pairs=[0, 35], suppress_eos=False)
+    # T1 / T2 = the training branch (losses) with the random draws recorded
+    for name in TRAIN_CASES:
+        capture_train_case(mod, name)
 
 
 if __name__ == "__main__":

@@ -350,3 +350,119 @@ def full_path(w, cfg, mask_features, img_meta, object_ids, pan, input_ids, text_
     rq["selected"] = sel
     rq["generations"] = gens
     return rq
+
+
+# --------------------------------------------------------------------------------------------
+# Training branch: V4:114-133 targets, V4:360-406 prepare_train, V4:437-461 sampler,
+# V4:186-196 + 463-482 existence loss, V4:260-285 + 293-341 teacher-forced LLM loss.  Forward arithmetic only
+# (the losses the reference back-propagates); pinned by tests/golden/T*.npz, captured from the real class with
+# dropout off and the random draws recorded.
+# --------------------------------------------------------------------------------------------
+def relation_targets(masks_info, gt_rels, num_relation_classes):
+    """V4:122-133 -> (relation_target [N,N,R], binary label [N*N], positive pair indices in nonzero() order)."""
+    n = len(masks_info)
+    target = torch.zeros(n, n, num_relation_classes)
+    for ii, jj, rc in gt_rels:
+        target[ii, jj, rc] = 1
+    binary = (target.sum(2) > 0).float().reshape(-1)
+    label_index = torch.nonzero(target, as_tuple=False)
+    return target, binary, label_index
+
+
+def train_object_masks(gt_thing_masks, gt_semantic_seg, masks_info, grid_hw):
+    """V4:371-399: thing masks bilinear (align_corners=False) to the patch grid, > 0.5; stuff masks = nearest
+    resampled semantic map == category.  gt_thing_masks [n_thing,H,W] float, gt_semantic_seg [1,H,W] -> bool [N, L]."""
+    tm = F.interpolate(gt_thing_masks[None].float(), size=tuple(grid_hw), mode="bilinear", align_corners=False)[0] > 0.5
+    ss = F.interpolate(gt_semantic_seg[None].float(), size=tuple(grid_hw), mode="nearest")[0]
+    out, ti = [], 0
+    for info in masks_info:
+        if info["is_thing"]:
+            out.append(tm[ti:ti + 1])
+            ti += 1
+        else:
+            out.append(ss == info["category"])
+    return torch.cat(out, dim=0).reshape(len(masks_info), -1)
+
+
+def qformer_sampler(relation_target, batch_size=32, neg_over_pos=3):
+    """V4:437-461 (draws from torch's global generator, like the reference)."""
+    t = relation_target.reshape(-1, relation_target.shape[-1]).sum(1)
+    pos = torch.nonzero(t, as_tuple=False)[:, 0]
+    neg = torch.nonzero(t == 0, as_tuple=False)[:, 0]
+    pn, nn_ = pos.shape[0], neg.shape[0]
+    if pn < batch_size:
+        sp = pos
+        sn = neg[torch.randint(0, nn_, (min(batch_size - pn, pn * neg_over_pos),))]
+    else:
+        sp = pos[torch.randint(0, pn, (batch_size // (neg_over_pos + 1),))]
+        sn = neg[torch.randint(0, nn_, (batch_size * neg_over_pos // (neg_over_pos + 1),))]
+    return torch.cat([sp, sn], dim=0)
+
+
+def existence_loss(logit, label, weight=50.0):
+    """V4:463-482, binary case: BCE-with-logits (mean) x rel_cls_loss_weight."""
+    return F.binary_cross_entropy_with_logits(logit, label) * weight
+
+
+def llm_label_text(relation_target_row, relation_classes):
+    """V4:269-276: ' {name} </s>' for every predicate that holds for the pair, in class order."""
+    return "".join(" {} </s>".format(relation_classes[r]) for r, e in enumerate(relation_target_row) if e)
+
+
+def llm_teacher_forcing_loss(w, cfg, pair_feature_si, prompt_ids, prompt_mask, label_ids, label_mask, n_layers=None):
+    """V4:294-301 + 327-341 for ONE selected pair.  The training forward is a plain `language_model(...)` call:
+    HF numbers the positions 0..T-1 over the PADDED sequence (unlike generate(), which uses cumsum(mask)-1), pads
+    are masked keys.  Loss = CE(logits[-Tl:-1], labels[1:]) over the non-pad label tokens (ignore_index -100)."""
+    m = cfg.llm
+    ids = torch.cat([prompt_ids, label_ids])
+    mask = torch.cat([prompt_mask, label_mask])
+    x, full_mask = llm_inputs(w, pair_feature_si, ids, mask)
+    T = x.shape[0]
+    L = m.layers if n_layers is None else n_layers
+    h = llama_forward(w, cfg, x, torch.arange(T), full_mask.bool(), [None] * L, L)
+    logits = F.linear(h, w["language_model.lm_head.weight"]).float()
+    Tl = label_ids.shape[0]
+    lg = logits[-Tl:]
+    labels = torch.where(label_mask.bool(), label_ids, torch.full_like(label_ids, -100))
+    return F.cross_entropy(lg[:-1], labels[1:], reduction="mean", ignore_index=-100), lg
+
+
+def train_forward(w, cfg, mask_features, masks_info, gt_rels, gt_thing_masks, gt_semantic_seg, input_ids, text_mask,
+                  llm_prompt, llm_label, relation_classes, sampled=None, selected=None, batch_size=32,
+                  neg_over_pos=3, loss_weight=50.0, max_llm_forward_num=4):
+    """The training branch end to end (dropout off).  input_ids / text_mask: BERT prompts of ALL N^2 pairs
+    (V4:146-152); llm_prompt / llm_label: callables(list of pair indices / list of label strings) -> (ids, mask),
+    left- / right-padded (V4:262-281).  `sampled` / `selected` replace the random draws (V4:173, 222-228)."""
+    import random
+    n = len(masks_info)
+    R = len(relation_classes)
+    target, binary, label_index = relation_targets(masks_info, gt_rels, R)
+    patches = patch_embed(w, mask_features, cfg.patch_size)[0]
+    fh, fw = mask_features.shape[-2:]
+    om = train_object_masks(gt_thing_masks, gt_semantic_seg, masks_info, (fh // cfg.patch_size, fw // cfg.patch_size))
+    pm = pair_masks(om)
+    if sampled is None:
+        sampled = qformer_sampler(target, batch_size, neg_over_pos)
+    sampled = torch.as_tensor(sampled, dtype=torch.long)
+    out_s = qformer_forward(w, cfg, input_ids[sampled], text_mask[sampled], patches, pm[sampled])
+    logit, _ = existence_head(w, out_s)
+    bce = existence_loss(logit, binary[sampled], loss_weight)
+    qout = torch.zeros(n * n, out_s.shape[1], out_s.shape[2])        # V4:177, 186: unsampled pairs stay zero
+    qout[sampled] = out_s
+    pair_feature = qout[:, 1:]
+    if selected is None:                                             # V4:221-228
+        selected = [int(x[0]) * n + int(x[1]) for x in label_index.tolist()]
+        selected = random.sample(selected, min(len(selected), max_llm_forward_num))
+        if len(selected) == 0:
+            selected = random.sample(list(range(n * n)), min(n * n, max_llm_forward_num))
+    tl = target.reshape(-1, R).tolist()
+    labels = [llm_label_text(tl[si], relation_classes) for si in selected]
+    pids, pmask = llm_prompt(selected)
+    lids, lmask = llm_label(labels)
+    losses, logits = [], []
+    for i, si in enumerate(selected):
+        ls, lg = llm_teacher_forcing_loss(w, cfg, pair_feature[si], pids[i], pmask[i], lids[i], lmask[i])
+        losses.append(ls)
+        logits.append(lg)
+    return dict(binary_rel_cls_loss=bce, rel_llm_loss=torch.stack(losses).mean(), sampled=sampled,
+                selected=list(selected), obj_masks=om, bce_logit=logit, llm_losses=losses, llm_logits=logits)

@@ -92,3 +92,37 @@ def rig_llm_chain(w, cfg, tok, chain=("over", ";", "in", "front", "of", "</s>"))
         w[p + "input_layernorm.weight"] = torch.ones(m.hidden)
         w[p + "post_attention_layernorm.weight"] = torch.ones(m.hidden)
     return ids
+
+
+# ---- training-branch cases (tests/golden/T*.npz) ------------------------------------------------------------------
+def load_train_case(name):
+    from openpsg_amd.synthetic import make_train_scene
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    llm = tiny_llm(int(g["llm_hidden"]), int(g["llm_layers"]), int(g["llm_inter"]), int(g["llm_vocab"]))
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=llm, max_object_num=30)
+    w = make_weights_numpy(cfg, seed=int(g["weight_seed"]))
+    inputs = make_train_scene(tuple(int(v) for v in g["pad_hw"]), [int(c) for c in g["categories"]],
+                              [tuple(int(v) for v in r) for r in g["gt_rels"]], seed=int(g["scene_seed"]))
+    return g, cfg, w, inputs
+
+
+def train_prompts(inputs):
+    """BERT prompts of all pairs and the Llama prompt / label tokenisers the training branch uses (V4:146-152,
+    260-281): prompts left-padded, labels right-padded."""
+    info = inputs["img_metas"][0]["masks_info"]
+    names = [object_categories[x["category"]] for x in info]
+    n = len(names)
+    enc = WordTokenizer("bert")([QFORMER_INSTRUCTION.format(names[i // n], names[i % n]) for i in range(n * n)])
+
+    def llm_prompt(selected):
+        tok = WordTokenizer("llama")
+        tok.padding_side = "left"
+        e = tok([LLM_INSTRUCTION.format(names[i // n], names[i % n]) for i in selected])
+        return e["input_ids"], e["attention_mask"]
+
+    def llm_label(labels):
+        tok = WordTokenizer("llama")
+        tok.padding_side = "right"
+        e = tok(labels)
+        return e["input_ids"], e["attention_mask"]
+    return enc["input_ids"], enc["attention_mask"], llm_prompt, llm_label

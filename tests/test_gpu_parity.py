@@ -713,3 +713,21 @@ def test_context_options_and_caller_provided_trace_buffer():
     ops.skinny_gemm(x, w)                                           # tracing off again: nothing is written
     torch.cuda.synchronize()
     assert int(buf.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B,N,R,C", [(1, 50, 56, 768), (2, 7, 3, 40), (1, 100, 56, 256), (1, 33, 5, 33)])
+def test_bilinear_scores_vs_einsum(B, N, R, C):
+    """The closed-set heads' scorer (relation_transformer_head_v2.py:204-209) against the reference's own
+    reshape + permute + einsum in fp64."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    sub = torch.randn(B, N, R * C, generator=g).to(dev)
+    obj = torch.randn(B, N, R * C, generator=g).to(dev)
+    got = ops.bilinear_scores(sub, obj, R)
+    s4 = sub.double().reshape(B, N, R, C).permute(0, 2, 1, 3)
+    o4 = obj.double().reshape(B, N, R, C).permute(0, 2, 1, 3)
+    want = torch.einsum('nrsc,nroc->nrso', s4, o4)
+    err = (got.double() - want).abs().max().item()
+    print(f"bilinear scorer B={B} N={N} R={R} C={C}: max err vs fp64 einsum {err:.2e}")
+    assert got.shape == (B, R, N, N) and err < 2e-4 * (C ** 0.5)

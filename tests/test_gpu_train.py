@@ -1,0 +1,112 @@
+"""Training branch of the head on the GPU (`-m gpu`): the two losses the reference
+back-propagates (V4:186-196 + 463-482 existence BCE x 50, V4:293-341 teacher-forced LLM cross entropy) against the
+goldens captured from the REAL class in training mode (tests/golden/T*.npz, random draws injected), and the
+training-only kernels against torch."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TRAIN = ["T1_train_512_n7", "T2_train_768x1024_n9"]
+
+
+def _head(cfg, w, dtype):
+    from openpsg_amd.head import RelationTransformerHeadV4
+    h = RelationTransformerHeadV4(dtype=dtype, device="cuda:0", qformer_vocab_size=cfg.qformer.vocab,
+                                  llm_config=cfg.llm, llm_feature_size=cfg.llm.hidden, tokenizers="word",
+                                  max_object_num=cfg.max_object_num)
+    h.load_weights(w)
+    return h
+
+
+def _to_dev(inputs):
+    out = dict(inputs)
+    out["mask_features"] = inputs["mask_features"].cuda()
+    out["gt_semantic_seg"] = [inputs["gt_semantic_seg"][0].cuda()]
+    return out
+
+
+@pytest.mark.parametrize("case", TRAIN)
+def test_training_losses_fp32_vs_reference(case):
+    g, cfg, w, inputs = H.load_train_case(case)
+    head = _head(cfg, w, "fp32")
+    head.train(True)
+    out = head.forward_train(_to_dev(inputs), sampled=g["sampled"], selected=g["selected"].tolist())
+    torch.cuda.synchronize()
+    assert set(out) == {"binary_rel_cls_loss", "rel_llm_loss"}                      # V4:345-351
+    L = int(g["num_patches"])
+    bits = head.last["bits"].cpu().numpy().view(np.uint64)
+    got = np.unpackbits(bits.view(np.uint8), axis=-1, bitorder="little")[:, :L].astype(bool)
+    assert np.array_equal(got, H.unpack_bits(g["obj_masks_bits"], L).numpy())       # prepare_train masks: exact
+    e_logit = np.abs(head.last["bce_logit"].cpu().numpy() - g["bce_logit"]).max()
+    e_bce = abs(float(out["binary_rel_cls_loss"]) - float(g["binary_rel_cls_loss"]))
+    e_llm = abs(float(out["rel_llm_loss"]) - float(g["rel_llm_loss"]))
+    print(f"{case}: |logit| {e_logit:.2e}, |bce loss| {e_bce:.2e} of {float(g['binary_rel_cls_loss']):.3f}, "
+          f"|llm loss| {e_llm:.2e} of {float(g['rel_llm_loss']):.3f}")
+    assert e_logit < 1e-3 and e_bce < 5e-3 and e_llm < 1e-3
+    # forward() in training mode is the same call; its random draws come from the same generators as the reference's
+    import random
+    seeds = {"T1_train_512_n7": 5, "T2_train_768x1024_n9": 6}
+    torch.manual_seed(seeds[case])
+    random.seed(seeds[case])
+    out2 = head(_to_dev(inputs))
+    assert head.last["sampled"].tolist() == g["sampled"].tolist() and head.last["selected"] == g["selected"].tolist()
+    assert abs(float(out2["rel_llm_loss"]) - float(out["rel_llm_loss"])) < 1e-6
+
+
+@pytest.mark.parametrize("case", TRAIN)
+def test_training_losses_bf16_bounded(case):
+    g, cfg, w, inputs = H.load_train_case(case)
+    head = _head(cfg, w, "bf16")
+    head.train(True)
+    out = head.forward_train(_to_dev(inputs), sampled=g["sampled"], selected=g["selected"].tolist())
+    r_bce = abs(float(out["binary_rel_cls_loss"]) / float(g["binary_rel_cls_loss"]) - 1)
+    r_llm = abs(float(out["rel_llm_loss"]) / float(g["rel_llm_loss"]) - 1)
+    print(f"{case} bf16: relative deviation of the losses: bce {r_bce:.3e}, llm {r_llm:.3e}")
+    assert r_bce < 0.05 and r_llm < 0.05
+
+
+@pytest.mark.parametrize("geo", [((512, 512), (8, 8)), ((768, 1024), (12, 16)), ((1024, 1344), (16, 21)),
+                                 ((800, 1088), (12, 17)), ((96, 160), (5, 7))])
+def test_train_object_bitmasks_vs_torch_interpolate(geo):
+    """V4:378-387 on random blob masks (not axis-aligned boxes) and non-integer resampling ratios: the kernel's
+    bilinear / nearest index arithmetic against torch's own interpolate on the same device and on the CPU."""
+    from openpsg_amd import ops
+    (Hh, Ww), (gh, gw) = geo
+    g = torch.Generator().manual_seed(Hh + gw)
+    n_thing = 5
+    tm = (torch.nn.functional.interpolate(torch.rand(1, n_thing, Hh // 16 + 1, Ww // 16 + 1, generator=g), size=(Hh, Ww),
+                                          mode="bilinear")[0] > 0.55).to(torch.uint8)
+    sem = torch.randint(80, 84, (Hh // 32 + 1, Ww // 32 + 1), generator=g).repeat_interleave(32, 0).repeat_interleave(32, 1)[:Hh, :Ww]
+    is_thing = torch.tensor([1, 0, 1, 1, 0, 1, 0, 1], dtype=torch.int32)
+    cat = torch.tensor([3, 80, 5, 7, 82, 9, 83, 11], dtype=torch.int32)
+    tidx = (torch.cumsum(is_thing, 0) - 1).clamp(min=0).to(torch.int32)
+    bits = ops.train_object_bitmasks(tm.cuda().contiguous(), sem.to(torch.int32).cuda().contiguous(), is_thing.cuda(),
+                                     cat.cuda(), tidx.cuda(), (gh, gw))
+    L = gh * gw
+    got = np.unpackbits(bits.cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[:, :L].astype(bool)
+    for dev in ("cpu", "cuda"):
+        t = torch.nn.functional.interpolate(tm[None].float().to(dev), size=(gh, gw), mode="bilinear",
+                                            align_corners=False)[0] > 0.5
+        s = torch.nn.functional.interpolate(sem[None, None].float().to(dev), size=(gh, gw), mode="nearest")[0, 0]
+        want = torch.stack([t[int(tidx[n])] if int(is_thing[n]) else (s == float(cat[n])) for n in range(8)]).reshape(8, -1)
+        assert np.array_equal(got, want.cpu().numpy()), f"{geo} vs torch on {dev}"
+
+
+def test_loss_kernels_vs_torch():
+    from openpsg_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(37, generator=g) * 4).cuda()
+    y = (torch.rand(37, generator=g) > 0.6).float().cuda()
+    want = torch.nn.functional.binary_cross_entropy_with_logits(x.double(), y.double()) * 50
+    assert abs(float(ops.bce_with_logits(x, y, 50.0)) - float(want)) < 1e-4
+    for dt in (torch.float32, torch.bfloat16):
+        lg = (torch.randn(11, 32000, generator=g) * 3).cuda().to(dt)
+        lab = torch.randint(0, 32000, (11,), generator=g).to(torch.int32).cuda()
+        lab[3] = -100
+        got = ops.cross_entropy_rows(lg, lab)
+        want = torch.nn.functional.cross_entropy(lg.double(), lab.long(), reduction="none", ignore_index=-100)
+        assert (got.double() - want).abs().max().item() < 2e-4 and float(got[3]) == 0.0
