@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-batched", action="store_true", help="skip the secondary 4-images-per-step measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="activation / weight dtype of the measured path (BASELINE config 5 names fp16)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the one-image strong-scaling figure")
     return ap.parse_args()
@@ -86,8 +88,9 @@ def setup_head(a, dev):
     from openpsg_amd.head import RelationTransformerHeadV4
     from openpsg_amd.weights import make_weights_device
     cfg = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=a.llm_layers), max_object_num=a.objects)
-    w = make_weights_device(cfg, 0, dev, llm_dtype=torch.bfloat16, with_llm=a.workload == "full")
-    head = RelationTransformerHeadV4(dtype="bf16", device=str(dev), tokenizers="word", max_object_num=a.objects,
+    tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    w = make_weights_device(cfg, 0, dev, llm_dtype=tdt, with_llm=a.workload == "full")
+    head = RelationTransformerHeadV4(dtype=a.dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
                                      llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True)
     head.load_weights(w)
     del w
@@ -102,8 +105,8 @@ def measure_decode_gemm(head, K):
     eng = head.llm_engine
     m = head.cfg.llm
     dev = eng.device
-    x_d = torch.randn(K, m.hidden, device=dev).bfloat16()
-    x_i = torch.randn(K, m.inter, device=dev).bfloat16()
+    x_d = torch.randn(K, m.hidden, device=dev).to(eng.dtype)
+    x_i = torch.randn(K, m.inter, device=dev).to(eng.dtype)
     mats = []
     for L in eng.layers:
         mats += [(x_d, L["wqkv"]), (x_d, L["wo"]), (x_d, L["wgu"]), (x_i, L["wdown"])]
@@ -384,7 +387,7 @@ def main():
         line = {
             "metric": METRIC, "value": round(images * pairs_per_image / elapsed, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": wl, "objects": N, "pairs_per_image": pairs_per_image, "images_per_step": ips,
                        "patches": (a.size // 64) ** 2, "llm_layers": a.llm_layers if a.workload == "full" else 0,
                        "parallelism": "single GPU" if world == 1 else f"pairs of every image sharded over {world} ranks"},

@@ -17,7 +17,8 @@
  *  - every launch takes the hipStream_t to enqueue on (void* stream; pass
  *    torch.cuda.current_stream().cuda_stream); no hidden synchronisation, so calls are HIP-graph
  *    capturable;
- *  - `dtype` selects the ACTIVATION storage type (PSG_F32 verification mode / PSG_BF16);
+ *  - `dtype` selects the ACTIVATION storage type (PSG_F32 verification mode / PSG_BF16 / PSG_F16: the matrix-core
+ *    kernels exist for both 16-bit types, with the matching MFMA opcodes);
  *    reductions, softmax and normalisation statistics are always fp32; LayerNorm/RMSNorm
  *    parameters, biases, embedding tables and the existence-head weights are fp32;
  *  - a psg_ctx is used by one host thread at a time; different contexts are independent.
@@ -41,7 +42,7 @@ enum psg_status {
   PSG_ERR_NO_DEVICE = -4
 };
 
-enum psg_dtype { PSG_F32 = 0, PSG_BF16 = 1 };
+enum psg_dtype { PSG_F32 = 0, PSG_BF16 = 1, PSG_F16 = 2 };
 
 /* cross-attention empty-pair-mask policy: additive finfo.min => uniform softmax */
 enum psg_empty_policy { PSG_EMPTY_UNIFORM = 0, PSG_EMPTY_UNMASKED = 1 };
@@ -204,7 +205,7 @@ int psg_silu_mul(psg_ctx*, const void* gate_up, int splits, int64_t rows, int in
 
 /* ---- K15: weight-streaming skinny GEMM of the batched decode step (HF-LL q/k/v/o/gate/up/down
  * projections and lm_head, all bias-free Linear layers): y[M][N] = x[M][K] . w[N][K]^T with
- * M <= 32 rows (the selected pairs), bf16 in / fp32 accumulate; every weight byte is read from
+ * M <= 32 rows (the selected pairs), 16-bit in (`dtype` = PSG_BF16 or PSG_F16) / fp32 accumulate; every weight byte is read from
  * HBM exactly once per call.  N % 16 == 0, K % 64 == 0.
  * K is split `splits` ways across workgroups (psg_skinny_gemm_plan chooses the count); the kernel
  * writes fp32 partials part[splits][M][N] and does NOT reduce them: the consumers below
@@ -213,7 +214,7 @@ int psg_silu_mul(psg_ctx*, const void* gate_up, int splits, int64_t rows, int in
  * psg_reduce_partials materialises y for any other consumer. */
 int psg_skinny_gemm_plan(psg_ctx*, int M, int N, int K, int* splits);
 int psg_skinny_gemm(psg_ctx*, const void* x, const void* w, float* part, int M, int N, int K,
-                    int splits, void* stream);
+                    int splits, int dtype, void* stream);
 int psg_reduce_partials(psg_ctx*, const float* part, int splits, int64_t n, void* y, int dtype,
                         void* stream);
 

@@ -7,7 +7,7 @@
 #include "psg_common.h"
 
 int psg_self_attn_mfma_launch(const void* qkv, const void* q_shared, const uint8_t* text_mask, int B, int T_, int nq, int heads,
-                              int query_rows_only, void* out, hipStream_t st);
+                              int query_rows_only, void* out, int dtype, hipStream_t st);
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) qformer_self_attn_kernel(const T* __restr
     float pr = expf(s - m);
     const float denom = wave_sum(pr);
     pr = pr / denom;
-    if (sizeof(T) == 2) pr = bf16_to_f32(f32_to_bf16(pr));
+    pr = Act<T>::rnd(pr);
     float o = 0.f;
 #pragma unroll
     for (int j = 0; j < 64; ++j)
@@ -86,8 +86,8 @@ extern "C" int psg_qformer_self_attn(psg_ctx* ctx, const void* qkv, const uint8_
   // bf16 activations with the standard geometry run on the matrix cores (psg_selfattn_mfma.hip);
   // option selfattn_scalar forces the scalar kernel (on-device cross-check)
   const int force_scalar = ctx->opt.selfattn_scalar;
-  if (dtype == PSG_BF16 && nq >= 32 && nq + T_ <= 64 && !force_scalar)
-    return psg_self_attn_mfma_launch(qkv, nullptr, text_mask, B, T_, nq, heads, query_rows_only, out, (hipStream_t)stream);
+  if ((dtype == PSG_BF16 || dtype == PSG_F16) && nq >= 32 && nq + T_ <= 64 && !force_scalar)
+    return psg_self_attn_mfma_launch(qkv, nullptr, text_mask, B, T_, nq, heads, query_rows_only, out, dtype, (hipStream_t)stream);
   int64_t units = (int64_t)B * heads;
   PSG_DISPATCH_DTYPE(dtype, "psg_qformer_self_attn",
                      (qformer_self_attn_kernel<T><<<(unsigned)((units + 3) / 4), 256, 0, (hipStream_t)stream>>>(
@@ -105,9 +105,9 @@ extern "C" int psg_qformer_self_attn_shared(psg_ctx* ctx, const void* qkv_query,
               "psg_qformer_self_attn_shared: NULL argument");
   PSG_REQUIRE(B > 0 && T_ >= 0 && nq > 0 && heads > 0 && nq + T_ <= 64, PSG_ERR_INVALID,
               "psg_qformer_self_attn_shared: B=%d T=%d nq=%d", B, T_, nq);
-  PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED, "psg_qformer_self_attn_shared: bf16 only");
+  PSG_REQUIRE(dtype == PSG_BF16 || dtype == PSG_F16, PSG_ERR_UNSUPPORTED, "psg_qformer_self_attn_shared: 16-bit only");
   return psg_self_attn_mfma_launch(qkv_text ? qkv_text : qkv_query, qkv_query, text_mask, B, T_, nq, heads, 0, out,
-                                   (hipStream_t)stream);
+                                   dtype, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) cross_attn_simple_kernel(const T* __restr
     const float inv = 1.0f / sum;
     for (int l = lane; l < L; l += 64) {
       float pv = sc[i * Lp + l] * inv;
-      if (sizeof(T) == 2) pv = bf16_to_f32(f32_to_bf16(pv));
+      pv = Act<T>::rnd(pv);
       sc[i * Lp + l] = pv;
     }
   }
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const void* __restrict
   const float v1 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane);
   const float v2 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane + 64);
   const float cs = cos_tab[pos * 64 + lane], sn = sin_tab[pos * 64 + lane];   // cos/sin(pos * inv_freq), HF-LL:115-128
-  auto rnd = [](float f) { return sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(f)) : f; };
+  auto rnd = [](float f) { return Act<T>::rnd(f); };
   const float qa = rnd(q1 * cs - q2 * sn), qb = rnd(q2 * cs + q1 * sn);      // stored dtype, as the unfused path
   const float ka = rnd(k1 * cs - k2 * sn), kb = rnd(k2 * cs + k1 * sn);
   const int64_t cbase = ((int64_t)tok_pair[row] * heads + h) * ctx * 128;
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
   if (pos < 0) return;                                        // whole workgroup (uniform)
   const int64_t cbase = ((int64_t)tok_pair[row] * heads + h) * ctx * 128;
   const float scale = 0.08838834764831845f;                   // 1/sqrt(128)
-  auto rnd = [](float f) { return sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(f)) : f; };
+  auto rnd = [](float f) { return Act<T>::rnd(f); };
   float vn1 = 0.f, vn2 = 0.f;
   if (wid == 0) {                                             // new token: rotary, cache append, own score
     const int64_t base = (int64_t)row * 3 * hidden + h * 128;

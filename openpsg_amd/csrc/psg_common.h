@@ -69,10 +69,17 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest 
   return (uint16_t)(u >> 16);
 }
 
+struct f16_t {
+  uint16_t v;
+};
+__device__ __forceinline__ float f16_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }  // RNE
+
 template <typename T>
 struct Act;
 template <>
 struct Act<float> {
+  static __device__ __forceinline__ float rnd(float v) { return v; }
   static __device__ __forceinline__ float ld(const float* p, int64_t i) { return p[i]; }
   static __device__ __forceinline__ void st(float* p, int64_t i, float v) { p[i] = v; }
   static __device__ __forceinline__ void ld4(const float* p, int64_t i, float (&o)[4]) {
@@ -85,6 +92,7 @@ struct Act<float> {
 };
 template <>
 struct Act<bf16_t> {
+  static __device__ __forceinline__ float rnd(float v) { return bf16_to_f32(f32_to_bf16(v)); }  // as stored
   static __device__ __forceinline__ float ld(const bf16_t* p, int64_t i) { return bf16_to_f32(p[i].v); }
   static __device__ __forceinline__ void st(bf16_t* p, int64_t i, float v) { p[i].v = f32_to_bf16(v); }
   static __device__ __forceinline__ void ld4(const bf16_t* p, int64_t i, float (&o)[4]) {
@@ -97,6 +105,77 @@ struct Act<bf16_t> {
     *reinterpret_cast<ushort4*>(p + i) = t;
   }
 };
+
+template <>
+struct Act<f16_t> {
+  static __device__ __forceinline__ float rnd(float v) { return f16_to_f32(f32_to_f16(v)); }
+  static __device__ __forceinline__ float ld(const f16_t* p, int64_t i) { return f16_to_f32(p[i].v); }
+  static __device__ __forceinline__ void st(f16_t* p, int64_t i, float v) { p[i].v = f32_to_f16(v); }
+  static __device__ __forceinline__ void ld4(const f16_t* p, int64_t i, float (&o)[4]) {
+    ushort4 t = *reinterpret_cast<const ushort4*>(p + i);
+    o[0] = f16_to_f32(t.x); o[1] = f16_to_f32(t.y); o[2] = f16_to_f32(t.z); o[3] = f16_to_f32(t.w);
+  }
+  static __device__ __forceinline__ void st4(f16_t* p, int64_t i, const float (&v)[4]) {
+    ushort4 t;
+    t.x = f32_to_f16(v[0]); t.y = f32_to_f16(v[1]); t.z = f32_to_f16(v[2]); t.w = f32_to_f16(v[3]);
+    *reinterpret_cast<ushort4*>(p + i) = t;
+  }
+};
+
+// ---- 16-bit element traits of the matrix-core kernels (bf16 / fp16: same kernels, other MFMA opcodes) ------------
+typedef float psg_f32x16 __attribute__((ext_vector_type(16)));
+typedef float psg_f32x4 __attribute__((ext_vector_type(4)));
+typedef float psg_f32x2 __attribute__((ext_vector_type(2)));
+struct EBf16 {
+  using act = bf16_t;
+  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  static constexpr uint32_t ONE = 0x3f80u, NEG_2_15 = 0xc700u;                  // 1.0, -32768.0
+  static __device__ __forceinline__ psg_f32x16 mfma32(v8 a, v8 b, psg_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ psg_f32x4 mfma16(v8 a, v8 b, psg_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {         // v_cvt_pk_bf16_f32 (RNE)
+    psg_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, v2));
+  }
+  static __device__ __forceinline__ float to_f32(uint16_t x) { return bf16_to_f32(x); }
+  static __device__ __forceinline__ uint16_t from_f32(float x) { return f32_to_bf16(x); }
+};
+struct EF16 {
+  using act = f16_t;
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  static constexpr uint32_t ONE = 0x3c00u, NEG_2_15 = 0xf800u;
+  static __device__ __forceinline__ psg_f32x16 mfma32(v8 a, v8 b, psg_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ psg_f32x4 mfma16(v8 a, v8 b, psg_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {         // RNE, not v_cvt_pkrtz
+    psg_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, v2));
+  }
+  static __device__ __forceinline__ float to_f32(uint16_t x) { return f16_to_f32(x); }
+  static __device__ __forceinline__ uint16_t from_f32(float x) { return f32_to_f16(x); }
+};
+// run BODY with `E` = the element traits of a 16-bit activation dtype
+#define PSG_DISPATCH_E16(dtype, NAME, ...)                                            \
+  do {                                                                                \
+    if ((dtype) == PSG_BF16) {                                                        \
+      using E = EBf16;                                                                \
+      __VA_ARGS__;                                                                    \
+    } else if ((dtype) == PSG_F16) {                                                  \
+      using E = EF16;                                                                 \
+      __VA_ARGS__;                                                                    \
+    } else {                                                                          \
+      psg_set_error("%s: needs a 16-bit activation dtype, got %d", NAME, (int)(dtype)); \
+      return PSG_ERR_UNSUPPORTED;                                                     \
+    }                                                                                 \
+  } while (0)
 
 // ---- wave (64 lanes) reductions ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -131,10 +210,8 @@ __device__ __forceinline__ void ld4_in(const void* __restrict__ in, int S, int64
     for (int s = 1; s < PSG_MAX_SPLITS; ++s)
       if (s < S) { a.x += t[s].x; a.y += t[s].y; a.z += t[s].z; a.w += t[s].w; }
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
-    if (sizeof(T) == 2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = bf16_to_f32(f32_to_bf16(o[e]));
-    }
+    for (int e = 0; e < 4; ++e) o[e] = Act<T>::rnd(o[e]);
   } else {
     Act<T>::ld4(reinterpret_cast<const T*>(in), i, o);
   }
@@ -151,7 +228,7 @@ __device__ __forceinline__ float ld1_in(const void* __restrict__ in, int S, int6
 #pragma unroll
     for (int s = 1; s < PSG_MAX_SPLITS; ++s)
       if (s < S) a += t[s];
-    return sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(a)) : a;
+    return Act<T>::rnd(a);
   }
   return Act<T>::ld(reinterpret_cast<const T*>(in), i);
 }
@@ -164,6 +241,9 @@ __device__ __forceinline__ float ld1_in(const void* __restrict__ in, int S, int6
       __VA_ARGS__;                                                 \
     } else if ((dtype) == PSG_BF16) {                              \
       using T = bf16_t;                                            \
+      __VA_ARGS__;                                                 \
+    } else if ((dtype) == PSG_F16) {                               \
+      using T = f16_t;                                             \
       __VA_ARGS__;                                                 \
     } else {                                                       \
       psg_set_error("%s: unknown dtype %d", NAME, (int)(dtype));   \

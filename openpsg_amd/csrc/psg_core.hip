@@ -285,6 +285,9 @@ extern "C" int psg_gather_rows(psg_ctx* ctx, const void* src, int src_dtype, con
   else if (src_dtype == PSG_F32 && dst_dtype == PSG_BF16) GR(float, bf16_t);
   else if (src_dtype == PSG_BF16 && dst_dtype == PSG_BF16) GR(bf16_t, bf16_t);
   else if (src_dtype == PSG_BF16 && dst_dtype == PSG_F32) GR(bf16_t, float);
+  else if (src_dtype == PSG_F32 && dst_dtype == PSG_F16) GR(float, f16_t);
+  else if (src_dtype == PSG_F16 && dst_dtype == PSG_F16) GR(f16_t, f16_t);
+  else if (src_dtype == PSG_F16 && dst_dtype == PSG_F32) GR(f16_t, float);
   else {
     psg_set_error("psg_gather_rows: bad dtypes %d -> %d", src_dtype, dst_dtype);
     return PSG_ERR_INVALID;

@@ -41,17 +41,19 @@
 
 #include "psg_common.h"
 
-typedef __bf16 gbf16x8_t __attribute__((ext_vector_type(8)));
 typedef float gf32x4_t __attribute__((ext_vector_type(4)));
 
 #define SG_ROWS 64      // weight rows per workgroup (4 waves x 16)
 #define SG_U 4          // K blocks per register set
 
+template <typename E>
 struct SgFrag {
-  gbf16x8_t v[SG_U][2];
+  typename E::v8 v[SG_U][2];
 };
 
-__device__ __forceinline__ void sg_load(SgFrag& f, const uint16_t* __restrict__ wp, int kb) {
+template <typename E>
+__device__ __forceinline__ void sg_load(SgFrag<E>& f, const uint16_t* __restrict__ wp, int kb) {
+  using gbf16x8_t = typename E::v8;
 #pragma unroll
   for (int u = 0; u < SG_U; ++u) {
     f.v[u][0] = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)(kb + u) * 64));
@@ -59,8 +61,10 @@ __device__ __forceinline__ void sg_load(SgFrag& f, const uint16_t* __restrict__ 
   }
 }
 
-__device__ __forceinline__ void sg_mma(const SgFrag& f, const unsigned char* xs0, const unsigned char* xs1, int kbl,
+template <typename E>
+__device__ __forceinline__ void sg_mma(const SgFrag<E>& f, const unsigned char* xs0, const unsigned char* xs1, int kbl,
                                        gf32x4_t& acc0, gf32x4_t& acc1) {
+  using gbf16x8_t = typename E::v8;
 #pragma unroll
   for (int u = 0; u < SG_U; ++u) {
     const int o = (kbl + u) * 128;
@@ -68,16 +72,18 @@ __device__ __forceinline__ void sg_mma(const SgFrag& f, const unsigned char* xs0
     const gbf16x8_t b01 = *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16);
     const gbf16x8_t b10 = *reinterpret_cast<const gbf16x8_t*>(xs1 + o);
     const gbf16x8_t b11 = *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[u][0], b00, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[u][0], b10, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[u][1], b01, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[u][1], b11, acc1, 0, 0, 0);
+    acc0 = E::mfma16(f.v[u][0], b00, acc0);
+    acc1 = E::mfma16(f.v[u][0], b10, acc1);
+    acc0 = E::mfma16(f.v[u][1], b01, acc0);
+    acc1 = E::mfma16(f.v[u][1], b11, acc1);
   }
 }
 
+template <typename E>
 __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __restrict__ x,
                                                           const uint16_t* __restrict__ w, float* __restrict__ part,
                                                           int M, int N, int K, int xstride) {
+  using gbf16x8_t = typename E::v8;
   extern __shared__ __attribute__((aligned(16))) unsigned char xs[];   // [M][xstride bytes]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
@@ -95,9 +101,9 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
     return w + (int64_t)r * K + (int64_t)kbA * 64 + kq * 16;
   };
   const int total = nslab * nb;                                     // flattened (slab, batch) stream
-  SgFrag fa, fb;
+  SgFrag<E> fa, fb;
   int lt = 0, lb = 0;                                               // load cursor
-  auto load_next = [&](SgFrag& f) {
+  auto load_next = [&](SgFrag<E>& f) {
     sg_load(f, wrow(lt), lb * SG_U);
     if (++lb == nb) { lb = 0; ++lt; }
   };
@@ -123,12 +129,10 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
       const gbf16x8_t a0 = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)kb * 64));
       const gbf16x8_t a1 = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)kb * 64 + 8));
       const int o = kb * 128;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, *reinterpret_cast<const gbf16x8_t*>(xs0 + o), acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, *reinterpret_cast<const gbf16x8_t*>(xs1 + o), acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16), acc0, 0, 0,
-                                                     0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16), acc1, 0, 0,
-                                                     0);
+      acc0 = E::mfma16(a0, *reinterpret_cast<const gbf16x8_t*>(xs0 + o), acc0);
+      acc1 = E::mfma16(a0, *reinterpret_cast<const gbf16x8_t*>(xs1 + o), acc1);
+      acc0 = E::mfma16(a1, *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16), acc0);
+      acc1 = E::mfma16(a1, *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16), acc1);
     }
     // D[row = weight row 4 kq + r][col = x row lane&15] -> part[by][m][n0 + 4 kq + r], 16-byte stores
     const int n0 = (gx + ct * G) * SG_ROWS + wid * 16;
@@ -199,11 +203,12 @@ struct SgdWait<UD, 0> {
   static __device__ __forceinline__ void go(int) { sgd_wait<0>(); }
 };
 
-template <int WAVES, int UD, int SGD_SLOTS, int AUX, int XDMA>
+template <typename E, int WAVES, int UD, int SGD_SLOTS, int AUX, int XDMA>
 __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint16_t* __restrict__ x,
                                                                      const uint16_t* __restrict__ w,
                                                                      float* __restrict__ part, int M, int N, int K,
                                                                      int xstride, long long* __restrict__ trace) {
+  using gbf16x8_t = typename E::v8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // trace != nullptr (psg_set_trace_buffer(PSG_TRACE_SKINNY_GEMM), debugging only): 8 cycle-counter stamps per wave
   long long* tr = trace ? trace + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 8
@@ -315,12 +320,10 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
       const gbf16x8_t a0 = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)kb * 64));
       const gbf16x8_t a1 = __builtin_nontemporal_load(reinterpret_cast<const gbf16x8_t*>(wp + (int64_t)kb * 64 + 8));
       const int o = kb * 128;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, *reinterpret_cast<const gbf16x8_t*>(xs0 + o), acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, *reinterpret_cast<const gbf16x8_t*>(xs1 + o), acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16), acc0, 0, 0,
-                                                     0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16), acc1, 0, 0,
-                                                     0);
+      acc0 = E::mfma16(a0, *reinterpret_cast<const gbf16x8_t*>(xs0 + o), acc0);
+      acc1 = E::mfma16(a0, *reinterpret_cast<const gbf16x8_t*>(xs1 + o), acc1);
+      acc0 = E::mfma16(a1, *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16), acc0);
+      acc1 = E::mfma16(a1, *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16), acc1);
     }
     // partial tile of the workgroup: [M][ROWS] fp32 through LDS, then full 512-byte rows to HBM
     // (per-wave 64-byte segments cost ~8 % of the kernel: half-line writes at a 4*N-byte stride)
@@ -368,10 +371,10 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
       const gbf16x8_t b01 = *reinterpret_cast<const gbf16x8_t*>(xs0 + o + 16);
       const gbf16x8_t b10 = *reinterpret_cast<const gbf16x8_t*>(xs1 + o);
       const gbf16x8_t b11 = *reinterpret_cast<const gbf16x8_t*>(xs1 + o + 16);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b00, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b10, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b01, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b11, acc1, 0, 0, 0);
+      acc0 = E::mfma16(a0, b00, acc0);
+      acc1 = E::mfma16(a0, b10, acc1);
+      acc0 = E::mfma16(a1, b01, acc0);
+      acc1 = E::mfma16(a1, b11, acc1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // ring reads retired before the slot is refilled
     if (++cb == nb) {
@@ -423,8 +426,9 @@ extern "C" int psg_skinny_gemm_plan(psg_ctx* ctx, int M, int N, int K, int* spli
   return PSG_OK;
 }
 
-extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K,
-                               int splits, void* stream) {
+template <typename E>
+static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K, int splits,
+                     void* stream) {
   PSG_REQUIRE(ctx && x && w && part, PSG_ERR_INVALID, "psg_skinny_gemm: NULL argument");
   PSG_REQUIRE(M >= 1 && M <= 32, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm: M=%d (1..32 rows)", M);
   PSG_REQUIRE(N > 0 && N % 16 == 0 && K >= 64 && K % 64 == 0, PSG_ERR_UNSUPPORTED,
@@ -437,7 +441,7 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm: x slice needs %zu B of LDS; use more splits",
               lds);
   if (lds > ctx->skinny_lds_configured && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)skinny_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)skinny_gemm_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) {
       psg_set_error("psg_skinny_gemm: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
@@ -473,9 +477,9 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
     const int nt = ctx->opt.skinny_nt, xdma = ctx->opt.skinny_xdma;
 #define SGD_L(WV, UD, SL, AUX, XD)                                                                                 \
   do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<WV, UD, SL, AUX, XD>,                            \
+    (void)hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<E, WV, UD, SL, AUX, XD>,                            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
-    skinny_gemm_dma_kernel<WV, UD, SL, AUX, XD><<<gridd, WV * 64, ldsd, st>>>(                                     \
+    skinny_gemm_dma_kernel<E, WV, UD, SL, AUX, XD><<<gridd, WV * 64, ldsd, st>>>(                                     \
         (const uint16_t*)x, (const uint16_t*)w, part, M, N, K, xstride, trace);                                    \
   } while (0)
 #define SGD(WV, UD, SL)                                                                                            \
@@ -501,10 +505,15 @@ extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float
     return PSG_OK;
   }
   dim3 grid(G, splits);
-  skinny_gemm_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const uint16_t*)x, (const uint16_t*)w, part, M, N, K,
+  skinny_gemm_kernel<E><<<grid, 256, lds, (hipStream_t)stream>>>((const uint16_t*)x, (const uint16_t*)w, part, M, N, K,
                                                               xstride);
   PSG_CHECK_LAUNCH("psg_skinny_gemm");
   return PSG_OK;
+}
+
+extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K,
+                               int splits, int dtype, void* stream) {
+  PSG_DISPATCH_E16(dtype, "psg_skinny_gemm", return sg_launch<E>(ctx, x, w, part, M, N, K, splits, stream));
 }
 
 // y[i] = sum_s part[s][i] in split order, converted to the activation dtype (tests, generic consumers)

@@ -16,16 +16,12 @@
 // for prompts longer than 64 rows.
 #include "psg_common.h"
 
-typedef __bf16 pa_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 pa_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float pa_f32x16 __attribute__((ext_vector_type(16)));
 typedef float pa_f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pa_pack(float lo, float hi) {
-  pa_f32x2 f = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, pa_bf16x2));
-}
 
+
+template <typename E>
 __global__ void __launch_bounds__(64)
 prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
                          const uint16_t* __restrict__ vc, const int32_t* __restrict__ tok_pos, int pairs, int S,
@@ -60,17 +56,17 @@ prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restr
   }
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    pa_bf16x8 qf[2], kf[2];
+    typename E::v8 qf[2], kf[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      qf[t] = *reinterpret_cast<const pa_bf16x8*>(qp[t] + s * 16);
-      kf[t] = *reinterpret_cast<const pa_bf16x8*>(kp[t] + s * 16);
+      qf[t] = *reinterpret_cast<const typename E::v8*>(qp[t] + s * 16);
+      kf[t] = *reinterpret_cast<const typename E::v8*>(kp[t] + s * 16);
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
-        sc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt], qf[qt], sc[kt][qt], 0, 0, 0);
+        sc[kt][qt] = E::mfma32(kf[kt], qf[qt], sc[kt][qt]);
   }
   // mask: key j is visible to query row i iff j <= i and key j is a real token (HF-LL causal + padding mask)
   const float C = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
@@ -117,13 +113,13 @@ prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restr
     for (int g = 0; g < 2; ++g) {
       union {
         uint32_t u[4];
-        pa_bf16x8 v;
+        typename E::v8 v;
       } pf[2], vf[4];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          pf[qt].u[e] = pa_pack(sc[kt][qt][8 * g + 2 * e], sc[kt][qt][8 * g + 2 * e + 1]);
+          pf[qt].u[e] = E::pack(sc[kt][qt][8 * g + 2 * e], sc[kt][qt][8 * g + 2 * e + 1]);
       uint16_t ve[4][8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
@@ -140,7 +136,7 @@ prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restr
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          o[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt].v, pf[qt].v, o[dt][qt], 0, 0, 0);
+          o[dt][qt] = E::mfma32(vf[dt].v, pf[qt].v, o[dt][qt]);
     }
   // lane (q = lane&31, hi) holds O[q][32 dt + (r&3) + 8 (r>>2) + 4 hi] for its row of each query tile;
   // padding rows get zeros (defined output, never consumed: same as the scalar kernel)
@@ -154,8 +150,8 @@ prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restr
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           uint2 wv;
-          wv.x = pa_pack(o[dt][qt][4 * rr] * inv_l[qt], o[dt][qt][4 * rr + 1] * inv_l[qt]);
-          wv.y = pa_pack(o[dt][qt][4 * rr + 2] * inv_l[qt], o[dt][qt][4 * rr + 3] * inv_l[qt]);
+          wv.x = E::pack(o[dt][qt][4 * rr] * inv_l[qt], o[dt][qt][4 * rr + 1] * inv_l[qt]);
+          wv.y = E::pack(o[dt][qt][4 * rr + 2] * inv_l[qt], o[dt][qt][4 * rr + 3] * inv_l[qt]);
           *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rr) = wv;
         }
     }
@@ -166,6 +162,7 @@ prefill_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restr
 // reads the fused projection output qkv [rows][3*hidden] directly, rotates Q and K in registers (a lane's
 // fragment for k-step s holds dims 16 s + 8 hi .. +7; the partner dims + 64 are k-step s + 4 of the same lane),
 // writes the rotated K and the V rows to the cache for the decode steps, and never materialises Q.
+template <typename E>
 __global__ void __launch_bounds__(64)
 prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ tok_pos,
                               const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, int pairs, int S,
@@ -208,7 +205,7 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
     union F8 {
       uint4 u;
       uint16_t h[8];
-      pa_bf16x8 v;
+      typename E::v8 v;
     };
     F8 qa[2], qb[2], ka[2], kb[2];
 #pragma unroll
@@ -229,13 +226,13 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
       F8 qa2, qb2, ka2, kb2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float q1 = bf16_to_f32(qa[t].h[e]), q2 = bf16_to_f32(qb[t].h[e]);
-        const float k1 = bf16_to_f32(ka[t].h[e]), k2 = bf16_to_f32(kb[t].h[e]);
+        const float q1 = E::to_f32(qa[t].h[e]), q2 = E::to_f32(qb[t].h[e]);
+        const float k1 = E::to_f32(ka[t].h[e]), k2 = E::to_f32(kb[t].h[e]);
         // q*cos + rotate_half(q)*sin, rotate_half(x) = cat(-x2, x1)
-        qa2.h[e] = f32_to_bf16(q1 * cs[e] - q2 * sn[e]);
-        qb2.h[e] = f32_to_bf16(q2 * cs[e] + q1 * sn[e]);
-        ka2.h[e] = f32_to_bf16(k1 * cs[e] - k2 * sn[e]);
-        kb2.h[e] = f32_to_bf16(k2 * cs[e] + k1 * sn[e]);
+        qa2.h[e] = E::from_f32(q1 * cs[e] - q2 * sn[e]);
+        qb2.h[e] = E::from_f32(q2 * cs[e] + q1 * sn[e]);
+        ka2.h[e] = E::from_f32(k1 * cs[e] - k2 * sn[e]);
+        kb2.h[e] = E::from_f32(k2 * cs[e] + k1 * sn[e]);
       }
       qa[t] = qa2;
       qb[t] = qb2;
@@ -251,8 +248,8 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        sc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[kt].v, qa[qt].v, sc[kt][qt], 0, 0, 0);
-        sc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[kt].v, qb[qt].v, sc[kt][qt], 0, 0, 0);
+        sc[kt][qt] = E::mfma32(ka[kt].v, qa[qt].v, sc[kt][qt]);
+        sc[kt][qt] = E::mfma32(kb[kt].v, qb[qt].v, sc[kt][qt]);
       }
   }
   const float C = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
@@ -298,13 +295,13 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
     for (int g = 0; g < 2; ++g) {
       union {
         uint32_t u[4];
-        pa_bf16x8 v;
+        typename E::v8 v;
       } pf[2], vf[4];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          pf[qt].u[e] = pa_pack(sc[kt][qt][8 * g + 2 * e], sc[kt][qt][8 * g + 2 * e + 1]);
+          pf[qt].u[e] = E::pack(sc[kt][qt][8 * g + 2 * e], sc[kt][qt][8 * g + 2 * e + 1]);
       uint16_t ve[4][8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
@@ -321,7 +318,7 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          o[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt].v, pf[qt].v, o[dt][qt], 0, 0, 0);
+          o[dt][qt] = E::mfma32(vf[dt].v, pf[qt].v, o[dt][qt]);
     }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -333,8 +330,8 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           uint2 wv;
-          wv.x = pa_pack(o[dt][qt][4 * r4] * inv_l[qt], o[dt][qt][4 * r4 + 1] * inv_l[qt]);
-          wv.y = pa_pack(o[dt][qt][4 * r4 + 2] * inv_l[qt], o[dt][qt][4 * r4 + 3] * inv_l[qt]);
+          wv.x = E::pack(o[dt][qt][4 * r4] * inv_l[qt], o[dt][qt][4 * r4 + 1] * inv_l[qt]);
+          wv.y = E::pack(o[dt][qt][4 * r4 + 2] * inv_l[qt], o[dt][qt][4 * r4 + 3] * inv_l[qt]);
           *reinterpret_cast<uint2*>(op + 32 * dt + 8 * r4) = wv;
         }
     }
@@ -346,16 +343,17 @@ extern "C" int psg_prefill_attn_rope(psg_ctx* ctx_, const void* qkv, const int32
                                      int ctx, void* k_cache, void* v_cache, void* out, int dtype, void* stream) {
   PSG_REQUIRE(ctx_ && qkv && tok_pos && rope_cos && rope_sin && k_cache && v_cache && out, PSG_ERR_INVALID,
               "psg_prefill_attn_rope: NULL argument");
-  PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED, "psg_prefill_attn_rope: bf16 only");
+  PSG_REQUIRE(dtype == PSG_BF16 || dtype == PSG_F16, PSG_ERR_UNSUPPORTED, "psg_prefill_attn_rope: 16-bit activations only");
   PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_prefill_attn_rope: head_dim=%d (kernel is built for 128)",
               head_dim);
   PSG_REQUIRE(rows_per_pair >= 1 && rows_per_pair <= 64 && rows_per_pair <= ctx, PSG_ERR_UNSUPPORTED,
               "psg_prefill_attn_rope: rows_per_pair=%d (1..64, <= ctx=%d)", rows_per_pair, ctx);
   PSG_REQUIRE(pairs >= 0 && heads > 0, PSG_ERR_INVALID, "psg_prefill_attn_rope: pairs=%d heads=%d", pairs, heads);
   if (pairs == 0) return PSG_OK;
-  prefill_attn_rope_mfma_kernel<<<(unsigned)(pairs * heads), 64, 0, (hipStream_t)stream>>>(
-      (const uint16_t*)qkv, tok_pos, rope_cos, rope_sin, pairs, rows_per_pair, heads, ctx, (uint16_t*)k_cache,
-      (uint16_t*)v_cache, (uint16_t*)out);
+  PSG_DISPATCH_E16(dtype, "psg_prefill_attn_rope",
+                   (prefill_attn_rope_mfma_kernel<E><<<(unsigned)(pairs * heads), 64, 0, (hipStream_t)stream>>>(
+                       (const uint16_t*)qkv, tok_pos, rope_cos, rope_sin, pairs, rows_per_pair, heads, ctx,
+                       (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out)));
   PSG_CHECK_LAUNCH("psg_prefill_attn_rope");
   return PSG_OK;
 }
@@ -364,15 +362,17 @@ extern "C" int psg_prefill_attn(psg_ctx* ctx_, const void* q, const void* k_cach
                                 const int32_t* tok_pos, int pairs, int rows_per_pair, int heads, int head_dim, int ctx,
                                 void* out, int dtype, void* stream) {
   PSG_REQUIRE(ctx_ && q && k_cache && v_cache && tok_pos && out, PSG_ERR_INVALID, "psg_prefill_attn: NULL argument");
-  PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED, "psg_prefill_attn: bf16 only (fp32: psg_llm_attn)");
+  PSG_REQUIRE(dtype == PSG_BF16 || dtype == PSG_F16, PSG_ERR_UNSUPPORTED,
+              "psg_prefill_attn: 16-bit activations only (fp32: psg_llm_attn)");
   PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_prefill_attn: head_dim=%d (kernel is built for 128)", head_dim);
   PSG_REQUIRE(rows_per_pair >= 1 && rows_per_pair <= 64 && rows_per_pair <= ctx, PSG_ERR_UNSUPPORTED,
               "psg_prefill_attn: rows_per_pair=%d (1..64, <= ctx=%d); longer prompts: psg_llm_attn", rows_per_pair, ctx);
   PSG_REQUIRE(pairs >= 0 && heads > 0, PSG_ERR_INVALID, "psg_prefill_attn: pairs=%d heads=%d", pairs, heads);
   if (pairs == 0) return PSG_OK;
-  prefill_attn_mfma_kernel<<<(unsigned)(pairs * heads), 64, 0, (hipStream_t)stream>>>(
-      (const uint16_t*)q, (const uint16_t*)k_cache, (const uint16_t*)v_cache, tok_pos, pairs, rows_per_pair, heads, ctx,
-      (uint16_t*)out);
+  PSG_DISPATCH_E16(dtype, "psg_prefill_attn",
+                   (prefill_attn_mfma_kernel<E><<<(unsigned)(pairs * heads), 64, 0, (hipStream_t)stream>>>(
+                       (const uint16_t*)q, (const uint16_t*)k_cache, (const uint16_t*)v_cache, tok_pos, pairs,
+                       rows_per_pair, heads, ctx, (uint16_t*)out)));
   PSG_CHECK_LAUNCH("psg_prefill_attn");
   return PSG_OK;
 }

@@ -188,6 +188,7 @@ __device__ __forceinline__ float gelu_erf_as(float v) {
   return 0.5f * v * (1.0f + copysignf(erf_abs, x));
 }
 
+template <typename E>
 __global__ void __launch_bounds__(256) bias_gelu_rows_bf16_kernel(const uint16_t* __restrict__ x,
                                                                    const float* __restrict__ bias, int64_t rows,
                                                                    int cols, uint16_t* __restrict__ out) {
@@ -204,9 +205,9 @@ __global__ void __launch_bounds__(256) bias_gelu_rows_bf16_kernel(const uint16_t
     uint32_t ow[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float v0 = __uint_as_float(xw[e] << 16) + b[2 * e];
-      const float v1 = __uint_as_float(xw[e] & 0xffff0000u) + b[2 * e + 1];
-      ow[e] = (uint32_t)f32_to_bf16(gelu_erf_as(v0)) | ((uint32_t)f32_to_bf16(gelu_erf_as(v1)) << 16);
+      const float v0 = E::to_f32((uint16_t)(xw[e] & 0xffffu)) + b[2 * e];
+      const float v1 = E::to_f32((uint16_t)(xw[e] >> 16)) + b[2 * e + 1];
+      ow[e] = (uint32_t)E::from_f32(gelu_erf_as(v0)) | ((uint32_t)E::from_f32(gelu_erf_as(v1)) << 16);
     }
     *reinterpret_cast<uint4*>(out + r * cols + c) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
   }
@@ -217,10 +218,11 @@ extern "C" int psg_bias_gelu(psg_ctx* ctx, const void* x, const float* bias, int
   PSG_REQUIRE(ctx && x && out, PSG_ERR_INVALID, "psg_bias_gelu: NULL argument");
   PSG_REQUIRE(cols > 0 && cols % 4 == 0, PSG_ERR_INVALID, "psg_bias_gelu: cols=%d must be a multiple of 4", cols);
   if (rows == 0) return PSG_OK;
-  if (dtype == PSG_BF16 && rows >= 256 && cols % 8 == 0) {
+  if ((dtype == PSG_BF16 || dtype == PSG_F16) && rows >= 256 && cols % 8 == 0) {
     const dim3 grid((unsigned)((cols / 8 + 255) / 256), (unsigned)(rows < 16384 ? rows : 16384));
-    bias_gelu_rows_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t*)x, bias, rows, cols,
-                                                                      (uint16_t*)out);
+    PSG_DISPATCH_E16(dtype, "psg_bias_gelu",
+                     (bias_gelu_rows_bf16_kernel<E><<<grid, 256, 0, (hipStream_t)stream>>>(
+                         (const uint16_t*)x, bias, rows, cols, (uint16_t*)out)));
     PSG_CHECK_LAUNCH("psg_bias_gelu");
     return PSG_OK;
   }
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, co
         for (int e = 0; e < 4; ++e) {
           v[c][e] += d[c][e];
           // the residual stream is stored in the activation dtype, as HF does (x = residual + attn)
-          if (sizeof(T) == 2) v[c][e] = bf16_to_f32(f32_to_bf16(v[c][e]));
+          v[c][e] = Act<T>::rnd(v[c][e]);
         }
       }
 #pragma unroll
@@ -431,7 +433,7 @@ __global__ void silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float s = g[e] / (1.0f + expf(-g[e]));
-      if (sizeof(T) == 2) s = bf16_to_f32(f32_to_bf16(s));  // HF rounds act_fn(gate) before the product
+      s = Act<T>::rnd(s);  // HF rounds act_fn(gate) before the product
       o[e] = s * u[e];
     }
     Act<T>::st4(out, r * inter + c, o);
@@ -440,6 +442,7 @@ __global__ void silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows
 
 // prompt pass (hundreds of dense bf16 rows): 8 columns per thread (16-byte loads), one row per blockIdx.y,
 // no index division; the decode step (<= 64 rows, split-K partials) keeps the kernel above
+template <typename E>
 __global__ void __launch_bounds__(256) silu_mul_rows_bf16_kernel(const uint16_t* __restrict__ gu, int64_t rows,
                                                                   int inter, uint16_t* __restrict__ out) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
@@ -451,12 +454,12 @@ __global__ void __launch_bounds__(256) silu_mul_rows_bf16_kernel(const uint16_t*
     uint32_t ow[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
-      const float u0 = __uint_as_float(uw[e] << 16), u1 = __uint_as_float(uw[e] & 0xffff0000u);
-      // same arithmetic as silu_mul_kernel<bf16_t>: silu in fp32, rounded to bf16 (HF rounds act_fn(gate)), product
-      const float s0 = bf16_to_f32(f32_to_bf16(g0 / (1.0f + expf(-g0))));
-      const float s1 = bf16_to_f32(f32_to_bf16(g1 / (1.0f + expf(-g1))));
-      ow[e] = (uint32_t)f32_to_bf16(s0 * u0) | ((uint32_t)f32_to_bf16(s1 * u1) << 16);
+      const float g0 = E::to_f32((uint16_t)(gw[e] & 0xffffu)), g1 = E::to_f32((uint16_t)(gw[e] >> 16));
+      const float u0 = E::to_f32((uint16_t)(uw[e] & 0xffffu)), u1 = E::to_f32((uint16_t)(uw[e] >> 16));
+      // same arithmetic as silu_mul_kernel<T>: silu in fp32, rounded to the activation type (HF rounds act_fn(gate)), product
+      const float s0 = E::to_f32(E::from_f32(g0 / (1.0f + expf(-g0))));
+      const float s1 = E::to_f32(E::from_f32(g1 / (1.0f + expf(-g1))));
+      ow[e] = (uint32_t)E::from_f32(s0 * u0) | ((uint32_t)E::from_f32(s1 * u1) << 16);
     }
     *reinterpret_cast<uint4*>(out + r * inter + c) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
   }
@@ -467,10 +470,11 @@ extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int splits, int64
   PSG_REQUIRE(ctx && gate_up && out, PSG_ERR_INVALID, "psg_silu_mul: NULL argument");
   PSG_REQUIRE(inter > 0 && inter % 4 == 0, PSG_ERR_INVALID, "psg_silu_mul: inter=%d must be a multiple of 4", inter);
   if (rows == 0) return PSG_OK;
-  if (dtype == PSG_BF16 && splits == 0 && rows > 64 && inter % 8 == 0) {
+  if ((dtype == PSG_BF16 || dtype == PSG_F16) && splits == 0 && rows > 64 && inter % 8 == 0) {
     const dim3 grid((unsigned)((inter / 8 + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
-    silu_mul_rows_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t*)gate_up, rows, inter,
-                                                                     (uint16_t*)out);
+    PSG_DISPATCH_E16(dtype, "psg_silu_mul",
+                     (silu_mul_rows_bf16_kernel<E><<<grid, 256, 0, (hipStream_t)stream>>>(
+                         (const uint16_t*)gate_up, rows, inter, (uint16_t*)out)));
     PSG_CHECK_LAUNCH("psg_silu_mul");
     return PSG_OK;
   }

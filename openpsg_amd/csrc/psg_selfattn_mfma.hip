@@ -12,16 +12,12 @@
 // The scalar kernel in psg_attn.hip (1.4 ms per layer at N = 50) stays as the fp32 verification path.
 #include "psg_common.h"
 
-typedef __bf16 sa_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 sa_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float sa_f32x16 __attribute__((ext_vector_type(16)));
 typedef float sa_f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t sa_pack(float lo, float hi) {
-  sa_f32x2 f = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, sa_bf16x2));
-}
 
+
+template <typename E>
 __global__ void __launch_bounds__(256, 2)
 self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ q_shared,
                       const uint8_t* __restrict__ text_mask, int B, int Tt, int nq, int heads, int q_only,
@@ -52,14 +48,14 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
   const unsigned long long exist64 = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
 
   // fragments: lane (idx = lane&31, hi) holds row (32 tile + idx), head dims 16 s + 8 hi .. +7
-  sa_bf16x8 kf[2][4], qf[2][4];
+  typename E::v8 kf[2][4], qf[2][4];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const uint16_t* rp = in_row(32 * t + l31) + h * 64 + hi * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qf[t][s] = *reinterpret_cast<const sa_bf16x8*>(rp + s * 16);
-      kf[t][s] = *reinterpret_cast<const sa_bf16x8*>(rp + hidden + s * 16);
+      qf[t][s] = *reinterpret_cast<const typename E::v8*>(rp + s * 16);
+      kf[t][s] = *reinterpret_cast<const typename E::v8*>(rp + hidden + s * 16);
     }
   }
   sa_f32x16 sc[2][2];                                           // [key tile][query tile]
@@ -70,7 +66,7 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
       sc[kt][qt] = (sa_f32x16){0};
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        sc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], sc[kt][qt], 0, 0, 0);
+        sc[kt][qt] = E::mfma32(kf[kt][s], qf[qt][s], sc[kt][qt]);
     }
   // masks for key tile 1 (keys 32..63), pre-shifted by 4*hi; tile 0 = first 32 query rows: always valid
   const uint32_t inv1 = (~(uint32_t)(valid64 >> 32)) >> (4 * hi);         // 1 = masked
@@ -116,13 +112,13 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
     for (int g = 0; g < 2; ++g) {
       union {
         uint32_t u[4];
-        sa_bf16x8 v;
+        typename E::v8 v;
       } pf[2], vf[2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          pf[qt].u[e] = sa_pack(sc[kt][qt][8 * g + 2 * e], sc[kt][qt][8 * g + 2 * e + 1]);
+          pf[qt].u[e] = E::pack(sc[kt][qt][8 * g + 2 * e], sc[kt][qt][8 * g + 2 * e + 1]);
       uint16_t ve[2][8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
@@ -139,7 +135,7 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          o[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt].v, pf[qt].v, o[dt][qt], 0, 0, 0);
+          o[dt][qt] = E::mfma32(vf[dt].v, pf[qt].v, o[dt][qt]);
     }
   // lane (q = lane&31, hi) holds O[q][32 dt + (r&3) + 8 (r>>2) + 4 hi] for its row of each query tile
   const int nrows = q_only ? nq : S;
@@ -153,8 +149,8 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           uint2 wv;
-          wv.x = sa_pack(o[dt][qt][4 * rr] * inv_l[qt], o[dt][qt][4 * rr + 1] * inv_l[qt]);
-          wv.y = sa_pack(o[dt][qt][4 * rr + 2] * inv_l[qt], o[dt][qt][4 * rr + 3] * inv_l[qt]);
+          wv.x = E::pack(o[dt][qt][4 * rr] * inv_l[qt], o[dt][qt][4 * rr + 1] * inv_l[qt]);
+          wv.y = E::pack(o[dt][qt][4 * rr + 2] * inv_l[qt], o[dt][qt][4 * rr + 3] * inv_l[qt]);
           *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rr) = wv;
         }
     }
@@ -162,11 +158,12 @@ self_attn_mfma_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
 }
 
 int psg_self_attn_mfma_launch(const void* qkv, const void* q_shared, const uint8_t* text_mask, int B, int T_, int nq,
-                              int heads, int query_rows_only, void* out, hipStream_t st) {
+                              int heads, int query_rows_only, void* out, int dtype, hipStream_t st) {
   const int64_t units = (int64_t)B * heads;
-  self_attn_mfma_kernel<<<(unsigned)((units + 3) / 4), 256, 0, st>>>((const uint16_t*)qkv, (const uint16_t*)q_shared,
-                                                                    text_mask, B, T_, nq, heads, query_rows_only,
-                                                                    (uint16_t*)out);
+  PSG_DISPATCH_E16(dtype, "psg_qformer_self_attn(mfma)",
+                   (self_attn_mfma_kernel<E><<<(unsigned)((units + 3) / 4), 256, 0, st>>>(
+                       (const uint16_t*)qkv, (const uint16_t*)q_shared, text_mask, B, T_, nq, heads, query_rows_only,
+                       (uint16_t*)out)));
   PSG_CHECK_LAUNCH("psg_qformer_self_attn(mfma)");
   return PSG_OK;
 }

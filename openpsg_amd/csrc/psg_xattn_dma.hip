@@ -22,8 +22,6 @@
 
 #include "psg_common.h"
 
-typedef __bf16 xd_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 xd_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float xd_f32x16 __attribute__((ext_vector_type(16)));
 typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t xd_u32x4 __attribute__((ext_vector_type(4)));
@@ -41,10 +39,7 @@ __device__ __forceinline__ float xd_xchg_sum(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ uint32_t xd_pack(float lo, float hi) {
-  xd_f32x2 f = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, xd_bf16x2));
-}
+
 // LDS traffic of the per-wave slots is inline asm: a compiler-visible ds access next to a pending LDS-DMA makes
 // hipcc wait vmcnt(0) (it treats the DMA as an LDS write that may alias), which would serialise DMA and compute.
 __device__ __forceinline__ xd_u32x4 xd_lds_read128(uint32_t a) {
@@ -65,7 +60,7 @@ __device__ __forceinline__ void xd_vmwait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int NC, int XD_WAVES>   // NC = key chunks of 128 (L <= 128 NC); XD_WAVES waves per workgroup (1 per CU)
+template <typename E, int NC, int XD_WAVES>   // NC = key chunks of 128 (L <= 128 NC); XD_WAVES waves per workgroup (1 per CU)
 __global__ void __launch_bounds__(XD_WAVES * 64, (XD_WAVES + 3) / 4)
 cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                       const uint64_t* __restrict__ bits, int words, const int32_t* __restrict__ pair_index, int N,
@@ -166,9 +161,9 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
   };
   union {
     uint32_t u[4];
-    xd_bf16x8 v;
+    typename E::v8 v;
   } b_one;
-  b_one.u[0] = hi ? 0u : 0x3f80u;
+  b_one.u[0] = hi ? 0u : E::ONE;
   b_one.u[1] = b_one.u[2] = b_one.u[3] = 0u;
   const float C8 = 0.125f * 1.4426950408889634f;
   const float bias_raw = policy == PSG_EMPTY_UNIFORM ? -3.4028234663852886e38f : -80000.0f;
@@ -242,7 +237,7 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
       const uint4 x = *reinterpret_cast<const uint4*>(vr + kk);
       const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sum += __uint_as_float(xs[e] << 16) + __uint_as_float(xs[e] & 0xffff0000u);
+      for (int e = 0; e < 4; ++e) sum += E::to_f32((uint16_t)(xs[e] & 0xffffu)) + E::to_f32((uint16_t)(xs[e] >> 16));
     }
     reinterpret_cast<float*>(mean_lds)[tid] = sum / (float)L;
   }
@@ -257,7 +252,7 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
     // fragment (row l31, piece c = 2 s4 + hi) sits at slot position c ^ (l31 & 7) of its row
     union {
       xd_u32x4 u;
-      xd_bf16x8 b;
+      typename E::v8 b;
     } qf[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
@@ -331,25 +326,25 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
         if (force_all) word = left >= 32 ? 0xffffffffu : (1u << left) - 1u;
         union {
           uint32_t u[4];
-          xd_bf16x8 v;
+          typename E::v8 v;
         } a_bias;
-        a_bias.u[0] = (((word >> l31) & 1u) | (uint32_t)hi) ? 0u : 0xc700u;   // 0 / -2^15 in bf16
+        a_bias.u[0] = (((word >> l31) & 1u) | (uint32_t)hi) ? 0u : E::NEG_2_15;   // 0 / -2^15 in bf16
         a_bias.u[1] = a_bias.u[2] = a_bias.u[3] = 0u;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_bias.v, b_one.v, (xd_f32x16){0}, 0, 0, 0);
+        acc = E::mfma32(a_bias.v, b_one.v, (xd_f32x16){0});
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          const xd_bf16x8 a = *reinterpret_cast<const xd_bf16x8*>(kp + s4 * 32);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s4].b, acc, 0, 0, 0);
+          const typename E::v8 a = *reinterpret_cast<const typename E::v8*>(kp + s4 * 32);
+          acc = E::mfma32(a, qf[s4].b, acc);
         }
       } else {
         {
-          const xd_bf16x8 a = *reinterpret_cast<const xd_bf16x8*>(kp);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0].b, (xd_f32x16){0}, 0, 0, 0);
+          const typename E::v8 a = *reinterpret_cast<const typename E::v8*>(kp);
+          acc = E::mfma32(a, qf[0].b, (xd_f32x16){0});
         }
 #pragma unroll
         for (int s4 = 1; s4 < 4; ++s4) {
-          const xd_bf16x8 a = *reinterpret_cast<const xd_bf16x8*>(kp + s4 * 32);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s4].b, acc, 0, 0, 0);
+          const typename E::v8 a = *reinterpret_cast<const typename E::v8*>(kp + s4 * 32);
+          acc = E::mfma32(a, qf[s4].b, acc);
         }
         const uint32_t inv = ~word >> (4 * hi);
         const bool has_pad = left < 32;
@@ -398,15 +393,15 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
       for (int gg = 0; gg < 2; ++gg) {
         union {
           uint32_t u[4];
-          xd_bf16x8 v;
+          typename E::v8 v;
         } pf;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf.u[e] = xd_pack(acc[8 * gg + 2 * e], acc[8 * gg + 2 * e + 1]);
+        for (int e = 0; e < 4; ++e) pf.u[e] = E::pack(acc[8 * gg + 2 * e], acc[8 * gg + 2 * e + 1]);
         const unsigned char* vp = vfrag_base + (t * 32 + 16 * gg) * 2;
-        const xd_bf16x8 a0 = *reinterpret_cast<const xd_bf16x8*>(vp);
-        const xd_bf16x8 a1 = *reinterpret_cast<const xd_bf16x8*>(vp + 32 * VS);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pf.v, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pf.v, o1, 0, 0, 0);
+        const typename E::v8 a0 = *reinterpret_cast<const typename E::v8*>(vp);
+        const typename E::v8 a1 = *reinterpret_cast<const typename E::v8*>(vp + 32 * VS);
+        o0 = E::mfma32(a0, pf.v, o0);
+        o1 = E::mfma32(a1, pf.v, o1);
       }
     }
     // ---- context tile: lane (q = l31, hi) holds O[q][32 dt + (r&3) + 8 (r>>2) + 4 hi]; 16-byte piece index of
@@ -417,10 +412,10 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       xd_u32x2 w0, w1;
-      w0[0] = xd_pack(o0[4 * rr] * inv_l, o0[4 * rr + 1] * inv_l);
-      w0[1] = xd_pack(o0[4 * rr + 2] * inv_l, o0[4 * rr + 3] * inv_l);
-      w1[0] = xd_pack(o1[4 * rr] * inv_l, o1[4 * rr + 1] * inv_l);
-      w1[1] = xd_pack(o1[4 * rr + 2] * inv_l, o1[4 * rr + 3] * inv_l);
+      w0[0] = E::pack(o0[4 * rr] * inv_l, o0[4 * rr + 1] * inv_l);
+      w0[1] = E::pack(o0[4 * rr + 2] * inv_l, o0[4 * rr + 3] * inv_l);
+      w1[0] = E::pack(o1[4 * rr] * inv_l, o1[4 * rr + 1] * inv_l);
+      w1[1] = E::pack(o1[4 * rr + 2] * inv_l, o1[4 * rr + 3] * inv_l);
       xd_lds_write64(sl + (uint32_t)(l31 * 128 + ((rr ^ (l31 & 7)) * 16) + hi * 8), w0);
       xd_lds_write64(sl + (uint32_t)(l31 * 128 + (((4 + rr) ^ (l31 & 7)) * 16) + hi * 8), w1);
     }
@@ -470,9 +465,10 @@ static size_t xd_lds_bytes(int N, int words, int L, int waves) {
 // smallest LDS footprint of the kernel family (8 waves); the dispatcher compares it with the 160 KiB of a CU
 extern "C" int psg_cross_attn_dma_lds_bytes(int N, int words, int L) { return (int)xd_lds_bytes(N, words, L, 8); }
 
-int psg_cross_attn_dma_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
-                              int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy,
-                              void* out, hipStream_t st) {
+template <typename E>
+static int xd_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits, int words,
+                     const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy, void* out,
+                     hipStream_t st) {
   const int Lpad = (L + 31) & ~31;
   // 8 waves per CU; option xattn_waves = 10 takes ten when the K/V image leaves room for ten slot pairs (L <= 256)
   const int waves = (ctx->opt.xattn_waves == 10 && xd_lds_bytes(N, words, L, 10) <= 160 * 1024) ? 10 : 8;
@@ -490,13 +486,13 @@ int psg_cross_attn_dma_launch(psg_ctx* ctx, const void* q, const void* k, const 
   long long* trace = (ctx->trace_kind == PSG_TRACE_CROSS_ATTN && ctx->trace_words >= trace_n) ? ctx->trace : nullptr;
 #define XDLAUNCH(NC_, W_)                                                                                          \
   do {                                                                                                             \
-    hipError_t e = hipFuncSetAttribute((const void*)cross_attn_dma_kernel<NC_, W_>,                                \
+    hipError_t e = hipFuncSetAttribute((const void*)cross_attn_dma_kernel<E, NC_, W_>,                                \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
     if (e != hipSuccess) {                                                                                         \
       psg_set_error("psg_qformer_cross_attn(dma): hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));       \
       return PSG_ERR_HIP;                                                                                          \
     }                                                                                                              \
-    cross_attn_dma_kernel<NC_, W_><<<(unsigned)(G * heads), W_ * 64, lds, st>>>(                                   \
+    cross_attn_dma_kernel<E, NC_, W_><<<(unsigned)(G * heads), W_ * 64, lds, st>>>(                                   \
         (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads,   \
         policy, (uint16_t*)out, trace);                                                                            \
   } while (0)
@@ -511,4 +507,11 @@ int psg_cross_attn_dma_launch(psg_ctx* ctx, const void* q, const void* k, const 
 #undef XDLAUNCH
   PSG_CHECK_LAUNCH("psg_qformer_cross_attn(dma)");
   return PSG_OK;
+}
+
+int psg_cross_attn_dma_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
+                              int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy,
+                              void* out, int dtype, hipStream_t st) {
+  PSG_DISPATCH_E16(dtype, "psg_qformer_cross_attn(dma)",
+                   return xd_launch<E>(ctx, q, k, v, bits, words, pair_index, N, P, L, nq, heads, policy, out, st));
 }

@@ -36,8 +36,6 @@
 
 #include "psg_common.h"
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
@@ -53,13 +51,9 @@ __device__ __forceinline__ float xchg32_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  f32x2_t f = {lo, hi};
-  bf16x2_t b = __builtin_convertvector(f, bf16x2_t);  // v_cvt_pk_bf16_f32 on gfx950
-  return __builtin_bit_cast(uint32_t, b);
-}
 
-template <int NC>   // NC = key chunks of 128 (L <= 128 NC): unrolled so the prefetched mask words index statically
+
+template <typename E, int NC>   // NC = key chunks of 128 (L <= 128 NC): unrolled so the prefetched mask words index statically
 __global__ void __launch_bounds__(256, 2)
 cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                        const uint64_t* __restrict__ bits, int words, const int32_t* __restrict__ pair_index, int N,
@@ -101,7 +95,7 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
   // the Q fragments and mask words of unit B are loading (its pair id arrived during the previous unit)
   // and the pair id of unit C is loading.  Nothing in a fetch waits on a load issued in the same step.
   struct XUnit {
-    bf16x8_t qf[4];
+    typename E::v8 qf[4];
     int pidx;                          // pair id p = i * N + j of this lane's row
     int64_t row;
     bool rvalid;
@@ -136,7 +130,7 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
     // Q fragments: B operand of S^T = K.Q^T; lane (q = lane&31, hi) holds Q[q][16 s + 8 hi .. +7]
     const uint16_t* qp = q + u.row * hidden + h * 64 + hi * 8;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) u.qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16);
+    for (int s = 0; s < 4; ++s) u.qf[s] = *reinterpret_cast<const typename E::v8*>(qp + s * 16);
     u.pidx = pair_index[pair];
   };
   const float rcpN = 1.0f / (float)N;
@@ -155,9 +149,9 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
   // B operand of the mask-bias MFMA: B'[k = 0][row] = 1 for every row, all other k-slots 0
   union {
     uint32_t u[4];
-    bf16x8_t v;
+    typename E::v8 v;
   } b_one;
-  b_one.u[0] = hi ? 0u : 0x3f80u;
+  b_one.u[0] = hi ? 0u : E::ONE;
   b_one.u[1] = b_one.u[2] = b_one.u[3] = 0u;
   const float C8 = 0.125f * 1.4426950408889634f;
   const float bias_raw = policy == PSG_EMPTY_UNIFORM ? -3.4028234663852886e38f : -80000.0f;  // generic path, pre-scale
@@ -175,7 +169,7 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
     constexpr bool AL = decltype(al_tag)::value;
     const int64_t row = cur.row;
     const bool rvalid = cur.rvalid;
-    bf16x8_t qf[4];
+    typename E::v8 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = cur.qf[s];
 
@@ -207,10 +201,10 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
             const float4 m0 = *reinterpret_cast<const float4*>(mean + 8 * rr + 4 * hi);
             const float4 m1 = *reinterpret_cast<const float4*>(mean + 32 + 8 * rr + 4 * hi);
             uint2 w0, w1;
-            w0.x = pack_bf16x2(m0.x, m0.y);
-            w0.y = pack_bf16x2(m0.z, m0.w);
-            w1.x = pack_bf16x2(m1.x, m1.y);
-            w1.y = pack_bf16x2(m1.z, m1.w);
+            w0.x = E::pack(m0.x, m0.y);
+            w0.y = E::pack(m0.z, m0.w);
+            w1.x = E::pack(m1.x, m1.y);
+            w1.y = E::pack(m1.z, m1.w);
             *reinterpret_cast<uint2*>(op + 8 * rr) = w0;
             *reinterpret_cast<uint2*>(op + 32 + 8 * rr) = w1;
           }
@@ -246,25 +240,25 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
         // A'[key = lane&31][k = 0] = 0 if the pair attends to this key, else -2^15 (bf16 0xc700)
         union {
           uint32_t u[4];
-          bf16x8_t v;
+          typename E::v8 v;
         } a_bias;
-        a_bias.u[0] = (((word >> l31) & 1u) | (uint32_t)hi) ? 0u : 0xc700u;
+        a_bias.u[0] = (((word >> l31) & 1u) | (uint32_t)hi) ? 0u : E::NEG_2_15;
         a_bias.u[1] = a_bias.u[2] = a_bias.u[3] = 0u;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_bias.v, b_one.v, (f32x16_t){0}, 0, 0, 0);
+        acc = E::mfma32(a_bias.v, b_one.v, (f32x16_t){0});
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(kp + s * 32);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
+          const typename E::v8 a = *reinterpret_cast<const typename E::v8*>(kp + s * 32);
+          acc = E::mfma32(a, qf[s], acc);
         }
       } else {
         {
-          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(kp);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0], (f32x16_t){0}, 0, 0, 0);
+          const typename E::v8 a = *reinterpret_cast<const typename E::v8*>(kp);
+          acc = E::mfma32(a, qf[0], (f32x16_t){0});
         }
 #pragma unroll
         for (int s = 1; s < 4; ++s) {
-          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(kp + s * 32);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
+          const typename E::v8 a = *reinterpret_cast<const typename E::v8*>(kp + s * 32);
+          acc = E::mfma32(a, qf[s], acc);
         }
         // additive mask per (row, key): register r of a lane is key (r&3) + 8 (r>>2) + 4 hi of the tile
         const uint32_t inv = ~word >> (4 * hi);
@@ -316,15 +310,15 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
       for (int gg = 0; gg < 2; ++gg) {
         union {
           uint32_t u[4];
-          bf16x8_t v;
+          typename E::v8 v;
         } pf;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(acc[8 * gg + 2 * e], acc[8 * gg + 2 * e + 1]);
+        for (int e = 0; e < 4; ++e) pf.u[e] = E::pack(acc[8 * gg + 2 * e], acc[8 * gg + 2 * e + 1]);
         const unsigned char* vp = vfrag_base + (t * 32 + 16 * gg) * 2;
-        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(vp);
-        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(vp + 32 * VS);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pf.v, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pf.v, o1, 0, 0, 0);
+        const typename E::v8 a0 = *reinterpret_cast<const typename E::v8*>(vp);
+        const typename E::v8 a1 = *reinterpret_cast<const typename E::v8*>(vp + 32 * VS);
+        o0 = E::mfma32(a0, pf.v, o0);
+        o1 = E::mfma32(a1, pf.v, o1);
       }
     }
     // epilogue: lane (q, hi) holds O[q][32 dt + (r&3) + 8 (r>>2) + 4 hi]
@@ -334,10 +328,10 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         uint2 w0, w1;
-        w0.x = pack_bf16x2(o0[4 * rr] * inv_l, o0[4 * rr + 1] * inv_l);
-        w0.y = pack_bf16x2(o0[4 * rr + 2] * inv_l, o0[4 * rr + 3] * inv_l);
-        w1.x = pack_bf16x2(o1[4 * rr] * inv_l, o1[4 * rr + 1] * inv_l);
-        w1.y = pack_bf16x2(o1[4 * rr + 2] * inv_l, o1[4 * rr + 3] * inv_l);
+        w0.x = E::pack(o0[4 * rr] * inv_l, o0[4 * rr + 1] * inv_l);
+        w0.y = E::pack(o0[4 * rr + 2] * inv_l, o0[4 * rr + 3] * inv_l);
+        w1.x = E::pack(o1[4 * rr] * inv_l, o1[4 * rr + 1] * inv_l);
+        w1.y = E::pack(o1[4 * rr + 2] * inv_l, o1[4 * rr + 3] * inv_l);
         *reinterpret_cast<uint2*>(op + 8 * rr) = w0;
         *reinterpret_cast<uint2*>(op + 32 + 8 * rr) = w1;
       }
@@ -420,7 +414,7 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
       const uint4 x = *reinterpret_cast<const uint4*>(vr + kk);
       const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sum += __uint_as_float(xs[e] << 16) + __uint_as_float(xs[e] & 0xffff0000u);
+      for (int e = 0; e < 4; ++e) sum += E::to_f32((uint16_t)(xs[e] & 0xffffu)) + E::to_f32((uint16_t)(xs[e] >> 16));
     }
     reinterpret_cast<float*>(mean_lds)[tid] = sum / (float)L;
   }
@@ -469,43 +463,26 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
 
 int psg_cross_attn_dma_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
                               int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy,
-                              void* out, hipStream_t st);
+                              void* out, int dtype, hipStream_t st);
 extern "C" int psg_cross_attn_dma_lds_bytes(int N, int words, int L);
 
 int psg_cross_attn_simple_launch(const void* q, const void* k, const void* v, const uint64_t* bits, int words,
                                  const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy,
                                  void* out, int dtype, hipStream_t st);
 
-extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
-                                      int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads,
-                                      int empty_policy, int variant, void* out, int dtype, void* stream) {
-  PSG_REQUIRE(ctx && q && k && v && bits && pair_index && out, PSG_ERR_INVALID, "psg_qformer_cross_attn: NULL argument");
-  PSG_REQUIRE(N > 0 && P >= 0 && L > 0 && nq > 0 && heads > 0 && words * 64 >= L, PSG_ERR_INVALID,
-              "psg_qformer_cross_attn: N=%d P=%d L=%d nq=%d heads=%d words=%d", N, P, L, nq, heads, words);
-  PSG_REQUIRE(empty_policy == PSG_EMPTY_UNIFORM || empty_policy == PSG_EMPTY_UNMASKED, PSG_ERR_INVALID,
-              "psg_qformer_cross_attn: empty_policy=%d", empty_policy);
-  if (P == 0) return PSG_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (variant == PSG_XATTN_SIMPLE)
-    return psg_cross_attn_simple_launch(q, k, v, bits, words, pair_index, N, P, L, nq, heads, empty_policy, out, dtype,
-                                        st);
-  PSG_REQUIRE(variant == PSG_XATTN_MFMA || variant == PSG_XATTN_MFMA_V1, PSG_ERR_INVALID,
-              "psg_qformer_cross_attn: variant=%d", variant);
-  PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_UNSUPPORTED,
-              "psg_qformer_cross_attn: the MFMA variants compute in bf16; use PSG_XATTN_SIMPLE for fp32");
-  // second-generation kernel (full-line Q / context traffic through LDS-DMA) whenever its LDS image fits
-  if (variant == PSG_XATTN_MFMA && ctx->opt.xattn_dma && psg_cross_attn_dma_lds_bytes(N, words, L) <= 160 * 1024 &&
-      L <= 384)
-    return psg_cross_attn_dma_launch(ctx, q, k, v, bits, words, pair_index, N, P, L, nq, heads, empty_policy, out, st);
+template <typename E>
+static int xa_v1_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits, int words,
+                        const int32_t* pair_index, int N, int P, int L, int nq, int heads, int empty_policy, void* out,
+                        hipStream_t st) {
   const int Lpad = (L + 31) & ~31;
   const size_t lds = (size_t)Lpad * XA_KSTRIDE + (size_t)64 * (Lpad * 2 + 16) + 256 + (((size_t)N * words * 8 + 15) & ~(size_t)15);
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn: L=%d needs %zu B of LDS (> 160 KiB)", L,
               lds);
   const int NC = (Lpad / 32 + 3) / 4;                     // template parameter: staging passes / 128 keys
   PSG_REQUIRE(NC >= 1 && NC <= 4, PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn: L=%d (MFMA variant handles L <= 512)", L);
-  const void* kfn = NC == 1 ? (const void*)cross_attn_mfma_kernel<1>
-                  : NC == 2 ? (const void*)cross_attn_mfma_kernel<2>
-                  : NC == 3 ? (const void*)cross_attn_mfma_kernel<3> : (const void*)cross_attn_mfma_kernel<4>;
+  const void* kfn = NC == 1 ? (const void*)cross_attn_mfma_kernel<E, 1>
+                  : NC == 2 ? (const void*)cross_attn_mfma_kernel<E, 2>
+                  : NC == 3 ? (const void*)cross_attn_mfma_kernel<E, 3> : (const void*)cross_attn_mfma_kernel<E, 4>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
@@ -524,7 +501,7 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
   const int64_t trace_n = G * heads * 4 * 32;
   long long* trace = (ctx->trace_kind == PSG_TRACE_CROSS_ATTN && ctx->trace_words >= trace_n) ? ctx->trace : nullptr;
 #define XLAUNCH(NC_)                                                                                           \
-  cross_attn_mfma_kernel<NC_><<<(unsigned)(G * heads), 256, lds, st>>>(                                        \
+  cross_attn_mfma_kernel<E, NC_><<<(unsigned)(G * heads), 256, lds, st>>>(                                        \
       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads, \
       empty_policy, (uint16_t*)out, trace)
   if (NC == 1) XLAUNCH(1);
@@ -535,3 +512,30 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
   PSG_CHECK_LAUNCH("psg_qformer_cross_attn");
   return PSG_OK;
 }
+
+extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
+                                      int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads,
+                                      int empty_policy, int variant, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && q && k && v && bits && pair_index && out, PSG_ERR_INVALID, "psg_qformer_cross_attn: NULL argument");
+  PSG_REQUIRE(N > 0 && P >= 0 && L > 0 && nq > 0 && heads > 0 && words * 64 >= L, PSG_ERR_INVALID,
+              "psg_qformer_cross_attn: N=%d P=%d L=%d nq=%d heads=%d words=%d", N, P, L, nq, heads, words);
+  PSG_REQUIRE(empty_policy == PSG_EMPTY_UNIFORM || empty_policy == PSG_EMPTY_UNMASKED, PSG_ERR_INVALID,
+              "psg_qformer_cross_attn: empty_policy=%d", empty_policy);
+  if (P == 0) return PSG_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (variant == PSG_XATTN_SIMPLE)
+    return psg_cross_attn_simple_launch(q, k, v, bits, words, pair_index, N, P, L, nq, heads, empty_policy, out, dtype,
+                                        st);
+  PSG_REQUIRE(variant == PSG_XATTN_MFMA || variant == PSG_XATTN_MFMA_V1, PSG_ERR_INVALID,
+              "psg_qformer_cross_attn: variant=%d", variant);
+  PSG_REQUIRE(dtype == PSG_BF16 || dtype == PSG_F16, PSG_ERR_UNSUPPORTED,
+              "psg_qformer_cross_attn: the MFMA variants compute in bf16 / fp16; use PSG_XATTN_SIMPLE for fp32");
+  // second-generation kernel (full-line Q / context traffic through LDS-DMA) whenever its LDS image fits
+  if (variant == PSG_XATTN_MFMA && ctx->opt.xattn_dma && psg_cross_attn_dma_lds_bytes(N, words, L) <= 160 * 1024 &&
+      L <= 384)
+    return psg_cross_attn_dma_launch(ctx, q, k, v, bits, words, pair_index, N, P, L, nq, heads, empty_policy, out, dtype,
+                                     st);
+  PSG_DISPATCH_E16(dtype, "psg_qformer_cross_attn", return xa_v1_launch<E>(ctx, q, k, v, bits, words, pair_index, N, P, L, nq,
+                                                                            heads, empty_policy, out, st));
+}
+

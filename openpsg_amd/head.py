@@ -31,7 +31,8 @@ from .tokenizers import WordTokenizer
 from .weights import head_shapes, llm_shapes
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
-           torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
+           "fp16": torch.float16, "float16": torch.float16, "half": torch.float16,
+           torch.bfloat16: torch.bfloat16, torch.float32: torch.float32, torch.float16: torch.float16}
 
 
 def _set_nested(root: nn.Module, dotted: str, tensor: torch.Tensor):
@@ -76,7 +77,8 @@ class RelationTransformerHeadV4(nn.Module):
                  relation_classes=relation_categories,
                  max_object_num=30,
                  # ---- build-specific, keyword only --------------------------------------------------
-                 dtype="bf16",                 # activation/weight dtype of the GPU path ('fp32' = verification)
+                 dtype="bf16",                 # activation/weight dtype of the GPU path: 'bf16' | 'fp16' (both on the
+                                               # matrix cores) | 'fp32' (verification mode)
                  device=None,                  # None -> RelationTransformerHeadV4.default_device
                  qformer_vocab_size=30522,
                  llm_config: LlamaConfig | None = None,

@@ -33,8 +33,8 @@ from .config import PSGConfig
 
 class LlamaDecodeEngine:
     def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, n_layers=None):
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise PsgHipError(f"activation dtype must be float32 or bfloat16, got {dtype}")
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise PsgHipError(f"activation dtype must be float32, bfloat16 or float16, got {dtype}")
         m = cfg.llm
         if m.head_dim != 128:
             raise PsgHipError(f"LLM head_dim {m.head_dim} unsupported (kernels are built for 128)")
@@ -70,9 +70,9 @@ class LlamaDecodeEngine:
         self.rope = (ang.cos().contiguous().to(self.device), ang.sin().contiguous().to(self.device))
 
     def linear(self, x, w):
-        """Bias-free projection.  Decode-step shapes (<= 32 rows, bf16) use the hand-written
+        """Bias-free projection.  Decode-step shapes (<= 32 rows, bf16 / fp16) use the hand-written
         weight-streaming kernel; prefill and the fp32 verification mode go through hipBLASLt."""
-        if (self.use_skinny and x.dtype == torch.bfloat16 and x.shape[0] <= 32 and w.shape[0] % 16 == 0
+        if (self.use_skinny and x.dtype in (torch.bfloat16, torch.float16) and x.shape[0] <= 32 and w.shape[0] % 16 == 0
                 and w.shape[1] % 64 == 0 and w.shape[1] >= 256):
             return ops.skinny_gemm(x, w)          # fp32 split-K partials, reduced by the consumer kernel
         return F.linear(x, w)
@@ -91,7 +91,7 @@ class LlamaDecodeEngine:
         q = torch.empty_like(resid)
         att = torch.empty_like(resid)
         act = torch.empty((rows, m.inter), device=self.device, dtype=self.dtype)
-        mfma_prefill = (prefill_shape is not None and self.dtype == torch.bfloat16 and m.head_dim == 128
+        mfma_prefill = (prefill_shape is not None and self.dtype in (torch.bfloat16, torch.float16) and m.head_dim == 128
                         and prefill_shape[1] <= 64 and os.environ.get("PSG_PREFILL_ATTN_SCALAR") != "1")
         for l, L in enumerate(self.layers):
             qkv = self.linear(n, L["wqkv"])

@@ -9,10 +9,10 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import (PSG_BF16, PSG_F32, PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED, PSG_XATTN_MFMA,
+from ._lib import (PSG_BF16, PSG_F16, PSG_F32, PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED, PSG_XATTN_MFMA,
                    PSG_XATTN_SIMPLE, PsgHipError, check)
 
-_DT = {torch.float32: PSG_F32, torch.bfloat16: PSG_BF16}
+_DT = {torch.float32: PSG_F32, torch.bfloat16: PSG_BF16, torch.float16: PSG_F16}
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -149,12 +149,12 @@ def qformer_self_attn(qkv, text_mask, B, T, nq, heads, query_rows_only, out):
 
 
 def qformer_self_attn_shared(qkv_query, qkv_text, text_mask, B, T, nq, heads, out):
-    """Layer-0 self-attention with ONE shared [nq, 3*hidden] projection of the query rows (bf16)."""
+    """Layer-0 self-attention with ONE shared [nq, 3*hidden] projection of the query rows (bf16 / fp16)."""
     lib, ctx, st = _env(qkv_query)
     hidden = qkv_query.shape[1] // 3
     assert qkv_query.shape == (nq, 3 * hidden) and qkv_text.shape == (B * T, 3 * hidden)
     assert out.shape == (B * (nq + T), hidden) and out.dtype == qkv_query.dtype == qkv_text.dtype
-    check(lib.psg_qformer_self_attn_shared(ctx, _p(qkv_query, torch.bfloat16, "qkv_query"), _p(qkv_text),
+    check(lib.psg_qformer_self_attn_shared(ctx, _p(qkv_query, name="qkv_query"), _p(qkv_text),
                                            _p(text_mask, torch.uint8, "text_mask"), B, T, nq, heads, _p(out),
                                            _dt(qkv_query), st), "psg_qformer_self_attn_shared")
     return out
@@ -169,7 +169,7 @@ def qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, out=None, empty_
     if variant is None:
         # the matrix-core kernel keeps all keys of one head in LDS (L <= 512 patches = images up to ~1450 px);
         # larger inputs take the row kernel (the reference runs them too)
-        variant = PSG_XATTN_MFMA if (q.dtype == torch.bfloat16 and L <= 512) else PSG_XATTN_SIMPLE
+        variant = PSG_XATTN_MFMA if (q.dtype in (torch.bfloat16, torch.float16) and L <= 512) else PSG_XATTN_SIMPLE
     out = torch.empty_like(q) if out is None else out
     check(lib.psg_qformer_cross_attn(ctx, _p(q), _p(k), _p(v), _p(bits, torch.int64, "bits"), bits.shape[1],
                                      _p(pair_index, torch.int32, "pair_index"), int(N), P, L, nq, heads,
@@ -272,21 +272,21 @@ def llm_attn(q, k_cache, v_cache, tok_pair, tok_pos, heads, head_dim, ctx_len, o
 
 
 def prefill_attn(q, k_cache, v_cache, tok_pos, pairs, rows_per_pair, heads, head_dim, ctx_len, out):
-    """Causal attention of a pair-major prompt batch on the matrix cores (bf16, rows_per_pair <= 64)."""
+    """Causal attention of a pair-major prompt batch on the matrix cores (bf16 / fp16, rows_per_pair <= 64)."""
     lib, ctx, st = _env(q)
     assert q.shape[0] == pairs * rows_per_pair
-    check(lib.psg_prefill_attn(ctx, _p(q, torch.bfloat16, "q"), _p(k_cache, q.dtype), _p(v_cache, q.dtype),
+    check(lib.psg_prefill_attn(ctx, _p(q, name="q"), _p(k_cache, q.dtype), _p(v_cache, q.dtype),
                                _p(tok_pos, torch.int32), pairs, rows_per_pair, heads, head_dim, ctx_len,
                                _p(out, q.dtype), _dt(q), st), "psg_prefill_attn")
     return out
 
 
 def prefill_attn_rope(qkv, tok_pos, rope, pairs, rows_per_pair, heads, head_dim, ctx_len, k_cache, v_cache, out):
-    """Rotary + KV-cache write + causal attention of a pair-major prompt batch in one launch (bf16)."""
+    """Rotary + KV-cache write + causal attention of a pair-major prompt batch in one launch (bf16 / fp16)."""
     lib, ctx, st = _env(out)
     assert qkv.shape == (pairs * rows_per_pair, 3 * heads * head_dim) and rope[0].shape[1] == head_dim // 2
     assert rope[0].shape[0] >= rows_per_pair
-    check(lib.psg_prefill_attn_rope(ctx, _p(qkv, torch.bfloat16, "qkv"), _p(tok_pos, torch.int32),
+    check(lib.psg_prefill_attn_rope(ctx, _p(qkv, out.dtype, "qkv"), _p(tok_pos, torch.int32),
                                     _p(rope[0], torch.float32), _p(rope[1], torch.float32), pairs, rows_per_pair, heads,
                                     head_dim, ctx_len, _p(k_cache, out.dtype), _p(v_cache, out.dtype), _p(out),
                                     _dt(out), st), "psg_prefill_attn_rope")
@@ -337,8 +337,10 @@ def skinny_gemm(x, w, splits=None) -> Partials:
         check(lib.psg_skinny_gemm_plan(ctx, M, N, K, ctypes.byref(s)), "psg_skinny_gemm_plan")
         splits = s.value
     part = torch.empty((splits, M, N), device=x.device, dtype=torch.float32)
-    check(lib.psg_skinny_gemm(ctx, _p(x, torch.bfloat16, "x"), _p(w, torch.bfloat16, "w"), _p(part), M, N, K, splits,
-                              st), "psg_skinny_gemm")
+    if x.dtype not in (torch.bfloat16, torch.float16) or w.dtype != x.dtype:
+        raise PsgHipError(f"skinny_gemm: x / w must both be bf16 or fp16, got {x.dtype} / {w.dtype}")
+    check(lib.psg_skinny_gemm(ctx, _p(x, name="x"), _p(w, name="w"), _p(part), M, N, K, splits, _dt(x), st),
+          "psg_skinny_gemm")
     return Partials(part)
 
 

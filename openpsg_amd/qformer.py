@@ -30,8 +30,8 @@ from .config import PSGConfig
 
 class RelationQueryEngine:
     def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, xattn_variant=None):
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise PsgHipError(f"activation dtype must be float32 or bfloat16, got {dtype}")
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise PsgHipError(f"activation dtype must be float32, bfloat16 or float16, got {dtype}")
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.xattn_variant = xattn_variant
         q = cfg.qformer
@@ -104,7 +104,7 @@ class RelationQueryEngine:
         X = torch.empty((R, H), device=self.device, dtype=self.dtype)
         # bf16 mode: the embedded query rows are ONE [33, 768] block for all pairs (learned tokens through the embedding
         # LayerNorm); layer 0 projects it once and uses it as a periodic residual, so rows [33, P*33) of X stay unwritten
-        shared0 = (len(self.layers) > 1 and T > 0 and self.dtype == torch.bfloat16 and self.share_query_qkv)
+        shared0 = (len(self.layers) > 1 and T > 0 and self.dtype != torch.float32 and self.share_query_qkv)
         if shared0:
             ops.qformer_embed_split(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
                                     q.ln_eps, X[:nq], X[RQ:])

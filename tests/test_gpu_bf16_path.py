@@ -307,3 +307,50 @@ def test_rope_kvwrite_split_inputs_vs_fp32_torch(splits):
     assert eq < 4e-2 and ek < 4e-2 and ev < 4e-2
     for kk in range(K):                                            # rows past a pair's length stay untouched
         assert torch.isnan(kcc[kk, :, int(lens[kk]):]).all()
+
+
+# ---- fp16 activation mode (BASELINE config 5) -------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["G1_c1_512_n10", "G5_c5geo_1024x1344_n8"])
+def test_fp16_mode_vs_reference(case):
+    """The same matrix-core kernels with the fp16 MFMA opcodes: 11 mantissa bits instead of bf16's 8, so the fp16
+    path must sit closer to the fp32 reference than the bf16 path does on the same case."""
+    g, cfg, w, scene = H.load_case(case)
+    dev = _dev()
+    ids = [int(i) for i in scene["object_id_list"]]
+    names = H.object_names(scene)
+    res = {}
+    for dt in ("fp16", "bf16"):
+        head = _head(cfg, w, dt, suppress_eos=bool(g["suppress_eos"]))
+        rq = head.run_relation_query(scene["mask_features"].to(dev), scene["img_meta"], ids, names,
+                                     scene["pan_results"].to(dev))
+        dec = head.decode_selected(rq, names, selected=torch.from_numpy(g["selected"].astype(np.int32)).to(dev))
+        e_logit = np.abs(rq["exist_logit"].cpu().numpy() - g["exist_logit"]).max()
+        fl = dec["first_logits"].float().cpu().numpy()
+        e_first = max(float(np.abs(fl[i][g["gen_top8_idx"][i]] - g["gen_top8_val"][i]).max()) for i in range(fl.shape[0]))
+        toks = dec["tokens_host"]
+        exact = 0
+        for i in range(toks.shape[0]):
+            want = g["gen_tokens"][i]
+            exact += [int(t) for t in toks[i] if t >= 0] == want[want >= 0].tolist()
+        overlap = len(set(rq["selected"].cpu().tolist()) & set(g["selected"].tolist()))
+        res[dt] = (e_logit, e_first, exact, overlap)
+        assert rq["hidden"].dtype == (torch.float16 if dt == "fp16" else torch.bfloat16)
+    print(f"{case}: max |existence logit - reference| fp16 {res['fp16'][0]:.3e} / bf16 {res['bf16'][0]:.3e}; first-step "
+          f"logits fp16 {res['fp16'][1]:.3e} / bf16 {res['bf16'][1]:.3e}; pairs with the reference's exact tokens fp16 "
+          f"{res['fp16'][2]}/20 / bf16 {res['bf16'][2]}/20; top-20 overlap fp16 {res['fp16'][3]} / bf16 {res['bf16'][3]}")
+    assert res["fp16"][0] < max(0.5 * res["bf16"][0], 0.03) and res["fp16"][1] < max(0.5 * res["bf16"][1], 0.1)
+    assert res["fp16"][2] >= res["bf16"][2] and res["fp16"][3] >= 19
+
+
+@pytest.mark.parametrize("M,N,K", [(20, 4096, 4096), (7, 32000, 4096), (32, 768, 2752)])
+def test_skinny_gemm_fp16_vs_fp32_reference(M, N, K):
+    from openpsg_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=gen).to(dev).half()
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev).half()
+    y = ops.skinny_gemm(x, w).reduce(torch.float16)
+    ref = x.float() @ w.float().t()
+    err = (y.float() - ref).abs().max().item()
+    print(f"fp16 skinny GEMM M={M} N={N} K={K}: err {err:.3e}")
+    assert err < 4e-3
