@@ -125,7 +125,8 @@ if __name__ == "__main__":
     if "mall" in a.what:
         mall()
     if "xattn" in a.what:
-        xattn(50, 256)
+        if "only100" not in a.what:
+            xattn(50, 256)
         if "only50" not in a.what:
             xattn(100, 256)
 
