@@ -128,3 +128,61 @@ def test_score_preserving_writer(tmp_path):
     assert rec["relations"] == [[0, 1, 5], [1, 0, 1]] and rec["relation_scores"] == [1, 1]      # predict.py:93-97
     assert rec["image_id"] == 7 and [s["category_id"] for s in rec["segments_info"]] == [1, 18]
     assert (tmp_path / "submission" / "panseg" / "img_7.png").exists()
+
+
+def _hf_tokenizers():
+    """Real HuggingFace fast tokenizers built in memory (no hub, no files): a BERT-style one for the Q-Former
+    prompts and a Llama-style one (BOS prepended, '</s>' a special token, no pad token) for the LLM."""
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    from openpsg_amd.tokenizers import default_words
+    pre = pre_tokenizers.Whitespace()
+    words = sorted({w for word in default_words() for w, _ in pre.pre_tokenize_str(word)})
+    bv = {t: i for i, t in enumerate(["[PAD]", "[UNK]", "[CLS]", "[SEP]"] + words)}
+    bt = Tokenizer(models.WordLevel(bv, unk_token="[UNK]"))
+    bt.normalizer, bt.pre_tokenizer = normalizers.Lowercase(), pre
+    bt.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]",
+                                                      special_tokens=[("[CLS]", 2), ("[SEP]", 3)])
+    bert = PreTrainedTokenizerFast(tokenizer_object=bt, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]",
+                                   sep_token="[SEP]")
+    lv = {t: i for i, t in enumerate(["<unk>", "<s>", "</s>"] + words)}
+    lt = Tokenizer(models.WordLevel(lv, unk_token="<unk>"))
+    lt.normalizer, lt.pre_tokenizer = normalizers.Lowercase(), pre
+    lt.post_processor = processors.TemplateProcessing(single="<s> $A", special_tokens=[("<s>", 1)])
+    llama = PreTrainedTokenizerFast(tokenizer_object=lt, unk_token="<unk>", bos_token="<s>", eos_token="</s>")
+    return bert, llama
+
+
+def test_hf_fast_tokenizers_drive_prompts_and_parse():
+    """The head with HuggingFace tokenizer OBJECTS (what `tokenizers='auto'` resolves to at deployment): prompt
+    tables (V4:146-152, 260-266), pad = unk (V4:105), left padding, and tokens -> triples through HF's batch_decode."""
+    from openpsg_amd.config import tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    bert, llama = _hf_tokenizers()
+    head = RelationTransformerHeadV4(device="cpu", qformer_vocab_size=512, llm_config=tiny_llm(256, 1, 256, 512),
+                                     llm_feature_size=256, tokenizers=(bert, llama))
+    assert head.llm_tokenizer.pad_token == "<unk>"                                  # V4:105
+    names = ["person", "wall-brick", "person", "dining table"]
+    uidx, U, rows = head._prompt_table("q", names)
+    assert U == 3 and uidx == [1, 2, 1, 0]                                          # sorted unique names
+    want = bert("Is there a relation between person and dining table?")["input_ids"]
+    assert rows[1 * U + 0].tolist() == want and want[0] == 2 and want[-1] == 3      # [CLS] ... [SEP], no padding kept
+    _, _, lrows = head._prompt_table("l", names)
+    lw = llama("What are the relations between wall-brick and person? Assistant: ")["input_ids"]
+    assert lrows[2 * U + 1].tolist() == lw and lw[0] == 1                           # BOS first, pads stripped
+    assert head.llm_tokenizer.padding_side == "left"                                # V4:262
+    assert len({len(r) for r in lrows}) > 1                                         # ragged -> the table really pads
+    # generated ids -> text -> triples (V4:313-326) through HF's own batch_decode
+    enc = lambda s: [llama.convert_tokens_to_ids(t) for t in s.split()]            # noqa: E731
+    toks = np.full((2, 8), -1, dtype=np.int32)
+    for i, s_ in enumerate(["holding </s> on </s>", "<s> parked on </s>"]):
+        ids = enc(s_)
+        toks[i, :len(ids)] = ids
+    pred, score = head.parse(toks, np.array([6, 9], dtype=np.int32), 4)
+    ri = relation_categories.index
+    assert pred == [[1, 2, ri("holding")], [2, 1, ri("parked on")]] and score == [1, 1]
+    # training labels (V4:269-281): '</s>' in the label text is the EOS token, labels are right padded
+    llama.padding_side = "right"
+    lab = llama([" over </s>", " over </s> in front of </s>"], return_tensors="pt", padding=True)
+    assert lab["input_ids"][0].tolist()[:3] == [1, llama.convert_tokens_to_ids("over"), 2]
+    assert lab["attention_mask"][0].sum() == 3 and lab["attention_mask"][1].sum() == 7
