@@ -218,6 +218,13 @@ int psg_skinny_gemm(psg_ctx*, const void* x, const void* w, float* part, int M, 
 int psg_reduce_partials(psg_ctx*, const float* part, int splits, int64_t n, void* y, int dtype,
                         void* stream);
 
+/* ---- Q-Former dense projections with fused epilogue (HF-IB:563-596 intermediate(_query): Linear + exact-erf GELU):
+ * out[M][N] = epilogue(x[M][K] . w[N][K]^T + bias[N]); x / w / out bf16 or fp16 row-major, bias fp32 (may be NULL),
+ * fp32 accumulate.  N % 256 == 0, K % 64 == 0.  One pass instead of a library GEMM + psg_bias_gelu. */
+enum psg_epilogue { PSG_EPI_NONE = 0, PSG_EPI_GELU = 1 };
+int psg_dense_gemm(psg_ctx*, const void* x, const void* w, const float* bias, int epilogue, void* out, int64_t M,
+                   int N, int K, int dtype, void* stream);
+
 /* ---- K16: greedy step (HF generate, num_beams=1, do_sample=False; V4:305-312).
  * logits [K][vocab] (dtype); token = argmax (first maximal index); suppress_token >= 0 is
  * excluded.  For each pair k not yet done: tokens[k][step] = token, done[k] |= (token == eos),

@@ -63,6 +63,7 @@ SIGNATURES = {
     "psg_masked_mean_pool_workspace": [_vp, _i, _i, _i, _i, C.POINTER(_i64)],
     "psg_masked_mean_pool": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i64, _vp],
     "psg_bilinear_scores": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "psg_dense_gemm": [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp],
     "psg_greedy_step": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
 }
 

@@ -20,6 +20,8 @@ struct psg_opts {
   int skinny_xdma = 1;          // x slice staged by LDS-DMA as well
   int selfattn_scalar = 0;      // Q-Former self-attention: scalar checker kernel even in bf16
   int decode_attn_1wave = 0;    // decode attention: one wave per (pair, head) instead of a workgroup
+  int dense_gemm_var = 0;       // psg_dense_gemm ablation builds (1: no MFMA, 2: no staging); 0 = the real kernel
+  int qformer_own_gemm = 1;     // Q-Former FFN1: psg_dense_gemm with fused bias + GELU instead of library GEMM + psg_bias_gelu
   int xattn_waves = 8;          // LDS-DMA cross-attention: waves per workgroup (8 or 10)
   int xattn_dma = 1;            // cross-attention: LDS-DMA kernel (psg_xattn_dma.hip) when its LDS image fits
 };

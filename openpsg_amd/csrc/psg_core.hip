@@ -28,6 +28,7 @@ static const OptName kOpts[] = {
     {"skinny_nt", &psg_opts::skinny_nt},               {"skinny_xdma", &psg_opts::skinny_xdma},
     {"selfattn_scalar", &psg_opts::selfattn_scalar},   {"decode_attn_1wave", &psg_opts::decode_attn_1wave},
     {"xattn_dma", &psg_opts::xattn_dma},               {"xattn_waves", &psg_opts::xattn_waves},
+    {"dense_gemm_var", &psg_opts::dense_gemm_var},     {"qformer_own_gemm", &psg_opts::qformer_own_gemm},
 };
 
 // "8x1x3" (waves x K blocks x ring slots) is accepted for skinny_dma next to a plain integer

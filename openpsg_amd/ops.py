@@ -407,3 +407,15 @@ def cross_entropy_rows(logits, labels):
     check(lib.psg_cross_entropy_rows(ctx, _p(logits), rows, vocab, _p(labels, torch.int32, "labels"), _p(loss),
                                      _dt(logits), st), "psg_cross_entropy_rows")
     return loss
+
+
+def dense_gemm(x, w, bias=None, gelu=False, out=None):
+    """out = [gelu](x @ w.T + bias) in one pass (bf16 / fp16; N % 256 == 0, K % 64 == 0)."""
+    lib, ctx, st = _env(x)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and w.dtype == x.dtype
+    out = torch.empty((M, N), device=x.device, dtype=x.dtype) if out is None else out
+    check(lib.psg_dense_gemm(ctx, _p(x, name="x"), _p(w, name="w"), _p(bias, torch.float32, "bias"), 1 if gelu else 0,
+                             _p(out, x.dtype), M, N, K, _dt(x), st), "psg_dense_gemm")
+    return out

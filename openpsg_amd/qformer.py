@@ -23,7 +23,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 from ._lib import PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED, PsgHipError
 from .config import PSGConfig
 
@@ -149,20 +149,29 @@ class RelationQueryEngine:
                 Xn = hidden_out
             else:
                 Xn = torch.empty((RQ if last else R, H), device=self.device, dtype=self.dtype)
-            iq = F.linear(Cq, L["w1q"])
-            ops.bias_gelu(iq, L["b1q"])
+            iq = self._ffn1(Cq, L["w1q"], L["b1q"])
             hq = F.linear(iq, L["w2q"])
             ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps, out=Xn[:RQ])
             del iq, hq
             if not last and T > 0:
-                it = F.linear(A[RQ:], L["w1t"])
-                ops.bias_gelu(it, L["b1t"])
+                it = self._ffn1(A[RQ:], L["w1t"], L["b1t"])
                 ht = F.linear(it, L["w2t"])
                 ops.add_layernorm(ht, A[RQ:], L["b2t"], L["ln_t"][0], L["ln_t"][1], q.ln_eps, out=Xn[RQ:])
                 del it, ht
             X = Xn
         logit, prob = ops.exist_head(X, self.exist_w, self.exist_b, P, nq)
         return X, logit, prob
+
+    def _ffn1(self, x, w, b):
+        """intermediate(_query): Linear + exact-erf GELU (HF-IB:563-577).  16-bit modes: one pass through
+        psg_dense_gemm (own MFMA GEMM with the bias + GELU epilogue fused; context option qformer_own_gemm);
+        fp32 verification mode and odd shapes: library GEMM + psg_bias_gelu."""
+        if (self.dtype != torch.float32 and w.shape[0] % 256 == 0 and w.shape[1] % 64 == 0 and x.shape[0] >= 256
+                and _lib.get_option(self.device.index or 0, "qformer_own_gemm")):
+            return ops.dense_gemm(x, w, b, gelu=True)
+        y = F.linear(x, w)
+        ops.bias_gelu(y, b)
+        return y
 
     def select(self, prob: torch.Tensor, k: int):
         """V4:235-237 on the device: descending, ties -> lower pair index.  int32 [k] (-1 if n < k)."""

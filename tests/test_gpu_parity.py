@@ -731,3 +731,32 @@ def test_bilinear_scores_vs_einsum(B, N, R, C):
     err = (got.double() - want).abs().max().item()
     print(f"bilinear scorer B={B} N={N} R={R} C={C}: max err vs fp64 einsum {err:.2e}")
     assert got.shape == (B, R, N, N) and err < 2e-4 * (C ** 0.5)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,gelu", [(3000, 3072, 768, True), (777, 768, 768, False), (256, 256, 64, True),
+                                        (4099, 2304, 3072, False)])
+def test_dense_gemm_fused_epilogue_vs_fp32_reference(dt, M, N, K, gelu):
+    """psg_dense_gemm (own MFMA GEMM, bias + exact-erf GELU fused; HF-IB:563-577) against fp32 torch, with a ragged
+    last row tile, and against the unfused product path (library GEMM + psg_bias_gelu)."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev).to(dt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(dt)
+    b = torch.randn(N, generator=g).to(dev)
+    out = torch.full((M + 3, N), 7.0, device=dev, dtype=dt)           # rows past M must stay untouched
+    ops.dense_gemm(x, w, b, gelu=gelu, out=out[:M])
+    ref = torch.nn.functional.linear(x.float(), w.float(), b)
+    lib = torch.nn.functional.linear(x, w)
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+        ops.bias_gelu(lib, b)
+    else:
+        lib = (lib.float() + b).to(dt)
+    tol = 2e-2 if dt == torch.bfloat16 else 3e-3                     # one 16-bit ulp of values up to ~4
+    e_own = ((out[:M].float() - ref).abs() / (1 + ref.abs())).max().item()
+    e_lib = ((lib.float() - ref).abs() / (1 + ref.abs())).max().item()
+    print(f"dense_gemm {dt} M={M} N={N} K={K} gelu={gelu}: rel err own {e_own:.3e}, library path {e_lib:.3e}")
+    assert e_own < tol and e_own <= 1.5 * e_lib + 1e-3
+    assert (out[M:] == 7.0).all()
