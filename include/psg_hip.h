@@ -218,6 +218,40 @@ int psg_skinny_gemm(psg_ctx*, const void* x, const void* w, float* part, int M, 
 int psg_reduce_partials(psg_ctx*, const float* part, int splits, int64_t n, void* y, int dtype,
                         void* stream);
 
+/* ---- Decode-step projection with its producer row operation in the SAME launch.  The decode step alternates a
+ * weight-streaming projection with a latency-bound row operation on <= 32 rows (RMSNorm HF-LL:53-67 + residual add,
+ * rotary + KV append + attention HF-LL:130-214, SwiGLU gate HF-LL:163-177); as separate launches each row operation
+ * costs a kernel (5-9 us) plus a boundary during which no weight byte moves.  Here the first workgroups of the
+ * projection's own grid run the row operation while every workgroup's weight ring fills, publish the x operand
+ * write-through, and the grid waits on ONE arrival counter before it stages x (agent-scope hand-off inside the launch;
+ * the grid is sized to be fully resident and the producers never wait, so it cannot deadlock; the poll is bounded).
+ *   kind RMSNORM     : in = split-K partials of the previous projection (or NULL), resid += sum(in); x = norm(resid)
+ *   kind DECODE_ATTN : in = q/k/v partials [in_splits][M][3*K]; rotary, cache append, attention; x = context
+ *   kind SILU_MUL    : in = gate/up partials [in_splits][M][2*K]; x = silu(gate) * up
+ * x [M][K] (activation dtype) is written by the prologue and then read as the GEMM operand.
+ * sync: two device words the CALLER zeroes before the launch (stream-ordered memset; one pair per launch inside a
+ * captured graph): [0] arrival counter, [1] set to a nonzero code if the bounded poll gave up. */
+enum psg_prologue_kind { PSG_PRO_NONE = 0, PSG_PRO_RMSNORM = 1, PSG_PRO_DECODE_ATTN = 2, PSG_PRO_SILU_MUL = 3 };
+typedef struct psg_prologue {
+  int kind;
+  int in_splits;              /* > 0: `in` holds fp32 split-K partials; 0: activation dtype */
+  const void* in;
+  void* resid;                /* RMSNORM: residual stream [M][K], updated in place when `in` != NULL */
+  const float* norm_w;        /* RMSNORM: weight [K] */
+  float eps;
+  int heads;                  /* DECODE_ATTN: K = heads * 128 */
+  int ctx;                    /* DECODE_ATTN: cache slots per (pair, head) */
+  const int32_t* tok_pair;    /* DECODE_ATTN: as psg_decode_attn */
+  const int32_t* tok_pos;
+  const float* rope_cos;
+  const float* rope_sin;
+  void* k_cache;
+  void* v_cache;
+  uint32_t* sync;
+} psg_prologue;
+int psg_skinny_gemm_fused(psg_ctx*, const psg_prologue* pro, void* x, const void* w, float* part, int M, int N, int K,
+                          int splits, int dtype, void* stream);
+
 /* ---- Q-Former dense projections with fused epilogue (HF-IB:563-596 intermediate(_query): Linear + exact-erf GELU):
  * out[M][N] = epilogue(x[M][K] . w[N][K]^T + bias[N]); x / w / out bf16 or fp16 row-major, bias fp32 (may be NULL),
  * fp32 accumulate.  N % 256 == 0, K % 64 == 0.  One pass instead of a library GEMM + psg_bias_gelu. */

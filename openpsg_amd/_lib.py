@@ -23,6 +23,15 @@ class PsgHipError(RuntimeError):
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
+PSG_PRO_NONE, PSG_PRO_RMSNORM, PSG_PRO_DECODE_ATTN, PSG_PRO_SILU_MUL = 0, 1, 2, 3
+
+
+class Prologue(C.Structure):
+    """`psg_prologue` of include/psg_hip.h (row operation fused into a decode projection)."""
+    _fields_ = [("kind", _i), ("in_splits", _i), ("input", _vp), ("resid", _vp), ("norm_w", _vp), ("eps", _f),
+                ("heads", _i), ("ctx", _i), ("tok_pair", _vp), ("tok_pos", _vp), ("rope_cos", _vp), ("rope_sin", _vp),
+                ("k_cache", _vp), ("v_cache", _vp), ("sync", _vp)]
+
 # name -> argtypes (return type is int unless noted).  Mirrors include/psg_hip.h one to one;
 # tests/test_abi_symbols.py checks the header and this table against the built library.
 SIGNATURES = {
@@ -59,6 +68,7 @@ SIGNATURES = {
     "psg_silu_mul": [_vp, _vp, _i, _i64, _i, _vp, _i, _vp],
     "psg_skinny_gemm_plan": [_vp, _i, _i, _i, C.POINTER(_i)],
     "psg_skinny_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "psg_skinny_gemm_fused": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "psg_reduce_partials": [_vp, _vp, _i, _i64, _vp, _i, _vp],
     "psg_masked_mean_pool_workspace": [_vp, _i, _i, _i, _i, C.POINTER(_i64)],
     "psg_masked_mean_pool": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i64, _vp],

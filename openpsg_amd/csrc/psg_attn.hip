@@ -436,15 +436,45 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
   const int64_t cbase = ((int64_t)tok_pair[row] * heads + h) * ctx * 128;
   const float scale = 0.08838834764831845f;                   // 1/sqrt(128)
   auto rnd = [](float f) { return Act<T>::rnd(f); };
+  const int kl = lane >> 2, part = lane & 3;
+  // Keys and values of the first 64 cached positions are requested BEFORE the new token's projections are summed:
+  // their addresses depend on `pos` only, so the cache read, the split-K partials and the rotary tables share one
+  // round trip instead of three dependent ones (projections -> barrier -> keys -> values).
+  typename Act<T>::raw4 t[8];
+  typename Act<T>::raw1 a[16], c[16];
+  auto load_kv = [&](int b0) {
+    const int j = b0 + 16 * wid + kl;
+    const T* kp = kc + cbase + (int64_t)(j < pos ? j : 0) * 128 + part * 32;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) t[d] = Act<T>::ldr4(kp, d * 4);
+    const int kbase = b0 + 16 * wid;
+    const int nk = min(16, pos - kbase);
+    const T* vp = vc + cbase + (int64_t)(nk > 0 ? kbase : 0) * 128;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int uu = u < nk ? u : 0;
+      a[u] = Act<T>::ldr(vp, (int64_t)uu * 128 + lane);
+      c[u] = Act<T>::ldr(vp, (int64_t)uu * 128 + lane + 64);
+    }
+  };
+  load_kv(0);                                                 // pos == 0: clamped to row 0, never used
   float vn1 = 0.f, vn2 = 0.f;
   if (wid == 0) {                                             // new token: rotary, cache append, own score
     const int64_t base = (int64_t)row * 3 * hidden + h * 128;
     const int64_t sl = (int64_t)rows * 3 * hidden;
-    const float q1 = ld1_in<T>(qkv, qs, sl, base + lane), q2 = ld1_in<T>(qkv, qs, sl, base + lane + 64);
-    const float k1 = ld1_in<T>(qkv, qs, sl, base + hidden + lane), k2 = ld1_in<T>(qkv, qs, sl, base + hidden + lane + 64);
-    const float v1 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane);
-    const float v2 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane + 64);
     const float cs = cos_tab[pos * 64 + lane], sn = sin_tab[pos * 64 + lane];
+    const int64_t idx[6] = {base + lane, base + lane + 64, base + hidden + lane, base + hidden + lane + 64,
+                            base + 2 * hidden + lane, base + 2 * hidden + lane + 64};
+    float x[6];
+    if (qs > 0) {                                             // split-K partials: all slices of q, k, v in one pass
+      ldn_splits<float, 6>(qkv, qs, sl, idx, x);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) x[e] = rnd(x[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) x[e] = Act<T>::ld(reinterpret_cast<const T*>(qkv), idx[e]);
+    }
+    const float q1 = x[0], q2 = x[1], k1 = x[2], k2 = x[3], v1 = x[4], v2 = x[5];
     const float qa = rnd(q1 * cs - q2 * sn), qb = rnd(q2 * cs + q1 * sn);
     const float ka = rnd(k1 * cs - k2 * sn), kb = rnd(k2 * cs + k1 * sn);
     Act<T>::st(kc, cbase + (int64_t)pos * 128 + lane, ka);
@@ -459,29 +489,26 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
     vn2 = rnd(v2);
   }
   __syncthreads();
-  const int kl = lane >> 2, part = lane & 3;
   float m_run = -INFINITY, l_run = 0.f, o1 = 0.f, o2 = 0.f;
   for (int b0 = 0; b0 < pos; b0 += 64) {
+    if (b0 > 0) load_kv(b0);
     const int j = b0 + 16 * wid + kl;
     float s = -INFINITY;
     {
-      const bool ok = j < pos;
-      const T* kp = kc + cbase + (int64_t)(ok ? j : 0) * 128 + part * 32;
-      float t[8][4];
-#pragma unroll
-      for (int d = 0; d < 8; ++d) Act<T>::ld4(kp, d * 4, t[d]);
       float acc = 0.f;
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
         const float* qq = s_q + part * 32 + d * 4;
-        acc = fmaf(qq[0], t[d][0], acc);
-        acc = fmaf(qq[1], t[d][1], acc);
-        acc = fmaf(qq[2], t[d][2], acc);
-        acc = fmaf(qq[3], t[d][3], acc);
+        float kf[4];
+        Act<T>::cv4(t[d], kf);
+        acc = fmaf(qq[0], kf[0], acc);
+        acc = fmaf(qq[1], kf[1], acc);
+        acc = fmaf(qq[2], kf[2], acc);
+        acc = fmaf(qq[3], kf[3], acc);
       }
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
-      if (ok) s = acc * scale;
+      if (j < pos) s = acc * scale;
     }
     const float m_new = fmaxf(m_run, wave_max(s));
     if (m_new == -INFINITY) continue;                          // this wave has no key in this pass (uniform)
@@ -492,21 +519,12 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
     o2 *= alpha;
     if (part == 0) s_p[wid][kl] = pj;
     __builtin_amdgcn_wave_barrier();
-    const int kbase = b0 + 16 * wid;
-    const int nk = min(16, pos - kbase);                       // > 0 here
-    const T* vp = vc + cbase + (int64_t)kbase * 128;
-    float a[16], c[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int uu = u < nk ? u : 0;
-      a[u] = Act<T>::ld(vp, (int64_t)uu * 128 + lane);
-      c[u] = Act<T>::ld(vp, (int64_t)uu * 128 + lane + 64);
-    }
+    const int nk = min(16, pos - (b0 + 16 * wid));             // > 0 here
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const float pv = u < nk ? s_p[wid][u] : 0.f;
-      o1 = fmaf(pv, a[u], o1);
-      o2 = fmaf(pv, c[u], o2);
+      o1 = fmaf(pv, Act<T>::cv(a[u]), o1);
+      o2 = fmaf(pv, Act<T>::cv(c[u]), o2);
     }
     __builtin_amdgcn_wave_barrier();
     m_run = m_new;

@@ -91,6 +91,13 @@ struct Act<float> {
   static __device__ __forceinline__ void st4(float* p, int64_t i, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  // raw loads: the value stays as stored until cv / cv4, so nothing forces a wait at the load site
+  typedef float raw1;
+  typedef float4 raw4;
+  static __device__ __forceinline__ raw1 ldr(const float* p, int64_t i) { return p[i]; }
+  static __device__ __forceinline__ raw4 ldr4(const float* p, int64_t i) { return *reinterpret_cast<const float4*>(p + i); }
+  static __device__ __forceinline__ float cv(raw1 r) { return r; }
+  static __device__ __forceinline__ void cv4(raw4 t, float (&o)[4]) { o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
 };
 template <>
 struct Act<bf16_t> {
@@ -105,6 +112,14 @@ struct Act<bf16_t> {
     ushort4 t;
     t.x = f32_to_bf16(v[0]); t.y = f32_to_bf16(v[1]); t.z = f32_to_bf16(v[2]); t.w = f32_to_bf16(v[3]);
     *reinterpret_cast<ushort4*>(p + i) = t;
+  }
+  typedef uint16_t raw1;
+  typedef ushort4 raw4;
+  static __device__ __forceinline__ raw1 ldr(const bf16_t* p, int64_t i) { return p[i].v; }
+  static __device__ __forceinline__ raw4 ldr4(const bf16_t* p, int64_t i) { return *reinterpret_cast<const ushort4*>(p + i); }
+  static __device__ __forceinline__ float cv(raw1 r) { return bf16_to_f32(r); }
+  static __device__ __forceinline__ void cv4(raw4 t, float (&o)[4]) {
+    o[0] = bf16_to_f32(t.x); o[1] = bf16_to_f32(t.y); o[2] = bf16_to_f32(t.z); o[3] = bf16_to_f32(t.w);
   }
 };
 
@@ -121,6 +136,14 @@ struct Act<f16_t> {
     ushort4 t;
     t.x = f32_to_f16(v[0]); t.y = f32_to_f16(v[1]); t.z = f32_to_f16(v[2]); t.w = f32_to_f16(v[3]);
     *reinterpret_cast<ushort4*>(p + i) = t;
+  }
+  typedef uint16_t raw1;
+  typedef ushort4 raw4;
+  static __device__ __forceinline__ raw1 ldr(const f16_t* p, int64_t i) { return p[i].v; }
+  static __device__ __forceinline__ raw4 ldr4(const f16_t* p, int64_t i) { return *reinterpret_cast<const ushort4*>(p + i); }
+  static __device__ __forceinline__ float cv(raw1 r) { return f16_to_f32(r); }
+  static __device__ __forceinline__ void cv4(raw4 t, float (&o)[4]) {
+    o[0] = f16_to_f32(t.x); o[1] = f16_to_f32(t.y); o[2] = f16_to_f32(t.z); o[3] = f16_to_f32(t.w);
   }
 };
 
@@ -233,6 +256,33 @@ __device__ __forceinline__ float ld1_in(const void* __restrict__ in, int S, int6
     return Act<T>::rnd(a);
   }
   return Act<T>::ld(reinterpret_cast<const T*>(in), i);
+}
+
+// NV values per slice in ONE pass: every load of every slice is issued before the first sum.  Separate ld4_in /
+// ld1_in calls serialise (each call's slice-count branches end in its own s_waitcnt: one HBM round trip per call —
+// six of them for q/k/v in the decode attention), and the decode row kernels are nothing but round trips.
+// Sums run in slice order per value, exactly as ld4_in / ld1_in.  V = float or float4; S >= 1.
+__device__ __forceinline__ void psg_acc(float& a, const float& b) { a += b; }
+__device__ __forceinline__ void psg_acc(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+template <typename V, int NV>
+__device__ __forceinline__ void ldn_splits(const void* __restrict__ in, int S, int64_t slice, const int64_t (&idx)[NV],
+                                           V (&o)[NV]) {
+  const float* p = reinterpret_cast<const float*>(in);
+  V t[PSG_MAX_SPLITS][NV];
+#pragma unroll
+  for (int s = 0; s < PSG_MAX_SPLITS; ++s)
+    if (s < S) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) t[s][v] = *reinterpret_cast<const V*>(p + (int64_t)s * slice + idx[v]);
+    }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) o[v] = t[0][v];
+#pragma unroll
+  for (int s = 1; s < PSG_MAX_SPLITS; ++s)
+    if (s < S) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) psg_acc(o[v], t[s][v]);
+    }
 }
 
 // dispatch on the activation dtype enum

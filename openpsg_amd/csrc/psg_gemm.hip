@@ -37,6 +37,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "psg_common.h"
@@ -203,11 +204,101 @@ struct SgdWait<UD, 0> {
   static __device__ __forceinline__ void go(int) { sgd_wait<0>(); }
 };
 
-template <typename E, int WAVES, int UD, int SGD_SLOTS, int AUX, int XDMA>
+// ---- row-operation prologues of the fused decode projections (psg_skinny_gemm_fused) ------------------------------
+// Outputs that other workgroups of the same launch read (the x operand) are stored WRITE-THROUGH: 8-byte relaxed
+// agent-scope atomic stores lower to `global_store_dwordx2 ... sc1`, so no release fence is needed before the counter.
+template <typename T>
+__device__ __forceinline__ void pro_store4(T* p, int64_t i, const float (&v)[4]) {
+  uint16_t h[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    T t;
+    Act<T>::st(&t, 0, v[e]);
+    h[e] = t.v;
+  }
+  const unsigned long long w = (unsigned long long)h[0] | ((unsigned long long)h[1] << 16) |
+                               ((unsigned long long)h[2] << 32) | ((unsigned long long)h[3] << 48);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + i), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// RMSNorm (+ residual add) of ONE row by a 512-thread workgroup, in the arithmetic ORDER of rmsnorm_kernel<T, 1>
+// launched with VT threads (psg_rmsnorm: VT = 1024 for hidden >= 4096, else 256): thread t also plays virtual thread
+// t + 512, the per-wave sums land in the virtual wave's slot and are added in slot order -> bit-identical results.
+template <typename E, int VT>
+__device__ __forceinline__ void pro_rmsnorm_row(const psg_prologue& p, int row, int M, int hidden,
+                                                typename E::act* __restrict__ xout, float* s_part, int tid) {
+  using T = typename E::act;
+  constexpr int NV = VT > 512 ? VT / 512 : 1;
+  const int lane = tid & 63, wid = tid >> 6;
+  T* resid = reinterpret_cast<T*>(p.resid);
+  float v[NV][4];
+  float4 g[NV], d4[NV];
+  typename Act<T>::raw4 vr[NV];
+  bool ok[NV];
+  int64_t idx[NV];
+  int col[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int t = tid + 512 * k;
+    ok[k] = t < VT && t * 4 < hidden;
+    col[k] = ok[k] ? t * 4 : 0;
+    idx[k] = (int64_t)row * hidden + col[k];
+    vr[k] = Act<T>::ldr4(resid, idx[k]);
+    g[k] = *reinterpret_cast<const float4*>(p.norm_w + col[k]);
+  }
+  const bool has_delta = p.in != nullptr;
+  if (has_delta) {
+    if (p.in_splits > 0) {
+      ldn_splits<float4, NV>(p.in, p.in_splits, (int64_t)M * hidden, idx, d4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        float t4[4];
+        Act<T>::ld4(reinterpret_cast<const T*>(p.in), idx[k], t4);
+        d4[k] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+      }
+    }
+  }
+  float ss[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    Act<T>::cv4(vr[k], v[k]);
+    if (has_delta) {
+      const float d[4] = {Act<T>::rnd(d4[k].x), Act<T>::rnd(d4[k].y), Act<T>::rnd(d4[k].z), Act<T>::rnd(d4[k].w)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[k][e] = Act<T>::rnd(v[k][e] + d[e]);
+    }
+    ss[k] = 0.f;
+    if (ok[k]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss[k] += v[k][e] * v[k][e];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float r = wave_sum(ss[k]);
+    if (lane == 0) s_part[wid + 8 * k] = r;
+  }
+  __syncthreads();
+  float tot = 0.f;
+  for (int i = 0; i < VT / 64; ++i) tot += s_part[i];
+  const float inv = 1.0f / sqrtf(tot / (float)hidden + p.eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (ok[k]) {
+      if (has_delta) Act<T>::st4(resid, idx[k], v[k]);          // read back by the next launch only: plain store
+      const float o[4] = {g[k].x * (v[k][0] * inv), g[k].y * (v[k][1] * inv), g[k].z * (v[k][2] * inv),
+                          g[k].w * (v[k][3] * inv)};
+      pro_store4<T>(xout, idx[k], o);
+    }
+}
+
+template <typename E, int WAVES, int UD, int SGD_SLOTS, int AUX, int XDMA, int PRO = 0>
 __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint16_t* __restrict__ x,
                                                                      const uint16_t* __restrict__ w,
                                                                      float* __restrict__ part, int M, int N, int K,
-                                                                     int xstride, long long* __restrict__ trace) {
+                                                                     int xstride, long long* __restrict__ trace,
+                                                                     const psg_prologue pro) {
   using gbf16x8_t = typename E::v8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // trace != nullptr (psg_set_trace_buffer(PSG_TRACE_SKINNY_GEMM), debugging only): 8 cycle-counter stamps per wave
@@ -256,10 +347,8 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
     if (++lb == nb) { lb = 0; ++lt; }
   };
   const int pieces = nkb * 8;
-  if constexpr (XDMA) {
-    // x slice by LDS-DMA as well: one instruction = up to 64 16-byte pieces of ONE row (lanes past the row's
-    // slice are masked off), issued ahead of the weight stream, no VGPR round trip and no ordinary load next to
-    // the DMAs (hipcc drains the whole DMA queue at every use of a plain load while a DMA is in flight)
+  auto stage_x_dma = [&](auto aux_tag) {
+    constexpr int XAUX = decltype(aux_tag)::value;
     const int cpr = (pieces + 63) >> 6;                             // 1 KiB chunks per row
     const int items = M * cpr;
     for (int it = wid; it < items; it += WAVES) {
@@ -268,12 +357,55 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
       if (c < pieces)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(x + (int64_t)r * K + (int64_t)kbA * 64 + c * 8),
-            (__attribute__((address_space(3))) void*)(xs + r * xstride + j * 1024), 16, 0, 0);
+            (__attribute__((address_space(3))) void*)(xs + r * xstride + j * 1024), 16, 0, XAUX);
     }
+  };
+  if constexpr (XDMA && PRO == 0) {
+    // x slice by LDS-DMA as well: one instruction = up to 64 16-byte pieces of ONE row (lanes past the row's
+    // slice are masked off), issued ahead of the weight stream, no VGPR round trip and no ordinary load next to
+    // the DMAs (hipcc drains the whole DMA queue at every use of a plain load while a DMA is in flight)
+    stage_x_dma(std::integral_constant<int, 0>{});
   }
   for (int i = 0; i < SGD_SLOTS - 1; ++i)
     if (i < total) issue();
   if (tr && lane == 0) tr[1] = __builtin_readcyclecounter();
+
+  if constexpr (PRO != 0) {
+    // ---- fused row operation: the first workgroups produce x while every ring fills ----
+    static_assert(XDMA == 1 && WAVES == 8, "fused prologues are built for the 8-wave LDS-DMA variant");
+    using T = typename E::act;
+    const int wg = by * G + gx;
+    float* scratch = reinterpret_cast<float*>(smem + WAVES * RING_BYTES);     // the partial-tile area, free until slab 0 ends
+    unsigned units = 0;
+    if constexpr (PRO == PSG_PRO_RMSNORM) {
+      if (wg < M) {
+        if (K >= 4096) pro_rmsnorm_row<E, 1024>(pro, wg, M, K, (T*)const_cast<uint16_t*>(x), scratch, tid);
+        else pro_rmsnorm_row<E, 256>(pro, wg, M, K, (T*)const_cast<uint16_t*>(x), scratch, tid);
+        units = 1;
+      }
+    }
+    if (tr && lane == 0) tr[6] = __builtin_readcyclecounter();      // row operation computed (or nothing to do)
+    // publish: every storing wave drains its write-through stores, then ONE lane counts the workgroup's units in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && units) __hip_atomic_fetch_add(pro.sync, units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // consume: one wave polls the ONE counter (relaxed, agent scope), bounded; x is then read with sc1 loads
+    // (write-through producer + sc1 consumer: no acquire fence, and nothing of x was cached by this launch before)
+    if (wid == 0) {
+      const unsigned want = PRO == PSG_PRO_RMSNORM ? (unsigned)M : 0u;
+      unsigned spins = 0;
+      while (__hip_atomic_load(pro.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) {                                  // ~seconds: a producer died; do not hang the GPU
+          if (lane == 0) __hip_atomic_store(pro.sync + 1, 0x5047u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (tr && lane == 0) tr[7] = __builtin_readcyclecounter();      // counter complete
+    stage_x_dma(std::integral_constant<int, 16>{});                 // aux 16 = sc1
+  }
 
   // stage x once per workgroup (plain loads -> ds_write); the DMAs above are already in flight
   // (issuing all of a thread's x loads at once, with or without a division-free row/piece mapping, was
@@ -385,8 +517,10 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
   if (tr && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tr[5] = __builtin_readcyclecounter();
-    tr[6] = nslab;
-    tr[7] = nkb;
+    if constexpr (PRO == 0) {
+      tr[6] = nslab;
+      tr[7] = nkb;
+    }
   }
 }
 
@@ -428,7 +562,7 @@ extern "C" int psg_skinny_gemm_plan(psg_ctx* ctx, int M, int N, int K, int* spli
 
 template <typename E>
 static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K, int splits,
-                     void* stream) {
+                     void* stream, const psg_prologue* pro = nullptr) {
   PSG_REQUIRE(ctx && x && w && part, PSG_ERR_INVALID, "psg_skinny_gemm: NULL argument");
   PSG_REQUIRE(M >= 1 && M <= 32, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm: M=%d (1..32 rows)", M);
   PSG_REQUIRE(N > 0 && N % 16 == 0 && K >= 64 && K % 64 == 0, PSG_ERR_UNSUPPORTED,
@@ -466,10 +600,37 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
     if (per_cu * wv > 16) per_cu = 16 / wv;               // and at most 16 waves per CU
     if (per_cu < 1) per_cu = 1;
     int Gd = (per_cu * ctx->num_cu + splits - 1) / splits;
+    if (pro) Gd = (per_cu * ctx->num_cu) / splits;        // fused hand-off: the whole grid must be resident at once
     if (Gd > nslab_d) Gd = nslab_d;
     if (Gd < 1) Gd = 1;
     dim3 gridd(Gd, splits);
     hipStream_t st = (hipStream_t)stream;
+    if (pro) {
+      PSG_REQUIRE(wv == 8 && ud == 1 && sl == 3 && ctx->opt.skinny_nt && ctx->opt.skinny_xdma, PSG_ERR_UNSUPPORTED,
+                  "psg_skinny_gemm_fused: needs the default skinny_dma=813 / nt / xdma kernel");
+      PSG_REQUIRE(Gd * splits <= per_cu * ctx->num_cu && Gd * splits >= M, PSG_ERR_UNSUPPORTED,
+                  "psg_skinny_gemm_fused: grid %d x %d cannot host the row operation (M=%d, %d CUs)", Gd, splits, M,
+                  ctx->num_cu);
+      const psg_prologue pv = *pro;
+      const int64_t trace_nf = (int64_t)Gd * splits * 8 * 8;
+      long long* trace_f = (ctx->trace_kind == PSG_TRACE_SKINNY_GEMM && ctx->trace_words >= trace_nf) ? ctx->trace : nullptr;
+#define SGD_F(PRO)                                                                                                 \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<E, 8, 1, 3, 2, 1, PRO>,                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+    skinny_gemm_dma_kernel<E, 8, 1, 3, 2, 1, PRO><<<gridd, 512, ldsd, st>>>((const uint16_t*)x, (const uint16_t*)w,   \
+                                                                           part, M, N, K, xstride, trace_f, pv);   \
+  } while (0)
+      switch (pv.kind) {
+        case PSG_PRO_RMSNORM: SGD_F(PSG_PRO_RMSNORM); break;
+        default:
+          psg_set_error("psg_skinny_gemm_fused: prologue kind %d not built", pv.kind);
+          return PSG_ERR_UNSUPPORTED;
+      }
+#undef SGD_F
+      PSG_CHECK_LAUNCH("psg_skinny_gemm_fused");
+      return PSG_OK;
+    }
     // per-wave stamps go to the caller's buffer (psg_set_trace_buffer) when it is large enough
     const int64_t trace_n = (int64_t)Gd * splits * wv * 8;
     long long* trace = (ctx->trace_kind == PSG_TRACE_SKINNY_GEMM && ctx->trace_words >= trace_n) ? ctx->trace : nullptr;
@@ -480,7 +641,7 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
     (void)hipFuncSetAttribute((const void*)skinny_gemm_dma_kernel<E, WV, UD, SL, AUX, XD>,                            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
     skinny_gemm_dma_kernel<E, WV, UD, SL, AUX, XD><<<gridd, WV * 64, ldsd, st>>>(                                     \
-        (const uint16_t*)x, (const uint16_t*)w, part, M, N, K, xstride, trace);                                    \
+        (const uint16_t*)x, (const uint16_t*)w, part, M, N, K, xstride, trace, psg_prologue{});                    \
   } while (0)
 #define SGD(WV, UD, SL)                                                                                            \
   do {                                                                                                             \
@@ -504,6 +665,7 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
     PSG_CHECK_LAUNCH("psg_skinny_gemm(dma)");
     return PSG_OK;
   }
+  PSG_REQUIRE(!pro, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm_fused: N=%d K=%d is below the LDS-DMA kernel's range", N, K);
   dim3 grid(G, splits);
   skinny_gemm_kernel<E><<<grid, 256, lds, (hipStream_t)stream>>>((const uint16_t*)x, (const uint16_t*)w, part, M, N, K,
                                                               xstride);
@@ -514,6 +676,19 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
 extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K,
                                int splits, int dtype, void* stream) {
   PSG_DISPATCH_E16(dtype, "psg_skinny_gemm", return sg_launch<E>(ctx, x, w, part, M, N, K, splits, stream));
+}
+
+extern "C" int psg_skinny_gemm_fused(psg_ctx* ctx, const psg_prologue* pro, void* x, const void* w, float* part, int M,
+                                     int N, int K, int splits, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && pro && pro->sync, PSG_ERR_INVALID, "psg_skinny_gemm_fused: NULL argument");
+  if (pro->kind == PSG_PRO_RMSNORM) {
+    PSG_REQUIRE(pro->resid && pro->norm_w, PSG_ERR_INVALID, "psg_skinny_gemm_fused(rmsnorm): NULL resid / norm_w");
+    PSG_REQUIRE(K == 4096 || (K <= 1024 && K % 4 == 0), PSG_ERR_UNSUPPORTED,
+                "psg_skinny_gemm_fused(rmsnorm): hidden=%d (built for 4096 and <= 1024)", K);
+    PSG_REQUIRE(pro->in_splits >= 0 && pro->in_splits <= PSG_MAX_SPLITS, PSG_ERR_INVALID,
+                "psg_skinny_gemm_fused: in_splits=%d", pro->in_splits);
+  }
+  PSG_DISPATCH_E16(dtype, "psg_skinny_gemm_fused", return sg_launch<E>(ctx, x, w, part, M, N, K, splits, stream, pro));
 }
 
 // y[i] = sum_s part[s][i] in split order, converted to the activation dtype (tests, generic consumers)

@@ -285,14 +285,24 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, co
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthr = blockDim.x;
   float v[NCH][4], d[NCH][4];
   float4 g[NCH];
+  typename Act<T>::raw4 vr[NCH];                              // converted after the partials are requested: no early wait
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * nthr + tid) * 4;
     if (col < hidden) {
-      Act<T>::ld4(resid, row * hidden + col, v[c]);
-      if (delta) ld4_in<T>(delta, dsplits, dslice, row * hidden + col, d[c]);
+      vr[c] = Act<T>::ldr4(resid, row * hidden + col);
       g[c] = *reinterpret_cast<const float4*>(w + col);
     }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden && delta) ld4_in<T>(delta, dsplits, dslice, row * hidden + col, d[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden) Act<T>::cv4(vr[c], v[c]);
   }
   float ss = 0.f;
 #pragma unroll
@@ -421,15 +431,23 @@ extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, int qkv_splits, 
 
 // ---- SwiGLU gate ------------------------------------------------------------------------------
 template <typename T>
-__global__ void silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows, int inter, T* __restrict__ out) {
+__global__ void __launch_bounds__(256) silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows, int inter, T* __restrict__ out) {
   const int64_t n4 = rows * inter / 4;
   const int i4 = inter / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / i4;
     const int c = (int)(i % i4) * 4;
     float g[4], u[4], o[4];
-    ld4_in<T>(gu, S, rows * 2 * inter, r * 2 * inter + c, g);
-    ld4_in<T>(gu, S, rows * 2 * inter, r * 2 * inter + inter + c, u);
+    if (S > 0) {                                              // gate and up partials of all slices in one pass
+      const int64_t idx[2] = {r * 2 * inter + c, r * 2 * inter + inter + c};
+      float4 gu4[2];
+      ldn_splits<float4, 2>(gu, S, rows * 2 * inter, idx, gu4);
+      g[0] = Act<T>::rnd(gu4[0].x); g[1] = Act<T>::rnd(gu4[0].y); g[2] = Act<T>::rnd(gu4[0].z); g[3] = Act<T>::rnd(gu4[0].w);
+      u[0] = Act<T>::rnd(gu4[1].x); u[1] = Act<T>::rnd(gu4[1].y); u[2] = Act<T>::rnd(gu4[1].z); u[3] = Act<T>::rnd(gu4[1].w);
+    } else {
+      Act<T>::ld4(reinterpret_cast<const T*>(gu), r * 2 * inter + c, g);
+      Act<T>::ld4(reinterpret_cast<const T*>(gu), r * 2 * inter + inter + c, u);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float s = g[e] / (1.0f + expf(-g[e]));

@@ -57,6 +57,11 @@ class LlamaDecodeEngine:
                 wdown=act(weights[p + "mlp.down_proj.weight"]),
                 ln1=f32(p + "input_layernorm.weight"), ln2=f32(p + "post_attention_layernorm.weight")))
         self.use_skinny = True
+        # row operations that run as the PROLOGUE of the projection that consumes them (one launch instead of two;
+        # psg_skinny_gemm_fused).  Built for "rmsnorm", bit-identical, and OFF by default: measured 26.6 vs 25.6 us
+        # per (RMSNorm + q/k/v projection), 75.2 vs 74.0 ms per image - the in-launch hand-off (write-through
+        # publish, counter, poll, x staged after it) costs what the separate launch costs
+        self.fuse_rowops = frozenset(os.environ.get("PSG_FUSE_ROWOPS", "none").replace(",", " ").split()) - {"none"}
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
         self.early_exit_chunk = 4        # natural-EOS decode: steps per graph between "all pairs done?" checks
         self.last_replays = 0
@@ -116,6 +121,49 @@ class LlamaDecodeEngine:
             nxt = self.layers[l + 1]["ln1"] if l + 1 < len(self.layers) else self.final_norm
             ops.rmsnorm(resid, d, nxt, m.rms_eps, n)                           # resid += d ; n = norm(resid)
         return n
+
+    def _can_fuse(self, rows):
+        m = self.cfg.llm
+        D = m.hidden
+        return (bool(self.fuse_rowops) and self.use_skinny and self.dtype in (torch.bfloat16, torch.float16)
+                and rows <= 32 and D in (1024, 4096) and m.inter >= 1024 and m.inter % 64 == 0
+                and m.vocab >= 1024 and m.vocab % 16 == 0)
+
+    def _decode_step_fused(self, st, sync):
+        """One decode step with the row operations named in `fuse_rowops` folded into the projection that consumes
+        them (same arithmetic, same order: bit-identical to the separate kernels).  Returns the lm_head partials.
+        sync: int32 [>= 2 * (4 * layers + 1)], zeroed."""
+        m = self.cfg.llm
+        x = st["x"]                                            # residual stream [K, D], embedding of the new tokens
+        K = x.shape[0]
+        n = torch.empty_like(x)
+        att = torch.empty_like(x)
+        act = torch.empty((K, m.inter), device=self.device, dtype=self.dtype)
+        f = self.fuse_rowops
+        slot = [0]
+
+        def words():
+            w = sync[2 * slot[0]:2 * slot[0] + 2]
+            slot[0] += 1
+            return w
+
+        def norm_proj(delta, ln, w):                           # x += delta ; n = norm(x) ; n @ w.T
+            if "rmsnorm" in f:
+                return ops.skinny_gemm_fused(ops.PSG_PRO_RMSNORM, n, w, words(), inp=delta, resid=x, norm_w=ln,
+                                             eps=m.rms_eps)
+            ops.rmsnorm(x, delta, ln, m.rms_eps, n)
+            return ops.skinny_gemm(n, w)
+
+        delta = None
+        for l, L in enumerate(self.layers):
+            qkv = norm_proj(delta, L["ln1"], L["wqkv"])
+            ops.decode_attn(qkv, st["dec_pair"], st["dec_pos"], self.rope, m.heads, m.head_dim, st["ctx_len"],
+                            st["kc"][l], st["vc"][l], att)
+            o = ops.skinny_gemm(att, L["wo"])
+            gu = norm_proj(o, L["ln2"], L["wgu"])
+            ops.silu_mul(gu, act)
+            delta = ops.skinny_gemm(act, L["wdown"])
+        return norm_proj(delta, self.final_norm, self.lm_head)
 
     def build_inputs(self, pair_feature_rows, prompt_ids, prompt_len):
         """V4:294-301 for all K pairs.  pair_feature_rows [K*32, 768] (activation dtype),
@@ -257,9 +305,16 @@ class LlamaDecodeEngine:
     def _steps(self, st, lo, hi):
         """Decode steps lo .. hi-1 (step s writes tokens[:, s])."""
         m = self.cfg.llm
+        fused = self._can_fuse(st["x"].shape[0]) and hi > lo
+        if fused:                                              # two counter words per fused launch, zeroed once per call
+            per_step = 2 * (4 * len(self.layers) + 1)
+            sync = torch.zeros((hi - lo) * per_step, device=self.device, dtype=torch.int32)
         for step in range(lo, hi):
             ops.gather_rows(self.embed, st["next_ids"], st["x"])
-            h = self._forward(st["x"], st["dec_pair"], st["dec_pos"], st["kc"], st["vc"], st["ctx_len"], decode=True)
-            logits = self.linear(h, self.lm_head)
+            if fused:
+                logits = self._decode_step_fused(st, sync[(step - lo) * per_step:(step - lo + 1) * per_step])
+            else:
+                h = self._forward(st["x"], st["dec_pair"], st["dec_pos"], st["kc"], st["vc"], st["ctx_len"], decode=True)
+                logits = self.linear(h, self.lm_head)
             ops.greedy_step(logits, step, st["max_new"], m.eos, st["sup"], st["tokens"], st["done"], st["next_ids"],
                             st["dec_pos"], dtype=self.dtype)

@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from ._lib import PSG_PRO_RMSNORM, PSG_PRO_DECODE_ATTN, PSG_PRO_SILU_MUL  # noqa: F401
 from ._lib import (PSG_BF16, PSG_F16, PSG_F32, PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED, PSG_XATTN_MFMA,
                    PSG_XATTN_SIMPLE, PsgHipError, check)
 
@@ -341,6 +342,42 @@ def skinny_gemm(x, w, splits=None) -> Partials:
         raise PsgHipError(f"skinny_gemm: x / w must both be bf16 or fp16, got {x.dtype} / {w.dtype}")
     check(lib.psg_skinny_gemm(ctx, _p(x, name="x"), _p(w, name="w"), _p(part), M, N, K, splits, _dt(x), st),
           "psg_skinny_gemm")
+    return Partials(part)
+
+
+def skinny_gemm_fused(kind, x_out, w, sync, *, inp=None, resid=None, norm_w=None, eps=0.0, attn=None, splits=None):
+    """Decode projection with its producer row operation in the same launch (psg_skinny_gemm_fused):
+    the prologue `kind` computes x_out [M, K] from `inp` (Partials / activation tensor / None), then
+    part = x_out @ w.T as in `skinny_gemm`.  sync: two zeroed int32 device words owned by this launch.
+    attn = (tok_pair, tok_pos, rope, heads, ctx_len, k_cache, v_cache) for the decode-attention prologue."""
+    import ctypes
+    from ._lib import Prologue
+    lib, ctx, st = _env(x_out)
+    M, K = x_out.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and w.dtype == x_out.dtype and sync.dtype == torch.int32 and sync.numel() >= 2
+    if splits is None:
+        s = ctypes.c_int(0)
+        check(lib.psg_skinny_gemm_plan(ctx, M, N, K, ctypes.byref(s)), "psg_skinny_gemm_plan")
+        splits = s.value
+    pro = Prologue()
+    pro.kind = int(kind)
+    if inp is not None:
+        pro.input, pro.in_splits = _in(inp, x_out.dtype)
+    if resid is not None:
+        pro.resid = _p(resid, x_out.dtype)
+        pro.norm_w = _p(norm_w, torch.float32)
+        pro.eps = float(eps)
+    if attn is not None:
+        tok_pair, tok_pos, rope, heads, ctx_len, kc, vc = attn
+        pro.tok_pair, pro.tok_pos = _p(tok_pair, torch.int32), _p(tok_pos, torch.int32)
+        pro.rope_cos, pro.rope_sin = _p(rope[0], torch.float32), _p(rope[1], torch.float32)
+        pro.heads, pro.ctx = int(heads), int(ctx_len)
+        pro.k_cache, pro.v_cache = _p(kc, x_out.dtype), _p(vc, x_out.dtype)
+    pro.sync = sync.data_ptr()
+    part = torch.empty((splits, M, N), device=x_out.device, dtype=torch.float32)
+    check(lib.psg_skinny_gemm_fused(ctx, ctypes.byref(pro), _p(x_out), _p(w), _p(part), M, N, K, splits, _dt(x_out), st),
+          "psg_skinny_gemm_fused")
     return Partials(part)
 
 
