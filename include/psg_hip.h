@@ -225,9 +225,11 @@ int psg_reduce_partials(psg_ctx*, const float* part, int splits, int64_t n, void
  * projection's own grid run the row operation while every workgroup's weight ring fills, publish the x operand
  * write-through, and the grid waits on ONE arrival counter before it stages x (agent-scope hand-off inside the launch;
  * the grid is sized to be fully resident and the producers never wait, so it cannot deadlock; the poll is bounded).
- *   kind RMSNORM     : in = split-K partials of the previous projection (or NULL), resid += sum(in); x = norm(resid)
- *   kind DECODE_ATTN : in = q/k/v partials [in_splits][M][3*K]; rotary, cache append, attention; x = context
- *   kind SILU_MUL    : in = gate/up partials [in_splits][M][2*K]; x = silu(gate) * up
+ *   kind RMSNORM     : in = split-K partials of the previous projection (or NULL), resid += sum(in); x = norm(resid);
+ *                      same arithmetic order as psg_rmsnorm: bit-identical.  K = 4096 or 1024.
+ *   kinds DECODE_ATTN / SILU_MUL: fields reserved, rejected with PSG_ERR_UNSUPPORTED - measured on MI355X the hand-off
+ *   costs as much as the launch it removes (26.6 vs 25.6 us per RMSNorm + q/k/v projection), so the engine keeps the
+ *   separate launches by default (llm.fuse_rowops) and the other two prologues were not built.
  * x [M][K] (activation dtype) is written by the prologue and then read as the GEMM operand.
  * sync: two device words the CALLER zeroes before the launch (stream-ordered memset; one pair per launch inside a
  * captured graph): [0] arrival counter, [1] set to a nonzero code if the bounded poll gave up. */
