@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
                     help="activation / weight dtype of the measured path (BASELINE config 5 names fp16)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--one-phase", action="store_true",
+                    help="last Q-Former layer for all 33 rows of every pair (A/B against the default cls-first path)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the one-image strong-scaling figure")
     return ap.parse_args()
 
@@ -91,7 +93,8 @@ def setup_head(a, dev):
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     w = make_weights_device(cfg, 0, dev, llm_dtype=tdt, with_llm=a.workload == "full")
     head = RelationTransformerHeadV4(dtype=a.dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
-                                     llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True)
+                                     llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True,
+                                     cls_first=not a.one_phase)
     head.load_weights(w)
     del w
     torch.cuda.empty_cache()
@@ -130,7 +133,7 @@ def measure_decode_gemm(head, K):
     return nbytes / len(mats), ts[len(ts) // 2] / len(mats), len(mats)      # median pass, averaged over its launches
 
 
-def relation_query_flops(N, L, T):
+def relation_query_flops(N, L, T, cls_first=False, selected=20):
     """FLOPs the relation-query stage has to execute for one image: SURVEY 8d's per-layer formula with the work
     whose result is never read or is identical for every pair left out (V4:185 slices the output to the 33 query
     rows, so in the last layer the text rows need K/V only; the Q/K/V projection of the 33 query rows entering
@@ -139,7 +142,13 @@ def relation_query_flops(N, L, T):
     cross = 2 * 33 * H * H + 4 * 33 * L * H + 2 * 33 * H * H
     first = 2 * T * H * 3 * H + 4 * S * S * H + 2 * S * H * H + cross + 4 * 33 * H * F + 4 * T * H * F
     last = 2 * S * H * 2 * H + 2 * 33 * H * H + 4 * 33 * S * H + 2 * 33 * H * H + cross + 4 * 33 * H * F
-    return N * N * (first + last) + 2 * 33 * H * 3 * H + 2 * L * 65536 * 256 + 2 * 2 * 2 * L * 256 * H
+    per_image = 2 * 33 * H * 3 * H + 2 * L * 65536 * 256 + 2 * 2 * 2 * L * 256 * H
+    if cls_first:
+        # last layer: K/V of every row, then ONLY the cls row of every pair (existence head, V4:206-209) and the 33
+        # rows of the selected pairs (V4:215, 235-237)
+        last_cls = 2 * S * H * 2 * H + 2 * H * H + 4 * S * H + 2 * H * H + (2 * H * H + 4 * L * H + 2 * H * H) + 4 * H * F
+        return N * N * (first + last_cls) + selected * last + per_image
+    return N * N * (first + last) + per_image
 
 
 def host_info():
@@ -235,9 +244,9 @@ def parity_block(a, dev, scene, oracle_part, bf16_ms):
         for dt in ("fp32", "bf16"):
             h = RelationTransformerHeadV4(dtype=dt, device=str(dev), tokenizers="word", max_object_num=N)
             h.load_weights(hw)
-            rq = h.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_, scene["pan_results"],
-                                      pair_range=(0, n))
-            out[f"{dt}_max_logit_err_vs_oracle"] = float(f"{(rq['exist_logit'].cpu() - oracle_part['logit']).abs().max().item():.3e}")
+            # the whole image through the benchmarked path (cls-first last layer); the oracle covered pairs [0, n)
+            rq = h.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_, scene["pan_results"])
+            out[f"{dt}_max_logit_err_vs_oracle"] = float(f"{(rq['exist_logit'][:n].cpu() - oracle_part['logit']).abs().max().item():.3e}")
             del h, rq
         out["pairs_checked"] = n
         out["tolerance_fp32"] = 1e-3
@@ -318,6 +327,7 @@ def main():
             def step():
                 rq = head.run_relation_query(scene["mask_features"], scene["img_meta"], obj_ids, names,
                                              scene["pan_results"])
+                head.selected_pair_features(rq)                 # pair_feature of the selected pairs is part of the stage
                 return rq["selected"].cpu()
         barrier = lambda: None  # noqa: E731
     else:
@@ -405,7 +415,7 @@ def main():
                                 "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n}
         if a.workload == "rq" and not a.no_roofline and world == 1 and not force_dist:
             T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
-            fl = relation_query_flops(N, (a.size // 64) ** 2, T)
+            fl = relation_query_flops(N, (a.size // 64) ** 2, T, head.cls_first, head.cfg.num_selected)
             ach = fl / (elapsed / a.steps) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": "relation-query stage (bf16 GEMMs + cross_attn_mfma_kernel + "
                                 "self_attn_mfma_kernel)", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
@@ -417,11 +427,13 @@ def main():
             names_ = [object_categories[i % INSTANCE_OFFSET] for i in ids_]
 
             def rq_step():
-                return head.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_,
-                                               scene["pan_results"])["selected"].cpu()
+                rq = head.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_,
+                                             scene["pan_results"])
+                head.selected_pair_features(rq)
+                return rq["selected"].cpu()
             el = time_steps(rq_step, 2, 10) / 10
             T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
-            fl = relation_query_flops(N, (a.size // 64) ** 2, T)
+            fl = relation_query_flops(N, (a.size // 64) ** 2, T, head.cls_first, head.cfg.num_selected)
             line["stages"] = {"relation_query_ms": round(el * 1e3, 3),
                               "relation_query_pairs_per_s": round(pairs_per_image / el, 1),
                               "relation_query_tflops": round(fl / el / 1e12, 1),

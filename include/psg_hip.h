@@ -126,6 +126,14 @@ int psg_qformer_self_attn(psg_ctx*, const void* qkv, const uint8_t* text_mask, i
 int psg_qformer_self_attn_shared(psg_ctx*, const void* qkv_query, const void* qkv_text,
                                  const uint8_t* text_mask, int B, int T, int nq, int heads, void* out,
                                  int dtype, void* stream);
+/* Last layer, selection phase: attention of the cls row (row 0) of every pair over the pair's nq + T keys - all that the
+ * existence head (V4:206-209) and therefore the selector (V4:235-237) can observe of the last layer's query rows 0.
+ * q_cls [B][hidden]: projected queries of the cls rows; kv [B*(nq+T)][2*hidden]: K | V projections of every row (rows
+ * ordered as in psg_qformer_self_attn; the queries of rows 1..32 are never projected); out [B][hidden] COMPACT.
+ * Rows 1..32 are then computed for the selected pairs only (psg_qformer_self_attn on the gathered pairs): results
+ * identical, 97 % of the last layer's query-row work gone. */
+int psg_qformer_self_attn_cls(psg_ctx*, const void* q_cls, const void* kv, const uint8_t* text_mask, int B, int T,
+                              int nq, int heads, void* out, int dtype, void* stream);
 
 /* ---- K6: relation-query cross-attention (primary kernel), HF-IB:464-466, 487-496 with the
  * V4:168-170 expand removed: K/V [L][hidden] are projected ONCE per image and shared by every

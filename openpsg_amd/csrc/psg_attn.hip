@@ -18,10 +18,13 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // V[j][d] for all j lives in lane d.  Per query row: 64 readlane+fma for q.K^T, a wave softmax,
 // 64 readlane+fma for P.V.  No LDS, no inter-wave traffic.
 // ---------------------------------------------------------------------------------------------
+// q_cls != nullptr (cls-only mode): queries come from the compact [B][hidden] tensor q_cls, and `qkv` holds K | V only
+// ([rows][2*hidden]: the last layer's selection phase never projects the queries of rows 1..32).
 template <typename T>
 __global__ void __launch_bounds__(256) qformer_self_attn_kernel(const T* __restrict__ qkv,
                                                                 const uint8_t* __restrict__ text_mask, int B, int Tt,
-                                                                int nq, int heads, int q_only, T* __restrict__ out) {
+                                                                int nq, int heads, int q_only, T* __restrict__ out,
+                                                                const T* __restrict__ q_cls = nullptr) {
   const int unit = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int lane = threadIdx.x & 63;
   if (unit >= B * heads) return;
@@ -31,6 +34,8 @@ __global__ void __launch_bounds__(256) qformer_self_attn_kernel(const T* __restr
   const int64_t qrow0 = (int64_t)p * nq;                      // query rows of this pair
   const int64_t trow0 = (int64_t)B * nq + (int64_t)p * Tt;    // text rows of this pair
   auto row_of = [&](int j) -> int64_t { return j < nq ? qrow0 + j : trow0 + (j - nq); };
+  const int rs = q_cls ? 2 * hidden : 3 * hidden;             // row stride of `qkv`
+  const int koff = q_cls ? 0 : hidden, voff = q_cls ? hidden : 2 * hidden;
 
   // K^T: lane j reads its own key row (64 contiguous elements)
   float kreg[64];
@@ -38,7 +43,7 @@ __global__ void __launch_bounds__(256) qformer_self_attn_kernel(const T* __restr
   if (valid && lane >= nq) valid = text_mask[(int64_t)p * Tt + (lane - nq)] != 0;
   {
     const int64_t r = row_of(lane < S ? lane : 0);
-    const T* kp = qkv + r * 3 * hidden + hidden + h * 64;
+    const T* kp = qkv + r * rs + koff + h * 64;
 #pragma unroll
     for (int d = 0; d < 64; d += 4) {
       float t[4];
@@ -51,12 +56,13 @@ __global__ void __launch_bounds__(256) qformer_self_attn_kernel(const T* __restr
 #pragma unroll
   for (int j = 0; j < 64; ++j) {
     vreg[j] = 0.f;
-    if (j < S) vreg[j] = Act<T>::ld(qkv, row_of(j) * 3 * hidden + 2 * hidden + h * 64 + lane);
+    if (j < S) vreg[j] = Act<T>::ld(qkv, row_of(j) * rs + voff + h * 64 + lane);
   }
-  const int nrows = q_only ? nq : S;
+  // q_only: 0 = every row, 1 = the nq query rows, 2 = the cls row (row 0) only, written COMPACT to out[p]
+  const int nrows = q_only == 2 ? 1 : (q_only ? nq : S);
   for (int i = 0; i < nrows; ++i) {
     const int64_t r = row_of(i);
-    const float qv = Act<T>::ld(qkv, r * 3 * hidden + h * 64 + lane);
+    const float qv = q_cls ? Act<T>::ld(q_cls, (int64_t)p * hidden + h * 64 + lane) : Act<T>::ld(qkv, r * 3 * hidden + h * 64 + lane);
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < 64; ++d) s = fmaf(readlane_f(qv, d), kreg[d], s);
@@ -72,7 +78,7 @@ __global__ void __launch_bounds__(256) qformer_self_attn_kernel(const T* __restr
 #pragma unroll
     for (int j = 0; j < 64; ++j)
       if (j < S) o = fmaf(readlane_f(pr, j), vreg[j], o);
-    Act<T>::st(out, r * hidden + h * 64 + lane, o);
+    Act<T>::st(out, (q_only == 2 ? (int64_t)p : r) * hidden + h * 64 + lane, o);
   }
 }
 
@@ -93,6 +99,135 @@ extern "C" int psg_qformer_self_attn(psg_ctx* ctx, const void* qkv, const uint8_
                      (qformer_self_attn_kernel<T><<<(unsigned)((units + 3) / 4), 256, 0, (hipStream_t)stream>>>(
                          (const T*)qkv, text_mask, B, T_, nq, heads, query_rows_only, (T*)out)));
   PSG_CHECK_LAUNCH("psg_qformer_self_attn");
+  return PSG_OK;
+}
+
+// cls-row attention for the last layer's selection phase, streaming version: ONE wave per pair, lane l < hidden/16 owns
+// 16 consecutive features (4 lanes = one head), so a key row is one 2 x 16-byte (bf16) request per lane - the scalar
+// kernel above, run per (pair, head) with 2-byte value gathers, took 285 us for 2500 pairs; this one is bound by the
+// 361 MB of K | V it reads.  Scores of a head live in the registers of its 4 lanes (quad reduce, no wave reductions),
+// the output features accumulate in the lane that stores them; 8 key rows are requested per step before the first
+// one is used; the probabilities pass through a per-wave LDS table.
+template <typename T>
+__global__ void __launch_bounds__(256) qformer_self_attn_cls_kernel(const T* __restrict__ q_cls, const T* __restrict__ kv,
+                                                                    const uint8_t* __restrict__ text_mask, int B, int Tt,
+                                                                    int nq, int heads, T* __restrict__ out) {
+  __shared__ float s_sc[4][16][64];                             // [wave][quad = head][key]
+  const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (p >= B) return;                                           // whole wave
+  const int hidden = heads * 64, S = nq + Tt;
+  const bool on = lane < hidden / 16;
+  const int e0 = (on ? lane : 0) * 16;
+  const int64_t qrow0 = (int64_t)p * nq, trow0 = (int64_t)B * nq + (int64_t)p * Tt;
+  auto row_of = [&](int j) -> int64_t {
+    j = j < S ? j : S - 1;
+    return j < nq ? qrow0 + j : trow0 + (j - nq);
+  };
+  bool kvalid = lane < S;
+  if (kvalid && lane >= nq) kvalid = text_mask[(int64_t)p * Tt + (lane - nq)] != 0;
+  const unsigned long long valid64 = __ballot(kvalid);
+  float qv[16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float t[4];
+    Act<T>::ld4(q_cls, (int64_t)p * hidden + e0 + 4 * c, t);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qv[4 * c + e] = t[e];
+  }
+  float* my = &s_sc[wv][lane >> 2][0];
+  const int nch = (S + 7) >> 3;
+#pragma unroll 1
+  for (int ch = 0; ch < nch; ++ch) {
+    typename Act<T>::raw4 kr[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const T* kp = kv + row_of(ch * 8 + u) * 2 * hidden + e0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) kr[u][c] = Act<T>::ldr4(kp, 4 * c);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float t[4];
+        Act<T>::cv4(kr[u][c], t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = fmaf(qv[4 * c + e], t[e], a);
+      }
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      const int j = ch * 8 + u;
+      a *= 0.125f;                                              // 1/sqrt(64)
+      a = ((valid64 >> j) & 1ull) ? a : PSG_FMIN;               // additive finfo.min absorbs the score
+      if ((lane & 3) == 0) my[j] = j < S ? a : -INFINITY;       // j >= S: not a key at all
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int nk = nch * 8;
+  float m = -INFINITY;
+  for (int j = 0; j < nk; ++j) m = fmaxf(m, my[j]);
+  float denom = 0.f;
+  for (int j = 0; j < nk; ++j) denom += expf(my[j] - m);
+  __builtin_amdgcn_wave_barrier();
+  if ((lane & 3) == 0)
+    for (int j = 0; j < nk; ++j) my[j] = Act<T>::rnd(expf(my[j] - m) / denom);
+  __builtin_amdgcn_wave_barrier();
+  float o[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll 1
+  for (int ch = 0; ch < nch; ++ch) {
+    typename Act<T>::raw4 vr[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const T* vp = kv + row_of(ch * 8 + u) * 2 * hidden + hidden + e0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vr[u][c] = Act<T>::ldr4(vp, 4 * c);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float pj = my[ch * 8 + u];                          // 0 for j >= S (exp(-inf))
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float t[4];
+        Act<T>::cv4(vr[u][c], t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[4 * c + e] = fmaf(pj, t[e], o[4 * c + e]);
+      }
+    }
+  }
+  if (on) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float t[4] = {o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]};
+      Act<T>::st4(out, (int64_t)p * hidden + e0 + 4 * c, t);
+    }
+  }
+}
+
+// Last-layer, first phase: only the cls row (row 0) of every pair feeds the existence head (V4:206-209), so its
+// attention over the pair's nq + T keys is all the selection needs; out [B][hidden] is compact (one row per pair).
+// The rows 1..32 of the SELECTED pairs are computed afterwards by the ordinary kernel on the gathered pairs.
+extern "C" int psg_qformer_self_attn_cls(psg_ctx* ctx, const void* q_cls, const void* kv, const uint8_t* text_mask, int B,
+                                         int T_, int nq, int heads, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && q_cls && kv && out && (text_mask || T_ == 0), PSG_ERR_INVALID,
+              "psg_qformer_self_attn_cls: NULL argument");
+  PSG_REQUIRE(B > 0 && T_ >= 0 && nq > 0 && heads > 0 && nq + T_ <= 64, PSG_ERR_INVALID,
+              "psg_qformer_self_attn_cls: B=%d T=%d nq=%d", B, T_, nq);
+  if (heads * 64 <= 1024) {                                     // one wave per pair, 16 features per lane
+    PSG_DISPATCH_DTYPE(dtype, "psg_qformer_self_attn_cls",
+                       (qformer_self_attn_cls_kernel<T><<<(unsigned)((B + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+                           (const T*)q_cls, (const T*)kv, text_mask, B, T_, nq, heads, (T*)out)));
+    PSG_CHECK_LAUNCH("psg_qformer_self_attn_cls");
+    return PSG_OK;
+  }
+  int64_t units = (int64_t)B * heads;
+  PSG_DISPATCH_DTYPE(dtype, "psg_qformer_self_attn_cls",
+                     (qformer_self_attn_kernel<T><<<(unsigned)((units + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+                         (const T*)kv, text_mask, B, T_, nq, heads, 2, (T*)out, (const T*)q_cls)));
+  PSG_CHECK_LAUNCH("psg_qformer_self_attn_cls");
   return PSG_OK;
 }
 

@@ -95,7 +95,9 @@ class HipBackend:
     def query_shard(self, scene, patches, p0, p1):
         rq = self.head.run_relation_query(scene["mask_features"], scene["img_meta"], self._ids(scene), self._names(scene),
                                           scene["pan_results"], pair_range=(p0, p1), patches=patches)
-        return rq["hidden"], rq["exist_prob"]
+        # cls-first head: the "hidden" handle is the pending selection-phase state (rows 1..32 are computed for the
+        # selected pairs only, in gather_features)
+        return (rq if "pending" in rq else rq["hidden"]), rq["exist_prob"]
 
     def query_shards(self, scenes, patches, p0, p1):
         """The shard [p0, p1) of every image in ONE Q-Former pass (per-image cross-attention only)."""
@@ -110,6 +112,12 @@ class HipBackend:
 
     def gather_features(self, hidden, rows):
         from . import ops
+        if isinstance(hidden, dict):                  # pending selection phase: rows = local pair * 33 + 1 + v, or -1
+            nv = self.q_rows - 1
+            r0 = rows.view(-1, nv)[:, 0].to(torch.int64)
+            p0 = hidden["pair_range"][0]
+            sel = torch.where(r0 >= 0, (r0 - 1) // self.q_rows + p0, torch.full_like(r0, -1))
+            return self.head.selected_pair_features(hidden, sel, zero_foreign=True)
         out = torch.empty((rows.numel(), self.hidden), device=self.device, dtype=self.feat_dtype)
         if hidden.shape[0] == 0:                      # empty shard: nothing owned here
             return out.zero_()

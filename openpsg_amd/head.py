@@ -45,6 +45,21 @@ def _set_nested(root: nn.Module, dotted: str, tensor: torch.Tensor):
     mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
+class _LazyRQ(dict):
+    """Relation-query result of the cls-first path: `hidden` (the last layer's 33 rows of EVERY pair) is not part
+    of the inference path any more; a reader that asks for it (tests, tools) gets it computed on demand."""
+    engine = None
+
+    def __missing__(self, key):
+        if key != "hidden":
+            raise KeyError(key)
+        hs = [self.engine.pair_hidden(st, torch.arange(off, off + c1 - c0, device=st["X"].device, dtype=torch.int32))
+              for c0, c1, st, off in self["pending"]]
+        h = hs[0] if len(hs) == 1 else torch.cat(hs)
+        self[key] = h
+        return h
+
+
 @HEADS.register_module()
 class RelationTransformerHeadV4(nn.Module):
     # What `tokenizers=None` / `device=None` resolve to.  A config dict such as the reference's
@@ -96,6 +111,8 @@ class RelationTransformerHeadV4(nn.Module):
                  exclude_diagonal=False,       # the reference never excludes the i == j pairs
                  max_selected=32,              # cap of the threshold selector (one decode batch)
                  prompt_bucket=8,              # Llama prompt grid rounded up to a multiple of this (graph reuse)
+                 cls_first=True,               # last Q-Former layer: cls row of every pair -> selection -> rows 1..32
+                                               # of the selected pairs only (same results; qformer.forward_pairs_cls)
                  **kwargs):
         super().__init__()
         if rel_cls_type != 'binary':
@@ -124,6 +141,7 @@ class RelationTransformerHeadV4(nn.Module):
         self.max_llm_forward_num = max_llm_forward_num
         self.max_selected = int(max_selected)
         self.prompt_bucket = int(prompt_bucket)
+        self.cls_first = bool(cls_first)
         self.act_dtype = _DTYPES[dtype]
         self.device = torch.device(self.default_device if device is None else device)
         if tokenizers is None:
@@ -274,7 +292,8 @@ class RelationTransformerHeadV4(nn.Module):
         if is_generation is None:
             is_generation = True
         out = self.decode_selected(rq, names) if is_generation else dict(tokens=None)
-        self.last = dict(rq, **out)
+        rq.update(out)                                        # keeps a lazy rq lazy (`hidden` on demand)
+        self.last = rq
         rel_pred, rel_score = self.parse(out["tokens_host"], out["selected_host"], N) if is_generation else ([], [])
         return dict(rel_pred=rel_pred, rel_score=rel_score)
 
@@ -500,6 +519,23 @@ class RelationTransformerHeadV4(nn.Module):
         p0, p1 = (0, B) if pair_range is None else pair_range
         q = self.cfg.qformer
         single = 0 < p1 - p0 <= self.pair_chunk                  # one chunk: take the engine's outputs as they are
+        if self.cls_first and p1 > p0:
+            # selection phase first (per chunk of pairs), the selected pairs' rows 1..32 on demand
+            pending, lgs, prs = [], [], []
+            for c0 in range(p0, p1, self.pair_chunk):
+                c1 = min(p1, c0 + self.pair_chunk)
+                ent = self._chunk_prompts(ck, N, c0, c1)
+                state, lg, pr = eng.forward_pairs_cls(kv, bits, N, ent[0], ent[1], ent[2])
+                pending.append((c0, c1, state, 0))
+                lgs.append(lg)
+                prs.append(pr)
+            logit, prob = (lgs[0], prs[0]) if len(lgs) == 1 else (torch.cat(lgs), torch.cat(prs))
+            out = _LazyRQ(patches=patches, bits=bits, exist_logit=logit, exist_prob=prob, num_objects=N,
+                          pair_range=(p0, p1), uidx=uidx, pending=pending)
+            out.engine = eng
+            if pair_range is None:
+                out["selected"] = self.select_pairs(prob, N)
+            return out
         if not single:
             np_ = max(0, p1 - p0)                                 # an empty shard (more ranks than pairs) is legal
             hidden = torch.empty((np_ * q.q_rows, q.hidden), device=dev, dtype=self.act_dtype)
@@ -533,7 +569,7 @@ class RelationTransformerHeadV4(nn.Module):
             outs = []
             for (feat, meta, obj_ids, names, pan), patches in zip(items, patches_list):
                 rq = self.run_relation_query(feat, meta, obj_ids, names, pan, pair_range=pair_range, patches=patches)
-                outs.append((rq["hidden"], rq["exist_prob"]))
+                outs.append((rq if "pending" in rq else rq["hidden"], rq["exist_prob"]))
             return outs
         segs, pidx, ids, msk = [], [], [], []
         for m, ((feat, meta, obj_ids, names, pan), patches) in enumerate(zip(items, patches_list)):
@@ -545,6 +581,17 @@ class RelationTransformerHeadV4(nn.Module):
             msk.append(ent[2])
         T = max(t.shape[1] for t in ids)                          # prompts of different images pad to the longest
         pad = lambda t: t if t.shape[1] == T else torch.cat([t, t.new_zeros((t.shape[0], T - t.shape[1]))], dim=1)  # noqa: E731
+        if self.cls_first:
+            state, logit, prob = eng.forward_pairs_cls(None, None, None, torch.cat(pidx), torch.cat([pad(t) for t in ids]),
+                                                       torch.cat([pad(t) for t in msk]), segments=segs)
+            outs = []
+            for m, (ps, pc, kv_m, bits_m, n_m) in enumerate(segs):
+                st_m = dict(state, kv=kv_m, bits=bits_m, num_objects=n_m, segments=None)   # image m's view of the pass
+                rq = _LazyRQ(exist_logit=logit[ps:ps + pc], exist_prob=prob[ps:ps + pc], num_objects=n_m,
+                             pair_range=(p0, p1), pending=[(p0, p1, st_m, ps)])
+                rq.engine = eng
+                outs.append((rq, rq["exist_prob"]))
+            return outs
         hidden, _, prob = eng.forward_pairs(None, None, None, torch.cat(pidx), torch.cat([pad(t) for t in ids]),
                                             torch.cat([pad(t) for t in msk]), segments=segs)
         q_rows = self.cfg.qformer.q_rows
@@ -568,6 +615,33 @@ class RelationTransformerHeadV4(nn.Module):
         k = max(1, min(cap, max(n_hit, min(self.max_llm_forward_num, B))))
         return order[:k].contiguous()
 
+    def selected_pair_features(self, rq, selected=None, zero_foreign=False):
+        """pair_feature = hidden[:, 1:] (V4:215) of the selected pairs, [K*32, 768].  zero_foreign: pairs outside the
+        rq's pair range (another rank's shard; negative ids) give zero rows instead of being an error."""
+        sel = rq["selected"] if selected is None else selected
+        q = self.cfg.qformer
+        K, nv = sel.numel(), q.num_query
+        if "pending" in rq and "hidden" not in rq:
+            # selection phase done (forward_pairs_cls): last layer in full for the K chosen pairs only.  Several
+            # chunks: every chunk computes all K slots (foreign pairs as its pair 0) and keeps its own - no host sync
+            pf = torch.zeros((K, nv, q.hidden), device=self.device, dtype=self.act_dtype) if zero_foreign else None
+            for c0, c1, st, off in rq["pending"]:
+                local = sel.to(torch.int64) - c0
+                mine = (local >= 0) & (local < c1 - c0)
+                pos = torch.where(mine, local + off, torch.zeros_like(local)).to(torch.int32)
+                hk = self.rq_engine.pair_hidden(st, pos)
+                pc = hk.view(K, q.q_rows, q.hidden)[:, 1:]
+                pf = pc if pf is None else torch.where(mine[:, None, None], pc, pf)
+            return pf.reshape(K * nv, q.hidden)
+        p0, p1 = rq.get("pair_range", (0, rq["num_objects"] ** 2))   # `hidden` holds the pairs [p0, p1)
+        local = sel.to(torch.int64) - p0
+        rows = local[:, None] * q.q_rows + 1 + torch.arange(nv, device=self.device)[None, :]
+        if zero_foreign:                                              # psg_gather_rows writes zeros for index < 0
+            rows = torch.where(((local >= 0) & (local < p1 - p0))[:, None], rows, torch.full_like(rows, -1))
+        pf = torch.empty((K * nv, q.hidden), device=self.device, dtype=self.act_dtype)
+        ops.gather_rows(rq["hidden"], rows.reshape(-1).to(torch.int32), pf)
+        return pf
+
     def llm_inputs(self, rq, names, selected=None, pair_features=None):
         """V4:240-301: LLM input embeddings X [K, 32+Tp, D] and prompt lengths [K] of the selected pairs.
         `pair_features` [K*32, 768] replaces the gather from rq["hidden"] (pair sharding: the features
@@ -578,14 +652,7 @@ class RelationTransformerHeadV4(nn.Module):
         K = sel.numel()
         q = self.cfg.qformer
         nv = q.num_query
-        if pair_features is None:
-            # pair_feature = hidden[:, 1:] (V4:215) rows of the selected pairs
-            rows = (sel.to(torch.int64)[:, None] * q.q_rows + 1 +
-                    torch.arange(nv, device=dev)[None, :]).reshape(-1).to(torch.int32)
-            pf = torch.empty((K * nv, q.hidden), device=dev, dtype=self.act_dtype)
-            ops.gather_rows(rq["hidden"], rows, pf)
-        else:
-            pf = pair_features
+        pf = self.selected_pair_features(rq, sel) if pair_features is None else pair_features
         # Llama prompts, compacted (left padding of V4:262 removed; see llm.py); cached per set of names
         ck = ("l", tuple(names))
         if ck not in self._table_cache:

@@ -149,6 +149,18 @@ def qformer_self_attn(qkv, text_mask, B, T, nq, heads, query_rows_only, out):
     return out
 
 
+def qformer_self_attn_cls(q_cls, kv, text_mask, B, T, nq, heads):
+    """Attention of the cls row (row 0) of every pair over its nq + T keys -> [B, hidden] (one row per pair).
+    q_cls [B, hidden]: projected cls queries; kv [B*(nq+T), 2*hidden]: K | V of every row."""
+    lib, ctx, st = _env(kv)
+    hidden = kv.shape[1] // 2
+    assert kv.shape[0] == B * (nq + T) and q_cls.shape == (B, hidden) and q_cls.dtype == kv.dtype
+    out = torch.empty((B, hidden), device=kv.device, dtype=kv.dtype)
+    check(lib.psg_qformer_self_attn_cls(ctx, _p(q_cls), _p(kv), _p(text_mask, torch.uint8, "text_mask"), B, T, nq,
+                                        heads, _p(out), _dt(kv), st), "psg_qformer_self_attn_cls")
+    return out
+
+
 def qformer_self_attn_shared(qkv_query, qkv_text, text_mask, B, T, nq, heads, out):
     """Layer-0 self-attention with ONE shared [nq, 3*hidden] projection of the query rows (bf16 / fp16)."""
     lib, ctx, st = _env(qkv_query)

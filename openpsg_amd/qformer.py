@@ -91,19 +91,15 @@ class RelationQueryEngine:
         return [(F.linear(pa, L["wk_x"], L["bk_x"]), F.linear(pa, L["wv_x"], L["bv_x"])) for L in self.layers]
 
     # ---- A6 + A7: Q-Former over a list of pairs ---------------------------------------------------
-    def forward_pairs(self, kv, bits, num_objects, pair_index, ids, text_mask, hidden_out=None, segments=None):
-        """pair_index int32 [P] (p = i*N + j), ids int32 [P,T], text_mask uint8 [P,T].
-        Returns (hidden [P*33, 768] in the activation dtype, exist_logit [P] fp32, exist_prob [P] fp32).
-        hidden_out: caller-owned [P*33, 768] buffer the last layer writes into (no copy when pairs are chunked).
-        segments: [(first pair, pair count, kv, bits, num_objects)] - the pairs come from several images (pair
-        sharding); everything but the cross-attention runs over all of them at once."""
+    def _embed(self, ids):
+        """HF-IB:728-757 for P pairs.  Returns (X [P*(33+T), 768], shared0): with shared0 the embedded query rows are
+        ONE [33, 768] block for all pairs (learned tokens through the embedding LayerNorm; 16-bit modes): layer 0
+        projects it once and uses it as a periodic residual, so rows [33, P*33) of X stay unwritten."""
         q = self.cfg.qformer
         nq, H = q.q_rows, q.hidden
         P, T = ids.shape
         R, RQ = P * (nq + T), P * nq
         X = torch.empty((R, H), device=self.device, dtype=self.dtype)
-        # bf16 mode: the embedded query rows are ONE [33, 768] block for all pairs (learned tokens through the embedding
-        # LayerNorm); layer 0 projects it once and uses it as a periodic residual, so rows [33, P*33) of X stay unwritten
         shared0 = (len(self.layers) > 1 and T > 0 and self.dtype != torch.float32 and self.share_query_qkv)
         if shared0:
             ops.qformer_embed_split(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
@@ -111,56 +107,136 @@ class RelationQueryEngine:
         else:
             ops.qformer_embed(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
                               q.ln_eps, X)
-        for li, L in enumerate(self.layers):
-            last = li == len(self.layers) - 1
-            ctx = torch.empty((R, H), device=self.device, dtype=self.dtype)
-            if li == 0 and shared0:
-                # the query rows entering layer 0 are identical for every pair: project the first pair's 33 rows once
-                qkv_q = F.linear(X[:nq], L["wqkv"], L["bqkv"])
-                qkv = F.linear(X[RQ:], L["wqkv"], L["bqkv"])
-                ops.qformer_self_attn_shared(qkv_q, qkv, text_mask, P, T, nq, q.heads, ctx)
-            else:
-                qkv = F.linear(X, L["wqkv"], L["bqkv"])
-                ops.qformer_self_attn(qkv, text_mask, P, T, nq, q.heads, last, ctx)
-            del qkv
-            ra = RQ if last else R
-            A = F.linear(ctx[:ra], L["wo"])
-            if li == 0 and shared0:
-                ops.add_layernorm_periodic(A[:RQ], X[:nq], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
-                ops.add_layernorm(A[RQ:], X[RQ:], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
-            else:
-                ops.add_layernorm(A, X[:ra], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
-            del ctx
-            qx = F.linear(A[:RQ], L["wq_x"], L["bq_x"])
-            if segments is None:
-                cx = ops.qformer_cross_attn(qx, kv[li][0], kv[li][1], bits, pair_index, num_objects, nq, q.heads,
-                                            empty_policy=self.empty_policy, variant=self.xattn_variant)
-            else:
-                cx = torch.empty_like(qx)
-                for ps, pc, kv_m, bits_m, n_m in segments:
-                    ops.qformer_cross_attn(qx[ps * nq:(ps + pc) * nq], kv_m[li][0], kv_m[li][1], bits_m,
-                                           pair_index[ps:ps + pc], n_m, nq, q.heads, out=cx[ps * nq:(ps + pc) * nq],
-                                           empty_policy=self.empty_policy, variant=self.xattn_variant)
-            Cq = F.linear(cx, L["wo_x"])
-            ops.add_layernorm(Cq, A[:RQ], L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
-            del qx, cx
-            if last and hidden_out is not None:
-                assert hidden_out.shape == (RQ, H) and hidden_out.dtype == self.dtype and hidden_out.is_contiguous()
-                Xn = hidden_out
-            else:
-                Xn = torch.empty((RQ if last else R, H), device=self.device, dtype=self.dtype)
-            iq = self._ffn1(Cq, L["w1q"], L["b1q"])
-            hq = F.linear(iq, L["w2q"])
-            ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps, out=Xn[:RQ])
-            del iq, hq
-            if not last and T > 0:
-                it = self._ffn1(A[RQ:], L["w1t"], L["b1t"])
-                ht = F.linear(it, L["w2t"])
-                ops.add_layernorm(ht, A[RQ:], L["b2t"], L["ln_t"][0], L["ln_t"][1], q.ln_eps, out=Xn[RQ:])
-                del it, ht
-            X = Xn
-        logit, prob = ops.exist_head(X, self.exist_w, self.exist_b, P, nq)
+        return X, shared0
+
+    def _cross(self, li, qx, nq, kv, bits, num_objects, pair_index, segments):
+        """Masked cross-attention of `nq` rows per pair (33, or 1 = the cls row alone) against the image's patches."""
+        q = self.cfg.qformer
+        if segments is None:
+            return ops.qformer_cross_attn(qx, kv[li][0], kv[li][1], bits, pair_index, num_objects, nq, q.heads,
+                                          empty_policy=self.empty_policy, variant=self.xattn_variant)
+        cx = torch.empty_like(qx)
+        for ps, pc, kv_m, bits_m, n_m in segments:
+            ops.qformer_cross_attn(qx[ps * nq:(ps + pc) * nq], kv_m[li][0], kv_m[li][1], bits_m,
+                                   pair_index[ps:ps + pc], n_m, nq, q.heads, out=cx[ps * nq:(ps + pc) * nq],
+                                   empty_policy=self.empty_policy, variant=self.xattn_variant)
+        return cx
+
+    def _layer(self, li, X, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0=False, hidden_out=None):
+        """One Q-Former layer (HF-IB:446-596) over P pairs; the last layer computes the query rows only."""
+        q = self.cfg.qformer
+        nq, H = q.q_rows, q.hidden
+        R, RQ = P * (nq + T), P * nq
+        L = self.layers[li]
+        last = li == len(self.layers) - 1
+        ctx = torch.empty((R, H), device=self.device, dtype=self.dtype)
+        if li == 0 and shared0:
+            # the query rows entering layer 0 are identical for every pair: project the first pair's 33 rows once
+            qkv_q = F.linear(X[:nq], L["wqkv"], L["bqkv"])
+            qkv = F.linear(X[RQ:], L["wqkv"], L["bqkv"])
+            ops.qformer_self_attn_shared(qkv_q, qkv, text_mask, P, T, nq, q.heads, ctx)
+        else:
+            qkv = F.linear(X, L["wqkv"], L["bqkv"])
+            ops.qformer_self_attn(qkv, text_mask, P, T, nq, q.heads, last, ctx)
+        del qkv
+        ra = RQ if last else R
+        A = F.linear(ctx[:ra], L["wo"])
+        if li == 0 and shared0:
+            ops.add_layernorm_periodic(A[:RQ], X[:nq], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+            ops.add_layernorm(A[RQ:], X[RQ:], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+        else:
+            ops.add_layernorm(A, X[:ra], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+        del ctx
+        qx = F.linear(A[:RQ], L["wq_x"], L["bq_x"])
+        cx = self._cross(li, qx, nq, kv, bits, num_objects, pair_index, segments)
+        Cq = F.linear(cx, L["wo_x"])
+        ops.add_layernorm(Cq, A[:RQ], L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
+        del qx, cx
+        if last and hidden_out is not None:
+            assert hidden_out.shape == (RQ, H) and hidden_out.dtype == self.dtype and hidden_out.is_contiguous()
+            Xn = hidden_out
+        else:
+            Xn = torch.empty((RQ if last else R, H), device=self.device, dtype=self.dtype)
+        iq = self._ffn1(Cq, L["w1q"], L["b1q"])
+        hq = F.linear(iq, L["w2q"])
+        ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps, out=Xn[:RQ])
+        del iq, hq
+        if not last and T > 0:
+            it = self._ffn1(A[RQ:], L["w1t"], L["b1t"])
+            ht = F.linear(it, L["w2t"])
+            ops.add_layernorm(ht, A[RQ:], L["b2t"], L["ln_t"][0], L["ln_t"][1], q.ln_eps, out=Xn[RQ:])
+            del it, ht
+        return Xn
+
+    def forward_pairs(self, kv, bits, num_objects, pair_index, ids, text_mask, hidden_out=None, segments=None):
+        """pair_index int32 [P] (p = i*N + j), ids int32 [P,T], text_mask uint8 [P,T].
+        Returns (hidden [P*33, 768] in the activation dtype, exist_logit [P] fp32, exist_prob [P] fp32).
+        hidden_out: caller-owned [P*33, 768] buffer the last layer writes into (no copy when pairs are chunked).
+        segments: [(first pair, pair count, kv, bits, num_objects)] - the pairs come from several images (pair
+        sharding); everything but the cross-attention runs over all of them at once."""
+        P, T = ids.shape
+        X, shared0 = self._embed(ids)
+        for li in range(len(self.layers)):
+            X = self._layer(li, X, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0,
+                            hidden_out if li == len(self.layers) - 1 else None)
+        logit, prob = ops.exist_head(X, self.exist_w, self.exist_b, P, self.cfg.qformer.q_rows)
         return X, logit, prob
+
+    def forward_pairs_cls(self, kv, bits, num_objects, pair_index, ids, text_mask, segments=None):
+        """Selection phase: everything the existence logits depend on, and nothing else.
+
+        The existence head reads row 0 (the cls row) of the last layer's output (V4:206-209), and rows 1..32
+        (`pair_feature`, V4:215) are used for the SELECTED pairs only (V4:235-237, 293-301).  In the last layer every
+        row-wise operation (projections, FFN, LayerNorm) is independent across rows and the attentions need the other
+        rows only as keys / values, so the cls row of all P pairs is computed here with the full K/V and rows 1..32
+        are computed afterwards for the chosen pairs (`pair_hidden`) - identical results, the last layer's query-row
+        work shrinks from 33 rows to 1 for all but the selected pairs.
+        Returns (state, exist_logit [P], exist_prob [P]); state feeds `pair_hidden`."""
+        q = self.cfg.qformer
+        nq, H = q.q_rows, q.hidden
+        P, T = ids.shape
+        RQ = P * nq
+        X, shared0 = self._embed(ids)
+        nl = len(self.layers)
+        for li in range(nl - 1):
+            X = self._layer(li, X, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0)
+        li, L = nl - 1, self.layers[nl - 1]
+        x_cls = X[:RQ].view(P, nq, H)[:, 0].contiguous()                     # [P, H] residual of the cls rows
+        kvs = F.linear(X, L["wqkv"][H:], L["bqkv"][H:])                     # keys | values of every row
+        q_cls = F.linear(x_cls, L["wqkv"][:H], L["bqkv"][:H])              # queries of the cls rows only
+        ctx = ops.qformer_self_attn_cls(q_cls, kvs, text_mask, P, T, nq, q.heads)
+        del kvs
+        A = F.linear(ctx, L["wo"])
+        ops.add_layernorm(A, x_cls, L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+        qx = F.linear(A, L["wq_x"], L["bq_x"])
+        cx = self._cross(li, qx, 1, kv, bits, num_objects, pair_index, segments)
+        Cq = F.linear(cx, L["wo_x"])
+        ops.add_layernorm(Cq, A, L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
+        iq = self._ffn1(Cq, L["w1q"], L["b1q"])
+        hq = F.linear(iq, L["w2q"])
+        Xc = ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps)
+        logit, prob = ops.exist_head(Xc, self.exist_w, self.exist_b, P, 1)
+        state = dict(X=X, P=P, T=T, text_mask=text_mask, pair_index=pair_index, kv=kv, bits=bits,
+                     num_objects=num_objects, segments=segments)
+        return state, logit, prob
+
+    def pair_hidden(self, state, sel):
+        """Last layer in full for the pairs `sel` (int32 [K], positions in the pair list of `forward_pairs_cls`;
+        negative = no pair, computed as pair 0 and to be ignored).  Returns hidden [K*33, 768]."""
+        q = self.cfg.qformer
+        nq = q.q_rows
+        P, T = state["P"], state["T"]
+        assert state["segments"] is None, "pair_hidden: one image per call"
+        s64 = sel.to(torch.int64).clamp(min=0)
+        K = s64.numel()
+        ar = torch.arange(nq, device=self.device)
+        rows = [(s64[:, None] * nq + ar[None, :]).reshape(-1)]
+        if T > 0:
+            rows.append((P * nq + s64[:, None] * T + torch.arange(T, device=self.device)[None, :]).reshape(-1))
+        Xs = state["X"].index_select(0, torch.cat(rows))                    # [K*(33+T), 768]: query rows, then text rows
+        tm = state["text_mask"].index_select(0, s64) if T > 0 else state["text_mask"]
+        pi = state["pair_index"].index_select(0, s64)
+        return self._layer(len(self.layers) - 1, Xs, K, T, tm, pi, state["kv"], state["bits"], state["num_objects"], None)
 
     def _ffn1(self, x, w, b):
         """intermediate(_query): Linear + exact-erf GELU (HF-IB:563-577).  16-bit modes: one pass through

@@ -166,9 +166,17 @@ def test_multi_image_shard_query_matches_per_image_calls(setup):
     for m, it in enumerate(items):
         one = head.run_relation_query(*it, pair_range=(p0, p1), patches=patches[m])
         dp = (multi[m][1] - one["exist_prob"]).abs().max().item()
-        dh = (multi[m][0].float() - one["hidden"].float()).abs().max().item()
+        hm = multi[m][0]["hidden"] if isinstance(multi[m][0], dict) else multi[m][0]   # cls-first: computed on demand
+        dh = (hm.float() - one["hidden"].float()).abs().max().item()
         print(f"image {m}: max |prob diff| {dp:.2e}, max |hidden diff| {dh:.2e}")
-        assert multi[m][0].shape == one["hidden"].shape and dp < 2e-2 and dh < 0.25   # bf16; GEMM tiles depend on M
+        assert hm.shape == one["hidden"].shape and dp < 2e-2 and dh < 0.25   # bf16; GEMM tiles depend on M
+        # the selected pairs' features through the shard handle == rows 1..32 of `hidden`; foreign pairs give zeros
+        sel = torch.tensor([p0 + 3, 7, p1 - 1, 2499], device="cuda:0", dtype=torch.int32)
+        if isinstance(multi[m][0], dict):
+            pf = head.selected_pair_features(multi[m][0], sel, zero_foreign=True).float().view(4, 32, -1)
+            assert (pf[1] == 0).all() and (pf[3] == 0).all()
+            assert (pf[0] - hm.float().view(-1, 33, 768)[3, 1:]).abs().max().item() < 0.1
+            assert (pf[2] - hm.float().view(-1, 33, 768)[p1 - 1 - p0, 1:]).abs().max().item() < 0.1
     empty = head.run_relation_query(*items[0], pair_range=(2500, 2500), patches=patches[0])
     assert empty["hidden"].shape[0] == 0 and empty["exist_prob"].numel() == 0
 
