@@ -36,5 +36,6 @@ for n in 50 100; do
     python tools/pmc_kernel.py cross_attn_dma "$(db /tmp/p_x${n}_$i)" >> "$f"
   done
   python tools/prof_summary.py "$(db /tmp/p_x${n}_1)" | grep cross_attn >> "$f"
+  python tools/xattn_derive.py "$f" $n > /dev/null
 done
 ls -la "$OUT"
