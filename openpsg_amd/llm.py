@@ -83,12 +83,16 @@ class LlamaDecodeEngine:
         return F.linear(x, w)
 
     # ---- one pass over `rows` token rows -------------------------------------------------------
-    def _forward(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, decode=False, prefill_shape=None, rope_pos=None):
+    def _forward(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, decode=False, prefill_shape=None, rope_pos=None,
+                 keep_rows=None):
         """resid [rows, D] is updated in place (residual stream); returns final-norm hidden [rows, D].
         decode=True: every row is the newest token of its pair -> fused rotary + KV append + attention.
         prefill_shape=(pairs, rows_per_pair): the rows are a pair-major prompt batch -> matrix-core attention
         (bf16, <= 64 rows per pair); otherwise the scalar cache-attention kernel.
-        rope_pos int32 [rows]: rotary positions when they differ from the cache slots `tok_pos` (training)."""
+        rope_pos int32 [rows]: rotary positions when they differ from the cache slots `tok_pos` (training).
+        keep_rows int32 [k]: the caller reads only these rows of the result (prompt pass: the last token of every
+        pair).  The last layer then writes K/V for every row (the cache needs them) and runs everything behind the
+        attention - output projection, norms, MLP - on those k rows only; returns [k, D]."""
         m = self.cfg.llm
         rows, D = resid.shape
         n = torch.empty_like(resid)
@@ -113,6 +117,15 @@ class LlamaDecodeEngine:
                                      ctx_len, att)
                 else:
                     ops.llm_attn(q, kc[l], vc[l], tok_pair, tok_pos, m.heads, m.head_dim, ctx_len, att)
+            if keep_rows is not None and l == len(self.layers) - 1:
+                k = keep_rows.numel()
+                att_k, resid_k = torch.empty((k, D), device=self.device, dtype=self.dtype), torch.empty(
+                    (k, D), device=self.device, dtype=self.dtype)
+                ops.gather_rows(att, keep_rows, att_k)
+                ops.gather_rows(resid, keep_rows, resid_k)
+                att, resid = att_k, resid_k
+                n = torch.empty_like(resid)
+                act = torch.empty((k, m.inter), device=self.device, dtype=self.dtype)
             o = self.linear(att, L["wo"])
             ops.rmsnorm(resid, o, L["ln2"], m.rms_eps, n)                      # resid += o ; n = norm(resid)
             gu = self.linear(n, L["wgu"])
@@ -283,10 +296,8 @@ class LlamaDecodeEngine:
         kc = [torch.empty((K, m.heads, ctx_len, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
         vc = [torch.empty((K, m.heads, ctx_len, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
         resid = X.reshape(K * maxlen, D).clone()
-        h = self._forward(resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape=(K, maxlen))
         last_rows = (torch.arange(K, device=dev, dtype=torch.int32) * maxlen + seq_len - 1).contiguous()
-        h_last = torch.empty((K, D), device=dev, dtype=self.dtype)
-        ops.gather_rows(h, last_rows, h_last)
+        h_last = self._forward(resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape=(K, maxlen), keep_rows=last_rows)
         logits = self.linear(h_last, self.lm_head)
         first_logits = None
         if return_first_logits:
