@@ -591,7 +591,21 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
   if (G < 1) G = 1;
   const int dma_cfg = ctx->opt.skinny_dma;     // <waves><K blocks per batch><ring slots>; 0 = register variant
   if (dma_cfg > 0 && N >= 1024 && K >= 1024) {
-    const int wv = dma_cfg / 100, ud = (dma_cfg / 10) % 10, sl = dma_cfg % 10;
+    int wv = dma_cfg / 100;
+    const int ud = (dma_cfg / 10) % 10, sl = dma_cfg % 10;
+    // Slab height against round quantisation (option skinny_wide): a workgroup walks ceil(slabs / G) slabs and the
+    // launch lasts as long as the workgroups with one slab more (one CU's DMA ring is latency-bound at about its
+    // share of the HBM rate, so the last, partly empty round takes as long as a full one).  gate/up (N = 22016,
+    // 4 slices): 172 slabs of 128 rows over 64 column groups = 2.69 -> 3 rounds; 126 slabs of 176 rows (11 waves)
+    // = 1.97 -> 2 rounds of 1.375x the rows: 8 % less.  Same per-row arithmetic: bit-identical partials.
+    if (ctx->opt.skinny_wide && !pro && wv == 8 && ud == 1 && sl == 3 && ctx->opt.skinny_nt && ctx->opt.skinny_xdma) {
+      auto cost = [&](int w) {
+        const int g = ctx->num_cu / splits > 0 ? ctx->num_cu / splits : 1;
+        const int ns = (N + 16 * w - 1) / (16 * w);
+        return ((ns + g - 1) / g) * w;
+      };
+      if ((double)cost(11) < 0.95 * cost(8)) wv = 11;
+    }
     const int rows = wv * 16;
     const int nslab_d = (N + rows - 1) / rows;
     const size_t ldsd = (size_t)wv * sl * ud * 2048 + (size_t)32 * (rows + 4) * 4 + lds;
@@ -650,6 +664,7 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
     else SGD_L(WV, UD, SL, 0, 0);                                                                                  \
   } while (0)
     if (wv == 8 && ud == 1 && sl == 3) SGD(8, 1, 3);
+    else if (wv == 11 && ud == 1 && sl == 3) SGD_L(11, 1, 3, 2, 1);
     else if (wv == 8 && ud == 1 && sl == 5) SGD(8, 1, 5);
     else if (wv == 8 && ud == 2 && sl == 3) SGD(8, 2, 3);
     else if (wv == 4 && ud == 1 && sl == 4) SGD(4, 1, 4);

@@ -84,3 +84,27 @@ def test_fused_decode_tokens_equal_separate_kernels():
         outs[mode] = t_eager
     for mode, t in outs.items():
         assert torch.equal(t, outs[""]), f"fuse_rowops={mode!r} changed the greedy tokens"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(20, 22016, 4096), (32, 22016, 4096), (20, 22000, 1024), (3, 5632, 2048)])
+def test_wide_slab_variant_bit_identical(dtype, M, N, K):
+    """Option skinny_wide: 11-wave (176-row) slabs where they save a round of slabs (the gate/up projection: 172 slabs
+    of 128 rows over 64 column groups = 3 rounds, 126 slabs of 176 rows = 2).  Same per-row arithmetic -> the partials
+    must be bit-identical to the 8-wave kernel, also with a partial last slab (N not a multiple of 176)."""
+    from openpsg_amd import _lib, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + K + M)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dev).to(dtype)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(dev).to(dtype)
+    try:
+        _lib.set_option(0, "skinny_wide", 0)
+        want = ops.skinny_gemm(x, w)
+        _lib.set_option(0, "skinny_wide", 1)
+        got = ops.skinny_gemm(x, w, splits=want.splits)
+    finally:
+        _lib.set_option(0, "skinny_wide", 1)
+    torch.cuda.synchronize()
+    assert torch.equal(got.t, want.t)
+    ref = (x.float() @ w.float().T)
+    assert (got.reduce(torch.float32) - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 1e-3
