@@ -179,12 +179,23 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
   const unsigned long long valid64 = __ballot(mypos >= 0);
   auto rclamp = [&](int j) { return j < S ? j : S - 1; };
 
-  // V rows of the real tokens -> cache (16-byte pieces, 16 per row)
-  for (int i = lane; i < S * 16; i += 64) {
-    const int r = i >> 4, c = i & 15;
-    if ((valid64 >> r) & 1ull) {
-      const uint4 x = *reinterpret_cast<const uint4*>(qkv + (row0 + r) * ld + 2 * hidden + h * 128 + c * 8);
-      *reinterpret_cast<uint4*>(vc + cbase + (int64_t)r * 128 + c * 8) = x;
+  // V rows of the real tokens -> cache (16-byte pieces, 16 per row).  All 16 requests of a lane are issued before the
+  // first store: as a load -> store loop this was up to 16 dependent round trips at the head of a latency-bound kernel.
+  // The stores are unconditional (a conditional one pulls its load down next to it): a piece of a padding row or past
+  // the last row is redirected to row 0, whose own data it then rewrites - cache rows of padding tokens stay untouched.
+  if (valid64 & 1ull) {                                        // compact sequences: a pair with any token has row 0
+    uint4 vx[16];
+    int rv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int i = lane + 64 * it, r = i >> 4, c = i & 15;
+      rv[it] = (i < S * 16 && ((valid64 >> (r & 63)) & 1ull)) ? r : 0;
+      vx[it] = *reinterpret_cast<const uint4*>(qkv + (row0 + rv[it]) * ld + 2 * hidden + h * 128 + c * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int c = (lane + 64 * it) & 15;
+      *reinterpret_cast<uint4*>(vc + cbase + (int64_t)rv[it] * 128 + c * 8) = vx[it];
     }
   }
 
@@ -200,44 +211,70 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
     rr[t] = rclamp(32 * t + l31);
     rreal[t] = (32 * t + l31 < S) && ((valid64 >> rr[t]) & 1ull);
   }
+  // Every request of the wave is issued before the first dependent instruction: Q / K fragments of all four k-steps,
+  // the rotary table rows, and (below) the V gathers.  One wave runs per SIMD here (pairs x heads = 640 waves on 1024
+  // SIMDs), so the kernel's time is its chain of memory round trips; per-k-step loads made it five of them.
+  union F8 {
+    uint4 u;
+    uint16_t h[8];
+    typename E::v8 v;
+  };
+  F8 qa[4][2], qb[4][2], ka[4][2], kb[4][2];
+  float4 csr[4][2][2], snr[4][2][2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    union F8 {
-      uint4 u;
-      uint16_t h[8];
-      typename E::v8 v;
-    };
-    F8 qa[2], qb[2], ka[2], kb[2];
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const uint16_t* rp = qkv + (row0 + rr[t]) * ld + h * 128 + 16 * s + 8 * hi;
-      qa[t].u = *reinterpret_cast<const uint4*>(rp);
-      qb[t].u = *reinterpret_cast<const uint4*>(rp + 64);
-      ka[t].u = *reinterpret_cast<const uint4*>(rp + hidden);
-      kb[t].u = *reinterpret_cast<const uint4*>(rp + hidden + 64);
+      qa[s][t].u = *reinterpret_cast<const uint4*>(rp);
+      qb[s][t].u = *reinterpret_cast<const uint4*>(rp + 64);
+      ka[s][t].u = *reinterpret_cast<const uint4*>(rp + hidden);
+      kb[s][t].u = *reinterpret_cast<const uint4*>(rp + hidden + 64);
       // position of a real token == its row index inside the pair (compact sequences)
       const float* cp = cos_tab + rr[t] * 64 + 16 * s + 8 * hi;
       const float* sp = sin_tab + rr[t] * 64 + 16 * s + 8 * hi;
-      float cs[8], sn[8];
-      *reinterpret_cast<float4*>(cs) = *reinterpret_cast<const float4*>(cp);
-      *reinterpret_cast<float4*>(cs + 4) = *reinterpret_cast<const float4*>(cp + 4);
-      *reinterpret_cast<float4*>(sn) = *reinterpret_cast<const float4*>(sp);
-      *reinterpret_cast<float4*>(sn + 4) = *reinterpret_cast<const float4*>(sp + 4);
+      csr[s][t][0] = *reinterpret_cast<const float4*>(cp);
+      csr[s][t][1] = *reinterpret_cast<const float4*>(cp + 4);
+      snr[s][t][0] = *reinterpret_cast<const float4*>(sp);
+      snr[s][t][1] = *reinterpret_cast<const float4*>(sp + 4);
+    }
+  // V^T fragments: lane (l31, hi) gathers head dim l31 + 32 dt of 8 keys per (key tile, half): 2-byte loads
+  const uint16_t* vbase = qkv + row0 * ld + 2 * hidden + h * 128 + l31;
+  uint16_t ve[2][2][4][8];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int key = rclamp(32 * kt + 16 * g + (m & 3) + 8 * (m >> 2) + 4 * hi);
+        const uint16_t* vp = vbase + (int64_t)key * ld;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ve[kt][g][dt][m] = vp[32 * dt];
+      }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float cs[8] = {csr[s][t][0].x, csr[s][t][0].y, csr[s][t][0].z, csr[s][t][0].w,
+                           csr[s][t][1].x, csr[s][t][1].y, csr[s][t][1].z, csr[s][t][1].w};
+      const float sn[8] = {snr[s][t][0].x, snr[s][t][0].y, snr[s][t][0].z, snr[s][t][0].w,
+                           snr[s][t][1].x, snr[s][t][1].y, snr[s][t][1].z, snr[s][t][1].w};
       F8 qa2, qb2, ka2, kb2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float q1 = E::to_f32(qa[t].h[e]), q2 = E::to_f32(qb[t].h[e]);
-        const float k1 = E::to_f32(ka[t].h[e]), k2 = E::to_f32(kb[t].h[e]);
+        const float q1 = E::to_f32(qa[s][t].h[e]), q2 = E::to_f32(qb[s][t].h[e]);
+        const float k1 = E::to_f32(ka[s][t].h[e]), k2 = E::to_f32(kb[s][t].h[e]);
         // q*cos + rotate_half(q)*sin, rotate_half(x) = cat(-x2, x1)
         qa2.h[e] = E::from_f32(q1 * cs[e] - q2 * sn[e]);
         qb2.h[e] = E::from_f32(q2 * cs[e] + q1 * sn[e]);
         ka2.h[e] = E::from_f32(k1 * cs[e] - k2 * sn[e]);
         kb2.h[e] = E::from_f32(k2 * cs[e] + k1 * sn[e]);
       }
-      qa[t] = qa2;
-      qb[t] = qb2;
-      ka[t] = ka2;
-      kb[t] = kb2;
+      qa[s][t] = qa2;
+      qb[s][t] = qb2;
+      ka[s][t] = ka2;
+      kb[s][t] = kb2;
       if (rreal[t]) {
         uint16_t* kp = kc + cbase + (int64_t)rr[t] * 128 + 16 * s + 8 * hi;
         *reinterpret_cast<uint4*>(kp) = ka2.u;
@@ -248,8 +285,8 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        sc[kt][qt] = E::mfma32(ka[kt].v, qa[qt].v, sc[kt][qt]);
-        sc[kt][qt] = E::mfma32(kb[kt].v, qb[qt].v, sc[kt][qt]);
+        sc[kt][qt] = E::mfma32(ka[s][kt].v, qa[s][qt].v, sc[kt][qt]);
+        sc[kt][qt] = E::mfma32(kb[s][kt].v, qb[s][qt].v, sc[kt][qt]);
       }
   }
   const float C = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
@@ -288,7 +325,6 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) o[dt][qt] = (pa_f32x16){0};
-  const uint16_t* vbase = qkv + row0 * ld + 2 * hidden + h * 128 + l31;
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -302,18 +338,11 @@ prefill_attn_rope_mfma_kernel(const uint16_t* __restrict__ qkv, const int32_t* _
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           pf[qt].u[e] = E::pack(sc[kt][qt][8 * g + 2 * e], sc[kt][qt][8 * g + 2 * e + 1]);
-      uint16_t ve[4][8];
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int key = rclamp(32 * kt + 16 * g + (m & 3) + 8 * (m >> 2) + 4 * hi);
-        const uint16_t* vp = vbase + (int64_t)key * ld;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ve[dt][m] = vp[32 * dt];
-      }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vf[dt].u[e] = (uint32_t)ve[dt][2 * e] | ((uint32_t)ve[dt][2 * e + 1] << 16);
+        for (int e = 0; e < 4; ++e)
+          vf[dt].u[e] = (uint32_t)ve[kt][g][dt][2 * e] | ((uint32_t)ve[kt][g][dt][2 * e + 1] << 16);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
