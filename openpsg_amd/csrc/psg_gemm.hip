@@ -524,6 +524,22 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_dma_kernel(const uint1
   }
 }
 
+// Cost of one launch in slab-rounds x slab height (x K range, the same for all candidates of one split count): a
+// workgroup walks ceil(slabs / column groups) slabs of 16 w rows.
+static int sg_round_cost(const psg_ctx* ctx, int N, int splits, int w) {
+  const int g = ctx->num_cu / splits > 0 ? ctx->num_cu / splits : 1;
+  const int ns = (N + 16 * w - 1) / (16 * w);
+  return ((ns + g - 1) / g) * w;
+}
+// LDS of the LDS-DMA variant: rings + partial tile + x slice
+static size_t sg_dma_lds(int M, int K, int splits, int w, int ud, int sl) {
+  const int KB = K >> 6, nkb_max = (KB + splits - 1) / splits;
+  return (size_t)w * sl * ud * 2048 + (size_t)32 * (16 * w + 4) * 4 + (size_t)M * (nkb_max * 128 + 16);
+}
+static bool sg_wide_ok(const psg_ctx* ctx) {
+  return ctx->opt.skinny_wide && ctx->opt.skinny_dma == 813 && ctx->opt.skinny_nt && ctx->opt.skinny_xdma;
+}
+
 // split count: K range per workgroup ~1024 elements (x slice <= 64 KiB of LDS at M = 32), and
 // enough workgroups to give every CU several waves.
 static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
@@ -548,6 +564,17 @@ static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
   if (S < 1) S = 1;
   // LDS bound: M * (ceil(KB/S)*128 + 16) <= 96 KiB
   while ((int64_t)M * (((KB + S - 1) / S) * 128 + 16) > 96 * 1024 && S < KB) ++S;
+  // Half the slices with 12-wave (192-row) slabs where the walk is as balanced (q/k/v: 96 slabs of 128 rows x 8
+  // slices = 3 rounds -> 64 slabs of 192 rows x 4 slices = 1 round of the same bytes): half the fp32 partials to
+  // write here and to read in the consumer, one slab epilogue instead of three.
+  if (forced <= 0 && sg_wide_ok(ctx) && N >= 1024 && K >= 1024 && S >= 8 && S % 2 == 0) {
+    const int S2 = S / 2;
+    const int cur = sg_round_cost(ctx, N, S, 8) < sg_round_cost(ctx, N, S, 11) ? sg_round_cost(ctx, N, S, 8)
+                                                                                : sg_round_cost(ctx, N, S, 11);
+    // per-workgroup bytes ~ rounds x rows x K / S: compare cost / S
+    if ((double)sg_round_cost(ctx, N, S2, 12) / S2 <= 1.001 * (double)cur / S && sg_dma_lds(M, K, S2, 12, 1, 3) <= 160 * 1024)
+      S = S2;
+  }
   return S;
 }
 
@@ -598,13 +625,13 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
     // share of the HBM rate, so the last, partly empty round takes as long as a full one).  gate/up (N = 22016,
     // 4 slices): 172 slabs of 128 rows over 64 column groups = 2.69 -> 3 rounds; 126 slabs of 176 rows (11 waves)
     // = 1.97 -> 2 rounds of 1.375x the rows: 8 % less.  Same per-row arithmetic: bit-identical partials.
-    if (ctx->opt.skinny_wide && !pro && wv == 8 && ud == 1 && sl == 3 && ctx->opt.skinny_nt && ctx->opt.skinny_xdma) {
-      auto cost = [&](int w) {
-        const int g = ctx->num_cu / splits > 0 ? ctx->num_cu / splits : 1;
-        const int ns = (N + 16 * w - 1) / (16 * w);
-        return ((ns + g - 1) / g) * w;
-      };
-      if ((double)cost(11) < 0.95 * cost(8)) wv = 11;
+    if (sg_wide_ok(ctx) && !pro) {
+      if ((double)sg_round_cost(ctx, N, splits, 11) < 0.95 * sg_round_cost(ctx, N, splits, wv) &&
+          sg_dma_lds(M, K, splits, 11, 1, 3) <= 160 * 1024)
+        wv = 11;
+      if ((double)sg_round_cost(ctx, N, splits, 12) < 0.95 * sg_round_cost(ctx, N, splits, wv) &&
+          sg_dma_lds(M, K, splits, 12, 1, 3) <= 160 * 1024)
+        wv = 12;
     }
     const int rows = wv * 16;
     const int nslab_d = (N + rows - 1) / rows;
@@ -665,6 +692,7 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
   } while (0)
     if (wv == 8 && ud == 1 && sl == 3) SGD(8, 1, 3);
     else if (wv == 11 && ud == 1 && sl == 3) SGD_L(11, 1, 3, 2, 1);
+    else if (wv == 12 && ud == 1 && sl == 3) SGD_L(12, 1, 3, 2, 1);
     else if (wv == 8 && ud == 1 && sl == 5) SGD(8, 1, 5);
     else if (wv == 8 && ud == 2 && sl == 3) SGD(8, 2, 3);
     else if (wv == 4 && ud == 1 && sl == 4) SGD(4, 1, 4);

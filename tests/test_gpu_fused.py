@@ -108,3 +108,28 @@ def test_wide_slab_variant_bit_identical(dtype, M, N, K):
     assert torch.equal(got.t, want.t)
     ref = (x.float() @ w.float().T)
     assert (got.reduce(torch.float32) - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_half_splits_12_wave_plan_for_qkv_shape(dtype):
+    """q/k/v projection (N = 12288, K = 4096, 20 rows): the planner halves the K slices (8 -> 4) and the launch uses
+    12-wave slabs (64 slabs of 192 rows = one round): half the fp32 partials.  Bit-identical to the 8-wave kernel run
+    with the same 4 slices, and the reduced result matches an fp32 matmul."""
+    from openpsg_amd import _lib, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(20, 4096, generator=g) * 0.5).to(dev).to(dtype)
+    w = (torch.randn(12288, 4096, generator=g) * 0.02).to(dev).to(dtype)
+    try:
+        _lib.set_option(0, "skinny_wide", 1)
+        got = ops.skinny_gemm(x, w)
+        assert got.splits == 4, got.splits
+        _lib.set_option(0, "skinny_wide", 0)
+        assert ops.skinny_gemm(x, w).splits == 8
+        want = ops.skinny_gemm(x, w, splits=4)
+    finally:
+        _lib.set_option(0, "skinny_wide", 1)
+    torch.cuda.synchronize()
+    assert torch.equal(got.t, want.t)
+    ref = x.float() @ w.float().T
+    assert (got.reduce(torch.float32) - ref).abs().max().item() < 1e-3 * ref.abs().max().item() + 1e-4
