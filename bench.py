@@ -409,7 +409,7 @@ def main():
             pmc = os.path.join(REPO, "profiles", "pmc_skinny_gemm.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            line["roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_dma_kernel (psg_skinny_gemm; 8-wave slabs, 11-wave slabs for the gate/up projection)", "achieved": round(ach, 1),
+            line["roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_dma_kernel (psg_skinny_gemm; 8-wave slabs, 11-wave for gate/up, 12-wave for q/k/v)", "achieved": round(ach, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                 "traffic": traffic, "bytes_per_launch": int(bpl),
                                 "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n}
