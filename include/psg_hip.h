@@ -219,7 +219,9 @@ int psg_silu_mul(psg_ctx*, const void* gate_up, int splits, int64_t rows, int in
  * writes fp32 partials part[splits][M][N] and does NOT reduce them: the consumers below
  * (psg_rmsnorm, psg_rope_kvwrite, psg_silu_mul, psg_greedy_step) take a `*_splits` argument and sum
  * the slices in split order while loading (deterministic, no atomics, no extra launch);
- * psg_reduce_partials materialises y for any other consumer. */
+ * psg_reduce_partials materialises y for any other consumer.
+ * The planner also fixes the slab height (8, 11 or 12 wavefronts x 16 rows per workgroup, option skinny_wide) so that
+ * the slabs divide evenly over the compute units: a launch lasts as long as the workgroups that walk one slab more. */
 int psg_skinny_gemm_plan(psg_ctx*, int M, int N, int K, int* splits);
 int psg_skinny_gemm(psg_ctx*, const void* x, const void* w, float* part, int M, int N, int K,
                     int splits, int dtype, void* stream);
