@@ -277,7 +277,10 @@ class RelationTransformerHeadV4(nn.Module):
         if not feat.is_cuda:
             raise PsgHipError("mask_features must live in HBM; this head has no CPU path")
         info = inputs['object_info'][0]
-        obj_ids = [int(x) for x in info['object_id_list'][:self.max_object_num]]           # V4:136
+        ids = list(info['object_id_list'][:self.max_object_num])                            # V4:136
+        if ids and torch.is_tensor(ids[0]) and ids[0].is_cuda:
+            ids = torch.stack([t.reshape(()) for t in ids]).cpu().tolist()                  # one copy, not N synchronisations
+        obj_ids = [int(x) for x in ids]
         names = [object_categories[i % INSTANCE_OFFSET] for i in obj_ids]                  # V4:138-139
         return feat, meta, info, obj_ids, names
 
