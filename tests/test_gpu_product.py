@@ -62,6 +62,10 @@ def test_head_forward_emits_the_rigged_relations(dtype):
     assert want[1] == [sel[0] // 10, sel[0] % 10, ri("in front of")]
     assert out["rel_pred"] == want and out["rel_score"] == [1] * 40
     assert head.llm_engine.last_replays < 4                        # stopped at the first all-EOS check, not after 16 steps
+    # DET2:177-181 hands the ids over as 0-d int32 tensors on the model's device: same result, fetched in one copy
+    inp = _inputs(scene)
+    inp["object_info"][0]["object_id_list"] = [t.cuda() for t in scene["object_id_list"]]
+    assert head(inp)["rel_pred"] == want
 
 
 def test_detector_simple_test_submission_and_infer_tool(tmp_path):
