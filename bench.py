@@ -381,10 +381,10 @@ def main():
         strong = {"workload": f"ONE {a.size}x{a.size} image, {n4} masks ({n4 * (n4 - 1)} pairs), pairs sharded over "
                               f"{world} rank(s), top-20 decodes dealt round-robin",
                   "ms_per_image": round(el1 * 1e3, 3), "value": round(n4 * (n4 - 1) / el1, 1), "unit": "pairs/s",
-                  "steps": ks, "single_gpu_reference_ms": 87.0,
+                  "steps": ks, "single_gpu_reference_ms": 77.6,
                   "bound": "16 passes over the 13.5 GB of Llama weights per image on every decoding rank (a decode "
                            "step streams all weights for 1 row as for 20; no tensor parallelism, SURVEY 8e): only the "
-                           "relation query (18 ms at 1 GPU) and the compute-bound prompt pass shrink with N"}
+                           "relation query (12 ms at 1 GPU) and the compute-bound prompt pass (15 ms) shrink with N"}
 
     if rank == 0:
         ips = a.images_per_step if (world == 1 and not force_dist and a.workload == "full") else world
