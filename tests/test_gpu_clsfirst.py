@@ -66,3 +66,31 @@ def test_cls_first_over_several_pair_chunks():
     np.testing.assert_allclose(a["pf"], b["pf"], atol=2e-5)
     np.testing.assert_allclose(a["hidden"], b["hidden"], atol=2e-5)
     assert np.array_equal(a["tokens"], b["tokens"])
+
+
+@pytest.mark.parametrize("size,dtype", [((1280, 1536), "bf16"), ((1536, 1536), "bf16"), ((1280, 1536), "fp32")])
+def test_cls_first_on_large_images(size, dtype):
+    """Patch grids beyond the LDS-DMA cross-attention kernel (L = 480: first-generation MFMA kernel; L = 576: the row
+    kernel): the selection phase calls the same kernels with one query row per pair and must agree with the one-phase
+    layer there too."""
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_device
+    dev = _dev()
+    cfg = PSGConfig(qformer=QFormerConfig(), llm=tiny_llm(256, 2, 512, 512), max_object_num=12)
+    w = make_weights_device(cfg, 3, dev, llm_dtype=torch.float32 if dtype == "fp32" else torch.bfloat16)
+    scene = make_scene(size, 12, seed=7, device="cuda:0")
+    logits = {}
+    for cf in (False, True):
+        head = RelationTransformerHeadV4(dtype=dtype, device="cuda:0", tokenizers="word", max_object_num=12,
+                                         llm_config=cfg.llm, llm_feature_size=256, on_parse_error="skip", cls_first=cf)
+        head.load_weights(w)
+        head(_inputs(scene))
+        torch.cuda.synchronize()
+        logits[cf] = head.last["exist_logit"].float().cpu().numpy()
+        feats = head.selected_pair_features(head.last).float()
+        assert torch.isfinite(feats).all()
+    err = np.abs(logits[False] - logits[True]).max()
+    print(f"{size} {dtype}: L = {size[0] // 64 * (size[1] // 64)}, max |logit diff| = {err:.3e}")
+    assert err < (2e-5 if dtype == "fp32" else 0.06)
