@@ -124,6 +124,18 @@ class HipBackend:
         ops.gather_rows(hidden, rows, out)
         return out
 
+    def gather_features_multi(self, hiddens, rows_list):
+        """gather_features for every image of a step at once: handles of one selection-phase pass share their last
+        layer (one pass over all images' selected pairs instead of one per image)."""
+        if not all(isinstance(h, dict) for h in hiddens):
+            return [self.gather_features(h, r) for h, r in zip(hiddens, rows_list)]
+        nv = self.q_rows - 1
+        sels = []
+        for h, rows in zip(hiddens, rows_list):
+            r0 = rows.view(-1, nv)[:, 0].to(torch.int64)
+            sels.append(torch.where(r0 >= 0, (r0 - 1) // self.q_rows + h["pair_range"][0], torch.full_like(r0, -1)))
+        return self.head.selected_pair_features_multi(hiddens, sels)
+
     def decode(self, scene, selected, features):
         rq = dict(num_objects=self.num_objects(scene))
         out = self.head.decode_selected(rq, self._names(scene), selected=selected, pair_features=features,
@@ -252,13 +264,16 @@ class PairShardedPipeline:
         # 4. selected pair features -> the image's decoding rank
         nv = be.q_rows - 1
         ar = torch.arange(nv, device=patches.device, dtype=torch.int64)
-        send = []
+        rows_list = []
         for m in range(R):
             s = sel[m].to(torch.int64)
             mine = (s >= p0) & (s < p1)
             rows = (s - p0)[:, None] * be.q_rows + 1 + ar[None, :]               # pair_feature = hidden[:, 1:]
-            rows = torch.where(mine[:, None], rows, torch.full_like(rows, -1)).reshape(-1).to(torch.int32)
-            send.append(be.gather_features(hidden[m], rows))
+            rows_list.append(torch.where(mine[:, None], rows, torch.full_like(rows, -1)).reshape(-1).to(torch.int32))
+        if hasattr(be, "gather_features_multi"):
+            send = be.gather_features_multi(hidden, rows_list)
+        else:
+            send = [be.gather_features(hidden[m], rows_list[m]) for m in range(R)]
         send = torch.stack(send).contiguous()                                      # [R, K*nv, hidden]
         recv = self._reduce_scatter_sum(send)
         # 5. decode my image; 6. token ids to everyone

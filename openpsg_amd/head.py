@@ -645,6 +645,38 @@ class RelationTransformerHeadV4(nn.Module):
         ops.gather_rows(rq["hidden"], rows.reshape(-1).to(torch.int32), pf)
         return pf
 
+    def selected_pair_features_multi(self, rqs, selected):
+        """`selected_pair_features(..., zero_foreign=True)` for several images whose shards went through ONE
+        selection-phase pass (`run_relation_query_shards`): one last-layer pass over all images' slots instead of
+        one per image.  rqs[m] / selected[m]: image m's handle and its K selected pair ids.  Returns a list of
+        [K*32, 768] tensors; falls back to per-image calls when the handles do not share a pass."""
+        q = self.cfg.qformer
+        nv = q.num_query
+        ok = all("pending" in r and "hidden" not in r and len(r["pending"]) == 1 for r in rqs)
+        if ok:
+            base = rqs[0]["pending"][0][2]["X"]
+            ok = all(r["pending"][0][2]["X"] is base for r in rqs)
+        if not ok or len(rqs) == 1:
+            return [self.selected_pair_features(r, s, zero_foreign=True) for r, s in zip(rqs, selected)]
+        pos, mine_all, segs, k0 = [], [], [], 0
+        for r, sel in zip(rqs, selected):
+            c0, c1, st, off = r["pending"][0]
+            local = sel.to(torch.int64) - c0
+            mine = (local >= 0) & (local < c1 - c0)
+            pos.append(torch.where(mine, local + off, torch.zeros_like(local)))
+            mine_all.append(mine)
+            segs.append((k0, sel.numel(), st["kv"], st["bits"], st["num_objects"]))
+            k0 += sel.numel()
+        st0 = rqs[0]["pending"][0][2]
+        hk = self.rq_engine.pair_hidden(st0, torch.cat(pos).to(torch.int32), segments=segs)
+        pf = hk.view(k0, q.q_rows, q.hidden)[:, 1:]
+        pf = torch.where(torch.cat(mine_all)[:, None, None], pf, torch.zeros_like(pf))
+        outs, k0 = [], 0
+        for sel in selected:
+            outs.append(pf[k0:k0 + sel.numel()].reshape(sel.numel() * nv, q.hidden))
+            k0 += sel.numel()
+        return outs
+
     def llm_inputs(self, rq, names, selected=None, pair_features=None):
         """V4:240-301: LLM input embeddings X [K, 32+Tp, D] and prompt lengths [K] of the selected pairs.
         `pair_features` [K*32, 768] replaces the gather from rq["hidden"] (pair sharding: the features

@@ -220,13 +220,15 @@ class RelationQueryEngine:
                      num_objects=num_objects, segments=segments)
         return state, logit, prob
 
-    def pair_hidden(self, state, sel):
+    def pair_hidden(self, state, sel, segments=None):
         """Last layer in full for the pairs `sel` (int32 [K], positions in the pair list of `forward_pairs_cls`;
-        negative = no pair, computed as pair 0 and to be ignored).  Returns hidden [K*33, 768]."""
+        negative = no pair, computed as pair 0 and to be ignored).  Returns hidden [K*33, 768].
+        segments: [(first slot, slot count, kv, bits, num_objects)] when the slots belong to several images of one
+        `forward_pairs_cls(segments=...)` pass (everything but the cross-attention runs over all slots at once)."""
         q = self.cfg.qformer
         nq = q.q_rows
         P, T = state["P"], state["T"]
-        assert state["segments"] is None, "pair_hidden: one image per call"
+        assert segments is not None or state["segments"] is None, "pair_hidden: pass the slots' segments"
         s64 = sel.to(torch.int64).clamp(min=0)
         K = s64.numel()
         ar = torch.arange(nq, device=self.device)
@@ -236,7 +238,8 @@ class RelationQueryEngine:
         Xs = state["X"].index_select(0, torch.cat(rows))                    # [K*(33+T), 768]: query rows, then text rows
         tm = state["text_mask"].index_select(0, s64) if T > 0 else state["text_mask"]
         pi = state["pair_index"].index_select(0, s64)
-        return self._layer(len(self.layers) - 1, Xs, K, T, tm, pi, state["kv"], state["bits"], state["num_objects"], None)
+        return self._layer(len(self.layers) - 1, Xs, K, T, tm, pi, state["kv"], state["bits"], state["num_objects"],
+                           segments)
 
     def _ffn1(self, x, w, b):
         """intermediate(_query): Linear + exact-erf GELU (HF-IB:563-577).  16-bit modes: one pass through

@@ -177,6 +177,18 @@ def test_multi_image_shard_query_matches_per_image_calls(setup):
             assert (pf[1] == 0).all() and (pf[3] == 0).all()
             assert (pf[0] - hm.float().view(-1, 33, 768)[3, 1:]).abs().max().item() < 0.1
             assert (pf[2] - hm.float().view(-1, 33, 768)[p1 - 1 - p0, 1:]).abs().max().item() < 0.1
+    # all images' selected pairs through ONE last-layer pass == one pass per image
+    if isinstance(multi[0][0], dict):
+        sels = [torch.tensor([p0 + 1 + m, 3, p1 - 2 - m, 2400], device="cuda:0", dtype=torch.int32) for m in range(4)]
+        one_by_one = [head.selected_pair_features(multi[m][0], sels[m], zero_foreign=True) for m in range(4)]
+        multi[0][0].pop("hidden", None)
+        for m in range(4):
+            multi[m][0].pop("hidden", None)                        # back to the pending state (lazy `hidden` was read above)
+        together = head.selected_pair_features_multi([multi[m][0] for m in range(4)], sels)
+        for m in range(4):
+            d = (together[m].float() - one_by_one[m].float()).abs().max().item()
+            assert together[m].shape == one_by_one[m].shape and d < 0.1, (m, d)
+            assert (together[m].view(4, 32, -1)[1] == 0).all() and (together[m].view(4, 32, -1)[3] == 0).all()
     empty = head.run_relation_query(*items[0], pair_range=(2500, 2500), patches=patches[0])
     assert empty["hidden"].shape[0] == 0 and empty["exist_prob"].numel() == 0
 
