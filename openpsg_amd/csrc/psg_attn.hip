@@ -231,6 +231,195 @@ extern "C" int psg_qformer_self_attn_cls(psg_ctx* ctx, const void* q_cls, const 
   return PSG_OK;
 }
 
+// The same attention with the key / value projections folded into the INPUT space (no K | V tensor at all).  For the
+// cls query q of a pair and head h, score_j = q_h . (W_k,h x_j + b_k,h) / 8 = (W_k,h^T q_h) . x_j / 8 + const_h, and the
+// constant drops out of the softmax; context_h = sum_j p_j (W_v,h x_j + b_v,h) = W_v,h (sum_j p_j x_j) + b_v,h.  So the
+// caller projects the queries back through W_k (g = W_k,h^T q_h: [heads][B][hidden] in fp32 - a 768-term dot product
+// of rounded factors would lose what the 64-term one keeps -, two tiny batched GEMMs around this kernel) and the kernel needs the layer's INPUT rows only: per pair it reads (nq + T) x hidden values once instead of
+// twice that of K | V, and the K | V projection of every row of every pair (277 GFLOP at 2500 pairs: the largest GEMM
+// of the selection phase) disappears.  One workgroup per pair: the rows are staged in LDS once (73 KB in bf16); the
+// scores g_h . x_j run on the matrix cores (16-bit rows; per-lane dot products + wave reductions in fp32 mode),
+// probabilities pass through an LDS table, xbar[h] = sum_j p_j x_j is accumulated in registers (wave w owns heads
+// 3w..3w+2, a lane owns features {4 lane + 256 k}).  Built for the Q-Former geometry (hidden 768 = 12 x 64).
+template <typename T> struct ClsE { using type = void; };
+template <> struct ClsE<bf16_t> { using type = EBf16; };
+template <> struct ClsE<f16_t> { using type = EF16; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __restrict__ x, const float* __restrict__ g,
+                                                                     const uint8_t* __restrict__ text_mask, int B, int Tt,
+                                                                     int nq, float* __restrict__ xbar) {
+  constexpr int H = 768, HPW = 3, NK = 3;
+  constexpr bool MM = !std::is_same<T, float>::value;             // 16-bit rows: scores on the matrix cores
+  constexpr int RSE = H + (MM ? 8 : 0);                           // LDS row stride in elements (+16 B: conflict-free fragment reads)
+  extern __shared__ __attribute__((aligned(16))) unsigned char cls_smem[];
+  const int S = nq + Tt;
+  T* xs = reinterpret_cast<T*>(cls_smem);                                       // [S][RSE]
+  float* sc = reinterpret_cast<float*>(cls_smem + (size_t)S * RSE * sizeof(T));  // [12][64]
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t qrow0 = (int64_t)p * nq, trow0 = (int64_t)B * nq + (int64_t)p * Tt;
+  constexpr int EPC = 16 / (int)sizeof(T), CPR = H / EPC;
+  const int nchunk = S * CPR;
+  for (int i0 = tid; i0 < nchunk; i0 += 256 * 6) {
+    uint4 v0, v1, v2, v3, v4, v5;
+    auto ldc = [&](int i) {                                       // chunk i (clamped: the tail re-reads the last chunk)
+      i = i < nchunk ? i : nchunk - 1;
+      const int j = i / CPR, c = i - j * CPR;
+      const int64_t row = j < nq ? qrow0 + j : trow0 + (j - nq);
+      return *reinterpret_cast<const uint4*>(x + row * H + c * EPC);
+    };
+    v0 = ldc(i0); v1 = ldc(i0 + 256); v2 = ldc(i0 + 512); v3 = ldc(i0 + 768); v4 = ldc(i0 + 1024); v5 = ldc(i0 + 1280);
+    auto stc = [&](int i, const uint4& v) {
+      if (i < nchunk) {
+        const int j = i / CPR, c = i - j * CPR;
+        *reinterpret_cast<uint4*>(xs + j * RSE + c * EPC) = v;
+      }
+    };
+    stc(i0, v0); stc(i0 + 256, v1); stc(i0 + 512, v2); stc(i0 + 768, v3); stc(i0 + 1024, v4); stc(i0 + 1280, v5);
+  }
+  bool kvalid = lane < S;
+  if (kvalid && lane >= nq) kvalid = text_mask[(int64_t)p * Tt + (lane - nq)] != 0;
+  const unsigned long long valid64 = __ballot(kvalid);
+  if constexpr (MM) {
+    // Scores on the matrix cores: wave w owns keys 16 w .. 16 w + 15 (S <= 64), D[head][key] = sum_c G[head][c] X[key][c] over
+    // 24 steps of 32 features.  A = G (rows 12..15 zero) is read from global as fp32 and split into a 16-bit head and
+    // a 16-bit remainder (two matrix instructions per step: the product keeps ~16 bits of g), B = the staged rows.
+    using E = typename ClsE<T>::type;
+    using v8 = typename E::v8;
+    __syncthreads();
+    if (wv * 16 < S) {
+      const int n = lane & 15, kq = lane >> 4;
+      const int jrow = wv * 16 + n < S ? wv * 16 + n : S - 1;     // rows past S: duplicates, their columns are never read
+      const unsigned char* xrow = reinterpret_cast<const unsigned char*>(xs + jrow * RSE) + kq * 16;
+      const bool hv = n < 12;
+      const float* gp = g + ((int64_t)(hv ? n : 0) * B + p) * H + kq * 8;
+      psg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      float4 ga = *reinterpret_cast<const float4*>(gp), gb = *reinterpret_cast<const float4*>(gp + 4);
+#pragma unroll 4
+      for (int ks = 0; ks < H / 32; ++ks) {
+        const int kn = ks + 1 < H / 32 ? ks + 1 : ks;
+        const float4 na = *reinterpret_cast<const float4*>(gp + kn * 32), nb = *reinterpret_cast<const float4*>(gp + kn * 32 + 4);
+        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a0 = hv ? gv[2 * i] : 0.f, a1 = hv ? gv[2 * i + 1] : 0.f;
+          hi[i] = E::pack(a0, a1);
+          lo[i] = E::pack(a0 - E::to_f32((uint16_t)(hi[i] & 0xffffu)), a1 - E::to_f32((uint16_t)(hi[i] >> 16)));
+        }
+        const uint4 hq = make_uint4(hi[0], hi[1], hi[2], hi[3]), lq = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        const v8 bx = *reinterpret_cast<const v8*>(xrow + ks * 64);
+        acc = E::mfma16(__builtin_bit_cast(v8, hq), bx, acc);
+        acc = E::mfma16(__builtin_bit_cast(v8, lq), bx, acc);
+        ga = na;
+        gb = nb;
+      }
+      const int j = wv * 16 + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int h = 4 * kq + r;
+        const float v = ((valid64 >> j) & 1ull) ? acc[r] * 0.125f : PSG_FMIN;   // 1/sqrt(64); finfo.min absorbs the score
+        if (h < 12) sc[h * 64 + j] = v;
+      }
+    }
+    __syncthreads();
+  } else {
+    float gq[HPW][NK][4];
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(g + ((int64_t)(wv * HPW + hh) * B + p) * H + lane * 4 + 256 * k);
+        gq[hh][k][0] = t.x; gq[hh][k][1] = t.y; gq[hh][k][2] = t.z; gq[hh][k][3] = t.w;
+      }
+    __syncthreads();
+    // fp32 verification mode: wave w owns heads 3w..3w+2, a lane owns features {4 lane + 256 k}, one wave reduction per
+    // (head, key)
+#pragma unroll 1
+    for (int j = 0; j < S; ++j) {
+      float xv[NK][4];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) Act<T>::ld4(xs, j * RSE + lane * 4 + 256 * k, xv[k]);
+#pragma unroll
+      for (int hh = 0; hh < HPW; ++hh) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a = fmaf(gq[hh][k][e], xv[k][e], a);
+        a = wave_sum_dpp(a) * 0.125f;                               // 1/sqrt(64)
+        a = ((valid64 >> j) & 1ull) ? a : PSG_FMIN;                 // additive finfo.min absorbs the score
+        if (lane == 0) sc[(wv * HPW + hh) * 64 + j] = a;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh) {
+    float* my = sc + (wv * HPW + hh) * 64;
+    const float v = lane < S ? my[lane] : -INFINITY;
+    const float m = wave_max(v);
+    const float e = expf(v - m);                                  // 0 for lane >= S
+    const float denom = wave_sum(e);
+    my[lane] = Act<T>::rnd(e / denom);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // weighted row means: wave w owns heads 3w..3w+2, a lane owns features {4 lane + 256 k}
+  float o[HPW][NK][4];
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[hh][k][e] = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < S; ++j) {
+    float xv[NK][4];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) Act<T>::ld4(xs, j * RSE + lane * 4 + 256 * k, xv[k]);
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh) {
+      const float pj = sc[(wv * HPW + hh) * 64 + j];
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[hh][k][e] = fmaf(pj, xv[k][e], o[hh][k][e]);
+    }
+  }
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+      *reinterpret_cast<float4*>(xbar + ((int64_t)(wv * HPW + hh) * B + p) * H + lane * 4 + 256 * k) =
+          make_float4(o[hh][k][0], o[hh][k][1], o[hh][k][2], o[hh][k][3]);
+}
+
+// g [heads][B][hidden] = W_k,h^T q_h (fp32), x: the layer's input rows ordered as in psg_qformer_self_attn,
+// xbar [heads][B][hidden] (fp32) = sum_j softmax_j(g_h . x_j / 8 + mask_j) x_j.  PSG_ERR_UNSUPPORTED outside hidden 768 /
+// 12 heads or when the rows of one pair do not fit the LDS (fp32 with more than 48 rows): use the K | V form then.
+extern "C" int psg_qformer_cls_attn_input(psg_ctx* ctx, const void* x, const void* g, const uint8_t* text_mask, int B,
+                                          int T_, int nq, int heads, int hidden, void* xbar, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && x && g && xbar && (text_mask || T_ == 0), PSG_ERR_INVALID, "psg_qformer_cls_attn_input: NULL argument");
+  PSG_REQUIRE(B > 0 && T_ >= 0 && nq > 0 && nq + T_ <= 64, PSG_ERR_INVALID, "psg_qformer_cls_attn_input: B=%d T=%d nq=%d", B,
+              T_, nq);
+  PSG_REQUIRE(hidden == 768 && heads == 12, PSG_ERR_UNSUPPORTED,
+              "psg_qformer_cls_attn_input: built for hidden 768 = 12 heads x 64, got %d / %d", hidden, heads);
+  const size_t esz = dtype == PSG_F32 ? 4 : 2;
+  const size_t lds = (size_t)(nq + T_) * (hidden + (esz == 2 ? 8 : 0)) * esz + (size_t)heads * 64 * sizeof(float);
+  PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_qformer_cls_attn_input: %zu B of LDS for %d rows", lds, nq + T_);
+#define CLS_IN(TT)                                                                                                     \
+  do {                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)qformer_cls_attn_input_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              160 * 1024);                                                                             \
+    qformer_cls_attn_input_kernel<TT><<<(unsigned)B, 256, lds, (hipStream_t)stream>>>((const TT*)x, (const float*)g,     \
+                                                                                    text_mask, B, T_, nq, (float*)xbar); \
+  } while (0)
+  PSG_DISPATCH_DTYPE(dtype, "psg_qformer_cls_attn_input", CLS_IN(T));
+#undef CLS_IN
+  PSG_CHECK_LAUNCH("psg_qformer_cls_attn_input");
+  return PSG_OK;
+}
+
 // First-layer variant: the nq query rows entering layer 0 are identical for every pair, so their fused Q/K/V
 // projection is one [nq][3*hidden] block shared by all pairs; qkv_text holds the text rows [B*T][3*hidden].
 extern "C" int psg_qformer_self_attn_shared(psg_ctx* ctx, const void* qkv_query, const void* qkv_text,

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 
 #include "../../include/psg_hip.h"
 
@@ -213,6 +214,23 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// Sum over the 64 lanes on the VALU's data-parallel-primitive path (row shifts + row broadcasts, no LDS crossbar
+// round trips as in __shfl_xor): ~8 instructions; the result is wave-uniform (read from lane 63).  Different
+// association than wave_sum - use one or the other consistently where bit-identity between kernels matters.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl, auto rows) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                  decltype(rows)::value, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});   // row_shr:1
+  v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});   // row_shr:2
+  v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});   // row_shr:4
+  v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8 -> lane 15 of a row = row sum
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1, 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 #define PSG_MAX_SPLITS 16  // split-K slices a consumer kernel can sum (psg_skinny_gemm_plan stays below)

@@ -161,6 +161,18 @@ def qformer_self_attn_cls(q_cls, kv, text_mask, B, T, nq, heads):
     return out
 
 
+def qformer_cls_attn_input(x, g, text_mask, B, T, nq, heads):
+    """cls-row attention in the input space (psg_qformer_cls_attn_input): x [B*(nq+T), hidden] layer input rows,
+    g fp32 [heads, B, hidden] = W_k,h^T q_h  ->  xbar fp32 [heads, B, hidden] = sum_j p_j x_j."""
+    lib, ctx, st = _env(x)
+    hidden = x.shape[1]
+    assert x.shape[0] == B * (nq + T) and g.shape == (heads, B, hidden) and g.is_contiguous()
+    xbar = torch.empty((heads, B, hidden), device=x.device, dtype=torch.float32)
+    check(lib.psg_qformer_cls_attn_input(ctx, _p(x), _p(g, torch.float32, "g"), _p(text_mask, torch.uint8, "text_mask"),
+                                         B, T, nq, heads, hidden, _p(xbar), _dt(x), st), "psg_qformer_cls_attn_input")
+    return xbar
+
+
 def qformer_self_attn_shared(qkv_query, qkv_text, text_mask, B, T, nq, heads, out):
     """Layer-0 self-attention with ONE shared [nq, 3*hidden] projection of the query rows (bf16 / fp16)."""
     lib, ctx, st = _env(qkv_query)

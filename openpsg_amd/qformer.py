@@ -68,9 +68,19 @@ class RelationQueryEngine:
                 w2t=act(weights[p + "output.dense.weight"]), b2t=f32(p + "output.dense.bias"),
                 ln_t=(f32(p + "output.LayerNorm.weight"), f32(p + "output.LayerNorm.bias")),
             )
+            if l == q.layers - 1:
+                # selection phase in the input space (forward_pairs_cls): per-head W_k and W_v^T of the ROUNDED weights in
+                # fp32 (4.7 MB) - the two small batched projections around psg_qformer_cls_attn_input run in fp32
+                H, hd = q.hidden, q.hidden // q.heads
+                L["wk"] = L["wqkv"][H:2 * H].view(q.heads, hd, H)
+                L["wk32"] = L["wk"].float().contiguous()
+                L["wv32t"] = L["wqkv"][2 * H:].float().view(q.heads, hd, H).transpose(1, 2).contiguous()
             self.layers.append(L)
         self.empty_policy = PSG_EMPTY_UNIFORM if cfg.empty_row_policy == "uniform" else PSG_EMPTY_UNMASKED
         self.share_query_qkv = os.environ.get("PSG_SHARE_QUERY_QKV", "1") != "0"
+        # selection phase of the last layer: cls-row attention in the input space (no K | V projection of all rows)
+        self.cls_input_space = os.environ.get("PSG_CLS_INPUT_SPACE", "1") != "0"
+        self._bmm_out_dtype = None       # torch.bmm(..., out_dtype=fp32) available? (probed at first use)
 
     # ---- A4: prepare_inference (V4:408-435) ----------------------------------------------------
     def patch_embed(self, mask_features: torch.Tensor) -> torch.Tensor:
@@ -202,10 +212,20 @@ class RelationQueryEngine:
             X = self._layer(li, X, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0)
         li, L = nl - 1, self.layers[nl - 1]
         x_cls = X[:RQ].view(P, nq, H)[:, 0].contiguous()                     # [P, H] residual of the cls rows
-        kvs = F.linear(X, L["wqkv"][H:], L["bqkv"][H:])                     # keys | values of every row
         q_cls = F.linear(x_cls, L["wqkv"][:H], L["bqkv"][:H])              # queries of the cls rows only
-        ctx = ops.qformer_self_attn_cls(q_cls, kvs, text_mask, P, T, nq, q.heads)
-        del kvs
+        hd = H // q.heads
+        lds = (nq + T) * (H + (8 if X.element_size() == 2 else 0)) * X.element_size() + q.heads * 256
+        if self.cls_input_space and H == 768 and q.heads == 12 and lds <= 160 * 1024:
+            # keys / values never materialised: the cls queries go back through W_k (g_h = W_k,h^T q_h), the kernel
+            # reads the layer's input rows once, the weighted row means go through W_v (psg_qformer_cls_attn_input)
+            g = self._bmm_f32(q_cls.view(P, q.heads, hd).transpose(0, 1), L["wk"], L["wk32"])  # fp32 [heads, P, H]
+            xbar = ops.qformer_cls_attn_input(X, g, text_mask, P, T, nq, q.heads)
+            ctx = (torch.bmm(xbar, L["wv32t"]).permute(1, 0, 2).reshape(P, H) + L["bqkv"][2 * H:].float()).to(self.dtype)
+            del g, xbar
+        else:
+            kvs = F.linear(X, L["wqkv"][H:], L["bqkv"][H:])                 # keys | values of every row
+            ctx = ops.qformer_self_attn_cls(q_cls, kvs, text_mask, P, T, nq, q.heads)
+            del kvs
         A = F.linear(ctx, L["wo"])
         ops.add_layernorm(A, x_cls, L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
         qx = F.linear(A, L["wq_x"], L["bq_x"])
@@ -240,6 +260,21 @@ class RelationQueryEngine:
         pi = state["pair_index"].index_select(0, s64)
         return self._layer(len(self.layers) - 1, Xs, K, T, tm, pi, state["kv"], state["bits"], state["num_objects"],
                            segments)
+
+    def _bmm_f32(self, a, b, b32):
+        """fp32 result of a batched product of activation-dtype operands (exact products, fp32 accumulation): the
+        library's 16-bit-in / fp32-out batched GEMM where this PyTorch has it, else the fp32 GEMM on widened copies."""
+        if a.dtype == torch.float32:
+            return torch.bmm(a, b32)
+        if self._bmm_out_dtype is None:
+            try:
+                torch.bmm(a[:, :1], b, out_dtype=torch.float32)
+                self._bmm_out_dtype = True
+            except (TypeError, RuntimeError):
+                self._bmm_out_dtype = False
+        if self._bmm_out_dtype:
+            return torch.bmm(a, b, out_dtype=torch.float32)
+        return torch.bmm(a.float(), b32)
 
     def _ffn1(self, x, w, b):
         """intermediate(_query): Linear + exact-erf GELU (HF-IB:563-577).  16-bit modes: one pass through

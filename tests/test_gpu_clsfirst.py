@@ -94,3 +94,43 @@ def test_cls_first_on_large_images(size, dtype):
     err = np.abs(logits[False] - logits[True]).max()
     print(f"{size} {dtype}: L = {size[0] // 64 * (size[1] // 64)}, max |logit diff| = {err:.3e}")
     assert err < (2e-5 if dtype == "fp32" else 0.06)
+
+
+@pytest.mark.parametrize("dtype,T", [("fp32", 14), ("fp32", 0), ("bf16", 14), ("bf16", 31), ("fp16", 9)])
+def test_cls_attention_in_input_space_matches_kv_form(dtype, T):
+    """psg_qformer_cls_attn_input (queries projected back through W_k, weighted row means projected through W_v) against
+    psg_qformer_self_attn_cls on the materialised K | V and against the fp64 formula (HF-IB:471-515, row 0 only)."""
+    from openpsg_amd import ops
+    dev = _dev()
+    tdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    P, nq, heads, Hd = 37, 33, 12, 768
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    X = (torch.randn(P * (nq + T), Hd, generator=gen) * 0.7).to(dev, tdt)
+    wq, wk, wv = [(torch.randn(Hd, Hd, generator=gen) * 0.06).to(dev, tdt) for _ in range(3)]
+    bq, bk, bv = [(torch.randn(Hd, generator=gen) * 0.1).to(dev, tdt) for _ in range(3)]
+    mask = (torch.rand(P, max(T, 1), generator=gen) < 0.7).to(torch.uint8)[:, :T].contiguous().to(dev)
+    if T:
+        mask[3] = 0                                                 # a pair whose text rows are all padding
+    x_cls = X[:P * nq].view(P, nq, Hd)[:, 0].contiguous()
+    q_cls = torch.nn.functional.linear(x_cls, wq, bq)
+    kvs = torch.nn.functional.linear(X, torch.cat([wk, wv]), torch.cat([bk, bv]))
+    ref_kv = ops.qformer_self_attn_cls(q_cls, kvs, mask, P, T, nq, heads).float().cpu()
+    g = torch.bmm(q_cls.float().view(P, heads, 64).transpose(0, 1), wk.float().view(heads, 64, Hd))
+    xbar = ops.qformer_cls_attn_input(X, g, mask, P, T, nq, heads)
+    got = (torch.bmm(xbar, wv.float().view(heads, 64, Hd).transpose(1, 2)).permute(1, 0, 2).reshape(P, Hd)
+           + bv.float()).to(tdt).float().cpu()
+    # fp64 formula on the same (rounded) inputs
+    Xd, qd = X.double().cpu(), q_cls.double().cpu()
+    rows = torch.cat([Xd[:P * nq].view(P, nq, Hd), Xd[P * nq:].view(P, T, Hd)], dim=1)           # [P, S, Hd]
+    K = rows @ wk.double().cpu().T + bk.double().cpu()
+    V = rows @ wv.double().cpu().T + bv.double().cpu()
+    valid = torch.cat([torch.ones(P, nq, dtype=torch.bool), mask.cpu().bool()], dim=1)
+    sc = torch.einsum("phd,pshd->phs", qd.view(P, heads, 64), K.view(P, -1, heads, 64)) / 8.0
+    sc = sc.masked_fill(~valid[:, None, :], float("-inf"))
+    ref = torch.einsum("phs,pshd->phd", sc.softmax(-1), V.view(P, -1, heads, 64)).reshape(P, Hd).float()
+    e_ref, e_kv = (got - ref).abs().max().item(), (ref_kv - ref).abs().max().item()
+    print(f"{dtype} T={T}: input-space vs fp64 {e_ref:.3e}, K|V form vs fp64 {e_kv:.3e}")
+    if dtype == "fp32":
+        assert e_ref < 2e-5 and (got - ref_kv).abs().max().item() < 2e-5
+    else:
+        assert e_ref < max(1.2 * e_kv, 0.02)                        # no K / V rounding: at least as close
