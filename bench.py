@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--workload", choices=["full", "rq"], default="full")
     ap.add_argument("--objects", type=int, default=50)
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--categories", type=int, default=133,
+                    help="classes the synthetic objects draw from (default: all 133, SURVEY 8d; real images repeat "
+                         "classes - fewer distinct prompts - which the relation query exploits)")
     ap.add_argument("--llm-layers", type=int, default=32)
     ap.add_argument("--images-per-step", type=int, default=1,
                     help="single-GPU throughput mode: images per step whose selected pairs are decoded together")
@@ -146,7 +149,11 @@ def relation_query_flops(N, L, T, cls_first=False, selected=20):
     if cls_first:
         # last layer: K/V of every row, then ONLY the cls row of every pair (existence head, V4:206-209) and the 33
         # rows of the selected pairs (V4:215, 235-237)
-        last_cls = 2 * S * H * 2 * H + 2 * H * H + 4 * S * H + 2 * H * H + (2 * H * H + 4 * L * H + 2 * H * H) + 4 * H * F
+        # selection phase in the input space (psg_qformer_cls_attn_input): no K | V projection of all rows; per pair
+        # the cls query (2 H H), its projection back through W_k (2 H H), 12 heads x S keys x 768 features for the
+        # scores and as many for the weighted row means (4 * 12 * S * H), the means through W_v (2 H H)
+        last_cls = (2 * H * H + 2 * H * H + 4 * 12 * S * H + 2 * H * H) + 2 * H * H + (
+            2 * H * H + 4 * L * H + 2 * H * H) + 4 * H * F
         return N * N * (first + last_cls) + selected * last + per_image
     return N * N * (first + last) + per_image
 
@@ -308,7 +315,7 @@ def main():
     pairs_per_image = N * (N - 1)
 
     if world == 1 and not force_dist:
-        scene = make_scene((a.size, a.size), N, seed=0, device=str(dev))
+        scene = make_scene((a.size, a.size), N, seed=0, device=str(dev), num_categories=a.categories)
         inputs = scene_inputs(scene)
         if a.workload == "full" and a.images_per_step > 1:
             batch = [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev)))
@@ -392,8 +399,8 @@ def main():
         wl = ("C3: 1024x1024, 50 masks, full path incl. LMM autoregressive relation decode (Llama-2-7B shape, top-20 "
               "pairs, 16 new tokens each, EOS suppressed)") if a.workload == "full" else \
              "C2: 1024x1024, 50 masks, relation-query transformer only"
-        if (a.size, a.objects) != (1024, 50):
-            wl = f"custom: {a.size}x{a.size}, {a.objects} masks, {a.workload}"
+        if (a.size, a.objects, a.categories) != (1024, 50, 133):
+            wl = f"custom: {a.size}x{a.size}, {a.objects} masks from {a.categories} classes, {a.workload}"
         line = {
             "metric": METRIC, "value": round(images * pairs_per_image / elapsed, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),

@@ -136,14 +136,17 @@ int psg_qformer_self_attn_cls(psg_ctx*, const void* q_cls, const void* kv, const
                               int nq, int heads, void* out, int dtype, void* stream);
 /* The same cls-row attention with the key / value projections (HF-IB:471-475) folded into the input space, so that no
  * K | V tensor exists: score_j = (W_k,h^T q_h) . x_j / 8 (+ a per-head constant that the softmax drops) and
- * context_h = W_v,h (sum_j p_j x_j) + b_v,h.  x [B*(nq+T)][hidden]: the layer's INPUT rows (ordered as in
- * psg_qformer_self_attn); g [heads][B][hidden] FP32 = W_k,h^T q_h, projected by the caller; xbar [heads][B][hidden] FP32 =
+ * context_h = W_v,h (sum_j p_j x_j) + b_v,h.  x_query [B*nq][hidden]: the layer's INPUT query rows, pair-major;
+ * x_text: its text rows in blocks of T - block text_index[p] for pair p, or block p when text_index is NULL; pairs with
+ * the same prompt may share one block and one row of text_mask (a text row entering the last layer depends on the prompt
+ * only); g [heads][B][hidden] FP32 = W_k,h^T q_h, projected by the caller; xbar [heads][B][hidden] FP32 =
  * sum_j p_j x_j, which the caller projects through W_v,h (+ b_v) - fp32 on both sides because a 768-term product of
- * rounded factors would lose what the 64-term q.k keeps.  Same function as psg_qformer_self_attn_cls up to
- * rounding (fp32: 1e-6); the K | V projection of every row of every pair is not computed at all.
+ * rounded factors would lose what the 64-term q.k keeps.  Same function as psg_qformer_self_attn_cls up to rounding
+ * (fp32: 1e-6); the K | V projection of every row of every pair is not computed at all.
  * hidden 768 = 12 heads only; PSG_ERR_UNSUPPORTED when a pair's rows exceed the LDS (fp32, > 48 rows). */
-int psg_qformer_cls_attn_input(psg_ctx*, const void* x, const void* g, const uint8_t* text_mask, int B, int T, int nq,
-                               int heads, int hidden, void* xbar, int dtype, void* stream);
+int psg_qformer_cls_attn_input(psg_ctx*, const void* x_query, const void* x_text, const int32_t* text_index,
+                               const void* g, const uint8_t* text_mask, int B, int T, int nq, int heads, int hidden,
+                               void* xbar, int dtype, void* stream);
 
 /* ---- K6: relation-query cross-attention (primary kernel), HF-IB:464-466, 487-496 with the
  * V4:168-170 expand removed: K/V [L][hidden] are projected ONCE per image and shared by every

@@ -52,7 +52,7 @@ SIGNATURES = {
     "psg_bias_gelu": [_vp, _vp, _vp, _i64, _i, _vp, _i, _vp],
     "psg_qformer_self_attn": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "psg_qformer_self_attn_cls": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp],
-    "psg_qformer_cls_attn_input": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "psg_qformer_cls_attn_input": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "psg_qformer_self_attn_shared": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp],
     "psg_qformer_cross_attn": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "psg_exist_head": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],

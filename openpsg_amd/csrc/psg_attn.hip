@@ -156,8 +156,7 @@ __global__ void __launch_bounds__(256) qformer_self_attn_cls_kernel(const T* __r
 #pragma unroll
         for (int e = 0; e < 4; ++e) a = fmaf(qv[4 * c + e], t[e], a);
       }
-      a += __shfl_xor(a, 1, 64);
-      a += __shfl_xor(a, 2, 64);
+      a = quad_sum(a);
       const int j = ch * 8 + u;
       a *= 0.125f;                                              // 1/sqrt(64)
       a = ((valid64 >> j) & 1ull) ? a : PSG_FMIN;               // additive finfo.min absorbs the score
@@ -245,7 +244,9 @@ template <> struct ClsE<bf16_t> { using type = EBf16; };
 template <> struct ClsE<f16_t> { using type = EF16; };
 
 template <typename T>
-__global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __restrict__ x, const float* __restrict__ g,
+__global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __restrict__ x, const T* __restrict__ xt,
+                                                                     const int32_t* __restrict__ text_index,
+                                                                     const float* __restrict__ g,
                                                                      const uint8_t* __restrict__ text_mask, int B, int Tt,
                                                                      int nq, float* __restrict__ xbar) {
   constexpr int H = 768, HPW = 3, NK = 3;
@@ -256,7 +257,10 @@ __global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __
   T* xs = reinterpret_cast<T*>(cls_smem);                                       // [S][RSE]
   float* sc = reinterpret_cast<float*>(cls_smem + (size_t)S * RSE * sizeof(T));  // [12][64]
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t qrow0 = (int64_t)p * nq, trow0 = (int64_t)B * nq + (int64_t)p * Tt;
+  // text rows: block `ti` of xt (the pair's own block, or the block of its prompt when the text rows are shared by all
+  // pairs with the same prompt: text_index); query rows: block p of x
+  const int ti = text_index ? text_index[p] : p;
+  const int64_t qrow0 = (int64_t)p * nq, trow0 = (int64_t)ti * Tt;
   constexpr int EPC = 16 / (int)sizeof(T), CPR = H / EPC;
   const int nchunk = S * CPR;
   // 16-bit rows: the first GD steps of this lane's g fragments (A operand of the score product, see below) are
@@ -276,8 +280,8 @@ __global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __
     auto ldc = [&](int i) {                                       // chunk i (clamped: the tail re-reads the last chunk)
       i = i < nchunk ? i : nchunk - 1;
       const int j = i / CPR, c = i - j * CPR;
-      const int64_t row = j < nq ? qrow0 + j : trow0 + (j - nq);
-      return *reinterpret_cast<const uint4*>(x + row * H + c * EPC);
+      const T* src = j < nq ? x + (qrow0 + j) * H : xt + (trow0 + (j - nq)) * H;
+      return *reinterpret_cast<const uint4*>(src + c * EPC);
     };
     v0 = ldc(i0); v1 = ldc(i0 + 256); v2 = ldc(i0 + 512); v3 = ldc(i0 + 768); v4 = ldc(i0 + 1024); v5 = ldc(i0 + 1280);
     auto stc = [&](int i, const uint4& v) {
@@ -289,7 +293,7 @@ __global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __
     stc(i0, v0); stc(i0 + 256, v1); stc(i0 + 512, v2); stc(i0 + 768, v3); stc(i0 + 1024, v4); stc(i0 + 1280, v5);
   }
   bool kvalid = lane < S;
-  if (kvalid && lane >= nq) kvalid = text_mask[(int64_t)p * Tt + (lane - nq)] != 0;
+  if (kvalid && lane >= nq) kvalid = text_mask[(int64_t)ti * Tt + (lane - nq)] != 0;
   const unsigned long long valid64 = __ballot(kvalid);
   if constexpr (MM) {
     // Scores on the matrix cores: wave w owns keys 16 w .. 16 w + 15 (S <= 64), D[head][key] = sum_c G[head][c] X[key][c] over
@@ -449,12 +453,16 @@ __global__ void __launch_bounds__(256) qformer_cls_attn_input_kernel(const T* __
   }
 }
 
-// g [heads][B][hidden] = W_k,h^T q_h (fp32), x: the layer's input rows ordered as in psg_qformer_self_attn,
-// xbar [heads][B][hidden] (fp32) = sum_j softmax_j(g_h . x_j / 8 + mask_j) x_j.  PSG_ERR_UNSUPPORTED outside hidden 768 /
-// 12 heads or when the rows of one pair do not fit the LDS (fp32 with more than 48 rows): use the K | V form then.
-extern "C" int psg_qformer_cls_attn_input(psg_ctx* ctx, const void* x, const void* g, const uint8_t* text_mask, int B,
-                                          int T_, int nq, int heads, int hidden, void* xbar, int dtype, void* stream) {
-  PSG_REQUIRE(ctx && x && g && xbar && (text_mask || T_ == 0), PSG_ERR_INVALID, "psg_qformer_cls_attn_input: NULL argument");
+// g [heads][B][hidden] = W_k,h^T q_h (fp32); x_query [B*nq][hidden]: the layer's input query rows; x_text: its text rows,
+// block text_index[p] (or p when text_index is NULL) of T rows per pair - pairs with the same prompt may share one block
+// (and one row of text_mask); xbar [heads][B][hidden] (fp32) = sum_j softmax_j(g_h . x_j / 8 + mask_j) x_j.
+// PSG_ERR_UNSUPPORTED outside hidden 768 / 12 heads or when the rows of one pair do not fit the LDS (fp32 with more
+// than 48 rows): use the K | V form then.
+extern "C" int psg_qformer_cls_attn_input(psg_ctx* ctx, const void* x_query, const void* x_text, const int32_t* text_index,
+                                          const void* g, const uint8_t* text_mask, int B, int T_, int nq, int heads,
+                                          int hidden, void* xbar, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && x_query && g && xbar && ((text_mask && x_text) || T_ == 0), PSG_ERR_INVALID,
+              "psg_qformer_cls_attn_input: NULL argument");
   PSG_REQUIRE(B > 0 && T_ >= 0 && nq > 0 && nq + T_ <= 64, PSG_ERR_INVALID, "psg_qformer_cls_attn_input: B=%d T=%d nq=%d", B,
               T_, nq);
   PSG_REQUIRE(hidden == 768 && heads == 12, PSG_ERR_UNSUPPORTED,
@@ -466,8 +474,8 @@ extern "C" int psg_qformer_cls_attn_input(psg_ctx* ctx, const void* x, const voi
   do {                                                                                                                 \
     (void)hipFuncSetAttribute((const void*)qformer_cls_attn_input_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               160 * 1024);                                                                             \
-    qformer_cls_attn_input_kernel<TT><<<(unsigned)B, 256, lds, (hipStream_t)stream>>>((const TT*)x, (const float*)g,     \
-                                                                                    text_mask, B, T_, nq, (float*)xbar); \
+    qformer_cls_attn_input_kernel<TT><<<(unsigned)B, 256, lds, (hipStream_t)stream>>>(                                  \
+        (const TT*)x_query, (const TT*)x_text, text_index, (const float*)g, text_mask, B, T_, nq, (float*)xbar);       \
   } while (0)
   PSG_DISPATCH_DTYPE(dtype, "psg_qformer_cls_attn_input", CLS_IN(T));
 #undef CLS_IN
@@ -885,8 +893,7 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
         acc = fmaf(qq[2], kf[2], acc);
         acc = fmaf(qq[3], kf[3], acc);
       }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
+      acc = quad_sum(acc);
       if (j < pos) s = acc * scale;
     }
     const float m_new = fmaxf(m_run, wave_max(s));

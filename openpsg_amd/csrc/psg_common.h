@@ -205,32 +205,40 @@ struct EF16 {
   } while (0)
 
 // ---- wave (64 lanes) reductions ------------------------------------------------------------
+// On the VALU's data-parallel-primitive path (row shifts + row broadcasts; the result is read from lane 63 and is
+// wave-uniform): ~8 instructions of a few cycles each.  The __shfl_xor butterfly these replaced goes through the LDS
+// crossbar (ds_bpermute, ~100 cycles per step, 6 dependent steps) - in the latency-bound row kernels of the decode
+// step and in the one-wave-per-row LayerNorm that was a visible share of the kernel.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float psg_dpp(float old, float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), CTRL,
+                                                                ROWS, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-// Sum over the 64 lanes on the VALU's data-parallel-primitive path (row shifts + row broadcasts, no LDS crossbar
-// round trips as in __shfl_xor): ~8 instructions; the result is wave-uniform (read from lane 63).  Different
-// association than wave_sum - use one or the other consistently where bit-identity between kernels matters.
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  auto dpp = [](float x, auto ctrl, auto rows) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
-                                                                  decltype(rows)::value, 0xf, false));
-  };
-  v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});   // row_shr:1
-  v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});   // row_shr:2
-  v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});   // row_shr:4
-  v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8 -> lane 15 of a row = row sum
-  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1, 3
-  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2, 3
+  v += psg_dpp<0x111, 0xf>(0.f, v);   // row_shr:1
+  v += psg_dpp<0x112, 0xf>(0.f, v);   // row_shr:2
+  v += psg_dpp<0x114, 0xf>(0.f, v);   // row_shr:4
+  v += psg_dpp<0x118, 0xf>(0.f, v);   // row_shr:8  -> lane 15 of every row of 16 = the row's sum
+  v += psg_dpp<0x142, 0xa>(0.f, v);   // row_bcast:15 into rows 1 and 3
+  v += psg_dpp<0x143, 0xc>(0.f, v);   // row_bcast:31 into rows 2 and 3 -> lane 63 = the wave's sum
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) { return wave_sum(v); }
+__device__ __forceinline__ float wave_max(float v) {               // lanes without a source keep their own value
+  v = fmaxf(v, psg_dpp<0x111, 0xf>(v, v));
+  v = fmaxf(v, psg_dpp<0x112, 0xf>(v, v));
+  v = fmaxf(v, psg_dpp<0x114, 0xf>(v, v));
+  v = fmaxf(v, psg_dpp<0x118, 0xf>(v, v));
+  v = fmaxf(v, psg_dpp<0x142, 0xa>(v, v));
+  v = fmaxf(v, psg_dpp<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// sum over the 4 lanes of a quad, in every lane of the quad (lane ^ 1, then lane ^ 2: same association as the
+// __shfl_xor pair it replaces)
+__device__ __forceinline__ float quad_sum(float v) {
+  v += psg_dpp<0xB1, 0xf>(0.f, v);    // quad_perm:[1,0,3,2]
+  v += psg_dpp<0x4E, 0xf>(0.f, v);    // quad_perm:[2,3,0,1]
+  return v;
 }
 
 #define PSG_MAX_SPLITS 16  // split-K slices a consumer kernel can sum (psg_skinny_gemm_plan stays below)

@@ -246,64 +246,66 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float* __restrict__ sc
   }
 }
 
-// Rank-based variant for the sizes the selector sees (n <= 12288 pairs, k <= 64): no k dependent rounds.  The scores
+// Rank-based variant for one image's worth of pairs (n <= 3072, k <= 64): no k dependent rounds.  The scores
 // sit in LDS; wave w ranks the elements of segment w among themselves (a lane compares its own <= n/1024 elements with
 // every element of the segment: LDS broadcast reads); an element can only be among the k best overall if fewer than k
 // elements of its own segment beat it, so at most 16 k candidates remain, which are ranked among themselves the same
 // way.  The order (larger score first, ties -> lower index, NaN last) is total, so ranks are unique: same output as
-// topk_kernel, 52 -> 6 us at n = 2500, k = 20.
-constexpr int TOPK_NMAX = 12288, TOPK_KMAX = 64, TOPK_OWN = TOPK_NMAX / 1024;
+// topk_kernel.
+constexpr int TOPK_NMAX = 3072, TOPK_KMAX = 64;
+// (score, index) as ONE unsigned 64-bit key whose order is the selector's order: the float's bits made monotone in the
+// high word, the complemented index in the low word (larger key = better).  One 64-bit compare per pair of elements:
+// the 16 waves of the workgroup share 4 SIMDs, so the n^2 / 16 comparisons are what the kernel costs.
+__device__ __forceinline__ unsigned long long topk_key(float v, int i) {
+  if (v != v) v = -INFINITY;                                      // NaN sorts last
+  if (v == 0.f) v = 0.f;                                          // -0 == +0 for the comparison
+  uint32_t u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+}
+template <int OWN>
 __global__ void __launch_bounds__(1024) topk_rank_kernel(const float* __restrict__ score, int n, int k,
                                                          int32_t* __restrict__ out_idx, float* __restrict__ out_val) {
-  __shared__ float s_v[TOPK_NMAX];
-  __shared__ float c_v[16 * TOPK_KMAX];
-  __shared__ int c_i[16 * TOPK_KMAX];
+  __shared__ unsigned long long s_k[TOPK_NMAX];
+  __shared__ unsigned long long c_k[16 * TOPK_KMAX];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int i = tid; i < n; i += 1024) {
-    float v = score[i];
-    s_v[i] = v != v ? -INFINITY : v;                              // NaN sorts last
-  }
-  for (int i = tid; i < 16 * k; i += 1024) {
-    c_v[i] = -INFINITY;
-    c_i[i] = 0x7fffffff;                                          // empty candidate slot: worse than any element
-  }
+  for (int i = tid; i < n; i += 1024) s_k[i] = topk_key(score[i], i);
+  for (int i = tid; i < 16 * k; i += 1024) c_k[i] = 0ull;          // empty candidate slot: below every real key
   if (tid < k) {                                                  // fewer than k elements: the tail stays "none"
     out_idx[tid] = -1;
     if (out_val) out_val[tid] = -INFINITY;
   }
   __syncthreads();
   const int seg = (n + 15) / 16, s0 = wid * seg, s1 = min(n, s0 + seg);
-  float own[TOPK_OWN];
-  int rank[TOPK_OWN];
+  unsigned long long own[OWN];
+  int rank[OWN];
 #pragma unroll
-  for (int u = 0; u < TOPK_OWN; ++u) {
+  for (int u = 0; u < OWN; ++u) {
     const int i = s0 + lane + 64 * u;
-    own[u] = i < s1 ? s_v[i] : -INFINITY;
+    own[u] = i < s1 ? s_k[i] : ~0ull;                             // no element: never a candidate
     rank[u] = 0;
   }
   for (int j = s0; j < s1; ++j) {
-    const float o = s_v[j];
+    const unsigned long long o = s_k[j];
 #pragma unroll
-    for (int u = 0; u < TOPK_OWN; ++u) rank[u] += topk_better(o, j, own[u], s0 + lane + 64 * u) ? 1 : 0;
+    for (int u = 0; u < OWN; ++u) rank[u] += o > own[u] ? 1 : 0;
   }
 #pragma unroll
-  for (int u = 0; u < TOPK_OWN; ++u) {
-    const int i = s0 + lane + 64 * u;
-    if (i < s1 && rank[u] < k) {
-      c_v[wid * k + rank[u]] = own[u];
-      c_i[wid * k + rank[u]] = i;
-    }
-  }
+  for (int u = 0; u < OWN; ++u)
+    if (s0 + lane + 64 * u < s1 && rank[u] < k) c_k[wid * k + rank[u]] = own[u];
   __syncthreads();
   const int nc = 16 * k;
-  if (tid < nc && c_i[tid] != 0x7fffffff) {
-    const float v = c_v[tid];
-    const int i = c_i[tid];
+  if (tid < nc && c_k[tid] != 0ull) {
+    const unsigned long long mine = c_k[tid];
     int r = 0;
-    for (int j = 0; j < nc; ++j) r += topk_better(c_v[j], c_i[j], v, i) ? 1 : 0;
+    for (int j = 0; j < nc; ++j) r += c_k[j] > mine ? 1 : 0;
     if (r < k) {
+      const int i = (int)(0xffffffffu - (uint32_t)mine);
       out_idx[r] = i;
-      if (out_val) out_val[r] = v;
+      if (out_val) {
+        const float v = score[i];
+        out_val[r] = v != v ? -INFINITY : v;
+      }
     }
   }
 }
@@ -312,9 +314,13 @@ extern "C" int psg_topk(psg_ctx* ctx, const float* score, int n, int k, int32_t*
                         void* stream) {
   PSG_REQUIRE(ctx && score && out_idx, PSG_ERR_INVALID, "psg_topk: NULL argument");
   PSG_REQUIRE(n > 0 && k > 0, PSG_ERR_INVALID, "psg_topk: n=%d k=%d", n, k);
-  if (n <= TOPK_NMAX && k <= TOPK_KMAX)
-    topk_rank_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(score, n, k, out_idx, out_val);
-  else
+  const int own = ((n + 15) / 16 + 63) / 64;                       // elements per lane of a segment's wave
+  if (own <= 3 && k <= TOPK_KMAX) {                               // n <= 3072: the n^2 / 16 comparisons of ONE workgroup beat k rounds
+    hipStream_t st = (hipStream_t)stream;                         // (2500 pairs: 23 vs 52 us; 10 000 pairs: 141 vs 80 us, so not there)
+    if (own <= 1) topk_rank_kernel<1><<<1, 1024, 0, st>>>(score, n, k, out_idx, out_val);
+    else if (own <= 2) topk_rank_kernel<2><<<1, 1024, 0, st>>>(score, n, k, out_idx, out_val);
+    else topk_rank_kernel<3><<<1, 1024, 0, st>>>(score, n, k, out_idx, out_val);
+  } else
     topk_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(score, n, k, out_idx, out_val);
   PSG_CHECK_LAUNCH("psg_topk");
   return PSG_OK;

@@ -17,7 +17,7 @@ __device__ __forceinline__ void ln_row(float (&v)[NCH][4], int hidden, float eps
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
-  const float mean = wave_sum(s) / (float)hidden;
+  const float mean = wave_sum_dpp(s) / (float)hidden;             // row-shift reductions: no LDS crossbar round trips
   float q = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
@@ -26,7 +26,7 @@ __device__ __forceinline__ void ln_row(float (&v)[NCH][4], int hidden, float eps
       float d = v[c][e] - mean;
       q += d * d;
     }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)hidden + eps);
+  const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)hidden + eps);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 256 + lane * 4;

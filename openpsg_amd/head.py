@@ -53,7 +53,7 @@ class _LazyRQ(dict):
     def __missing__(self, key):
         if key != "hidden":
             raise KeyError(key)
-        hs = [self.engine.pair_hidden(st, torch.arange(off, off + c1 - c0, device=st["X"].device, dtype=torch.int32))
+        hs = [self.engine.pair_hidden(st, torch.arange(off, off + c1 - c0, device=st["pair_index"].device, dtype=torch.int32))
               for c0, c1, st, off in self["pending"]]
         h = hs[0] if len(hs) == 1 else torch.cat(hs)
         self[key] = h
@@ -507,7 +507,12 @@ class RelationTransformerHeadV4(nn.Module):
             trow = u_d[pidx // N] * U + u_d[pidx % N]
             if len(self._gather_cache) > 64:
                 self._gather_cache.clear()
-            ent = self._gather_cache[gk] = (pidx.to(torch.int32), tbl_d[trow].contiguous(), msk_d[trow].contiguous())
+            # the distinct prompts among these pairs and every pair's row in that table (the engine runs the
+            # prompt-only part of the Q-Former once per distinct prompt); one host round trip, cached with the rest
+            uniq, inv = torch.unique(trow, return_inverse=True)
+            prompts = (tbl_d[uniq].contiguous(), msk_d[uniq].contiguous(), inv.to(torch.int32).contiguous())
+            ent = self._gather_cache[gk] = (pidx.to(torch.int32), tbl_d[trow].contiguous(), msk_d[trow].contiguous(),
+                                            prompts)
         return ent
 
     def run_relation_query(self, feat, meta, obj_ids, names, pan, pair_range=None, patches=None):
@@ -528,7 +533,7 @@ class RelationTransformerHeadV4(nn.Module):
             for c0 in range(p0, p1, self.pair_chunk):
                 c1 = min(p1, c0 + self.pair_chunk)
                 ent = self._chunk_prompts(ck, N, c0, c1)
-                state, lg, pr = eng.forward_pairs_cls(kv, bits, N, ent[0], ent[1], ent[2])
+                state, lg, pr = eng.forward_pairs_cls(kv, bits, N, ent[0], ent[1], ent[2], prompts=ent[3])
                 pending.append((c0, c1, state, 0))
                 lgs.append(lg)
                 prs.append(pr)
@@ -654,8 +659,8 @@ class RelationTransformerHeadV4(nn.Module):
         nv = q.num_query
         ok = all("pending" in r and "hidden" not in r and len(r["pending"]) == 1 for r in rqs)
         if ok:
-            base = rqs[0]["pending"][0][2]["X"]
-            ok = all(r["pending"][0][2]["X"] is base for r in rqs)
+            base = rqs[0]["pending"][0][2].get("X")                 # one shared multi-image pass (never prompt-deduplicated)
+            ok = base is not None and all(r["pending"][0][2].get("X") is base for r in rqs)
         if not ok or len(rqs) == 1:
             return [self.selected_pair_features(r, s, zero_foreign=True) for r, s in zip(rqs, selected)]
         pos, mine_all, segs, k0 = [], [], [], 0

@@ -161,15 +161,25 @@ def qformer_self_attn_cls(q_cls, kv, text_mask, B, T, nq, heads):
     return out
 
 
-def qformer_cls_attn_input(x, g, text_mask, B, T, nq, heads):
-    """cls-row attention in the input space (psg_qformer_cls_attn_input): x [B*(nq+T), hidden] layer input rows,
+def qformer_cls_attn_input(x, g, text_mask, B, T, nq, heads, x_text=None, text_index=None):
+    """cls-row attention in the input space (psg_qformer_cls_attn_input).  x [B*(nq+T), hidden]: the layer's input rows
+    (query rows, then text rows) - or, with x_text [U*T, hidden] / text_index int32 [B], x [B*nq, hidden] holds the
+    query rows only and pair p reads the text block (and text_mask row) text_index[p].
     g fp32 [heads, B, hidden] = W_k,h^T q_h  ->  xbar fp32 [heads, B, hidden] = sum_j p_j x_j."""
     lib, ctx, st = _env(x)
     hidden = x.shape[1]
-    assert x.shape[0] == B * (nq + T) and g.shape == (heads, B, hidden) and g.is_contiguous()
+    assert g.shape == (heads, B, hidden) and g.is_contiguous()
+    if x_text is None:
+        assert x.shape[0] == B * (nq + T) and text_index is None
+        xt = x[B * nq:]
+    else:
+        assert x.shape[0] >= B * nq and x_text.dtype == x.dtype and x_text.shape[1] == hidden and text_index is not None
+        xt = x_text
     xbar = torch.empty((heads, B, hidden), device=x.device, dtype=torch.float32)
-    check(lib.psg_qformer_cls_attn_input(ctx, _p(x), _p(g, torch.float32, "g"), _p(text_mask, torch.uint8, "text_mask"),
-                                         B, T, nq, heads, hidden, _p(xbar), _dt(x), st), "psg_qformer_cls_attn_input")
+    check(lib.psg_qformer_cls_attn_input(ctx, _p(x), _p(xt) if T > 0 else None,
+                                         _p(text_index, torch.int32, "text_index") if text_index is not None else None,
+                                         _p(g, torch.float32, "g"), _p(text_mask, torch.uint8, "text_mask"), B, T, nq,
+                                         heads, hidden, _p(xbar), _dt(x), st), "psg_qformer_cls_attn_input")
     return xbar
 
 

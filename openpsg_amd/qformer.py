@@ -81,6 +81,10 @@ class RelationQueryEngine:
         # selection phase of the last layer: cls-row attention in the input space (no K | V projection of all rows)
         self.cls_input_space = os.environ.get("PSG_CLS_INPUT_SPACE", "1") != "0"
         self._bmm_out_dtype = None       # torch.bmm(..., out_dtype=fp32) available? (probed at first use)
+        # two-layer Q-Former: everything in front of layer 0's cross-attention and every text row entering the last
+        # layer depend on the PROMPT (class pair) only - computed once per distinct prompt when the caller hands the
+        # prompt table over (forward_pairs_cls(prompts=...)) and it has fewer rows than 0.9 x the pairs
+        self.dedup_prompts = os.environ.get("PSG_DEDUP_PROMPTS", "1") != "0"
 
     # ---- A4: prepare_inference (V4:408-435) ----------------------------------------------------
     def patch_embed(self, mask_features: torch.Tensor) -> torch.Tensor:
@@ -192,7 +196,7 @@ class RelationQueryEngine:
         logit, prob = ops.exist_head(X, self.exist_w, self.exist_b, P, self.cfg.qformer.q_rows)
         return X, logit, prob
 
-    def forward_pairs_cls(self, kv, bits, num_objects, pair_index, ids, text_mask, segments=None):
+    def forward_pairs_cls(self, kv, bits, num_objects, pair_index, ids, text_mask, segments=None, prompts=None):
         """Selection phase: everything the existence logits depend on, and nothing else.
 
         The existence head reads row 0 (the cls row) of the last layer's output (V4:206-209), and rows 1..32
@@ -201,30 +205,52 @@ class RelationQueryEngine:
         rows only as keys / values, so the cls row of all P pairs is computed here with the full K/V and rows 1..32
         are computed afterwards for the chosen pairs (`pair_hidden`) - identical results, the last layer's query-row
         work shrinks from 33 rows to 1 for all but the selected pairs.
+        prompts = (ids_u int32 [U, T], mask_u uint8 [U, T], inv int32 [P]): the distinct prompts of these pairs and
+        each pair's row in that table (ids == ids_u[inv]); lets the prompt-only work run on U rows instead of P.
         Returns (state, exist_logit [P], exist_prob [P]); state feeds `pair_hidden`."""
         q = self.cfg.qformer
         nq, H = q.q_rows, q.hidden
         P, T = ids.shape
         RQ = P * nq
-        X, shared0 = self._embed(ids)
         nl = len(self.layers)
+        in_space = (self.cls_input_space and H == 768 and q.heads == 12
+                    and (nq + T) * (H + (8 if self.dtype != torch.float32 else 0)) * (
+                        4 if self.dtype == torch.float32 else 2) + q.heads * 256 <= 160 * 1024)
+        if (prompts is not None and segments is None and nl == 2 and T > 0 and in_space and self.dedup_prompts
+                and prompts[0].shape[0] <= 0.9 * P):
+            return self._forward_pairs_cls_dedup(kv, bits, num_objects, pair_index, text_mask, prompts)
+        X, shared0 = self._embed(ids)
         for li in range(nl - 1):
             X = self._layer(li, X, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0)
-        li, L = nl - 1, self.layers[nl - 1]
-        x_cls = X[:RQ].view(P, nq, H)[:, 0].contiguous()                     # [P, H] residual of the cls rows
+        logit, prob = self._cls_phase(X[:RQ], X[RQ:], None, text_mask, P, T, kv, bits, num_objects, pair_index, segments,
+                                      in_space, X)
+        state = dict(X=X, P=P, T=T, text_mask=text_mask, pair_index=pair_index, kv=kv, bits=bits,
+                     num_objects=num_objects, segments=segments)
+        return state, logit, prob
+
+    def _cls_phase(self, Xq, Xt, text_index, mask, P, T, kv, bits, num_objects, pair_index, segments, in_space, X=None):
+        """Last layer for the cls row of every pair.  Xq [P*33, H] query rows entering the layer; Xt: text rows, block
+        text_index[p] (None: block p) per pair, `mask` indexed the same way.  X: the two as one tensor (K | V form)."""
+        q = self.cfg.qformer
+        nq, H = q.q_rows, q.hidden
+        li, L = len(self.layers) - 1, self.layers[-1]
+        x_cls = Xq.view(P, nq, H)[:, 0].contiguous()                         # [P, H] residual of the cls rows
         q_cls = F.linear(x_cls, L["wqkv"][:H], L["bqkv"][:H])              # queries of the cls rows only
         hd = H // q.heads
-        lds = (nq + T) * (H + (8 if X.element_size() == 2 else 0)) * X.element_size() + q.heads * 256
-        if self.cls_input_space and H == 768 and q.heads == 12 and lds <= 160 * 1024:
+        if in_space:
             # keys / values never materialised: the cls queries go back through W_k (g_h = W_k,h^T q_h), the kernel
             # reads the layer's input rows once, the weighted row means go through W_v (psg_qformer_cls_attn_input)
             g = self._bmm_f32(q_cls.view(P, q.heads, hd).transpose(0, 1), L["wk"], L["wk32"])  # fp32 [heads, P, H]
-            xbar = ops.qformer_cls_attn_input(X, g, text_mask, P, T, nq, q.heads)
+            if X is not None:
+                xbar = ops.qformer_cls_attn_input(X, g, mask, P, T, nq, q.heads)
+            else:
+                xbar = ops.qformer_cls_attn_input(Xq, g, mask, P, T, nq, q.heads, x_text=Xt, text_index=text_index)
             ctx = (torch.bmm(xbar, L["wv32t"]).permute(1, 0, 2).reshape(P, H) + L["bqkv"][2 * H:].float()).to(self.dtype)
             del g, xbar
         else:
+            assert X is not None
             kvs = F.linear(X, L["wqkv"][H:], L["bqkv"][H:])                 # keys | values of every row
-            ctx = ops.qformer_self_attn_cls(q_cls, kvs, text_mask, P, T, nq, q.heads)
+            ctx = ops.qformer_self_attn_cls(q_cls, kvs, mask, P, T, nq, q.heads)
             del kvs
         A = F.linear(ctx, L["wo"])
         ops.add_layernorm(A, x_cls, L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
@@ -235,9 +261,57 @@ class RelationQueryEngine:
         iq = self._ffn1(Cq, L["w1q"], L["b1q"])
         hq = F.linear(iq, L["w2q"])
         Xc = ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps)
-        logit, prob = ops.exist_head(Xc, self.exist_w, self.exist_b, P, 1)
-        state = dict(X=X, P=P, T=T, text_mask=text_mask, pair_index=pair_index, kv=kv, bits=bits,
-                     num_objects=num_objects, segments=segments)
+        return ops.exist_head(Xc, self.exist_w, self.exist_b, P, 1)
+
+    def _forward_pairs_cls_dedup(self, kv, bits, num_objects, pair_index, text_mask, prompts):
+        """forward_pairs_cls with the prompt-only work done per DISTINCT prompt (two layers).  Layer 0's input is the
+        learned query block plus the prompt's embeddings, so its whole self-attention block (HF-IB:471-530) is a
+        function of the prompt; a pair enters at the cross-attention (its object masks).  The text rows never see the
+        cross-attention at all: their layer-0 output - the last layer's text keys / values - is per prompt too."""
+        q = self.cfg.qformer
+        nq, H = q.q_rows, q.hidden
+        ids_u, mask_u, inv = prompts
+        U, T = ids_u.shape
+        P = inv.numel()
+        RQu = U * nq
+        L = self.layers[0]
+        Xu, shared0 = self._embed(ids_u)
+        ctx = torch.empty((U * (nq + T), H), device=self.device, dtype=self.dtype)
+        if shared0:
+            qkv_q = F.linear(Xu[:nq], L["wqkv"], L["bqkv"])
+            qkv = F.linear(Xu[RQu:], L["wqkv"], L["bqkv"])
+            ops.qformer_self_attn_shared(qkv_q, qkv, mask_u, U, T, nq, q.heads, ctx)
+        else:
+            qkv = F.linear(Xu, L["wqkv"], L["bqkv"])
+            ops.qformer_self_attn(qkv, mask_u, U, T, nq, q.heads, False, ctx)
+        del qkv
+        A = F.linear(ctx, L["wo"])
+        if shared0:
+            ops.add_layernorm_periodic(A[:RQu], Xu[:nq], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+            ops.add_layernorm(A[RQu:], Xu[RQu:], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+        else:
+            ops.add_layernorm(A, Xu, L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+        del ctx
+        it = self._ffn1(A[RQu:], L["w1t"], L["b1t"])                        # text rows: straight to their layer-0 output
+        ht = F.linear(it, L["w2t"])
+        Xt_u = ops.add_layernorm(ht, A[RQu:], L["b2t"], L["ln_t"][0], L["ln_t"][1], q.ln_eps)
+        del it, ht
+        # the pair enters: its prompt's 33 self-attention rows, then cross-attention with the pair's masks and the FFN
+        rows = (inv.to(torch.int64)[:, None] * nq + torch.arange(nq, device=self.device)[None, :]).reshape(-1).to(torch.int32)
+        A_q = torch.empty((P * nq, H), device=self.device, dtype=self.dtype)
+        ops.gather_rows(A[:RQu], rows, A_q)
+        qx = F.linear(A_q, L["wq_x"], L["bq_x"])
+        cx = self._cross(0, qx, nq, kv, bits, num_objects, pair_index, None)
+        Cq = F.linear(cx, L["wo_x"])
+        ops.add_layernorm(Cq, A_q, L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
+        del qx, cx, A_q
+        iq = self._ffn1(Cq, L["w1q"], L["b1q"])
+        hq = F.linear(iq, L["w2q"])
+        Xq = ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps)
+        del iq, hq, Cq
+        logit, prob = self._cls_phase(Xq, Xt_u, inv, mask_u, P, T, kv, bits, num_objects, pair_index, None, True)
+        state = dict(Xq=Xq, Xt_u=Xt_u, inv=inv, P=P, T=T, text_mask=text_mask, pair_index=pair_index, kv=kv, bits=bits,
+                     num_objects=num_objects, segments=None)
         return state, logit, prob
 
     def pair_hidden(self, state, sel, segments=None):
@@ -253,9 +327,14 @@ class RelationQueryEngine:
         K = s64.numel()
         ar = torch.arange(nq, device=self.device)
         rows = [(s64[:, None] * nq + ar[None, :]).reshape(-1)]
-        if T > 0:
-            rows.append((P * nq + s64[:, None] * T + torch.arange(T, device=self.device)[None, :]).reshape(-1))
-        Xs = state["X"].index_select(0, torch.cat(rows))                    # [K*(33+T), 768]: query rows, then text rows
+        if "Xt_u" in state:                                                  # text rows live in the per-prompt table
+            trows = (state["inv"].to(torch.int64).index_select(0, s64)[:, None] * T
+                     + torch.arange(T, device=self.device)[None, :]).reshape(-1)
+            Xs = torch.cat([state["Xq"].index_select(0, rows[0]), state["Xt_u"].index_select(0, trows)])
+        else:
+            if T > 0:
+                rows.append((P * nq + s64[:, None] * T + torch.arange(T, device=self.device)[None, :]).reshape(-1))
+            Xs = state["X"].index_select(0, torch.cat(rows))                # [K*(33+T), 768]: query rows, then text rows
         tm = state["text_mask"].index_select(0, s64) if T > 0 else state["text_mask"]
         pi = state["pair_index"].index_select(0, s64)
         return self._layer(len(self.layers) - 1, Xs, K, T, tm, pi, state["kv"], state["bits"], state["num_objects"],

@@ -14,8 +14,10 @@ from .categories import INSTANCE_OFFSET
 
 
 def make_scene(pad_hw, num_objects, seed=0, ori_hw=None, img_hw=None, void_id=133, channels=256,
-               force_id0=False, tiny_object=False, features=True, device="cpu"):
-    """Returns dict(mask_features, pan_results, object_id_list, img_meta, categories)."""
+               force_id0=False, tiny_object=False, features=True, device="cpu", num_categories=133):
+    """Returns dict(mask_features, pan_results, object_id_list, img_meta, categories).
+    num_categories < 133: the objects draw from that many classes only (real images repeat classes: several
+    instances of `person`, ...), so many pairs share a prompt."""
     rng = np.random.default_rng(seed)
     pad_h, pad_w = pad_hw
     img_h, img_w = img_hw if img_hw is not None else pad_hw
@@ -26,6 +28,8 @@ def make_scene(pad_hw, num_objects, seed=0, ori_hw=None, img_hw=None, void_id=13
     counts, ids, cats = {}, [], []
     for k in range(num_objects):
         cat = int(rng.integers(0, 133))
+        if num_categories < 133:
+            cat = (cat * 7) % 133 % num_categories * (133 // num_categories)   # spread over things and stuff
         if force_id0 and k == 0:
             cat = 0
         inst = counts.get(cat, -1) + 1

@@ -134,3 +134,54 @@ def test_cls_attention_in_input_space_matches_kv_form(dtype, T):
         assert e_ref < 2e-5 and (got - ref_kv).abs().max().item() < 2e-5
     else:
         assert e_ref < max(1.2 * e_kv, 0.02)                        # no K / V rounding: at least as close
+
+
+@pytest.mark.parametrize("dtype,chunk", [("fp32", 4096), ("fp32", 100), ("bf16", 4096)])
+def test_prompt_dedup_equals_per_pair_path(dtype, chunk, monkeypatch):
+    """Scenes with repeated classes (many pairs share a prompt): the selection phase with the prompt-only work done
+    once per distinct prompt (qformer._forward_pairs_cls_dedup) against the per-pair path - same logits, selection,
+    selected pairs' features and tokens (fp32: 2e-5), also over several pair chunks."""
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_device
+    dev = _dev()
+    N = 16
+    cfg = PSGConfig(qformer=QFormerConfig(), llm=tiny_llm(256, 2, 512, 512), max_object_num=N)
+    w = make_weights_device(cfg, 5, dev, llm_dtype=torch.float32 if dtype == "fp32" else torch.bfloat16)
+    scene = make_scene((1024, 1024), N, seed=11, device="cuda:0", num_categories=4)
+    runs = {}
+    for dd in (False, True):
+        head = RelationTransformerHeadV4(dtype=dtype, device="cuda:0", tokenizers="word", max_object_num=N,
+                                         llm_config=cfg.llm, llm_feature_size=256, on_parse_error="skip",
+                                         suppress_eos=True, cls_first=True, pair_chunk=chunk)
+        head.load_weights(w)
+        head.rq_engine.dedup_prompts = dd
+        seen = []
+        orig = head.rq_engine._forward_pairs_cls_dedup
+        monkeypatch.setattr(head.rq_engine, "_forward_pairs_cls_dedup", lambda *a, **k: (seen.append(1), orig(*a, **k))[1])
+        head(_inputs(scene))
+        torch.cuda.synchronize()
+        assert bool(seen) == dd                                     # the path under test really ran (or did not)
+        last = head.last
+        runs[dd] = dict(logit=last["exist_logit"].float().cpu().numpy(), sel=last["selected"].cpu().tolist(),
+                        pf=head.selected_pair_features(last).float().cpu().numpy(),
+                        hidden=last["hidden"].float().cpu().numpy(), tokens=last["tokens_host"].copy())
+    a, b = runs[False], runs[True]
+    err = np.abs(a["logit"] - b["logit"]).max()
+    print(f"{dtype} chunk {chunk}: max |logit(per pair) - logit(per prompt)| = {err:.3e}")
+    # pairs with the same prompt and the same mask union are exact ties in exact arithmetic (repeated classes make
+    # them common): which of them makes the cut may differ, the selected SCORES may not
+    la, lb = np.sort(a["logit"][a["sel"]]), np.sort(b["logit"][b["sel"]])
+    common = [s for s in a["sel"] if s in b["sel"]]
+    ia, ib = [a["sel"].index(s) for s in common], [b["sel"].index(s) for s in common]
+    pa = a["pf"].reshape(len(a["sel"]), 32, -1)[ia]
+    pb = b["pf"].reshape(len(b["sel"]), 32, -1)[ib]
+    if dtype == "fp32":
+        assert err < 2e-5 and np.abs(la - lb).max() < 2e-5 and len(common) >= len(a["sel"]) - 4
+        np.testing.assert_allclose(pa, pb, atol=2e-5)
+        np.testing.assert_allclose(a["hidden"], b["hidden"], atol=2e-5)       # last layer of EVERY pair, both ways
+        assert np.array_equal(a["tokens"][ia], b["tokens"][ib])
+    else:
+        assert err < 0.06 and len(common) >= len(a["sel"]) - 6
+        assert np.abs(pa - pb).max() < 0.15
