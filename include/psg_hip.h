@@ -108,6 +108,12 @@ int psg_add_layernorm(psg_ctx*, const void* x, const void* residual, const float
 int psg_add_layernorm_periodic(psg_ctx*, const void* x, const void* residual_table, int table_rows,
                                const float* bias, const float* gamma, const float* beta, float eps,
                                int64_t rows, int hidden, void* out, int dtype, void* stream);
+/* residual row of output row r = residual_table[block_index[r / group] * group + r % group]: rows in groups (the 33
+ * query rows of a pair), several groups sharing one block of the table (the rows of the pair's PROMPT: layer 0's
+ * self-attention output depends on the prompt only, so it is computed per distinct prompt, HF-IB:519-530). */
+int psg_add_layernorm_indexed(psg_ctx*, const void* x, const void* residual_table, const int32_t* block_index, int group,
+                              const float* bias, const float* gamma, const float* beta, float eps, int64_t rows,
+                              int hidden, void* out, int dtype, void* stream);
 
 /* ---- BertIntermediate activation, HF-IB:563-577: out = gelu_erf(x + bias); bias may be NULL. */
 int psg_bias_gelu(psg_ctx*, const void* x, const float* bias, int64_t rows, int cols, void* out,

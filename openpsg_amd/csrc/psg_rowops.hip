@@ -93,11 +93,15 @@ extern "C" int psg_qformer_embed(psg_ctx* ctx, const int32_t* ids, int B, int T_
 template <typename T, int NCH>
 __global__ void add_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ bias,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                     int64_t rows, int hidden, T* __restrict__ out, int res_period) {
+                                     int64_t rows, int hidden, T* __restrict__ out, int res_period,
+                                     const int32_t* __restrict__ res_index) {
   const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const int64_t rrow = res_period > 0 ? row % res_period : row;   // periodic residual: a [res_period][hidden] table
+  // periodic residual: a [res_period][hidden] table; indexed: rows come in groups of res_period, group g takes block
+  // res_index[g] of the table
+  int64_t rrow = res_period > 0 ? row % res_period : row;
+  if (res_index) rrow += (int64_t)res_index[row / res_period] * res_period;
   float v[NCH][4];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -120,7 +124,7 @@ __global__ void add_layernorm_kernel(const T* __restrict__ x, const T* __restric
 }
 
 static int add_layernorm_launch(const char* who, psg_ctx* ctx, const void* x, const void* residual, int res_period,
-                                const float* bias, const float* gamma, const float* beta, float eps, int64_t rows,
+                                const int32_t* res_index, const float* bias, const float* gamma, const float* beta, float eps, int64_t rows,
                                 int hidden, void* out, int dtype, void* stream) {
   PSG_REQUIRE(ctx && x && gamma && beta && out, PSG_ERR_INVALID, "%s: NULL argument", who);
   PSG_REQUIRE(hidden == 768, PSG_ERR_UNSUPPORTED, "%s: hidden=%d (kernel is built for 768)", who, hidden);
@@ -128,7 +132,8 @@ static int add_layernorm_launch(const char* who, psg_ctx* ctx, const void* x, co
   dim3 grid((unsigned)((rows + 3) / 4));
   PSG_DISPATCH_DTYPE(dtype, who,
                      (add_layernorm_kernel<T, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
-                         (const T*)x, (const T*)residual, bias, gamma, beta, eps, rows, hidden, (T*)out, res_period)));
+                         (const T*)x, (const T*)residual, bias, gamma, beta, eps, rows, hidden, (T*)out, res_period,
+                         res_index)));
   PSG_CHECK_LAUNCH(who);
   return PSG_OK;
 }
@@ -136,8 +141,8 @@ static int add_layernorm_launch(const char* who, psg_ctx* ctx, const void* x, co
 extern "C" int psg_add_layernorm(psg_ctx* ctx, const void* x, const void* residual, const float* bias,
                                  const float* gamma, const float* beta, float eps, int64_t rows, int hidden, void* out,
                                  int dtype, void* stream) {
-  return add_layernorm_launch("psg_add_layernorm", ctx, x, residual, 0, bias, gamma, beta, eps, rows, hidden, out, dtype,
-                              stream);
+  return add_layernorm_launch("psg_add_layernorm", ctx, x, residual, 0, nullptr, bias, gamma, beta, eps, rows, hidden, out,
+                              dtype, stream);
 }
 
 // residual row of output row r is residual_table[r % table_rows]: the layer-0 query rows of every pair share ONE
@@ -146,8 +151,19 @@ extern "C" int psg_add_layernorm_periodic(psg_ctx* ctx, const void* x, const voi
                                           const float* bias, const float* gamma, const float* beta, float eps,
                                           int64_t rows, int hidden, void* out, int dtype, void* stream) {
   PSG_REQUIRE(residual_table && table_rows > 0, PSG_ERR_INVALID, "psg_add_layernorm_periodic: table_rows=%d", table_rows);
-  return add_layernorm_launch("psg_add_layernorm_periodic", ctx, x, residual_table, table_rows, bias, gamma, beta, eps,
-                              rows, hidden, out, dtype, stream);
+  return add_layernorm_launch("psg_add_layernorm_periodic", ctx, x, residual_table, table_rows, nullptr, bias, gamma, beta,
+                              eps, rows, hidden, out, dtype, stream);
+}
+
+// residual row of output row r is residual_table[block_index[r / group] * group + r % group]: the rows come in groups
+// (the 33 query rows of a pair) and several groups share one block of the table (the pair's prompt)
+extern "C" int psg_add_layernorm_indexed(psg_ctx* ctx, const void* x, const void* residual_table, const int32_t* block_index,
+                                         int group, const float* bias, const float* gamma, const float* beta, float eps,
+                                         int64_t rows, int hidden, void* out, int dtype, void* stream) {
+  PSG_REQUIRE(residual_table && block_index && group > 0 && rows % group == 0, PSG_ERR_INVALID,
+              "psg_add_layernorm_indexed: group=%d rows=%lld", group, (long long)rows);
+  return add_layernorm_launch("psg_add_layernorm_indexed", ctx, x, residual_table, group, block_index, bias, gamma, beta,
+                              eps, rows, hidden, out, dtype, stream);
 }
 
 // ---- bias + GELU(erf) -------------------------------------------------------------------------

@@ -131,6 +131,20 @@ def add_layernorm_periodic(x, residual_table, bias, gamma, beta, eps, out=None):
     return out
 
 
+def add_layernorm_indexed(x, residual_table, block_index, group, bias, gamma, beta, eps, out=None):
+    """LayerNorm(x + bias + residual_table[block_index[row // group] * group + row % group]); in place unless `out`."""
+    lib, ctx, st = _env(x)
+    out = x if out is None else out
+    rows, hidden = x.shape
+    assert residual_table.shape[1] == hidden and residual_table.dtype == x.dtype and rows % group == 0
+    assert block_index.numel() == rows // group
+    check(lib.psg_add_layernorm_indexed(ctx, _p(x), _p(residual_table), _p(block_index, torch.int32, "block_index"), group,
+                                        _p(bias, torch.float32), _p(gamma, torch.float32), _p(beta, torch.float32),
+                                        float(eps), rows, hidden, _p(out, x.dtype), _dt(x), st),
+          "psg_add_layernorm_indexed")
+    return out
+
+
 def bias_gelu(x, bias=None, out=None):
     lib, ctx, st = _env(x)
     out = x if out is None else out

@@ -296,15 +296,17 @@ class RelationQueryEngine:
         ht = F.linear(it, L["w2t"])
         Xt_u = ops.add_layernorm(ht, A[RQu:], L["b2t"], L["ln_t"][0], L["ln_t"][1], q.ln_eps)
         del it, ht
-        # the pair enters: its prompt's 33 self-attention rows, then cross-attention with the pair's masks and the FFN
+        # the pair enters at the cross-attention: its queries are its prompt's 33 projected rows (projected per prompt,
+        # gathered per pair - the cross-attention kernel streams its Q tiles by DMA and takes no index), the residual
+        # of the output LayerNorm is read from the prompt's block through the index
+        qx_u = F.linear(A[:RQu], L["wq_x"], L["bq_x"])
         rows = (inv.to(torch.int64)[:, None] * nq + torch.arange(nq, device=self.device)[None, :]).reshape(-1).to(torch.int32)
-        A_q = torch.empty((P * nq, H), device=self.device, dtype=self.dtype)
-        ops.gather_rows(A[:RQu], rows, A_q)
-        qx = F.linear(A_q, L["wq_x"], L["bq_x"])
+        qx = torch.empty((P * nq, H), device=self.device, dtype=self.dtype)
+        ops.gather_rows(qx_u, rows, qx)
         cx = self._cross(0, qx, nq, kv, bits, num_objects, pair_index, None)
         Cq = F.linear(cx, L["wo_x"])
-        ops.add_layernorm(Cq, A_q, L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
-        del qx, cx, A_q
+        ops.add_layernorm_indexed(Cq, A[:RQu], inv, nq, L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
+        del qx, cx, qx_u
         iq = self._ffn1(Cq, L["w1q"], L["b1q"])
         hq = F.linear(iq, L["w2q"])
         Xq = ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps)

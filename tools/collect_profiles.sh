@@ -38,4 +38,7 @@ for n in 50 100; do
   python tools/prof_summary.py "$(db /tmp/p_x${n}_1)" | grep cross_attn >> "$f"
   python tools/xattn_derive.py "$f" $n > /dev/null
 done
+# 5. what one image / one relation-query step costs per kernel (differential traces)
+bash tools/per_image_profile.sh "$OUT/${TAG}_per_image_kernels.csv"
+bash tools/per_image_profile.sh "$OUT/${TAG}_per_step_rq_kernels.csv" --workload rq
 ls -la "$OUT"
