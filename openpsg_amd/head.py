@@ -160,7 +160,8 @@ class RelationTransformerHeadV4(nn.Module):
         self._llm_weights = None
         self._rq_engine = None
         self._llm_engine = None
-        self._prompt_cache = {"q": {}, "l": {}}
+        self._prompt_store = {k: dict(names=[], index={}, ids=np.zeros((0, 0, 0), np.int32), lens=np.zeros((0, 0), np.int32))
+                              for k in ("q", "l")}
         self._table_cache = {}
         # tokenizers (V4:85-86, 104-105)
         if tokenizers == "word":
@@ -248,13 +249,17 @@ class RelationTransformerHeadV4(nn.Module):
 
     # ---- prompts (V4:146-152, 260-266) ---------------------------------------------------------------
     def _prompt_table(self, kind: str, names):
-        """ids / mask for every ordered pair of the UNIQUE names of this image, tokenised once per
-        pair of names (cached across images).  Returns (uniq index per object, ids [U*U,T], mask)."""
+        """Token ids of the prompt of every ordered pair of the UNIQUE names of this image.  A prompt is tokenised once
+        per pair of names, ever: the head keeps one padded store per tokenizer over all names seen so far
+        ([G, G, Tcap] ids with -1 behind the valid tokens, [G, G] lengths), and an image's table is a slice of it -
+        a new image costs a few array operations on the host, not a tokenizer call or a Python loop per pair.
+        Returns (uniq index per object, U, ids [U*U, Tcap] int32 (-1 padded, valid tokens first), lens [U*U] int32)."""
+        st = self._prompt_store[kind]
         uniq = sorted(set(names))
-        uidx = [uniq.index(n) for n in names]
-        cache = self._prompt_cache[kind]
-        todo = [(a, b) for a in uniq for b in uniq if (a, b) not in cache]
-        if todo:
+        new = [n for n in uniq if n not in st["index"]]
+        if new:
+            old = list(st["names"])
+            todo = [(a, b) for a in old + new for b in new] + [(a, b) for a in new for b in old]
             if kind == "q":
                 tok, tmpl = self.relation_qformer_tokenizer, self.qformer_instruction
             else:
@@ -263,10 +268,38 @@ class RelationTransformerHeadV4(nn.Module):
             enc = tok([tmpl.format(a, b) for a, b in todo], return_tensors="pt", padding=True,
                       return_attention_mask=True)
             ids, mask = np.asarray(enc["input_ids"]), np.asarray(enc["attention_mask"]).astype(bool)
-            for r, key in enumerate(todo):
-                cache[key] = ids[r][mask[r]].astype(np.int32)      # valid tokens only, original order
-        rows = [cache[(a, b)] for a in uniq for b in uniq]
-        return uidx, len(uniq), rows
+            lens = mask.sum(1).astype(np.int32)
+            for n in new:
+                st["index"][n] = len(st["names"])
+                st["names"].append(n)
+            G, cap = len(st["names"]), max(int(lens.max()), st["ids"].shape[2])
+            gi = np.full((G, G, cap), -1, dtype=np.int32)
+            gl = np.zeros((G, G), dtype=np.int32)
+            g0 = st["ids"].shape[0]
+            gi[:g0, :g0, :st["ids"].shape[2]] = st["ids"]
+            gl[:g0, :g0] = st["lens"]
+            ia = np.array([st["index"][a] for a, _ in todo]), np.array([st["index"][b] for _, b in todo])
+            order = np.argsort(~mask, axis=1, kind="stable")                               # valid tokens first, original order
+            comp = np.take_along_axis(ids, order, axis=1).astype(np.int32)
+            comp[np.arange(ids.shape[1])[None, :] >= lens[:, None]] = -1
+            gi[ia[0], ia[1], :ids.shape[1]] = comp
+            gl[ia[0], ia[1]] = lens
+            st["ids"], st["lens"] = gi, gl
+        uidx = [uniq.index(n) for n in names]
+        g = np.array([st["index"][n] for n in uniq])
+        U = len(uniq)
+        ids = st["ids"][np.ix_(g, g)].reshape(U * U, -1)
+        lens = st["lens"][np.ix_(g, g)].reshape(U * U)
+        return uidx, U, ids, lens
+
+    def warm_prompts(self, names=None):
+        """Tokenises the prompts of every ordered pair of `names` (default: all 133 object classes, 17 689 pairs per
+        tokenizer) into the prompt stores in two tokenizer calls, so that no image ever waits for a tokenizer.  A
+        deployment calls this once after construction (tools/infer.py does); without it the stores fill as classes
+        appear."""
+        names = sorted(set(object_categories if names is None else names))
+        for kind in ("q", "l"):
+            self._prompt_table(kind, names)
 
     # ---- forward ---------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -353,7 +386,8 @@ class RelationTransformerHeadV4(nn.Module):
         if sampled is None:
             sampled = self.qformer_sampler(target)
         sampled = torch.as_tensor(sampled, dtype=torch.int64)
-        uidx, U, rows = self._prompt_table("q", names)
+        uidx, U, tab, tlen = self._prompt_table("q", names)
+        rows = [tab[r, :tlen[r]] for r in range(U * U)]
         T = max(len(rows[uidx[i] * U + uidx[j]]) for i in range(N) for j in range(N))
         ids = np.zeros((len(sampled), T), dtype=np.int32)
         msk = np.zeros((len(sampled), T), dtype=np.uint8)
@@ -483,18 +517,15 @@ class RelationTransformerHeadV4(nn.Module):
         # BERT prompts: [U*U, T] table gathered per pair on the device (cached per set of names)
         ck = ("q", tuple(names))
         if ck not in self._table_cache:
-            uidx, U, rows = self._prompt_table("q", names)
-            used = {uidx[i] * U + uidx[j] for i in range(N) for j in range(N)}
-            T = max(len(rows[r]) for r in used)                                             # padding=True
-            tbl = np.zeros((U * U, T), dtype=np.int32)
-            msk = np.zeros((U * U, T), dtype=np.uint8)
-            for r in used:
-                tbl[r, :len(rows[r])] = rows[r]
-                msk[r, :len(rows[r])] = 1
+            uidx, U, tab, tlen = self._prompt_table("q", names)                             # every class pair occurs: i, j
+            T = int(tlen.max())                                                             # range over all objects
+            msk = (np.arange(T)[None, :] < tlen[:, None])                                   # padding=True
+            tbl = np.where(msk, tab[:, :T], 0).astype(np.int32)
+            msk = msk.astype(np.uint8)
             if len(self._table_cache) > 64:
                 self._table_cache.clear()
-            self._table_cache[ck] = (uidx, U, torch.from_numpy(tbl).to(dev), torch.from_numpy(msk).to(dev),
-                                     torch.tensor(uidx, dtype=torch.int64, device=dev))
+            self._table_cache[ck] = (np.asarray(uidx, dtype=np.int64), U, torch.from_numpy(tbl).to(dev),
+                                     torch.from_numpy(msk).to(dev), torch.tensor(uidx, dtype=torch.int64, device=dev))
         return patches, kv, bits, ck
 
     def _chunk_prompts(self, ck, N, c0, c1):
@@ -508,9 +539,13 @@ class RelationTransformerHeadV4(nn.Module):
             if len(self._gather_cache) > 64:
                 self._gather_cache.clear()
             # the distinct prompts among these pairs and every pair's row in that table (the engine runs the
-            # prompt-only part of the Q-Former once per distinct prompt); one host round trip, cached with the rest
-            uniq, inv = torch.unique(trow, return_inverse=True)
-            prompts = (tbl_d[uniq].contiguous(), msk_d[uniq].contiguous(), inv.to(torch.int32).contiguous())
+            # prompt-only part of the Q-Former once per distinct prompt): a few host array operations, no device
+            # round trip
+            ph = np.arange(c0, c1, dtype=np.int64)
+            uniq_h, inv_h = np.unique(uidx[ph // N] * U + uidx[ph % N], return_inverse=True)
+            uniq = torch.from_numpy(uniq_h).to(self.device)
+            prompts = (tbl_d[uniq].contiguous(), msk_d[uniq].contiguous(),
+                       torch.from_numpy(inv_h.astype(np.int32)).to(self.device))
             ent = self._gather_cache[gk] = (pidx.to(torch.int32), tbl_d[trow].contiguous(), msk_d[trow].contiguous(),
                                             prompts)
         return ent
@@ -523,7 +558,7 @@ class RelationTransformerHeadV4(nn.Module):
         N = len(obj_ids)
         B = N * N
         patches, kv, bits, ck = self._prepare_image(feat, meta, obj_ids, names, pan, patches)
-        uidx = self._table_cache[ck][0]
+        uidx = self._table_cache[ck][0].tolist()
         p0, p1 = (0, B) if pair_range is None else pair_range
         q = self.cfg.qformer
         single = 0 < p1 - p0 <= self.pair_chunk                  # one chunk: take the engine's outputs as they are
@@ -696,18 +731,17 @@ class RelationTransformerHeadV4(nn.Module):
         # Llama prompts, compacted (left padding of V4:262 removed; see llm.py); cached per set of names
         ck = ("l", tuple(names))
         if ck not in self._table_cache:
-            uidx, U, prow = self._prompt_table("l", names)
-            Tp = max(len(r) for r in prow)
+            uidx, U, tab, lens = self._prompt_table("l", names)
+            Tp = int(lens.max())
             # the longest prompt changes from image to image (its class names); the prompt grid is rounded up so
             # that the decode graphs, keyed by input shape, are reused (rows past a pair's length carry pos = -1
             # and are skipped by every kernel)
             if self.prompt_bucket > 1:
                 Tp = -(-Tp // self.prompt_bucket) * self.prompt_bucket
-            tbl = np.full((U * U, Tp), -1, dtype=np.int32)
-            lens = np.zeros(U * U, dtype=np.int32)
-            for r, ids in enumerate(prow):
-                tbl[r, :len(ids)] = ids
-                lens[r] = len(ids)
+            tbl = np.full((U * U, Tp), -1, dtype=np.int32)                                 # valid ids first, -1 after
+            w = min(Tp, tab.shape[1])
+            tbl[:, :w] = tab[:, :w]
+            lens = lens.astype(np.int32)
             if len(self._table_cache) > 64:
                 self._table_cache.clear()
             self._table_cache[ck] = (uidx, U, torch.from_numpy(tbl).to(dev), torch.from_numpy(lens).to(dev),

@@ -163,11 +163,25 @@ def test_hf_fast_tokenizers_drive_prompts_and_parse():
                                      llm_feature_size=256, tokenizers=(bert, llama))
     assert head.llm_tokenizer.pad_token == "<unk>"                                  # V4:105
     names = ["person", "wall-brick", "person", "dining table"]
-    uidx, U, rows = head._prompt_table("q", names)
+    uidx, U, tab, tlen = head._prompt_table("q", names)
+    rows = [tab[r, :tlen[r]] for r in range(U * U)]                                 # [U*U, Tcap] store, -1 behind the ids
+    assert (tab[np.arange(tab.shape[1])[None, :] >= tlen[:, None]] == -1).all()
     assert U == 3 and uidx == [1, 2, 1, 0]                                          # sorted unique names
     want = bert("Is there a relation between person and dining table?")["input_ids"]
     assert rows[1 * U + 0].tolist() == want and want[0] == 2 and want[-1] == 3      # [CLS] ... [SEP], no padding kept
-    _, _, lrows = head._prompt_table("l", names)
+    _, _, ltab, llen = head._prompt_table("l", names)
+    lrows = [ltab[r, :llen[r]] for r in range(U * U)]
+    # a second image with one new name extends the store without disturbing what is there
+    _, U2, tab2, tlen2 = head._prompt_table("q", ["person", "cat"])
+    assert U2 == 2 and tab2[1 * U2 + 1, :tlen2[3]].tolist() == rows[1 * U + 1].tolist()   # (person, person) unchanged
+    # warm_prompts fills the stores for a class list up front; tables built afterwards are the same
+    head2 = RelationTransformerHeadV4(device="cpu", qformer_vocab_size=512, llm_config=tiny_llm(256, 1, 256, 512),
+                                      llm_feature_size=256, tokenizers=(bert, llama))
+    head2.warm_prompts(["zebra", "person", "dining table", "wall-brick", "cat"])
+    n_store = len(head2._prompt_store["q"]["names"])
+    _, U3, tab3, tlen3 = head2._prompt_table("q", names)
+    assert len(head2._prompt_store["q"]["names"]) == n_store == 5               # nothing new to tokenise
+    assert [tab3[r, :tlen3[r]].tolist() for r in range(U3 * U3)] == [r.tolist() for r in rows]
     lw = llama("What are the relations between wall-brick and person? Assistant: ")["input_ids"]
     assert lrows[2 * U + 1].tolist() == lw and lw[0] == 1                           # BOS first, pads stripped
     assert head.llm_tokenizer.padding_side == "left"                                # V4:262

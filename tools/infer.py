@@ -59,6 +59,7 @@ def build_head(a, dev):
         sd = sd.get("state_dict", sd)
         head.load_state_dict({k[len("relation_head."):]: v for k, v in sd.items() if k.startswith("relation_head.")},
                              strict=False)
+    head.warm_prompts()                 # all class-pair prompts tokenised once: no image waits for a tokenizer
     return head
 
 
