@@ -445,6 +445,21 @@ def main():
                               "relation_query_pairs_per_s": round(pairs_per_image / el, 1),
                               "relation_query_tflops": round(fl / el / 1e12, 1),
                               "relation_query_mfma_frac": round(fl / el / 2.5e15, 4), "prompt_tokens": T}
+            if world == 1 and not force_dist and a.images_per_step == 1:
+                # the timed region repeats ONE scene (hot per-names caches); what an image with a class list never seen
+                # before costs: six other scenes, each run once (head.warm_prompts() as a deployment does at start-up)
+                try:
+                    head.warm_prompts()
+                    fresh = [make_scene((a.size, a.size), N, seed=100 + m, device=str(dev), num_categories=a.categories)
+                             for m in range(6)]
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for sc in fresh:
+                        head(scene_inputs(sc))
+                    torch.cuda.synchronize()
+                    line["stages"]["new_scene_ms_per_image"] = round((time.perf_counter() - t0) / len(fresh) * 1e3, 3)
+                except Exception as e:  # noqa: BLE001
+                    line["stages"]["new_scene_ms_per_image"] = f"failed: {e}"
         if (not a.no_batched and a.workload == "full" and world == 1 and not force_dist
                 and a.images_per_step == 1):
             # secondary figure, not `value`: four such images per step, their 80 selected pairs decoded together

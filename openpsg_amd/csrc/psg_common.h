@@ -26,6 +26,7 @@ struct psg_opts {
   int qformer_own_gemm = 1;     // Q-Former FFN1: psg_dense_gemm with fused bias + GELU instead of library GEMM + psg_bias_gelu
   int xattn_waves = 8;          // LDS-DMA cross-attention: waves per workgroup (8 or 10)
   int xattn_dma = 1;            // cross-attention: LDS-DMA kernel (psg_xattn_dma.hip) when its LDS image fits
+  int ln_half_wave = 1;         // add + LayerNorm on 16-bit rows: half a wave per row, 16-byte accesses
 };
 
 struct psg_ctx {

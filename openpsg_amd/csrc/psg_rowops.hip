@@ -123,12 +123,108 @@ __global__ void add_layernorm_kernel(const T* __restrict__ x, const T* __restric
   for (int c = 0; c < NCH; ++c) Act<T>::st4(out, row * hidden + c * 256 + lane * 4, v[c]);
 }
 
+// 16-bit rows of 768: HALF a wave per row, 16-byte accesses (a lane owns 3 x 8 consecutive features), the two sums by
+// row shifts + one row broadcast inside each half (no LDS crossbar, no block barrier).  Same arithmetic as
+// add_layernorm_kernel (fp32 sums in another association): x + bias + residual -> LayerNorm -> 16-bit.
+template <typename E>
+__global__ void __launch_bounds__(256) add_layernorm16_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
+                                                              const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, int64_t rows,
+                                                              uint16_t* __restrict__ out, int res_period,
+                                                              const int32_t* __restrict__ res_index) {
+  constexpr int H = 768;
+  const int lane = threadIdx.x & 63, hl = lane & 31;
+  int64_t row = ((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 1) + (lane >> 5);
+  const bool live = row < rows;
+  if (!live) row = rows - 1;                                      // keeps the half-wave in step; nothing is stored
+  int64_t rrow = res_period > 0 ? row % res_period : row;
+  if (res_index) rrow += (int64_t)res_index[row / res_period] * res_period;
+  float v[3][8];
+  uint4 xw[3], rw[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int col = (c * 32 + hl) * 8;
+    xw[c] = *reinterpret_cast<const uint4*>(x + row * H + col);
+    if (res) rw[c] = *reinterpret_cast<const uint4*>(res + rrow * H + col);
+  }
+  auto unpack = [](const uint4& w, float (&f)[8]) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = E::to_f32((uint16_t)(u[i] & 0xffffu));
+      f[2 * i + 1] = E::to_f32((uint16_t)(u[i] >> 16));
+    }
+  };
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int col = (c * 32 + hl) * 8;
+    unpack(xw[c], v[c]);
+    if (bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+      v[c][0] += b0.x; v[c][1] += b0.y; v[c][2] += b0.z; v[c][3] += b0.w;
+      v[c][4] += b1.x; v[c][5] += b1.y; v[c][6] += b1.z; v[c][7] += b1.w;
+    }
+    if (res) {
+      float r[8];
+      unpack(rw[c], r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c][e] += r[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[c][e];
+  }
+  auto half_sum = [&](float t) {                                  // sum over the 32 lanes of this lane's half
+    t += psg_dpp<0x111, 0xf>(0.f, t);
+    t += psg_dpp<0x112, 0xf>(0.f, t);
+    t += psg_dpp<0x114, 0xf>(0.f, t);
+    t += psg_dpp<0x118, 0xf>(0.f, t);
+    t += psg_dpp<0x142, 0xa>(0.f, t);                             // row 0 -> row 1, row 2 -> row 3: lanes 31 / 63 hold the halves
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 31));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+    return lane < 32 ? lo : hi;
+  };
+  const float mean = half_sum(s) * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = v[c][e] - mean;
+      q += d * d;
+    }
+  const float rstd = 1.0f / sqrtf(half_sum(q) * (1.0f / H) + eps);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int col = (c * 32 + hl) * 8;
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + col), g1 = *reinterpret_cast<const float4*>(gamma + col + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + col), b1 = *reinterpret_cast<const float4*>(beta + col + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+    if (live)
+      *reinterpret_cast<uint4*>(out + row * H + col) =
+          make_uint4(E::pack(o[0], o[1]), E::pack(o[2], o[3]), E::pack(o[4], o[5]), E::pack(o[6], o[7]));
+  }
+}
+
 static int add_layernorm_launch(const char* who, psg_ctx* ctx, const void* x, const void* residual, int res_period,
                                 const int32_t* res_index, const float* bias, const float* gamma, const float* beta, float eps, int64_t rows,
                                 int hidden, void* out, int dtype, void* stream) {
   PSG_REQUIRE(ctx && x && gamma && beta && out, PSG_ERR_INVALID, "%s: NULL argument", who);
   PSG_REQUIRE(hidden == 768, PSG_ERR_UNSUPPORTED, "%s: hidden=%d (kernel is built for 768)", who, hidden);
   if (rows == 0) return PSG_OK;
+  if ((dtype == PSG_BF16 || dtype == PSG_F16) && ctx->opt.ln_half_wave) {     // 8 rows per 256-thread workgroup
+    dim3 grid16((unsigned)((rows + 7) / 8));
+    PSG_DISPATCH_E16(dtype, who,
+                     (add_layernorm16_kernel<E><<<grid16, 256, 0, (hipStream_t)stream>>>(
+                         (const uint16_t*)x, (const uint16_t*)residual, bias, gamma, beta, eps, rows, (uint16_t*)out,
+                         res_period, res_index)));
+    PSG_CHECK_LAUNCH(who);
+    return PSG_OK;
+  }
   dim3 grid((unsigned)((rows + 3) / 4));
   PSG_DISPATCH_DTYPE(dtype, who,
                      (add_layernorm_kernel<T, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
