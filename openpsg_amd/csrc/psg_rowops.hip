@@ -451,6 +451,62 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, co
   }
 }
 
+// Prompt pass (hundreds of 16-bit rows): one WAVE per row, 16-byte accesses (a lane owns NCH x 8 features), the sum of
+// squares by DPP - no LDS, no workgroup barrier.  Per-element arithmetic as in rmsnorm_kernel.
+template <typename E, int NCH>
+__global__ void __launch_bounds__(256) rmsnorm_rows16_kernel(uint16_t* __restrict__ resid, const uint16_t* __restrict__ delta,
+                                                             const float* __restrict__ w, float eps, int64_t rows, int hidden,
+                                                             uint16_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;                                        // whole wave
+  uint4 rw[NCH], dw[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    rw[c] = *reinterpret_cast<const uint4*>(resid + row * hidden + col);
+    if (delta) dw[c] = *reinterpret_cast<const uint4*>(delta + row * hidden + col);
+  }
+  auto unpack = [](const uint4& q, float (&f)[8]) {
+    const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = E::to_f32((uint16_t)(u[i] & 0xffffu));
+      f[2 * i + 1] = E::to_f32((uint16_t)(u[i] >> 16));
+    }
+  };
+  float v[NCH][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    unpack(rw[c], v[c]);
+    if (delta) {
+      float d[8];
+      unpack(dw[c], d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c][e] = E::to_f32(E::from_f32(v[c][e] + d[e]));   // the residual stream is 16-bit (HF)
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += v[c][e] * v[c][e];
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (delta)
+      *reinterpret_cast<uint4*>(resid + row * hidden + col) =
+          make_uint4(E::pack(v[c][0], v[c][1]), E::pack(v[c][2], v[c][3]), E::pack(v[c][4], v[c][5]), E::pack(v[c][6], v[c][7]));
+    const float4 g0 = *reinterpret_cast<const float4*>(w + col), g1 = *reinterpret_cast<const float4*>(w + col + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = g[e] * (v[c][e] * inv);
+    *reinterpret_cast<uint4*>(out + row * hidden + col) =
+        make_uint4(E::pack(o[0], o[1]), E::pack(o[2], o[3]), E::pack(o[4], o[5]), E::pack(o[6], o[7]));
+  }
+}
+
 extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int delta_splits, const float* w, float eps,
                            int64_t rows, int hidden, void* out, int dtype, void* stream) {
   PSG_REQUIRE(ctx && resid && w && out, PSG_ERR_INVALID, "psg_rmsnorm: NULL argument");
@@ -463,6 +519,20 @@ extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int del
               PSG_MAX_SPLITS);
   dim3 grid((unsigned)rows);
   hipStream_t st = (hipStream_t)stream;
+  if (rows > 64 && delta_splits == 0 && (dtype == PSG_BF16 || dtype == PSG_F16) && (hidden == 4096 || hidden == 1024 ||
+      hidden == 512) && ctx->opt.ln_half_wave) {                  // prompt pass: a wave per row, 16-byte accesses
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+#define RNR(N)                                                                                                       \
+  PSG_DISPATCH_E16(dtype, "psg_rmsnorm",                                                                             \
+                   (rmsnorm_rows16_kernel<E, N><<<blocks, 256, 0, st>>>((uint16_t*)resid, (const uint16_t*)delta, w, eps, \
+                                                                       rows, hidden, (uint16_t*)out)))
+    if (hidden == 4096) RNR(8);
+    else if (hidden == 1024) RNR(2);
+    else RNR(1);
+#undef RNR
+    PSG_CHECK_LAUNCH("psg_rmsnorm");
+    return PSG_OK;
+  }
   // decode-sized launches (a handful of rows) are latency bound: spread each row over 16 waves
   const int nthr = (rows <= 64 && hidden >= 4096) ? 1024 : 256;
   const int nch = (hidden + 4 * nthr - 1) / (4 * nthr);
