@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--one-phase", action="store_true",
                     help="last Q-Former layer for all 33 rows of every pair (A/B against the default cls-first path)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the one-image strong-scaling figure")
+    ap.add_argument("--pair-chunk", type=int, default=0, help="pairs per Q-Former pass (0: the head's default)")
     return ap.parse_args()
 
 
@@ -99,6 +100,8 @@ def setup_head(a, dev):
                                      llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True,
                                      cls_first=not a.one_phase)
     head.load_weights(w)
+    if getattr(a, "pair_chunk", 0) > 0:
+        head.pair_chunk = a.pair_chunk
     del w
     torch.cuda.empty_cache()
     return head

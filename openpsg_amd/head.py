@@ -105,7 +105,9 @@ class RelationTransformerHeadV4(nn.Module):
                  on_parse_error="raise",       # V4:315-316 raises IndexError when no '<s>' was generated
                  implicit_bos=True,            # parse the generation as following an implicit '<s>' (see parse())
                  suppress_eos=False,
-                 pair_chunk=4096,
+                 pair_chunk=12288,             # pairs per Q-Former pass: one pass for up to 110 objects (~6 GB of
+                                               # activations at 10 000 pairs in bf16; fewer, larger GEMMs and one prompt
+                                               # table per image: 9.5 -> 8.1 ms at 100 objects against chunks of 4096)
                  xattn_variant=None,
                  pair_selector="topk",         # 'topk' (V4:235-237) | 'threshold' (the commented V4:230-234 logic)
                  exclude_diagonal=False,       # the reference never excludes the i == j pairs
