@@ -394,7 +394,7 @@ def main():
                   "steps": ks, "single_gpu_reference_ms": 77.6,
                   "bound": "16 passes over the 13.5 GB of Llama weights per image on every decoding rank (a decode "
                            "step streams all weights for 1 row as for 20; no tensor parallelism, SURVEY 8e): only the "
-                           "relation query (12 ms at 1 GPU) and the compute-bound prompt pass (15 ms) shrink with N"}
+                           "relation query (8 ms at 1 GPU) and the compute-bound prompt pass (15 ms) shrink with N"}
 
     if rank == 0:
         ips = a.images_per_step if (world == 1 and not force_dist and a.workload == "full") else world
