@@ -534,6 +534,50 @@ def test_topk_ties_and_order():
     assert ops.topk(big.to(dev), 20)[0].cpu().tolist() == want
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows", [1, 7, 66, 33 * 9])
+def test_add_layernorm_16bit_variants_vs_fp32_torch(dtype, rows):
+    """add + LayerNorm on 16-bit rows (HF-IB:519-530, 579-596): the half-wave-per-row kernel (option ln_half_wave) and the
+    wave-per-row kernel give the fp32 torch result to one rounding of the output; residual taken from the same-shaped
+    tensor, from one shared block (periodic) and from a block table through an index (the pair's prompt)."""
+    from openpsg_amd import _lib, ops
+    dev = _dev()
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 768, generator=g).to(dev, tdt)
+    r = torch.randn(rows, 768, generator=g).to(dev, tdt)
+    b = torch.randn(768, generator=g).to(dev)
+    gam, bet = (1 + 0.2 * torch.randn(768, generator=g)).to(dev), torch.randn(768, generator=g).to(dev)
+    ulp = 2.0 ** (-8 if dtype == "bf16" else -11)
+
+    def close(got, want):
+        return ((got.float() - want).abs() / (1 + want.abs())).max().item() < 1.5 * ulp
+
+    outs = {}
+    G = rows // 33
+    tab = torch.randn(4 * 33, 768, generator=g).to(dev, tdt)
+    idx = torch.randint(0, 4, (max(G, 1),), generator=g)[:G].to(dev, torch.int32)
+    try:
+        for hw in (1, 0):
+            _lib.set_option(0, "ln_half_wave", hw)
+            want = torch.nn.functional.layer_norm(x.float() + b + r.float(), (768,), gam, bet, 1e-12)
+            got = ops.add_layernorm(x.clone(), r, b, gam, bet, 1e-12)
+            assert close(got, want)
+            outs[hw] = [got]
+            if rows % 33 == 0:                                     # groups of 33 rows (the query rows of a pair)
+                wantp = torch.nn.functional.layer_norm(x.float() + b + tab[:33].float().repeat(G, 1), (768,), gam, bet, 1e-12)
+                gotp = ops.add_layernorm_periodic(x.clone(), tab[:33].contiguous(), b, gam, bet, 1e-12)
+                rows_i = (idx.long()[:, None] * 33 + torch.arange(33, device=dev)[None, :]).reshape(-1)
+                wanti = torch.nn.functional.layer_norm(x.float() + b + tab[rows_i].float(), (768,), gam, bet, 1e-12)
+                goti = ops.add_layernorm_indexed(x.clone(), tab, idx, 33, b, gam, bet, 1e-12)
+                assert close(gotp, wantp) and close(goti, wanti)
+                outs[hw] += [gotp, goti]
+    finally:
+        _lib.set_option(0, "ln_half_wave", 1)
+    for a_, b_ in zip(outs[0], outs[1]):                           # the two kernels: same rounding class
+        assert ((a_.float() - b_.float()).abs() / (1 + b_.float().abs())).max().item() < 2.1 * ulp
+
+
 def test_row_kernels_vs_torch():
     from openpsg_amd import ops
     dev = _dev()
