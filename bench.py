@@ -143,7 +143,9 @@ def relation_query_flops(N, L, T, cls_first=False, selected=20):
     """FLOPs the relation-query stage has to execute for one image: SURVEY 8d's per-layer formula with the work
     whose result is never read or is identical for every pair left out (V4:185 slices the output to the 33 query
     rows, so in the last layer the text rows need K/V only; the Q/K/V projection of the 33 query rows entering
-    layer 0 is the same for all pairs and is computed once).  Plus the per-image patch embedding and shared K/V."""
+    layer 0 is the same for all pairs and is computed once).  Plus the per-image patch embedding and shared K/V.
+    Counted PER PAIR: the head additionally computes the prompt-only share once per distinct prompt, which this
+    count does not subtract - the figure is algorithmic work per second, not executed instructions."""
     S, H, F = 33 + T, 768, 3072
     cross = 2 * 33 * H * H + 4 * 33 * L * H + 2 * 33 * H * H
     first = 2 * T * H * 3 * H + 4 * S * S * H + 2 * S * H * H + cross + 4 * 33 * H * F + 4 * T * H * F
@@ -427,8 +429,8 @@ def main():
             T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
             fl = relation_query_flops(N, (a.size // 64) ** 2, T, head.cls_first, head.cfg.num_selected)
             ach = fl / (elapsed / a.steps) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "relation-query stage (bf16 GEMMs + cross_attn_mfma_kernel + "
-                                "self_attn_mfma_kernel)", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            line["roofline"] = {"bound": "mfma", "kernel": "relation-query stage (bf16 GEMMs + cross_attn_dma_kernel + "
+                                "self_attn_mfma_kernel + qformer_cls_attn_input_kernel)", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                                 "frac": round(ach / 2500.0, 4), "traffic": None, "flops_per_step": int(fl)}
         if world == 1 and not force_dist and a.images_per_step == 1 and a.workload == "full":
             # stage split (not part of the contract): relation-query stage alone, against the dense bf16 MFMA peak
