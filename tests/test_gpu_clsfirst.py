@@ -185,3 +185,29 @@ def test_prompt_dedup_equals_per_pair_path(dtype, chunk, monkeypatch):
     else:
         assert err < 0.06 and len(common) >= len(a["sel"]) - 6
         assert np.abs(pa - pb).max() < 0.15
+
+
+@pytest.mark.parametrize("N,cats", [(2, 1), (3, 1), (5, 2)])
+def test_prompt_dedup_tiny_scenes(N, cats):
+    """Two or three objects of ONE class (a single distinct prompt for all pairs) and five of two: the per-prompt path
+    against the per-pair path in fp32."""
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_device
+    dev = _dev()
+    cfg = PSGConfig(qformer=QFormerConfig(), llm=tiny_llm(256, 1, 256, 256), max_object_num=8)
+    w = make_weights_device(cfg, 9, dev, llm_dtype=torch.float32)
+    scene = make_scene((512, 512), N, seed=3, device="cuda:0", num_categories=cats)
+    logits = {}
+    for dd in (False, True):
+        head = RelationTransformerHeadV4(dtype="fp32", device="cuda:0", tokenizers="word", max_object_num=8,
+                                         llm_config=cfg.llm, llm_feature_size=256, on_parse_error="skip", cls_first=True)
+        head.load_weights(w)
+        head.rq_engine.dedup_prompts = dd
+        out = head(_inputs(scene))
+        torch.cuda.synchronize()
+        assert set(out) >= {"rel_pred", "rel_score"}
+        logits[dd] = head.last["exist_logit"].float().cpu().numpy()
+        assert logits[dd].shape == (N * N,)
+    assert np.abs(logits[False] - logits[True]).max() < 2e-5
