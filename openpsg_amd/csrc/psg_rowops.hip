@@ -703,7 +703,49 @@ __global__ void __launch_bounds__(1024) greedy_step_kernel(const void* __restric
   // 4 vocabulary entries per thread and pass (16-byte loads per split-K slice): one workgroup per pair has to
   // pull 4 slices x 128 KB through a single CU, and scalar 4-byte loads made that 38 us of a decode step
   const int v4 = (vocab % 4 == 0 && ((int64_t)k * vocab) % 4 == 0) ? vocab / 4 : 0;
-  for (int i4 = tid; i4 < v4; i4 += blockDim.x) {
+  int i4_begin = tid;
+  if (S >= 1 && S <= 4 && v4 > 0) {
+    // split-K logits of the lm_head (<= 4 slices): four positions per thread and round trip - every slice of all four
+    // requested before the first sum (one position per trip made the 8 passes over the vocabulary 8 dependent trips:
+    // 16 us).  Sums in slice order, rounded to the activation type: the same values as ld4_in.
+    constexpr int NB = 4;
+    const float* p = reinterpret_cast<const float*>(logits) + (int64_t)k * vocab;
+    const int bd = (int)blockDim.x;
+    for (int i0 = tid; i0 < v4; i0 += NB * bd) {
+      float4 t[4][NB];
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx)
+        if (sidx < S) {
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const int j4 = i0 + u * bd < v4 ? i0 + u * bd : v4 - 1;
+            t[sidx][u] = *reinterpret_cast<const float4*>(p + (int64_t)sidx * slice + 4 * j4);
+          }
+        }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        float4 a = t[0][u];
+#pragma unroll
+        for (int sidx = 1; sidx < 4; ++sidx)
+          if (sidx < S) { a.x += t[sidx][u].x; a.y += t[sidx][u].y; a.z += t[sidx][u].z; a.w += t[sidx][u].w; }
+        const float v[4] = {Act<T>::rnd(a.x), Act<T>::rnd(a.y), Act<T>::rnd(a.z), Act<T>::rnd(a.w)};
+        const int j4 = i0 + u * bd;
+        if (j4 < v4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * j4 + e;
+            const float x = i == suppress ? -INFINITY : v[e];
+            if (x > best || (x == best && i < bi)) {
+              best = x;
+              bi = i;
+            }
+          }
+        }
+      }
+    }
+    i4_begin = v4;                                               // the generic loop below has nothing left
+  }
+  for (int i4 = i4_begin; i4 < v4; i4 += blockDim.x) {
     float v[4];
     ld4_in<T>(logits, S, slice, (int64_t)k * vocab + 4 * i4, v);
 #pragma unroll
