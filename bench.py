@@ -25,8 +25,10 @@ The JSON line also carries
   cpu_baseline - the CPU oracle (oracle/psg_oracle.py, a restatement of the reference's PyTorch path)
                  timed on this box's host cores on a bounded sample, rank 0, N = 1 only;
   parity       - the same scene through the fp32 verification mode (ms/step, pairs/s: the mode the 1e-3 claim is
-                 made in) and the deviation of the fp32 and the bf16 relation query from the CPU oracle on the
-                 pairs the cpu_baseline leg computed (same weights, same scene).
+                 made in); per 16-bit mode (bf16, fp16, mixed = fp16 operands + fp32 residual stream): ms/step of the
+                 full path, deviation of the existence logits from the CPU oracle on ALL pairs of the scene, top-20
+                 overlap, and the DECODE leg at Llama-2-7B width (2 full-width layers, the oracle's pair features
+                 injected): first-step logit deviation and token-exact sequences against the oracle's greedy decode.
 """
 from __future__ import annotations
 
@@ -62,8 +64,11 @@ def parse():
     ap.add_argument("--no-batched", action="store_true", help="skip the secondary 4-images-per-step measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
-                    help="activation / weight dtype of the measured path (BASELINE config 5 names fp16)")
+    ap.add_argument("--dtype", choices=["bf16", "fp16", "mixed"], default="bf16",
+                    help="activation / weight dtype of the measured path (BASELINE config 5 names fp16); mixed = fp16 "
+                         "GEMM operands with the Llama residual stream kept in fp32")
+    ap.add_argument("--no-untruncated", action="store_true",
+                    help="cpu_baseline: skip the un-truncated 32-layer fp32 decode of one pair (27 GB of host memory)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--one-phase", action="store_true",
                     help="last Q-Former layer for all 33 rows of every pair (A/B against the default cls-first path)")
@@ -94,9 +99,10 @@ def setup_head(a, dev):
     from openpsg_amd.head import RelationTransformerHeadV4
     from openpsg_amd.weights import make_weights_device
     cfg = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=a.llm_layers), max_object_num=a.objects)
-    tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    dtype = getattr(a, "dtype_override", None) or a.dtype
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
     w = make_weights_device(cfg, 0, dev, llm_dtype=tdt, with_llm=a.workload == "full")
-    head = RelationTransformerHeadV4(dtype=a.dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
+    head = RelationTransformerHeadV4(dtype=dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
                                      llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True,
                                      cls_first=not a.one_phase)
     head.load_weights(w)
@@ -176,10 +182,12 @@ def host_info():
 
 
 def cpu_baseline(a, scene_cpu):
-    """The CPU oracle on a bounded sample of the same workload (10-30 s of host work).  Returns the JSON object
-    and what the parity block reuses: (weights, cfg, pair count, oracle existence logits of those pairs)."""
+    """The CPU oracle on this box's host cores: the relation query over ALL pairs of the scene (3 repetitions, median),
+    the LMM decode on a bounded sample (serial batch-1 decodes as V4:293-312; 2 and 4 full-width fp32 layers
+    extrapolated linearly to 32, plus ONE un-truncated 32-layer decode when the host has the memory).  Returns the
+    JSON object and what the parity block reuses (weights, cfg, oracle logits / features / greedy decodes)."""
     from openpsg_amd.config import LlamaConfig, PSGConfig, QFormerConfig
-    from openpsg_amd.weights import make_weights_numpy
+    from openpsg_amd.weights import _std_for, llm_shapes, make_weights_numpy
     from oracle import psg_oracle as O
     from tests import helpers as H
     N = a.objects
@@ -188,8 +196,8 @@ def cpu_baseline(a, scene_cpu):
     cfg = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=max(lay)), max_object_num=N)
     w = make_weights_numpy(cfg, seed=1, with_llm=a.workload == "full")
     ids, tmask = H.qformer_prompts(scene_cpu)
-    n_rq = min(B, 512)
     host_cores, host_model = host_info()
+    n_dec = 4                                                       # pairs decoded by the oracle at 2 layers (parity)
     with torch.no_grad():
         # torch's CPU kernels oversubscribe badly on a many-core host (256 threads were 20x slower
         # than 8 on these shapes): pick the fastest thread count on a small probe, report it as `cores`.
@@ -212,36 +220,108 @@ def cpu_baseline(a, scene_cpu):
                            scene_cpu["img_meta"]["pad_shape"], (fh // 16, fw // 16))
         pm = O.pair_masks(O.object_masks(grid, [int(i) for i in scene_cpu["object_id_list"]]))
         t_prep = time.time() - t0
-        t0 = time.time()
-        out = O.qformer_forward(w, cfg, ids[:n_rq], tmask[:n_rq], patches, pm[:n_rq], chunk=64)
-        logit, _ = O.existence_head(w, out)
-        t_rq = time.time() - t0
-        rq_rate = n_rq / t_rq
-        t_image = t_prep + B / rq_rate
-        sample = (f"relation-query: patch-embed + {n_rq} of {B} pairs through the fp32 oracle ({rq_rate:.0f} pairs/s, "
-                  f"{t_rq:.1f}s)")
+        reps = []
+        for _ in range(3):
+            t0 = time.time()
+            out = O.qformer_forward(w, cfg, ids, tmask, patches, pm, chunk=64)
+            logit, prob = O.existence_head(w, out)
+            reps.append(time.time() - t0)
+        t_rq = sorted(reps)[1]
+        rq_rate = B / t_rq
+        t_image = t_prep + t_rq
+        sel = O.select_topk(prob, 20)
+        sample = (f"relation-query: patch-embed + all {B} pairs through the fp32 oracle, 3 repetitions "
+                  f"({', '.join(f'{r:.1f}s' for r in reps)}; median {rq_rate:.0f} pairs/s)")
+        decodes = None
         if a.workload == "full":
-            pids, pmask = H.llm_prompts(scene_cpu, [1])
-            x, mask = O.llm_inputs(w, out[1, 1:], pids[0], pmask[0])
+            pids, pmask = H.llm_prompts(scene_cpu, sel)
             ts = {}
-            for nl in lay:
+            decodes = []
+            for i in range(n_dec):                                  # the oracle's own top-20 order, first n_dec pairs
+                x, mask = O.llm_inputs(w, out[sel[i], 1:], pids[i], pmask[i])
                 t0 = time.time()
-                O.llm_generate(w, cfg, x, mask, n_layers=nl, suppress_eos=True)
-                ts[nl] = time.time() - t0
+                toks, lgs = O.llm_generate(w, cfg, x, mask, n_layers=lay[0], suppress_eos=True)
+                if i == 0:
+                    ts[lay[0]] = time.time() - t0
+                decodes.append((toks, lgs[0]))
+            x, mask = O.llm_inputs(w, out[sel[0], 1:], pids[0], pmask[0])
+            t0 = time.time()
+            O.llm_generate(w, cfg, x, mask, n_layers=lay[1], suppress_eos=True)
+            ts[lay[1]] = time.time() - t0
             per_layer = max((ts[lay[1]] - ts[lay[0]]) / (lay[1] - lay[0]), 1e-6)
             t_pair = ts[lay[0]] + (a.llm_layers - lay[0]) * per_layer
-            t_image += 20 * t_pair
             sample += (f"; LMM decode: 1 of 20 selected pairs, 16 new tokens, {lay[0]} and {lay[1]} full-width fp32 "
                        f"layers timed ({ts[lay[0]]:.2f}s, {ts[lay[1]]:.2f}s) and extrapolated linearly to "
-                       f"{a.llm_layers} layers ({t_pair:.1f}s per pair, serial batch-1 as V4:293-312; an untruncated "
-                       f"run needs 27 GB of fp32 weights generated on the host and is not part of the default run)")
+                       f"{a.llm_layers} layers ({t_pair:.1f}s per pair, serial batch-1 as V4:293-312)")
+            untrunc = None
+            if not a.no_untruncated and a.llm_layers == 32:
+                try:
+                    import psutil
+                    avail = psutil.virtual_memory().available
+                except Exception:  # noqa: BLE001
+                    avail = 0
+                if avail >= 64 << 30:
+                    # ONE un-truncated decode: 32 fp32 layers (27 GB of seeded numpy PCG64 weights, one generator per
+                    # tensor on a thread pool)
+                    import numpy as np
+                    from concurrent.futures import ThreadPoolExecutor
+                    cfg32 = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=32), max_object_num=N)
+                    w32 = dict(w)
+                    todo = [(i, key, shp) for i, (key, shp) in enumerate(sorted(llm_shapes(cfg32).items()))
+                            if key not in w32]
+
+                    def fill(job):                                  # numpy releases the GIL: one generator per tensor
+                        i, key, shp = job
+                        mean, std = _std_for(key, shp)
+                        arr = np.random.default_rng(1000 + i).standard_normal(shp, dtype=np.float32)
+                        arr *= np.float32(std)
+                        arr += np.float32(mean)
+                        return key, torch.from_numpy(arr)
+                    with ThreadPoolExecutor(max_workers=min(32, host_cores)) as ex:
+                        w32.update(ex.map(fill, todo))
+                    t0 = time.time()
+                    O.llm_generate(w32, cfg32, x, mask, n_layers=32, suppress_eos=True)
+                    untrunc = time.time() - t0
+                    del w32
+                    sample += f"; ONE un-truncated 32-layer fp32 decode of a pair measured: {untrunc:.1f}s (used)"
+                    t_pair = untrunc
+                else:
+                    sample += "; un-truncated run skipped (host has < 64 GB available)"
+            t_image += 20 * t_pair
     obj = dict(value=round(N * (N - 1) / t_image, 3), unit="pairs/s", cores=cores, kind="port", sample=sample,
                host_cores=host_cores, host_cpu=host_model)
-    return obj, dict(w=w, cfg=cfg, n=n_rq, logit=logit)
+    return obj, dict(w=w, cfg=cfg, n=B, logit=logit, hidden=out, selected=sel, decodes=decodes, n_layers=lay[0])
 
 
-def parity_block(a, dev, scene, oracle_part, bf16_ms):
-    """fp32 verification mode on the bench scene (full path timed) + fp32 / bf16 deviation from the CPU oracle."""
+def decode_parity(h, oracle_part, scene, names, eos):
+    """Decode leg against the oracle at Llama-2-7B width: the oracle's pair features of its first selected pairs are
+    injected, the head (LLM truncated to the oracle's layer count) decodes them in one batch."""
+    dev = h.device
+    dec = oracle_part["decodes"]
+    sel = oracle_part["selected"][:len(dec)]
+    feats = torch.cat([oracle_part["hidden"][p, 1:] for p in sel]).to(dev, h.act_dtype).contiguous()
+    rq = dict(num_objects=len(names))
+    out = h.decode_selected(rq, names, selected=torch.tensor(sel, dtype=torch.int32, device=dev), pair_features=feats)
+    fl = out["first_logits"].float().cpu()
+    err, exact, matched, total = 0.0, 0, 0, 0
+    for i, (toks, lg0) in enumerate(dec):
+        o = lg0.clone()
+        g_ = fl[i].clone()
+        o[eos] = 0.0
+        g_[eos] = 0.0                                            # suppress_eos writes -inf there
+        err = max(err, float((o - g_).abs().max()))
+        got = [int(t) for t in out["tokens_host"][i] if t >= 0]
+        exact += got == toks
+        matched += next((s_ for s_ in range(min(len(got), len(toks))) if got[s_] != toks[s_]), min(len(got), len(toks)))
+        total += len(toks)
+    return dict(first_step_logit_err=float(f"{err:.3e}"), exact_sequences=f"{exact}/{len(dec)}",
+                tokens_before_first_divergence=f"{matched}/{total}")
+
+
+def parity_block(a, dev, scene, oracle_part, headline_ms):
+    """fp32 verification mode on the bench scene (full path timed) + per-dtype deviation from the CPU oracle (relation
+    query on all pairs; decode leg at 7B width with 2 layers) + ms/step of the full path in every 16-bit mode."""
+    import copy
     from openpsg_amd.categories import INSTANCE_OFFSET, object_categories
     from openpsg_amd.config import LlamaConfig, PSGConfig, QFormerConfig
     from openpsg_amd.head import RelationTransformerHeadV4
@@ -250,18 +330,29 @@ def parity_block(a, dev, scene, oracle_part, bf16_ms):
     out = {}
     ids_ = [int(i) for i in scene["object_id_list"]]
     names_ = [object_categories[i % INSTANCE_OFFSET] for i in ids_]
+    modes = {}
     if oracle_part is not None:
         w, n = oracle_part["w"], oracle_part["n"]
-        hw = {k: v for k, v in w.items() if not k.startswith("language_model.")}
-        for dt in ("fp32", "bf16"):
-            h = RelationTransformerHeadV4(dtype=dt, device=str(dev), tokenizers="word", max_object_num=N)
-            h.load_weights(hw)
-            # the whole image through the benchmarked path (cls-first last layer); the oracle covered pairs [0, n)
+        full = a.workload == "full" and oracle_part["decodes"] is not None
+        ocfg = oracle_part["cfg"]
+        k = min(20, n)
+        for dt in ("fp32", "bf16", "fp16", "mixed"):
+            kw = dict(llm_config=ocfg.llm, llm_truncate_num=oracle_part["n_layers"], suppress_eos=True) if full else {}
+            h = RelationTransformerHeadV4(dtype=dt, device=str(dev), tokenizers="word", max_object_num=N,
+                                          on_parse_error="skip", **kw)
+            h.load_weights(w if full else {k_: v for k_, v in w.items() if not k_.startswith("language_model.")})
+            # the whole image through the benchmarked path (cls-first last layer) against the oracle's logits of ALL pairs
             rq = h.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_, scene["pan_results"])
-            out[f"{dt}_max_logit_err_vs_oracle"] = float(f"{(rq['exist_logit'][:n].cpu() - oracle_part['logit']).abs().max().item():.3e}")
+            m = dict(max_logit_err_vs_oracle=float(f"{(rq['exist_logit'][:n].cpu() - oracle_part['logit']).abs().max().item():.3e}"),
+                     top20_overlap=f"{len(set(rq['selected'].cpu().tolist()) & set(oracle_part['selected']))}/{k}")
+            if full:
+                m["decode_7b_width_2_layers"] = decode_parity(h, oracle_part, scene, names_, ocfg.llm.eos)
+            modes[dt] = m
             del h, rq
+            torch.cuda.empty_cache()
         out["pairs_checked"] = n
         out["tolerance_fp32"] = 1e-3
+        out["fp32_max_logit_err_vs_oracle"] = modes["fp32"]["max_logit_err_vs_oracle"]
     if a.workload == "full":
         cfg = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=a.llm_layers), max_object_num=N)
         w32 = make_weights_device(cfg, 0, dev, llm_dtype=torch.float32)
@@ -272,9 +363,23 @@ def parity_block(a, dev, scene, oracle_part, bf16_ms):
         inputs = scene_inputs(scene)
         el = time_steps(lambda: h(inputs), 1, 3) / 3
         out.update(fp32_mode_ms_per_step=round(el * 1e3, 2), fp32_mode_pairs_per_s=round(N * (N - 1) / el, 1),
-                   bf16_over_fp32_speed=round(el * 1e3 / bf16_ms, 2))
+                   headline_over_fp32_speed=round(el * 1e3 / headline_ms, 2))
         del h
         torch.cuda.empty_cache()
+        # the full path in the other 16-bit modes (same scene, same step, their own 32-layer engine)
+        for dt in ("bf16", "fp16", "mixed"):
+            m = modes.setdefault(dt, {})
+            if dt == a.dtype:
+                m["ms_per_step"] = round(headline_ms, 3)
+                continue
+            b = copy.copy(a)
+            b.dtype_override = dt
+            h = setup_head(b, dev)
+            el = time_steps(lambda: h(inputs), 2, 5) / 5
+            m["ms_per_step"] = round(el * 1e3, 3)
+            del h
+            torch.cuda.empty_cache()
+    out["modes"] = modes
     return out
 
 
@@ -390,13 +495,21 @@ def main():
         t = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el1 = float(t.item()) / ks
+        # the single-GPU reference of the same image, measured in this run (every rank runs it at the same time;
+        # rank 0's figure is reported)
+        inputs4 = scene_inputs(scene4)
+        ref1 = time_steps(lambda: head(inputs4) if a.workload == "full" else head.run_relation_query(
+            scene4["mask_features"], scene4["img_meta"], [int(i) for i in scene4["object_id_list"]],
+            pipe1.be._names(scene4), scene4["pan_results"]), 1, 3) / 3
+        dist.barrier()
         strong = {"workload": f"ONE {a.size}x{a.size} image, {n4} masks ({n4 * (n4 - 1)} pairs), pairs sharded over "
                               f"{world} rank(s), top-20 decodes dealt round-robin",
                   "ms_per_image": round(el1 * 1e3, 3), "value": round(n4 * (n4 - 1) / el1, 1), "unit": "pairs/s",
-                  "steps": ks, "single_gpu_reference_ms": 77.6,
+                  "steps": ks, "single_gpu_reference_ms": round(ref1 * 1e3, 3),
+                  "speedup_vs_single_gpu": round(ref1 / el1, 3),
                   "bound": "16 passes over the 13.5 GB of Llama weights per image on every decoding rank (a decode "
                            "step streams all weights for 1 row as for 20; no tensor parallelism, SURVEY 8e): only the "
-                           "relation query (8 ms at 1 GPU) and the compute-bound prompt pass (15 ms) shrink with N"}
+                           "relation query and the compute-bound prompt pass shrink with N"}
 
     if rank == 0:
         ips = a.images_per_step if (world == 1 and not force_dist and a.workload == "full") else world
@@ -423,7 +536,10 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             line["roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_dma_kernel (psg_skinny_gemm; 8-wave slabs, 11-wave for gate/up, 12-wave for q/k/v)", "achieved": round(ach, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                "traffic": traffic, "bytes_per_launch": int(bpl),
+                                "traffic": traffic,
+                                "traffic_source": "profiles/pmc_skinny_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                  "passes of this kernel; not re-measured in this run)",
+                                "bytes_per_launch": int(bpl),
                                 "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n}
         if a.workload == "rq" and not a.no_roofline and world == 1 and not force_dist:
             T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")

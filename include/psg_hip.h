@@ -51,6 +51,12 @@ enum psg_empty_policy { PSG_EMPTY_UNIFORM = 0, PSG_EMPTY_UNMASKED = 1 };
  * the first-generation kernel), the scalar fp32 checker kernel, or the first-generation matrix-core kernel */
 enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFMA_V1 = 2 };
 
+/* ABI version: bumped whenever an entry point's argument list changes.  psg_version() returns the version the
+ * library was built with; a binding compares it with the PSG_ABI_VERSION of the header it was written against
+ * (openpsg_amd/_lib.py does, at load time) instead of passing shifted arguments silently.
+ *   100  round 1        200  round 2 (psg_skinny_gemm / psg_rope_kvwrite gained, psg_qformer_cross_attn lost an argument)
+ *   300  round 3 (psg_rmsnorm: resid_dtype) */
+#define PSG_ABI_VERSION 300
 int psg_version(void);
 const char* psg_last_error(void);
 int psg_create(int device, psg_ctx** out);
@@ -179,9 +185,11 @@ int psg_gather_rows(psg_ctx*, const void* src, int src_dtype, const int32_t* idx
 /* ---- K12: Llama RMSNorm, HF-LL:53-67, fused with the residual add of HF-LL decoder layer:
  * if delta != NULL: resid += delta (written back); out = w * (resid * rsqrt(mean(resid^2)+eps)).
  * delta_splits > 0: delta is fp32 split-K partials [delta_splits][rows][hidden] of psg_skinny_gemm
- * (summed here, rounded once to the activation dtype); 0: delta is an activation-dtype tensor. */
+ * (summed here, rounded once to the activation dtype); 0: delta is an activation-dtype tensor.
+ * resid_dtype: storage type of the residual stream `resid` - `dtype` (what HF keeps for a model cast to 16 bits) or
+ * PSG_F32 with a 16-bit `dtype` (mixed mode: 16-bit GEMM operands `out`, residual stream never rounded to 16 bits). */
 int psg_rmsnorm(psg_ctx*, void* resid, const void* delta, int delta_splits, const float* w, float eps,
-                int64_t rows, int hidden, void* out, int dtype, void* stream);
+                int64_t rows, int hidden, void* out, int dtype, int resid_dtype, void* stream);
 
 /* ---- K13: rotary embedding (half-split, HF-LL:130-160) + KV-cache write.
  * qkv [rows][3*hidden]; tok_pair / tok_pos int32 [rows] give the cache row (pair) and the

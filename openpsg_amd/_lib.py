@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpsg_hip.so")
 
+PSG_ABI_VERSION = 300            # include/psg_hip.h; checked against psg_version() of the loaded library
 PSG_F32, PSG_BF16, PSG_F16 = 0, 1, 2
 PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED = 0, 1
 PSG_XATTN_MFMA, PSG_XATTN_SIMPLE, PSG_XATTN_MFMA_V1 = 0, 1, 2
@@ -59,7 +60,7 @@ SIGNATURES = {
     "psg_exist_head": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "psg_topk": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "psg_gather_rows": [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _i, _i64, _vp],
-    "psg_rmsnorm": [_vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _i, _vp],
+    "psg_rmsnorm": [_vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _i, _i, _vp],
     "psg_rope_kvwrite": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "psg_train_object_bitmasks": [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "psg_bce_with_logits": [_vp, _vp, _vp, _i, _f, _vp, _vp],
@@ -106,6 +107,10 @@ def load():
             raise PsgHipError(f"{LIB_PATH} does not export {name}; rebuild the library")
         fn.restype = _i
         fn.argtypes = argtypes
+    built = lib.psg_version()
+    if built != PSG_ABI_VERSION:
+        raise PsgHipError(f"{LIB_PATH} was built with ABI version {built}, this binding is written against "
+                          f"{PSG_ABI_VERSION} (include/psg_hip.h): rebuild with `python -m openpsg_amd.csrc.build --force`")
     _lib = lib
     return lib
 

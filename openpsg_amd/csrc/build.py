@@ -35,18 +35,35 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> str:
+    """One object per source (compiled in parallel, kept under csrc/_obj/ and reused while the source and the
+    headers are older), then one link: a change to one kernel file costs one compile, not twelve."""
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc",
-           "-Wno-unused-result", "-o", LIB] + srcs
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(HERE, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
     if save_temps:
-        tmp = os.path.join(HERE, "_temps")
-        os.makedirs(tmp, exist_ok=True)
-        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=HERE)
+        os.makedirs(os.path.join(HERE, "_temps"), exist_ok=True)
+        flags += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    hdr_t = max(os.path.getmtime(os.path.join(HERE, h)) for h in HEADERS)
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(HERE, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(obj_dir, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or save_temps or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([_hipcc()] + flags + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=HERE)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, (os.cpu_count() or 2) - 1))) as ex:
+        list(ex.map(run, jobs))
+    run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + objs)
     return LIB
 
 

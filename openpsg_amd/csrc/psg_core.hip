@@ -16,7 +16,7 @@ void psg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* psg_last_error(void) { return g_err; }
-extern "C" int psg_version(void) { return 100; }
+extern "C" int psg_version(void) { return PSG_ABI_VERSION; }
 
 struct OptName {
   const char* name;

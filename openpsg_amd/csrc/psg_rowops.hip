@@ -388,8 +388,10 @@ extern "C" int psg_exist_head(psg_ctx* ctx, const void* x, const float* w, const
 // One 256-thread workgroup per row (decode has only K ~ 20 rows of 4096: a single wave walking a
 // row serialises ~16 dependent HBM round trips).  Thread t owns the 4-element chunks t, t+256, ...;
 // every load is issued before the first store; the sum of squares is reduced wave -> LDS -> block.
-template <typename T, int NCH>
-__global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, const void* __restrict__ delta,
+// R = storage type of the residual stream: T (HF: a model cast to 16 bits keeps x = residual + attn in 16 bits) or float
+// (mixed mode: 16-bit GEMM operands, fp32 residual stream - the sum of 2 x layers updates is never rounded to 16 bits).
+template <typename T, int NCH, typename R = T>
+__global__ void __launch_bounds__(1024) rmsnorm_kernel(R* __restrict__ resid, const void* __restrict__ delta,
                                                       int dsplits, int64_t dslice, const float* __restrict__ w,
                                                       float eps, int hidden, T* __restrict__ out) {
   __shared__ float s_part[16];
@@ -397,12 +399,12 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, co
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthr = blockDim.x;
   float v[NCH][4], d[NCH][4];
   float4 g[NCH];
-  typename Act<T>::raw4 vr[NCH];                              // converted after the partials are requested: no early wait
+  typename Act<R>::raw4 vr[NCH];                              // converted after the partials are requested: no early wait
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * nthr + tid) * 4;
     if (col < hidden) {
-      vr[c] = Act<T>::ldr4(resid, row * hidden + col);
+      vr[c] = Act<R>::ldr4(resid, row * hidden + col);
       g[c] = *reinterpret_cast<const float4*>(w + col);
     }
   }
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, co
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * nthr + tid) * 4;
-    if (col < hidden) Act<T>::cv4(vr[c], v[c]);
+    if (col < hidden) Act<R>::cv4(vr[c], v[c]);
   }
   float ss = 0.f;
 #pragma unroll
@@ -425,8 +427,8 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[c][e] += d[c][e];
-          // the residual stream is stored in the activation dtype, as HF does (x = residual + attn)
-          v[c][e] = Act<T>::rnd(v[c][e]);
+          // the residual stream is rounded to its storage type (16 bits as HF does, x = residual + attn; or fp32)
+          v[c][e] = Act<R>::rnd(v[c][e]);
         }
       }
 #pragma unroll
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, co
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * nthr + tid) * 4;
     if (col < hidden) {
-      if (delta) Act<T>::st4(resid, row * hidden + col, v[c]);
+      if (delta) Act<R>::st4(resid, row * hidden + col, v[c]);
       float o[4] = {g[c].x * (v[c][0] * inv), g[c].y * (v[c][1] * inv), g[c].z * (v[c][2] * inv),
                     g[c].w * (v[c][3] * inv)};
       Act<T>::st4(out, row * hidden + col, o);
@@ -453,18 +455,27 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(T* __restrict__ resid, co
 
 // Prompt pass (hundreds of 16-bit rows): one WAVE per row, 16-byte accesses (a lane owns NCH x 8 features), the sum of
 // squares by DPP - no LDS, no workgroup barrier.  Per-element arithmetic as in rmsnorm_kernel.
-template <typename E, int NCH>
-__global__ void __launch_bounds__(256) rmsnorm_rows16_kernel(uint16_t* __restrict__ resid, const uint16_t* __restrict__ delta,
+// R32: the residual stream is fp32 (two 16-byte accesses per 8 features), delta and out stay 16-bit.
+template <typename E, int NCH, bool R32 = false>
+__global__ void __launch_bounds__(256) rmsnorm_rows16_kernel(void* __restrict__ resid_, const uint16_t* __restrict__ delta,
                                                              const float* __restrict__ w, float eps, int64_t rows, int hidden,
                                                              uint16_t* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (row >= rows) return;                                        // whole wave
+  uint16_t* resid = reinterpret_cast<uint16_t*>(resid_);
+  float* resid32 = reinterpret_cast<float*>(resid_);
   uint4 rw[NCH], dw[NCH];
+  float4 rf[NCH][2];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * 64 + lane) * 8;
-    rw[c] = *reinterpret_cast<const uint4*>(resid + row * hidden + col);
+    if (R32) {
+      rf[c][0] = *reinterpret_cast<const float4*>(resid32 + row * hidden + col);
+      rf[c][1] = *reinterpret_cast<const float4*>(resid32 + row * hidden + col + 4);
+    } else {
+      rw[c] = *reinterpret_cast<const uint4*>(resid + row * hidden + col);
+    }
     if (delta) dw[c] = *reinterpret_cast<const uint4*>(delta + row * hidden + col);
   }
   auto unpack = [](const uint4& q, float (&f)[8]) {
@@ -479,12 +490,18 @@ __global__ void __launch_bounds__(256) rmsnorm_rows16_kernel(uint16_t* __restric
   float ss = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    unpack(rw[c], v[c]);
+    if (R32) {
+      v[c][0] = rf[c][0].x; v[c][1] = rf[c][0].y; v[c][2] = rf[c][0].z; v[c][3] = rf[c][0].w;
+      v[c][4] = rf[c][1].x; v[c][5] = rf[c][1].y; v[c][6] = rf[c][1].z; v[c][7] = rf[c][1].w;
+    } else {
+      unpack(rw[c], v[c]);
+    }
     if (delta) {
       float d[8];
       unpack(dw[c], d);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[c][e] = E::to_f32(E::from_f32(v[c][e] + d[e]));   // the residual stream is 16-bit (HF)
+      for (int e = 0; e < 8; ++e)                                  // the residual stream is 16-bit (HF) or fp32 (mixed mode)
+        v[c][e] = R32 ? v[c][e] + d[e] : E::to_f32(E::from_f32(v[c][e] + d[e]));
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) ss += v[c][e] * v[c][e];
@@ -494,9 +511,15 @@ __global__ void __launch_bounds__(256) rmsnorm_rows16_kernel(uint16_t* __restric
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * 64 + lane) * 8;
-    if (delta)
-      *reinterpret_cast<uint4*>(resid + row * hidden + col) =
-          make_uint4(E::pack(v[c][0], v[c][1]), E::pack(v[c][2], v[c][3]), E::pack(v[c][4], v[c][5]), E::pack(v[c][6], v[c][7]));
+    if (delta) {
+      if (R32) {
+        *reinterpret_cast<float4*>(resid32 + row * hidden + col) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+        *reinterpret_cast<float4*>(resid32 + row * hidden + col + 4) = make_float4(v[c][4], v[c][5], v[c][6], v[c][7]);
+      } else {
+        *reinterpret_cast<uint4*>(resid + row * hidden + col) =
+            make_uint4(E::pack(v[c][0], v[c][1]), E::pack(v[c][2], v[c][3]), E::pack(v[c][4], v[c][5]), E::pack(v[c][6], v[c][7]));
+      }
+    }
     const float4 g0 = *reinterpret_cast<const float4*>(w + col), g1 = *reinterpret_cast<const float4*>(w + col + 4);
     const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
     float o[8];
@@ -508,8 +531,11 @@ __global__ void __launch_bounds__(256) rmsnorm_rows16_kernel(uint16_t* __restric
 }
 
 extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int delta_splits, const float* w, float eps,
-                           int64_t rows, int hidden, void* out, int dtype, void* stream) {
+                           int64_t rows, int hidden, void* out, int dtype, int resid_dtype, void* stream) {
   PSG_REQUIRE(ctx && resid && w && out, PSG_ERR_INVALID, "psg_rmsnorm: NULL argument");
+  PSG_REQUIRE(resid_dtype == dtype || resid_dtype == PSG_F32, PSG_ERR_INVALID,
+              "psg_rmsnorm: resid_dtype=%d must be the activation dtype (%d) or PSG_F32", resid_dtype, dtype);
+  const bool r32 = resid_dtype == PSG_F32 && dtype != PSG_F32;
   PSG_REQUIRE(delta_splits >= 0 && (delta || delta_splits == 0), PSG_ERR_INVALID, "psg_rmsnorm: delta_splits=%d",
               delta_splits);
   PSG_REQUIRE(hidden % 4 == 0 && hidden > 0 && hidden <= 8192, PSG_ERR_UNSUPPORTED,
@@ -523,9 +549,14 @@ extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int del
       hidden == 512) && ctx->opt.ln_half_wave) {                  // prompt pass: a wave per row, 16-byte accesses
     const unsigned blocks = (unsigned)((rows + 3) / 4);
 #define RNR(N)                                                                                                       \
-  PSG_DISPATCH_E16(dtype, "psg_rmsnorm",                                                                             \
-                   (rmsnorm_rows16_kernel<E, N><<<blocks, 256, 0, st>>>((uint16_t*)resid, (const uint16_t*)delta, w, eps, \
-                                                                       rows, hidden, (uint16_t*)out)))
+  if (r32) {                                                                                                         \
+    PSG_DISPATCH_E16(dtype, "psg_rmsnorm",                                                                           \
+                     (rmsnorm_rows16_kernel<E, N, true><<<blocks, 256, 0, st>>>(resid, (const uint16_t*)delta, w, eps, \
+                                                                               rows, hidden, (uint16_t*)out)));      \
+  } else                                                                                                             \
+    PSG_DISPATCH_E16(dtype, "psg_rmsnorm",                                                                           \
+                     (rmsnorm_rows16_kernel<E, N><<<blocks, 256, 0, st>>>(resid, (const uint16_t*)delta, w, eps,      \
+                                                                         rows, hidden, (uint16_t*)out)))
     if (hidden == 4096) RNR(8);
     else if (hidden == 1024) RNR(2);
     else RNR(1);
@@ -537,9 +568,14 @@ extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int del
   const int nthr = (rows <= 64 && hidden >= 4096) ? 1024 : 256;
   const int nch = (hidden + 4 * nthr - 1) / (4 * nthr);
 #define RN(N)                                                                                                        \
-  PSG_DISPATCH_DTYPE(dtype, "psg_rmsnorm",                                                                           \
-                     (rmsnorm_kernel<T, N><<<grid, nthr, 0, st>>>((T*)resid, delta, delta_splits, rows * hidden, w, eps, \
-                                                                 hidden, (T*)out)))
+  if (r32) {                                                                                                         \
+    PSG_DISPATCH_DTYPE(dtype, "psg_rmsnorm",                                                                         \
+                       (rmsnorm_kernel<T, N, float><<<grid, nthr, 0, st>>>((float*)resid, delta, delta_splits,       \
+                                                                          rows * hidden, w, eps, hidden, (T*)out))); \
+  } else                                                                                                             \
+    PSG_DISPATCH_DTYPE(dtype, "psg_rmsnorm",                                                                         \
+                       (rmsnorm_kernel<T, N><<<grid, nthr, 0, st>>>((T*)resid, delta, delta_splits, rows * hidden, w, \
+                                                                   eps, hidden, (T*)out)))
   switch (nch) {
     case 1: RN(1); break;
     case 2: RN(2); break;

@@ -31,7 +31,7 @@ from .tokenizers import WordTokenizer
 from .weights import head_shapes, llm_shapes
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
-           "fp16": torch.float16, "float16": torch.float16, "half": torch.float16,
+           "fp16": torch.float16, "float16": torch.float16, "half": torch.float16, "mixed": torch.float16,
            torch.bfloat16: torch.bfloat16, torch.float32: torch.float32, torch.float16: torch.float16}
 
 
@@ -93,7 +93,10 @@ class RelationTransformerHeadV4(nn.Module):
                  max_object_num=30,
                  # ---- build-specific, keyword only --------------------------------------------------
                  dtype="bf16",                 # activation/weight dtype of the GPU path: 'bf16' | 'fp16' (both on the
-                                               # matrix cores) | 'fp32' (verification mode)
+                                               # matrix cores) | 'fp32' (verification mode) | 'mixed' = fp16 GEMM
+                                               # operands with residual_dtype='fp32'
+                 residual_dtype=None,          # storage type of the residual streams: None = `dtype` (what HF keeps
+                                               # for a model cast to 16 bits) | 'fp32' (never rounded to 16 bits)
                  device=None,                  # None -> RelationTransformerHeadV4.default_device
                  qformer_vocab_size=30522,
                  llm_config: LlamaConfig | None = None,
@@ -115,6 +118,9 @@ class RelationTransformerHeadV4(nn.Module):
                  prompt_bucket=8,              # Llama prompt grid rounded up to a multiple of this (graph reuse)
                  cls_first=True,               # last Q-Former layer: cls row of every pair -> selection -> rows 1..32
                                                # of the selected pairs only (same results; qformer.forward_pairs_cls)
+                 train_losses_without_grad=False,   # forward() in training mode returns the two losses WITHOUT a graph
+                                               # (forward_train); off: it raises, so that an mmdet-style loop cannot sum
+                                               # them and silently train nothing in this head
                  **kwargs):
         super().__init__()
         if rel_cls_type != 'binary':
@@ -144,7 +150,13 @@ class RelationTransformerHeadV4(nn.Module):
         self.max_selected = int(max_selected)
         self.prompt_bucket = int(prompt_bucket)
         self.cls_first = bool(cls_first)
+        self.train_losses_without_grad = bool(train_losses_without_grad)
         self.act_dtype = _DTYPES[dtype]
+        if residual_dtype is None and dtype == "mixed":
+            residual_dtype = "fp32"
+        self.resid_dtype = self.act_dtype if residual_dtype is None else _DTYPES[residual_dtype]
+        if self.resid_dtype not in (self.act_dtype, torch.float32):
+            raise PsgHipError(f"residual_dtype must be the activation dtype or 'fp32', got {residual_dtype!r}")
         self.device = torch.device(self.default_device if device is None else device)
         if tokenizers is None:
             tokenizers = self.default_tokenizers
@@ -215,8 +227,11 @@ class RelationTransformerHeadV4(nn.Module):
                                       error_msgs)
         unexpected_keys[:] = [k for k in unexpected_keys if not k.startswith(lm)]
         self._rq_engine = None
+        # this hook runs BEFORE torch recurses into the children, i.e. before language_projection.* of this
+        # checkpoint is loaded: the decode engine's packed copy of the projection is refreshed at its next use
+        self._proj_stale = True
         if llm:
-            self.load_llm_weights(llm)        # language_projection is re-synchronised when rq_engine is rebuilt
+            self.load_llm_weights(llm)
 
     def load_llm_weights(self, weights: dict):
         """`language_model.*` tensors (HF LlamaForCausalLM names); V4:99-103."""
@@ -229,7 +244,8 @@ class RelationTransformerHeadV4(nn.Module):
         w = dict(weights)
         w["language_projection.weight"] = self.language_projection.weight.data
         w["language_projection.bias"] = self.language_projection.bias.data
-        self._llm_engine = LlamaDecodeEngine(w, self.cfg, self.device, self.act_dtype, n_layers=n_layers)
+        self._llm_engine = LlamaDecodeEngine(w, self.cfg, self.device, self.act_dtype, n_layers=n_layers,
+                                             resid_dtype=self.resid_dtype)
         return self
 
     @property
@@ -237,9 +253,7 @@ class RelationTransformerHeadV4(nn.Module):
         if self._rq_engine is None:
             w = {k: v.data for k, v in self.named_parameters()}
             self._rq_engine = RelationQueryEngine(w, self.cfg, self.device, self.act_dtype, self.xattn_variant)
-            if self._llm_engine is not None:     # language_projection may have been (re)loaded
-                self._llm_engine.proj_w = w["language_projection.weight"].to(self.act_dtype).contiguous()
-                self._llm_engine.proj_b = w["language_projection.bias"].to(self.act_dtype).contiguous()
+            self._proj_stale = True              # language_projection may have been (re)loaded: see llm_engine
         return self._rq_engine
 
     @property
@@ -247,6 +261,10 @@ class RelationTransformerHeadV4(nn.Module):
         if self._llm_engine is None:
             raise PsgHipError("the LLM weights are not loaded: reference checkpoints do not contain "
                               "`language_model.*` (part_checkpoint_hook.py:96-116); call load_llm_weights()")
+        if getattr(self, "_proj_stale", False):               # language_projection was (re)loaded after the engine was built
+            self._llm_engine.proj_w = self.language_projection.weight.data.to(self.act_dtype).contiguous()
+            self._llm_engine.proj_b = self.language_projection.bias.data.to(self.act_dtype).contiguous()
+            self._proj_stale = False
         return self._llm_engine
 
     # ---- prompts (V4:146-152, 260-266) ---------------------------------------------------------------
@@ -321,6 +339,12 @@ class RelationTransformerHeadV4(nn.Module):
 
     def forward(self, inputs, is_generation=None):
         if self.training:
+            if not self.train_losses_without_grad:
+                raise NotImplementedError(
+                    "RelationTransformerHeadV4.forward in training mode: this build computes the reference's two losses "
+                    "(V4:327-351, 463-482) on the HIP path but has no backward, so a training loop would train nothing "
+                    "here.  Call forward_train(inputs) for the loss values, or construct the head with "
+                    "train_losses_without_grad=True to get them from forward().")
             return self.forward_train(inputs)
         feat, meta, info, obj_ids, names = self._unpack(inputs)
         N = len(obj_ids)

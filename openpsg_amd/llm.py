@@ -32,9 +32,15 @@ from .config import PSGConfig
 
 
 class LlamaDecodeEngine:
-    def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, n_layers=None):
+    def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, n_layers=None, resid_dtype=None):
+        """resid_dtype: storage type of the residual stream; None = `dtype` (what HF keeps for a model cast to 16
+        bits), torch.float32 with a 16-bit `dtype` = mixed mode (16-bit GEMM operands, the residual stream - the sum
+        of 2 x layers updates - never rounded to 16 bits; costs 160 KB more traffic per decode row kernel)."""
         if dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise PsgHipError(f"activation dtype must be float32, bfloat16 or float16, got {dtype}")
+        self.resid_dtype = dtype if resid_dtype is None else resid_dtype
+        if self.resid_dtype not in (dtype, torch.float32):
+            raise PsgHipError(f"residual dtype must be {dtype} or float32, got {self.resid_dtype}")
         m = cfg.llm
         if m.head_dim != 128:
             raise PsgHipError(f"LLM head_dim {m.head_dim} unsupported (kernels are built for 128)")
@@ -95,10 +101,10 @@ class LlamaDecodeEngine:
         attention - output projection, norms, MLP - on those k rows only; returns [k, D]."""
         m = self.cfg.llm
         rows, D = resid.shape
-        n = torch.empty_like(resid)
+        n = torch.empty((rows, D), device=self.device, dtype=self.dtype)
         ops.rmsnorm(resid, None, self.layers[0]["ln1"], m.rms_eps, n)
-        q = torch.empty_like(resid)
-        att = torch.empty_like(resid)
+        q = torch.empty_like(n)
+        att = torch.empty_like(n)
         act = torch.empty((rows, m.inter), device=self.device, dtype=self.dtype)
         mfma_prefill = (prefill_shape is not None and self.dtype in (torch.bfloat16, torch.float16) and m.head_dim == 128
                         and prefill_shape[1] <= 64 and os.environ.get("PSG_PREFILL_ATTN_SCALAR") != "1")
@@ -120,11 +126,11 @@ class LlamaDecodeEngine:
             if keep_rows is not None and l == len(self.layers) - 1:
                 k = keep_rows.numel()
                 att_k, resid_k = torch.empty((k, D), device=self.device, dtype=self.dtype), torch.empty(
-                    (k, D), device=self.device, dtype=self.dtype)
+                    (k, D), device=self.device, dtype=resid.dtype)
                 ops.gather_rows(att, keep_rows, att_k)
                 ops.gather_rows(resid, keep_rows, resid_k)
                 att, resid = att_k, resid_k
-                n = torch.empty_like(resid)
+                n = torch.empty_like(att)
                 act = torch.empty((k, m.inter), device=self.device, dtype=self.dtype)
             o = self.linear(att, L["wo"])
             ops.rmsnorm(resid, o, L["ln2"], m.rms_eps, n)                      # resid += o ; n = norm(resid)
@@ -139,7 +145,7 @@ class LlamaDecodeEngine:
         m = self.cfg.llm
         D = m.hidden
         return (bool(self.fuse_rowops) and self.use_skinny and self.dtype in (torch.bfloat16, torch.float16)
-                and rows <= 32 and D in (1024, 4096) and m.inter >= 1024 and m.inter % 64 == 0
+                and self.resid_dtype == self.dtype and rows <= 32 and D in (1024, 4096) and m.inter >= 1024 and m.inter % 64 == 0
                 and m.vocab >= 1024 and m.vocab % 16 == 0)
 
     def _decode_step_fused(self, st, sync):
@@ -207,7 +213,7 @@ class LlamaDecodeEngine:
         tok_pair = torch.arange(K, device=dev, dtype=torch.int32)[:, None].expand(-1, S).reshape(-1).contiguous()
         kc = [torch.empty((K, m.heads, S, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
         vc = [torch.empty((K, m.heads, S, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
-        resid = X.reshape(K * S, D).clone()
+        resid = X.reshape(K * S, D).to(self.resid_dtype, copy=True)
         h = self._forward(resid, tok_pair, tok_pos, kc, vc, S, rope_pos=rope_pos.contiguous())
         h_rows = torch.empty((rows.numel(), D), device=dev, dtype=self.dtype)
         ops.gather_rows(h, rows.to(torch.int32).contiguous(), h_rows)
@@ -295,7 +301,7 @@ class LlamaDecodeEngine:
         # no zero fill (650 MB of stores per image for Llama-2-7B): every kernel reads only cache rows that were written
         kc = [torch.empty((K, m.heads, ctx_len, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
         vc = [torch.empty((K, m.heads, ctx_len, m.head_dim), device=dev, dtype=self.dtype) for _ in self.layers]
-        resid = X.reshape(K * maxlen, D).clone()
+        resid = X.reshape(K * maxlen, D).to(self.resid_dtype, copy=True)
         last_rows = (torch.arange(K, device=dev, dtype=torch.int32) * maxlen + seq_len - 1).contiguous()
         h_last = self._forward(resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape=(K, maxlen), keep_rows=last_rows)
         logits = self.linear(h_last, self.lm_head)
@@ -309,7 +315,7 @@ class LlamaDecodeEngine:
         dec_pair = torch.arange(K, device=dev, dtype=torch.int32)
         sup = m.eos if suppress_eos else -1
         ops.greedy_step(logits, 0, max_new, m.eos, sup, tokens, done, next_ids, dec_pos, dtype=self.dtype)
-        x = torch.empty((K, D), device=dev, dtype=self.dtype)
+        x = torch.empty((K, D), device=dev, dtype=self.resid_dtype)   # residual stream of the decode rows
         return dict(kc=kc, vc=vc, ctx_len=ctx_len, tokens=tokens, done=done, next_ids=next_ids, dec_pos=dec_pos,
                     dec_pair=dec_pair, sup=sup, x=x, max_new=max_new, first_logits=first_logits)
 

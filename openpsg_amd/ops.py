@@ -291,11 +291,15 @@ def _in(x, dtype):
 
 
 def rmsnorm(resid, delta, w, eps, out):
+    """resid += delta; out = RMSNorm(resid) * w.  `out` has the activation dtype; `resid` has it too, or is fp32 with
+    16-bit activations (mixed mode: the residual stream is never rounded to 16 bits)."""
     lib, ctx, st = _env(resid)
     rows, hidden = resid.shape
-    dp, ds = (None, 0) if delta is None else _in(delta, resid.dtype)
+    dp, ds = (None, 0) if delta is None else _in(delta, out.dtype)
+    if resid.dtype != out.dtype and resid.dtype != torch.float32:
+        raise PsgHipError(f"rmsnorm: residual stream must be {out.dtype} or float32, got {resid.dtype}")
     check(lib.psg_rmsnorm(ctx, _p(resid), dp, ds, _p(w, torch.float32), float(eps), rows, hidden,
-                          _p(out, resid.dtype), _dt(resid), st), "psg_rmsnorm")
+                          _p(out), _dt(out), _dt(resid), st), "psg_rmsnorm")
     return out
 
 
@@ -306,6 +310,12 @@ def rope_kvwrite(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, q_out, 
     rows = q_out.shape[0]
     qp, qs = _in(qkv, q_out.dtype)
     assert rope[0].shape[0] >= ctx_len and rope[0].shape[1] == head_dim // 2
+    if rope_pos is not None:
+        # positions of the reference's PADDED sequence may exceed the compact context length: the kernel indexes the
+        # rotary tables with them unchecked, so bound them here (training forward only; one scalar read-back)
+        top = int(rope_pos.max().item()) if rope_pos.numel() else -1
+        if top >= rope[0].shape[0]:
+            raise PsgHipError(f"rope_kvwrite: rotary position {top} exceeds the {rope[0].shape[0]}-row rotary table")
     check(lib.psg_rope_kvwrite(ctx, qp, qs, _p(tok_pair, torch.int32), _p(tok_pos, torch.int32),
                                _p(rope_pos, torch.int32), _p(rope[0], torch.float32), _p(rope[1], torch.float32), rows, heads, head_dim, ctx_len, _p(q_out),
                                _p(k_cache, q_out.dtype), _p(v_cache, q_out.dtype), _dt(q_out), st), "psg_rope_kvwrite")
@@ -469,6 +479,9 @@ def train_object_bitmasks(thing_masks, sem, is_thing, category, thing_index, gri
     words = (gh * gw + 63) // 64
     bits = torch.empty((N, words), device=sem.device, dtype=torch.int64)
     n_thing = 0 if thing_masks is None else thing_masks.shape[0]
+    if n_thing and tuple(thing_masks.shape[1:]) != (H, W):
+        raise PsgHipError(f"train_object_bitmasks: thing masks are {tuple(thing_masks.shape[1:])}, the semantic map is "
+                          f"{(H, W)}; both must be at the padded image resolution (V4:371-399)")
     check(lib.psg_train_object_bitmasks(ctx, _p(thing_masks, torch.uint8, "thing_masks") if n_thing else None, n_thing,
                                         _p(sem, torch.int32, "sem"), H, W, _p(is_thing, torch.int32),
                                         _p(category, torch.int32), _p(thing_index, torch.int32), N, gh, gw, _p(bits),

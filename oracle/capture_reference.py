@@ -15,7 +15,8 @@ tests/golden/.  Recipe:
      `head(inputs)`; catch the UnboundLocalError the committed binary branch raises at V4:355
       - every capture is complete by then.
 
-Usage:  python oracle/capture_reference.py            (writes tests/golden/G*.npz)
+Usage:  python oracle/capture_reference.py            (writes tests/golden/G*.npz, T*.npz and the state-dict schema)
+        python oracle/capture_reference.py G6 T1     (only the cases whose names start with one of the arguments)
 """
 from __future__ import annotations
 
@@ -393,35 +394,50 @@ def capture_train_case(mod, name):
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def main():
+def main(only=()):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     mod = import_reference_head()
     os.makedirs(os.path.join(REPO, "tests", "golden"), exist_ok=True)
-    capture_state_dict_keys(mod)
-    capture_mask_grid_case(mod)
-    # G5 = the C5 geometry (480x640 -> 1000x1333 -> pad 1024x1344, L = 16*21 = 336, not a multiple of 32/64)
-    capture_scene_case(mod, "G5_c5geo_1024x1344_n8",
-                       dict(pad_hw=(1024, 1344), num_objects=8, seed=5, ori_hw=(480, 640), img_hw=(1000, 1333),
-                            void_id=0, force_id0=True, tiny_object=True),
-                       tiny_llm(256, 2, 512, 512), weight_seed=15, keep_pairs=[0, 9, 63], suppress_eos=True)
-    # G1 = BASELINE config C1 (512x512, 10 masks), void aliased with person#0, one vanishing object
-    capture_scene_case(mod, "G1_c1_512_n10",
-                       dict(pad_hw=(512, 512), num_objects=10, seed=1, void_id=0, force_id0=True, tiny_object=True),
-                       tiny_llm(256, 2, 512, 512), weight_seed=11, keep_pairs=[0, 7, 55, 99], suppress_eos=False)
-    # G2 = resized + padded geometry, L = 12*16 = 192 (not a multiple of 64/128), N=12
-    capture_scene_case(mod, "G2_768x1024_n12",
-                       dict(pad_hw=(768, 1024), num_objects=12, seed=2, ori_hw=(720, 960), img_hw=(750, 1000),
-                            void_id=133, tiny_object=True),
-                       tiny_llm(256, 2, 512, 512), weight_seed=12, keep_pairs=[0, 13, 77, 143], suppress_eos=True)
-    # G4 = wider / deeper LLM (8 heads x 128, 3 layers), natural EOS
-    capture_scene_case(mod, "G4_llm_wide_n6",
-                       dict(pad_hw=(512, 512), num_objects=6, seed=4, void_id=133),
-                       tiny_llm(1024, 3, 2752, 512), weight_seed=14, keep_pairs=[0, 35], suppress_eos=False)
+    want = lambda name: not only or any(name.startswith(o) for o in only)  # noqa: E731
+    if want("reference_state_dict_keys"):
+        capture_state_dict_keys(mod)
+    if want("G3_mask_grid"):
+        capture_mask_grid_case(mod)
+    scene_cases = [
+        # G5 = the C5 geometry (480x640 -> 1000x1333 -> pad 1024x1344, L = 16*21 = 336, not a multiple of 32/64)
+        ("G5_c5geo_1024x1344_n8",
+         dict(pad_hw=(1024, 1344), num_objects=8, seed=5, ori_hw=(480, 640), img_hw=(1000, 1333),
+              void_id=0, force_id0=True, tiny_object=True),
+         tiny_llm(256, 2, 512, 512), 15, [0, 9, 63], True),
+        # G1 = BASELINE config C1 (512x512, 10 masks), void aliased with person#0, one vanishing object
+        ("G1_c1_512_n10",
+         dict(pad_hw=(512, 512), num_objects=10, seed=1, void_id=0, force_id0=True, tiny_object=True),
+         tiny_llm(256, 2, 512, 512), 11, [0, 7, 55, 99], False),
+        # G2 = resized + padded geometry, L = 12*16 = 192 (not a multiple of 64/128), N=12
+        ("G2_768x1024_n12",
+         dict(pad_hw=(768, 1024), num_objects=12, seed=2, ori_hw=(720, 960), img_hw=(750, 1000),
+              void_id=133, tiny_object=True),
+         tiny_llm(256, 2, 512, 512), 12, [0, 13, 77, 143], True),
+        # G4 = wider / deeper LLM (8 heads x 128, 3 layers), natural EOS
+        ("G4_llm_wide_n6",
+         dict(pad_hw=(512, 512), num_objects=6, seed=4, void_id=133),
+         tiny_llm(1024, 3, 2752, 512), 14, [0, 35], False),
+        # G6 = the LLM at the width the reference instantiates (V4:99-100: Llama-2-7B = 4096 / 32 heads x 128 / 11008 /
+        # vocabulary 32000), first 2 layers (the reference's own llm_truncate_num knob, V4:101-103): 2.7 GB of fp32
+        # weights, the decode leg of BASELINE C3 at the benchmarked shape; EOS suppressed as in the benchmark
+        ("G6_llm_7b_width_n6",
+         dict(pad_hw=(512, 512), num_objects=6, seed=6, void_id=133),
+         tiny_llm(4096, 2, 11008, 32000), 16, [0, 21], True),
+    ]
+    for name, scene_kw, llm, wseed, keep, sup in scene_cases:
+        if want(name):
+            capture_scene_case(mod, name, scene_kw, llm, weight_seed=wseed, keep_pairs=keep, suppress_eos=sup)
     # T1 / T2 = the training branch (losses) with the random draws recorded
     for name in TRAIN_CASES:
-        capture_train_case(mod, name)
+        if want(name):
+            capture_train_case(mod, name)
 
 
 if __name__ == "__main__":
-    main()
+    main(tuple(sys.argv[1:]))

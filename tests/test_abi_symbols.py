@@ -45,3 +45,11 @@ def test_no_gpu_is_a_loud_error():
         assert "no HIP device" in str(e)
     else:
         raise AssertionError("psg_create succeeded without a GPU")
+
+
+def test_abi_version_of_header_binding_and_library_agree():
+    """psg_version() of the built library == PSG_ABI_VERSION of include/psg_hip.h == the binding's constant
+    (an integrator built against another header gets an error at load time, not shifted arguments)."""
+    m = re.search(r"#define\s+PSG_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert m, "PSG_ABI_VERSION missing from psg_hip.h"
+    assert int(m.group(1)) == _lib.PSG_ABI_VERSION == _lib.load().psg_version()

@@ -20,7 +20,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6", "G5_c5geo_1024x1344_n8"]
+CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6", "G5_c5geo_1024x1344_n8", "G6_llm_7b_width_n6"]
 # Bounds.  The yardstick is PyTorch's own bf16 CPU path: the oracle run with bf16 weights AND bf16 activations is what
 # the reference's modules compute when the model is cast to bf16 (HF semantics: finfo(bf16).min masks, fp32 softmax
 # and RMSNorm statistics cast back).  The HIP bf16 path keeps fp32 accumulators through more of the chain, so it must

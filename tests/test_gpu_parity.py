@@ -14,7 +14,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6", "G5_c5geo_1024x1344_n8"]
+CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6", "G5_c5geo_1024x1344_n8", "G6_llm_7b_width_n6"]
 
 
 def _dev():

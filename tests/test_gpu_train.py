@@ -47,7 +47,11 @@ def test_training_losses_fp32_vs_reference(case):
     print(f"{case}: |logit| {e_logit:.2e}, |bce loss| {e_bce:.2e} of {float(g['binary_rel_cls_loss']):.3f}, "
           f"|llm loss| {e_llm:.2e} of {float(g['rel_llm_loss']):.3f}")
     assert e_logit < 1e-3 and e_bce < 5e-3 and e_llm < 1e-3
-    # forward() in training mode is the same call; its random draws come from the same generators as the reference's
+    # forward() in training mode: raises by default (no backward: an mmdet-style loop must not sum these losses and
+    # train nothing); with the explicit opt-in it is the same call, drawing from the same generators as the reference
+    with pytest.raises(NotImplementedError):
+        head(_to_dev(inputs))
+    head.train_losses_without_grad = True
     import random
     seeds = {"T1_train_512_n7": 5, "T2_train_768x1024_n9": 6}
     torch.manual_seed(seeds[case])

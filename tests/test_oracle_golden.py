@@ -7,7 +7,7 @@ import torch
 from oracle import psg_oracle as O
 from tests import helpers as H
 
-CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6", "G5_c5geo_1024x1344_n8"]
+CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6", "G5_c5geo_1024x1344_n8", "G6_llm_7b_width_n6"]
 
 
 def test_mask_grid_goldens():
