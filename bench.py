@@ -64,9 +64,11 @@ def parse():
     ap.add_argument("--no-batched", action="store_true", help="skip the secondary 4-images-per-step measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--dtype", choices=["bf16", "fp16", "mixed"], default="bf16",
-                    help="activation / weight dtype of the measured path (BASELINE config 5 names fp16); mixed = fp16 "
-                         "GEMM operands with the Llama residual stream kept in fp32")
+    ap.add_argument("--dtype", choices=["bf16", "fp16", "mixed"], default=None,
+                    help="precision mode of the measured path.  mixed (default of the full path) = fp16 GEMM operands "
+                         "and KV cache, fp32 accumulation, fp32 Llama residual stream: 8x closer to the fp32 engine "
+                         "than bf16 at 32 layers for +0.2 %% time (tests/test_gpu_llm7b.py); bf16 (default of "
+                         "--workload rq, BASELINE config 2 names it); fp16 (BASELINE config 5)")
     ap.add_argument("--no-untruncated", action="store_true",
                     help="cpu_baseline: skip the un-truncated 32-layer fp32 decode of one pair (27 GB of host memory)")
     ap.add_argument("--no-parity", action="store_true")
@@ -401,6 +403,8 @@ def time_steps(step, warmup, steps):
 
 def main():
     a = parse()
+    if a.dtype is None:
+        a.dtype = "mixed" if a.workload == "full" else "bf16"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)                                                 # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -522,9 +526,13 @@ def main():
         line = {
             "metric": METRIC, "value": round(images * pairs_per_image / elapsed, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp16" if a.dtype == "mixed" else a.dtype, "data": "synthetic",
             "config": {"workload": wl, "objects": N, "pairs_per_image": pairs_per_image, "images_per_step": ips,
                        "patches": (a.size // 64) ** 2, "llm_layers": a.llm_layers if a.workload == "full" else 0,
+                       "precision": {"mixed": "mixed: fp16 GEMM operands / KV cache, fp32 accumulation, fp32 Llama residual "
+                                              "stream", "fp16": "fp16 operands and residual stream, fp32 accumulation",
+                                     "bf16": "bf16 operands and residual stream, fp32 accumulation"}[a.dtype],
                        "parallelism": "single GPU" if world == 1 else f"pairs of every image sharded over {world} ranks"},
         }
         if not a.no_roofline and a.workload == "full":

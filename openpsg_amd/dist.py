@@ -45,16 +45,8 @@ def shard_images(num_images: int, world: int, rank: int):
     return list(range(rank, num_images, world))
 
 
-def gather_image_results(indexed_results, num_images: int, group=None):
-    """Every rank hands in [(image index, result)] for its share; every rank gets the full list in
-    image order.  Results are host objects (numpy maps, python lists), so this is an object gather."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        parts = [indexed_results]
-    else:
-        parts = [None] * world
-        dist.all_gather_object(parts, indexed_results, group=group)
+def merge_image_results(parts, num_images: int):
+    """parts[r] = [(image index, result)] of rank r -> the full list in image order; every image exactly once."""
     out = [None] * num_images
     for part in parts:
         for idx, res in part:
@@ -67,8 +59,21 @@ def gather_image_results(indexed_results, num_images: int, group=None):
     return out
 
 
+def gather_image_results(indexed_results, num_images: int, group=None):
+    """Every rank hands in [(image index, result)] for its share; every rank gets the full list in
+    image order.  Results are host objects (numpy maps, python lists), so this is an object gather."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        parts = [indexed_results]
+    else:
+        parts = [None] * world
+        dist.all_gather_object(parts, indexed_results, group=group)
+    return merge_image_results(parts, num_images)
+
+
 class HipBackend:
-    """Adapter from the pipeline's five compute calls to `RelationTransformerHeadV4` on one GPU."""
+    """Adapter from the pipeline's compute calls to `RelationTransformerHeadV4` on one GPU."""
 
     def __init__(self, head):
         from .categories import INSTANCE_OFFSET, object_categories
@@ -78,10 +83,6 @@ class HipBackend:
         self._names = lambda scene: [object_categories[i % INSTANCE_OFFSET] for i in self._ids(scene)]
         self.device = head.device
         self.feat_dtype = head.act_dtype
-        if head.pair_selector != "topk":
-            raise NotImplementedError("pair sharding needs a selection size known on every rank before the "
-                                      "exchange: pair_selector='topk' only")
-        self.k = head.cfg.num_selected
         self.q_rows = head.cfg.qformer.q_rows
         self.hidden = head.cfg.qformer.hidden
         self.max_new = head.cfg.max_new_tokens
@@ -99,16 +100,16 @@ class HipBackend:
         # selected pairs only, in gather_features)
         return (rq if "pending" in rq else rq["hidden"]), rq["exist_prob"]
 
-    def query_shards(self, scenes, patches, p0, p1):
-        """The shard [p0, p1) of every image in ONE Q-Former pass (per-image cross-attention only)."""
+    def query_shards(self, scenes, patches, ranges):
+        """The shard ranges[m] = (p0, p1) of image m, all images in ONE Q-Former pass where the head can (per-image
+        cross-attention only)."""
         items = [(s["mask_features"], s["img_meta"], self._ids(s), self._names(s), s["pan_results"]) for s in scenes]
-        return self.head.run_relation_query_shards(items, (p0, p1), [patches[m] for m in range(len(scenes))])
+        return self.head.run_relation_query_shards(items, list(ranges), [patches[m] for m in range(len(scenes))])
 
-    def topk(self, prob, k):
-        n = int(round(prob.numel() ** 0.5))
-        sel = self.head.select_pairs(prob, n)          # honours exclude_diagonal (V4 never excludes; SURVEY 0.6)
-        assert sel.numel() == k
-        return sel
+    def select(self, prob, num_objects):
+        """The head's selector on the gathered probabilities: 'topk' (V4:235-237) or 'threshold' (the commented
+        V4:230-234 logic; the count is data dependent, and identical on every rank because the input is)."""
+        return self.head.select_pairs(prob, num_objects)      # honours exclude_diagonal (V4 never excludes; SURVEY 0.6)
 
     def gather_features(self, hidden, rows):
         from . import ops
@@ -148,14 +149,76 @@ def deal_indices(k: int, world: int, rank: int):
     return list(range(rank, k, world))
 
 
+class LoopbackWorld:
+    """R ranks inside ONE process (the single-process "fake world").  The pipelines below are written as
+    generators that yield their collective requests; here the R rank generators advance in lockstep and every request
+    is served from Python lists - all_gather / all_reduce / reduce_scatter / broadcast with the semantics of
+    torch.distributed.  With `HipBackend` ranks sharing one head on one GPU this drives the whole sharded path -
+    shard arithmetic, padding, selection, feature routing, dealt decodes - through the real kernels without a
+    cluster (tests/test_gpu_fakeworld.py); the ranks run one after the other between two exchange points."""
+
+    def __init__(self, world: int):
+        self.world = int(world)
+
+    def pipelines(self, backends, decode=True):
+        """One PairShardedPipeline per rank; backends: one backend (shared by all ranks) or a list of R."""
+        bes = backends if isinstance(backends, (list, tuple)) else [backends] * self.world
+        return [PairShardedPipeline(bes[r], decode=decode, world=self.world, rank=r) for r in range(self.world)]
+
+    def run(self, gens):
+        """gens[r]: rank r's generator.  Returns the list of their return values."""
+        R = self.world
+        assert len(gens) == R
+        results, reqs, sends, started = [None] * R, [None] * R, [None] * R, False
+        while True:
+            done = 0
+            for r in range(R):                        # advance every rank to its next exchange point
+                try:
+                    reqs[r] = gens[r].send(sends[r]) if started else next(gens[r])
+                except StopIteration as e:
+                    results[r] = e.value
+                    done += 1
+            started = True
+            if done:
+                if done != R:
+                    raise RuntimeError("ranks left the pipeline at different exchange points")
+                return results
+            kinds = {q[0] for q in reqs}
+            if len(kinds) != 1:
+                raise RuntimeError(f"ranks issued different collectives: {sorted(kinds)}")
+            kind = kinds.pop()
+            if kind == "all_gather":
+                g = torch.stack([q[1].contiguous() for q in reqs])
+                sends = [g] * R
+            elif kind == "all_reduce":
+                tot = reqs[0][1].clone()
+                for q in reqs[1:]:
+                    tot += q[1]
+                sends = [tot.clone() for _ in range(R)]
+            elif kind == "reduce_scatter":
+                tot = reqs[0][1].clone()
+                for q in reqs[1:]:
+                    tot += q[1]
+                sends = [tot[r].contiguous() for r in range(R)]
+            elif kind == "broadcast":
+                src = reqs[0][2]
+                sends = [reqs[src][1]] * R
+            else:
+                raise RuntimeError(f"unknown collective {kind!r}")
+
+
 class PairShardedPipeline:
-    def __init__(self, head_or_backend, group=None, decode=True):
+    def __init__(self, head_or_backend, group=None, decode=True, world=None, rank=None):
+        """world / rank given explicitly: a rank of a LoopbackWorld (no process group is touched; use the `*_gen`
+        generators).  Otherwise the ranks of `group` (RCCL on GPUs, gloo in the CPU tests)."""
         self.be = head_or_backend if hasattr(head_or_backend, "query_shard") else HipBackend(head_or_backend)
         self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        if world is None:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.world, self.rank = int(world), int(rank)
         self.decode = decode
 
+    # ---- the collectives behind a generator's requests ---------------------------------------------------------------
     def _all_gather(self, t):
         flat = t.contiguous().view(-1)
         out = torch.empty(self.world * flat.numel(), device=t.device, dtype=t.dtype)
@@ -172,32 +235,73 @@ class PairShardedPipeline:
         dist.reduce_scatter_tensor(recv.view(-1), send.contiguous().view(-1), op=dist.ReduceOp.SUM, group=self.group)
         return recv
 
+    def _broadcast(self, t, src, device):
+        g_src = dist.get_global_rank(self.group, src) if self.group is not None else src
+        meta = torch.zeros(8, dtype=torch.int64, device=device)
+        if self.rank == src:
+            meta[0] = t.dim()
+            for i, d in enumerate(t.shape):
+                meta[1 + i] = d
+        dist.broadcast(meta, src=g_src, group=self.group)
+        if self.rank != src:
+            shape = [int(x) for x in meta[1:1 + int(meta[0])].tolist()]
+            t = torch.empty(shape, device=device, dtype=torch.float32)
+        dist.broadcast(t, src=g_src, group=self.group)
+        return t
+
+    def _drive(self, gen):
+        """Runs a pipeline generator against the process group."""
+        try:
+            req = next(gen)
+            while True:
+                kind = req[0]
+                if kind == "all_gather":
+                    res = self._all_gather(req[1])
+                elif kind == "all_reduce":
+                    res = req[1]
+                    if self.world > 1:
+                        dist.all_reduce(res, op=dist.ReduceOp.SUM, group=self.group)
+                elif kind == "reduce_scatter":
+                    res = self._reduce_scatter_sum(req[1])
+                elif kind == "broadcast":
+                    res = req[1] if self.world == 1 else self._broadcast(req[1], req[2], req[3])
+                else:
+                    raise RuntimeError(f"unknown collective {kind!r}")
+                req = gen.send(res)
+        except StopIteration as e:
+            return e.value
+
     def step_one_image(self, scene, deal_decodes=True):
         """Strong scaling: ONE image, its pairs sharded over all ranks; returns dict(exist_prob [B], selected [K],
         tokens [K, max_new]) identical on every rank."""
+        return self._drive(self.step_one_image_gen(scene, deal_decodes))
+
+    def step(self, scenes):
+        """scenes[m] = inputs of image m, resident on every rank (object counts and image sizes may differ).
+        Returns dict with per-image lists: existence probabilities, selections and (if decoding) token ids."""
+        return self._drive(self.step_gen(scenes))
+
+    @staticmethod
+    def _device(scene):
+        return scene["mask_features"].device
+
+    # ---- the pipelines, as generators yielding ("collective", tensor, ...) requests --------------------------------
+    def step_one_image_gen(self, scene, deal_decodes=True):
         be, R, r = self.be, self.world, self.rank
         N = be.num_objects(scene)
         B = N * N
-        K = min(be.k, B)
+        dev = self._device(scene)
         # 1. patches from the rank that holds the feature map (rank 0) - 256 KB instead of 67 MB
         patches = be.patch_embed(scene) if r == 0 else None
-        if R > 1:
-            shape = torch.zeros(2, dtype=torch.int64, device=self._device(scene))
-            if r == 0:
-                shape[0], shape[1] = patches.shape
-            dist.broadcast(shape, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                           group=self.group)
-            if r != 0:
-                patches = torch.empty((int(shape[0]), int(shape[1])), device=shape.device, dtype=torch.float32)
-            dist.broadcast(patches, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                           group=self.group)
-        # 2. my pair shard; 3. probabilities everywhere, identical top-K everywhere
+        patches = yield ("broadcast", patches, 0, dev)
+        # 2. my pair shard; 3. probabilities everywhere, identical selection everywhere
         p0, p1, shard = shard_range(B, R, r)
         hidden, prob = be.query_shard(scene, patches, p0, p1)
         prob_pad = torch.full((shard,), -1.0, device=patches.device, dtype=torch.float32)
         prob_pad[:p1 - p0] = prob
-        probs = self._all_gather(prob_pad).reshape(-1)[:B].contiguous()
-        sel = be.topk(probs, K)
+        probs = (yield ("all_gather", prob_pad)).reshape(-1)[:B].contiguous()
+        sel = be.select(probs, N)                                                    # K may be data dependent
+        K = sel.numel()
         out = dict(exist_prob=probs, selected=sel)
         if not self.decode:
             return out
@@ -208,8 +312,7 @@ class PairShardedPipeline:
         rows = (s64 - p0)[:, None] * be.q_rows + 1 + torch.arange(nv, device=patches.device, dtype=torch.int64)[None, :]
         rows = torch.where(mine[:, None], rows, torch.full_like(rows, -1)).reshape(-1).to(torch.int32)
         feats = be.gather_features(hidden, rows)                                    # [K*nv, hidden], zeros where not mine
-        if R > 1:
-            dist.all_reduce(feats, op=dist.ReduceOp.SUM, group=self.group)
+        feats = yield ("all_reduce", feats)
         # 5. the K decodes dealt round-robin; 6. token ids to everyone
         if deal_decodes and R > 1:
             per = (K + R - 1) // R
@@ -219,7 +322,7 @@ class PairShardedPipeline:
                 it = torch.tensor(idx, device=patches.device, dtype=torch.int64)
                 frow = (it[:, None] * nv + torch.arange(nv, device=patches.device)[None, :]).reshape(-1)
                 tok_pad[:len(idx)] = be.decode(scene, sel[it].contiguous(), feats[frow].contiguous())
-            allt = self._all_gather(tok_pad)                                         # [R, per, max_new]
+            allt = yield ("all_gather", tok_pad)                                     # [R, per, max_new]
             tokens = torch.empty((K, be.max_new), device=patches.device, dtype=torch.int32)
             for rr in range(R):
                 ii = deal_indices(K, R, rr)
@@ -230,53 +333,70 @@ class PairShardedPipeline:
         out["tokens"] = tokens
         return out
 
-    @staticmethod
-    def _device(scene):
-        return scene["mask_features"].device
-
-    def step(self, scenes):
-        """scenes[m] = inputs of image m, resident on every rank.  Returns dict with the per-image
-        existence probabilities, selections and (if decoding) all token ids."""
+    def step_gen(self, scenes):
         be, R, r = self.be, self.world, self.rank
         assert len(scenes) == R, "one image per rank per step"
-        N = be.num_objects(scenes[0])
-        assert all(be.num_objects(s) == N for s in scenes), "images of one step must have the same object count"
-        B = N * N
-        K = min(be.k, B)
-        # 1. patches of my image -> everyone
-        patches = self._all_gather(be.patch_embed(scenes[r]))                     # [R, L, C]
-        # 2. my pair shard of every image
-        p0, p1, shard = shard_range(B, R, r)
-        prob_pad = torch.full((R, shard), -1.0, device=patches.device, dtype=torch.float32)
+        Ns = [be.num_objects(s) for s in scenes]
+        Bs = [n * n for n in Ns]
+        # 1. patches of my image -> everyone (images of different sizes: padded to the longest patch list)
+        mine_p = be.patch_embed(scenes[r])
+        ps = self._patch_size()
+        Ls = [(s["mask_features"].shape[-2] // ps) * (s["mask_features"].shape[-1] // ps) for s in scenes]
+        assert mine_p.shape[0] == Ls[r]
+        Lmax = max(Ls)
+        if mine_p.shape[0] < Lmax:
+            mine_p = torch.cat([mine_p, mine_p.new_zeros((Lmax - mine_p.shape[0], mine_p.shape[1]))])
+        allp = yield ("all_gather", mine_p)                                         # [R, Lmax, C]
+        patches = [allp[m, :Ls[m]].contiguous() for m in range(R)]
+        dev = allp.device
+        # 2. my pair shard of every image (the shard length depends on the image's object count)
+        ranges = [shard_range(Bs[m], R, r) for m in range(R)]
+        smax = max(1, max(rg[2] for rg in ranges))
+        prob_pad = torch.full((R, smax), -1.0, device=dev, dtype=torch.float32)
         hidden = []
-        shards = be.query_shards(scenes, patches, p0, p1) if hasattr(be, "query_shards") else \
-            [be.query_shard(scenes[m], patches[m], p0, p1) for m in range(R)]
+        if hasattr(be, "query_shards"):
+            shards = be.query_shards(scenes, patches, [(rg[0], rg[1]) for rg in ranges])
+        else:
+            shards = [be.query_shard(scenes[m], patches[m], ranges[m][0], ranges[m][1]) for m in range(R)]
         for m, (h, prob) in enumerate(shards):
             hidden.append(h)
-            prob_pad[m, :p1 - p0] = prob
-        gathered = self._all_gather(prob_pad)                                     # [rank, image, shard]
-        probs = gathered.permute(1, 0, 2).reshape(R, R * shard)[:, :B].contiguous()
-        # 3. identical deterministic top-K everywhere
-        sel = [be.topk(probs[m], K) for m in range(R)]
-        out = dict(exist_prob=probs, selected=torch.stack(sel))
+            prob_pad[m, :ranges[m][1] - ranges[m][0]] = prob
+        gathered = yield ("all_gather", prob_pad)                                   # [rank, image, smax]
+        probs = [gathered[:, m, :ranges[m][2]].reshape(-1)[:Bs[m]].contiguous() for m in range(R)]
+        # 3. identical deterministic selection everywhere (K_m may be data dependent: threshold selector, tiny images)
+        sel = [be.select(probs[m], Ns[m]) if Bs[m] else torch.zeros(0, dtype=torch.int32, device=dev) for m in range(R)]
+        Ks = [int(s.numel()) for s in sel]
+        out = dict(exist_prob=probs, selected=sel)
         if not self.decode:
             return out
         # 4. selected pair features -> the image's decoding rank
         nv = be.q_rows - 1
-        ar = torch.arange(nv, device=patches.device, dtype=torch.int64)
+        Kmax = max(1, max(Ks))
+        ar = torch.arange(nv, device=dev, dtype=torch.int64)
         rows_list = []
         for m in range(R):
             s = sel[m].to(torch.int64)
+            p0, p1 = ranges[m][0], ranges[m][1]
             mine = (s >= p0) & (s < p1)
             rows = (s - p0)[:, None] * be.q_rows + 1 + ar[None, :]               # pair_feature = hidden[:, 1:]
             rows_list.append(torch.where(mine[:, None], rows, torch.full_like(rows, -1)).reshape(-1).to(torch.int32))
+        live = [m for m in range(R) if Ks[m]]
         if hasattr(be, "gather_features_multi"):
-            send = be.gather_features_multi(hidden, rows_list)
+            got = be.gather_features_multi([hidden[m] for m in live], [rows_list[m] for m in live])
         else:
-            send = [be.gather_features(hidden[m], rows_list[m]) for m in range(R)]
-        send = torch.stack(send).contiguous()                                      # [R, K*nv, hidden]
-        recv = self._reduce_scatter_sum(send)
+            got = [be.gather_features(hidden[m], rows_list[m]) for m in live]
+        send = torch.zeros((R, Kmax * nv, be.hidden), device=dev, dtype=got[0].dtype if got else torch.float32)
+        for m, f in zip(live, got):
+            send[m, :Ks[m] * nv] = f
+        recv = yield ("reduce_scatter", send)                                      # [Kmax*nv, hidden] of MY image
         # 5. decode my image; 6. token ids to everyone
-        tokens = be.decode(scenes[r], sel[r], recv)
-        out["tokens"] = self._all_gather(tokens)
+        tok_pad = torch.full((Kmax, be.max_new), -1, device=dev, dtype=torch.int32)
+        if Ks[r]:
+            tok_pad[:Ks[r]] = be.decode(scenes[r], sel[r], recv[:Ks[r] * nv].contiguous())
+        allt = yield ("all_gather", tok_pad)                                        # [R, Kmax, max_new]
+        out["tokens"] = [allt[m, :Ks[m]].contiguous() for m in range(R)]
         return out
+
+    def _patch_size(self):
+        head = getattr(self.be, "head", None)
+        return head.cfg.patch_size if head is not None else getattr(self.be, "patch_size", 16)

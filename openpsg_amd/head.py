@@ -627,24 +627,30 @@ class RelationTransformerHeadV4(nn.Module):
         return out
 
     def run_relation_query_shards(self, items, pair_range, patches_list):
-        """Pair sharding over R images: the shard [p0, p1) of EVERY image in one Q-Former pass -
-        the dense projections see all R*(p1-p0) pairs at once (as many rows as one whole image), only the
-        cross-attention runs per image (its K/V and object masks are per image).  items[m] =
-        (feat, meta, obj_ids, names, pan); returns [(hidden_m [(p1-p0)*33, 768], exist_prob_m [p1-p0])]."""
+        """Pair sharding over R images: a shard of EVERY image in one Q-Former pass - the dense projections
+        see all the images' shard pairs at once (as many rows as one whole image), only the cross-attention runs per
+        image (its K/V and object masks are per image).  items[m] = (feat, meta, obj_ids, names, pan); pair_range:
+        one (p0, p1) for all images or a list with image m's own range (images with different object counts).
+        Returns [(hidden_m or pending handle, exist_prob_m [p1_m - p0_m])]."""
         eng = self.rq_engine
-        p0, p1 = pair_range
-        P = p1 - p0
-        if P <= 0 or len(items) * P > self.pair_chunk or len(items) < 4:   # measured: 8 images 7.0 -> 6.4 ms, 2 images no gain
+        ranges = [tuple(pair_range)] * len(items) if isinstance(pair_range, tuple) else [tuple(rg) for rg in pair_range]
+        Ps = [max(0, p1 - p0) for p0, p1 in ranges]
+        if min(Ps) <= 0 or sum(Ps) > self.pair_chunk or len(items) < 4:   # measured: 8 images 7.0 -> 6.4 ms, 2 images no gain
             outs = []
-            for (feat, meta, obj_ids, names, pan), patches in zip(items, patches_list):
-                rq = self.run_relation_query(feat, meta, obj_ids, names, pan, pair_range=pair_range, patches=patches)
+            for (feat, meta, obj_ids, names, pan), patches, rg in zip(items, patches_list, ranges):
+                if len(obj_ids) == 0:
+                    outs.append((torch.zeros((0, self.cfg.qformer.hidden), device=self.device, dtype=self.act_dtype),
+                                 torch.zeros(0, device=self.device)))
+                    continue
+                rq = self.run_relation_query(feat, meta, obj_ids, names, pan, pair_range=rg, patches=patches)
                 outs.append((rq if "pending" in rq else rq["hidden"], rq["exist_prob"]))
             return outs
-        segs, pidx, ids, msk = [], [], [], []
+        segs, pidx, ids, msk, off = [], [], [], [], 0
         for m, ((feat, meta, obj_ids, names, pan), patches) in enumerate(zip(items, patches_list)):
             _, kv, bits, ck = self._prepare_image(feat, meta, obj_ids, names, pan, patches)
-            ent = self._chunk_prompts(ck, len(obj_ids), p0, p1)
-            segs.append((m * P, P, kv, bits, len(obj_ids)))
+            ent = self._chunk_prompts(ck, len(obj_ids), ranges[m][0], ranges[m][1])
+            segs.append((off, Ps[m], kv, bits, len(obj_ids)))
+            off += Ps[m]
             pidx.append(ent[0])
             ids.append(ent[1])
             msk.append(ent[2])
@@ -657,14 +663,14 @@ class RelationTransformerHeadV4(nn.Module):
             for m, (ps, pc, kv_m, bits_m, n_m) in enumerate(segs):
                 st_m = dict(state, kv=kv_m, bits=bits_m, num_objects=n_m, segments=None)   # image m's view of the pass
                 rq = _LazyRQ(exist_logit=logit[ps:ps + pc], exist_prob=prob[ps:ps + pc], num_objects=n_m,
-                             pair_range=(p0, p1), pending=[(p0, p1, st_m, ps)])
+                             pair_range=ranges[m], pending=[(ranges[m][0], ranges[m][1], st_m, ps)])
                 rq.engine = eng
                 outs.append((rq, rq["exist_prob"]))
             return outs
         hidden, _, prob = eng.forward_pairs(None, None, None, torch.cat(pidx), torch.cat([pad(t) for t in ids]),
                                             torch.cat([pad(t) for t in msk]), segments=segs)
         q_rows = self.cfg.qformer.q_rows
-        return [(hidden[m * P * q_rows:(m + 1) * P * q_rows], prob[m * P:(m + 1) * P]) for m in range(len(items))]
+        return [(hidden[ps * q_rows:(ps + pc) * q_rows], prob[ps:ps + pc]) for ps, pc, _, _, _ in segs]
 
     def select_pairs(self, prob, N):
         """A8.  'topk': first num_selected of the full descending order (V4:235-237).  'threshold'
@@ -783,11 +789,14 @@ class RelationTransformerHeadV4(nn.Module):
         sel = rq["selected"] if selected is None else selected
         K = sel.numel()
         sel_in = sel
-        if self.pair_selector == "threshold" and pair_features is None and K % 4:
+        if self.pair_selector == "threshold" and K % 4:
             # the pair count is data dependent here: round it up to a multiple of 4 with copies of the last pair
             # (decode is weight-streaming-bound, extra rows are almost free) so that the engine keeps a few
             # decode graphs instead of one per count
             sel_in = torch.cat([sel, sel[-1:].expand(4 - K % 4)]).contiguous()
+            if pair_features is not None:
+                nv = self.cfg.qformer.num_query
+                pair_features = torch.cat([pair_features, pair_features[-nv:].repeat(4 - K % 4, 1)]).contiguous()
         X, plen = self.llm_inputs(rq, names, sel_in, pair_features)
         tokens, first_logits = self.llm_engine.generate(X, plen, suppress_eos=self.suppress_eos,
                                                         return_first_logits=True)

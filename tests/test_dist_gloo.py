@@ -13,11 +13,18 @@ import torch.multiprocessing as mp
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 class OracleBackend:
     """Implements the five compute calls of PairShardedPipeline with oracle/psg_oracle.py."""
 
-    def __init__(self, cfg, w, k=5, max_new=4):
-        self.cfg, self.w, self.k, self.max_new = cfg, w, k, max_new
+    def __init__(self, cfg, w, k=5, max_new=4, threshold=None):
+        self.cfg, self.w, self.k, self.max_new, self.threshold = cfg, w, k, max_new, threshold
         self.q_rows, self.hidden = cfg.qformer.q_rows, cfg.qformer.hidden
         self.calls = []
 
@@ -43,8 +50,12 @@ class OracleBackend:
         _, prob = O.existence_head(self.w, out)
         return out.reshape(-1, self.hidden).contiguous(), prob
 
-    def topk(self, prob, k):
+    def select(self, prob, num_objects):
+        """'topk' (V4:235-237), or with a threshold the data-dependent count of the commented V4:230-234 logic."""
         from oracle import psg_oracle as O
+        k = min(self.k, prob.numel())
+        if self.threshold is not None:
+            k = max(1, min(int((prob > self.threshold).sum()), 12))
         return torch.tensor(O.select_topk(prob, k), dtype=torch.int32)
 
     def gather_features(self, hidden, rows):
@@ -61,7 +72,7 @@ class OracleBackend:
         return (selected.long()[:, None] * 10 + torch.arange(self.max_new)[None, :]).to(torch.int32)
 
 
-def _worker(rank, world, port, n_obj, ret):
+def _worker(rank, world, port, n_obj, ret, threshold=None):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -73,19 +84,22 @@ def _worker(rank, world, port, n_obj, ret):
     from oracle import psg_oracle as O
     cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 1, 512, 512))
     w = make_weights_numpy(cfg, seed=3, with_llm=False)
-    scenes = [make_scene((256, 256), n_obj, seed=40 + m, tiny_object=True) for m in range(world)]
-    be = OracleBackend(cfg, w)
+    # n_obj: one count for every image, or one count per image (different object counts AND image sizes in one step)
+    counts = [n_obj] * world if isinstance(n_obj, int) else list(n_obj)
+    sizes = [(256, 256)] * world if isinstance(n_obj, int) else [(256, 256), (256, 384)][:world]
+    scenes = [make_scene(sizes[m], counts[m], seed=40 + m, tiny_object=True) for m in range(world)]
+    be = OracleBackend(cfg, w, threshold=threshold)
     with torch.no_grad():
         out = PairShardedPipeline(be, dist.group.WORLD, decode=True).step(scenes)
         # single-process reference: the whole pair range of every image on one rank
-        B = n_obj * n_obj
         ok = True
         for m in range(world):
-            be1 = OracleBackend(cfg, w)
+            B = counts[m] * counts[m]
+            be1 = OracleBackend(cfg, w, threshold=threshold)
             h, prob = be1.query_shard(scenes[m], be1.patch_embed(scenes[m]), 0, B)
             # shard-wise BLAS calls round differently from one big call: compare with a tolerance
-            ok &= torch.allclose(out["exist_prob"][m], prob, atol=1e-5)
-            sel = O.select_topk(out["exist_prob"][m], be.k)
+            ok &= out["exist_prob"][m].shape == prob.shape and torch.allclose(out["exist_prob"][m], prob, atol=1e-5)
+            sel = be.select(out["exist_prob"][m], counts[m]).tolist()
             ok &= out["selected"][m].tolist() == sel
             want_tok = be1.decode(scenes[m], torch.tensor(sel), h[:1])
             ok &= torch.equal(out["tokens"][m], want_tok)
@@ -93,8 +107,8 @@ def _worker(rank, world, port, n_obj, ret):
                 # features routed through the reduce-scatter == rows of the single-rank hidden state
                 rows = (torch.tensor(sel)[:, None] * 33 + 1 + torch.arange(32)[None, :]).reshape(-1)
                 ok &= torch.allclose(be.received, h[rows], atol=1e-4)
-        p0, p1, shard = shard_range(B, world, rank)
-        ok &= all(c == (p0, p1) for c in be.calls)
+        want_calls = [shard_range(counts[m] ** 2, world, rank)[:2] for m in range(world)]
+        ok &= be.calls == want_calls
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
@@ -102,10 +116,23 @@ def _worker(rank, world, port, n_obj, ret):
 @pytest.mark.parametrize("n_obj", [4, 3])          # 16 pairs (even shards) and 9 pairs (uneven: 5 + 4)
 def test_pair_sharding_world2_gloo(n_obj):
     world = 2
-    port = 29500 + os.getpid() % 2000 + n_obj
+    port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, n_obj, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+@pytest.mark.parametrize("threshold", [None, 0.5])
+def test_pair_sharding_unequal_images_world2_gloo(threshold):
+    """Images of one step with different object counts (4 and 3 objects: 16 and 9 pairs, shards 8+8 and 5+4) and
+    different sizes (patch lists of 16 and 24 rows), with the fixed-size and the data-dependent selector (different
+    K per image: padded feature / token exchanges)."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, (4, 3), ret, threshold), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
 
 
@@ -134,7 +161,7 @@ def _one_image_worker(rank, world, port, n_obj, ret):
         be1 = OracleBackend(cfg, w)
         h, prob = be1.query_shard(full_scene, be1.patch_embed(full_scene), 0, B)
         ok = torch.allclose(out["exist_prob"], prob, atol=1e-5)
-        sel = O.select_topk(out["exist_prob"], be.k)
+        sel = O.select_topk(out["exist_prob"], min(be.k, B))
         ok &= out["selected"].tolist() == sel
         ok &= torch.equal(out["tokens"], be1.decode(full_scene, torch.tensor(sel), h[:1]))
         mine = deal_indices(len(sel), world, rank)              # this rank decoded exactly its dealt pairs
@@ -149,7 +176,7 @@ def test_one_image_strong_scaling_world2_gloo(n_obj):
     """SURVEY 8e incl. item 3: one image for both ranks - patches broadcast from rank 0, pair shards, identical
     top-K, selected features all-reduced, the K decodes dealt round-robin, tokens gathered in selection order."""
     world = 2
-    port = 33500 + os.getpid() % 2000 + n_obj
+    port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_one_image_worker, args=(world, port, n_obj, ret), nprocs=world, join=True)
@@ -188,7 +215,7 @@ def _image_worker(rank, world, port, n_img, ret):
 def test_image_sharding_world2_gloo(n_img):
     """C5: whole images dealt round-robin to the ranks; every rank gets all results back in image order."""
     world = 2
-    port = 31500 + os.getpid() % 2000 + n_img
+    port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_image_worker, args=(world, port, n_img, ret), nprocs=world, join=True)

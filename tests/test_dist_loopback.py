@@ -1,0 +1,84 @@
+"""The single-process "fake world" (SURVEY 4): `LoopbackWorld` advances R rank generators of the pair-sharded pipelines
+in lockstep and serves their collectives from Python lists.  Here with the CPU oracle as the compute backend (world
+sizes 2-4, unequal images, data-dependent selection, dealt decodes); tests/test_gpu_fakeworld.py drives the HIP head
+through the same object."""
+import pytest
+import torch
+
+from tests.test_dist_gloo import OracleBackend
+
+
+def _setup(threshold=None):
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.weights import make_weights_numpy
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 1, 512, 512))
+    w = make_weights_numpy(cfg, seed=3, with_llm=False)
+    return cfg, w
+
+
+@pytest.mark.parametrize("world,counts,threshold", [(2, (4, 3), None), (3, (3, 4, 2), 0.5), (4, (3, 3, 3, 3), None)])
+def test_loopback_step_matches_single_rank(world, counts, threshold):
+    from openpsg_amd.dist import LoopbackWorld, shard_range
+    from openpsg_amd.synthetic import make_scene
+    torch.set_num_threads(4)
+    cfg, w = _setup()
+    sizes = [(256, 256), (256, 384), (192, 256), (256, 256)]
+    scenes = [make_scene(sizes[m], counts[m], seed=40 + m, tiny_object=True) for m in range(world)]
+    bes = [OracleBackend(cfg, w, threshold=threshold) for _ in range(world)]
+    fw = LoopbackWorld(world)
+    with torch.no_grad():
+        outs = fw.run([p.step_gen(scenes) for p in fw.pipelines(bes)])
+        for m in range(world):
+            B = counts[m] ** 2
+            be1 = OracleBackend(cfg, w, threshold=threshold)
+            h, prob = be1.query_shard(scenes[m], be1.patch_embed(scenes[m]), 0, B)
+            sel = be1.select(prob, counts[m]).tolist()
+            rows = (torch.tensor(sel)[:, None] * 33 + 1 + torch.arange(32)[None, :]).reshape(-1)
+            assert torch.allclose(bes[m].received, h[rows], atol=1e-4)            # rank m decoded image m
+            for r in range(world):                                                # every rank holds every result
+                assert torch.allclose(outs[r]["exist_prob"][m], prob, atol=1e-5)
+                assert outs[r]["selected"][m].tolist() == sel
+                assert torch.equal(outs[r]["tokens"][m], be1.decode(scenes[m], torch.tensor(sel), h[:1]))
+    for r in range(world):
+        assert bes[r].calls == [shard_range(counts[m] ** 2, world, r)[:2] for m in range(world)]
+
+
+@pytest.mark.parametrize("world,n_obj", [(2, 4), (3, 3), (4, 4), (8, 3)])
+def test_loopback_one_image_dealt_decodes(world, n_obj):
+    from openpsg_amd.dist import LoopbackWorld, deal_indices
+    from openpsg_amd.synthetic import make_scene
+    torch.set_num_threads(4)
+    cfg, w = _setup()
+    scene = make_scene((256, 256), n_obj, seed=77, tiny_object=True)
+    nan_scene = dict(scene, mask_features=torch.full_like(scene["mask_features"], float("nan")))
+    bes = [OracleBackend(cfg, w) for _ in range(world)]
+    fw = LoopbackWorld(world)
+    with torch.no_grad():
+        # only rank 0 holds the feature map; the others see NaN and must work from the broadcast patches
+        outs = fw.run([p.step_one_image_gen(scene if r == 0 else nan_scene) for r, p in enumerate(fw.pipelines(bes))])
+        B = n_obj * n_obj
+        be1 = OracleBackend(cfg, w)
+        h, prob = be1.query_shard(scene, be1.patch_embed(scene), 0, B)
+        sel = be1.select(prob, n_obj).tolist()
+        for r in range(world):
+            assert torch.allclose(outs[r]["exist_prob"], prob, atol=1e-5)
+            assert outs[r]["selected"].tolist() == sel
+            assert torch.equal(outs[r]["tokens"], be1.decode(scene, torch.tensor(sel), h[:1]))
+            mine = deal_indices(len(sel), world, r)
+            if mine:
+                rows = (torch.tensor([sel[i] for i in mine])[:, None] * 33 + 1 + torch.arange(32)[None, :]).reshape(-1)
+                assert torch.allclose(bes[r].received, h[rows], atol=1e-4)
+            else:
+                assert not hasattr(bes[r], "received")                            # more ranks than selected pairs
+
+
+def test_loopback_rejects_diverging_ranks():
+    from openpsg_amd.dist import LoopbackWorld
+
+    def a():
+        yield ("all_gather", torch.zeros(1))
+
+    def b():
+        yield ("all_reduce", torch.zeros(1))
+    with pytest.raises(RuntimeError):
+        LoopbackWorld(2).run([a(), b()])

@@ -131,30 +131,59 @@ def test_16bit_heads_at_7b_width_are_bounded_by_weight_rounding(g6):
 
 
 # ---- the 32-layer engine of bench.py ----------------------------------------------------------------------------------
+MODES = dict(bf16=(torch.bfloat16, None), bf16_res32=(torch.bfloat16, torch.float32), fp16=(torch.float16, None),
+             mixed=(torch.float16, torch.float32))
+
+
 @pytest.fixture(scope="module")
 def bench_engine():
+    """Llama-2-7B shape, 32 layers, random weights generated in HBM at bf16 precision (so that every engine - fp32,
+    bf16, fp16 - holds the SAME weight values: what is compared is the arithmetic, not the weight rounding)."""
     from openpsg_amd.config import LlamaConfig, PSGConfig, QFormerConfig
     from openpsg_amd.llm import LlamaDecodeEngine
     from openpsg_amd.weights import make_weights_device
     dev = torch.device("cuda:0")
     cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=LlamaConfig(layers=32), max_object_num=50)
     w = make_weights_device(cfg, 0, dev, llm_dtype=torch.bfloat16)
-    engines = {}
-    for name, (dt, rdt) in dict(bf16=(torch.bfloat16, None), mixed_bf16=(torch.bfloat16, torch.float32)).items():
-        engines[name] = LlamaDecodeEngine(w, cfg, dev, dt, resid_dtype=rdt)      # the engines share nothing mutable
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     K, Tp = 20, 16
     X = torch.randn((K, 32 + Tp, 4096), device=dev, generator=g).to(torch.bfloat16)
     plen = torch.randint(9, Tp + 1, (K,), device=dev, generator=g, dtype=torch.int32)
-    return cfg, engines, X, plen
+    # the truth: the same engine code in fp32 (library GEMMs, fp32 kernels; 27 GB of weights)
+    e32 = LlamaDecodeEngine(w, cfg, dev, torch.float32)
+    t32, f32 = e32.generate(X.float(), plen, suppress_eos=True, return_first_logits=True)
+    torch.cuda.synchronize()
+    del e32
+    torch.cuda.empty_cache()
+    return dict(cfg=cfg, w=w, X=X, plen=plen, t32=t32, f32=f32, dev=dev)
 
 
-@pytest.mark.parametrize("mode", ["bf16", "mixed_bf16"])
-def test_32_layer_engine_graph_replay_equals_eager_and_batch_invariance(bench_engine, mode):
-    cfg, engines, X, plen = bench_engine
-    eng = engines[mode]
-    eng.use_graph = True
+def _engine(be, mode):
+    from openpsg_amd.llm import LlamaDecodeEngine
+    dt, rdt = MODES[mode]
+    return LlamaDecodeEngine(be["w"], be["cfg"], be["dev"], dt, resid_dtype=rdt)
+
+
+def _vs_truth(be, tokens, first):
+    eos = be["cfg"].llm.eos
+    a, b = first.float().clone(), be["f32"].float().clone()
+    a[:, eos] = 0
+    b[:, eos] = 0
+    err = (a - b).abs().max(dim=1).values                                         # per pair
+    exact = int((tokens == be["t32"]).all(dim=1).sum())
+    same = (tokens == be["t32"]).int().cumprod(dim=1).sum().item()               # tokens before the first divergence
+    return err, exact, int(same)
+
+
+_RESULTS = {}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_32_layer_engine_graph_replay_and_accuracy_against_the_fp32_engine(bench_engine, mode):
+    be = bench_engine
+    cfg, X, plen = be["cfg"], be["X"].to(MODES[mode][0]), be["plen"]
+    eng = _engine(be, mode)
     tg, fg = eng.generate(X, plen, suppress_eos=True, return_first_logits=True)
     tg2 = eng.generate(X, plen, suppress_eos=True)                       # second replay of the same graph
     eng.use_graph = False
@@ -164,42 +193,55 @@ def test_32_layer_engine_graph_replay_equals_eager_and_batch_invariance(bench_en
     assert tg.shape == (20, 16) and int(tg.min()) >= 0 and int(tg.max()) < cfg.llm.vocab
     assert torch.equal(tg, te) and torch.equal(tg, tg2), "HIP-graph replay differs from the eager launch sequence"
     assert torch.equal(fg, fe)
-    # natural-EOS graphs (chunks of 4 steps) == the single worst-case graph up to the first EOS
+    # natural-EOS graphs (chunks of 4 steps) == the single worst-case graph for every pair that never emits EOS
     tn = eng.generate(X, plen, suppress_eos=False)
     torch.cuda.synchronize()
     for i in range(20):
         row = tn[i].tolist()
-        n = row.index(cfg.llm.eos) + 1 if cfg.llm.eos in row else 16
         if cfg.llm.eos not in row:
             assert row == tg[i].tolist()
-    # batch invariance: the decode projections' split-K order per row does not depend on the batch.  The prompt pass
-    # goes through the library GEMM, whose kernel choice depends on the row count, so first-step logits agree to
-    # rounding (bounded) and a token may differ only at a near-tie of the batch-20 run's own logits.
-    flips = 0
+    err20, exact20, same20 = _vs_truth(be, tg, fg)
+    # the same pairs decoded alone / in a batch of 4: the prompt pass goes through the library GEMM, whose kernel choice
+    # depends on the row count, and 32 random layers amplify every rounding difference - so the check is not equality
+    # but that a pair decoded in ANOTHER batch is as close to the fp32 engine as it is in the batch of 20
+    worst = 0.0
     for idx in ([0], [7], [19], [3, 4, 5, 6]):
         ii = torch.tensor(idx, device=X.device)
         ts, fs = eng.generate(X[ii].contiguous(), plen[ii].contiguous(), suppress_eos=True, return_first_logits=True)
         torch.cuda.synchronize()
-        d = (fs.float() - fg[ii].float()).abs().max().item()
-        assert d < 0.25, f"first-step logits of pairs {idx} move by {d} with the batch size"
-        for r, i in enumerate(idx):
-            if not torch.equal(ts[r], tg[i]):
-                flips += 1
-                s = next(k for k in range(16) if int(ts[r, k]) != int(tg[i, k]))
-                if s == 0:                                           # margin of the two candidates in the batch-20 logits
-                    lg = fg[i].float()
-                    lg[cfg.llm.eos] = -1e30
-                    assert float(lg[tg[i, 0]] - lg[ts[r, 0]]) < 0.25
-    print(f"{mode}: pairs whose 16 tokens differ between batch 20 and batch 1 / 4: {flips} of 7")
-    assert flips <= 2
+        a, b = fs.float().clone(), be["f32"][ii].float().clone()
+        a[:, cfg.llm.eos] = 0
+        b[:, cfg.llm.eos] = 0
+        worst = max(worst, float((a - b).abs().max()))
+    _RESULTS[mode] = (float(err20.max()), float(err20.mean()), exact20, same20, worst)
+    print(f"32 layers, {mode}: first-step logits vs the fp32 engine: max {err20.max():.3f} mean {err20.mean():.3f} (batch of "
+          f"20), max {worst:.3f} (same pairs in batches of 1 and 4); pairs with the fp32 engine's 16 tokens {exact20}/20; "
+          f"tokens before the first divergence {same20}/320")
+    assert worst < 1.6 * float(err20.max()) + 0.05, "a pair is less accurate alone than in the batch of 20"
+    del eng
+    torch.cuda.empty_cache()
+
+
+def test_32_layer_accuracy_ordering_of_the_modes(bench_engine):
+    """fp16 operands beat bf16 operands, and keeping the residual stream in fp32 does not hurt: the mixed mode is the
+    most accurate 16-bit mode at the benchmarked depth."""
+    if len(_RESULTS) < len(MODES):
+        pytest.skip("needs the per-mode results of the previous test")
+    r = _RESULTS
+    for m in r:
+        print(m, r[m])
+    assert r["fp16"][1] < 0.6 * r["bf16"][1] and r["mixed"][1] < 0.6 * r["bf16_res32"][1]
+    assert r["mixed"][1] <= 1.1 * r["fp16"][1] and r["bf16_res32"][1] <= 1.1 * r["bf16"][1]
+    assert r["mixed"][3] >= r["bf16"][3]
 
 
 def test_decode_steps_are_batch_invariant_bit_for_bit(bench_engine):
     """The hand-written decode step (weight-streaming GEMM + row kernels) for a row of a 20-row batch == that row in a
     batch of 1 and of 4, bit for bit: same KV cache contents, same residual in, same logits out."""
     from openpsg_amd import ops
-    cfg, engines, X, plen = bench_engine
-    eng = engines["bf16"]
+    be = bench_engine
+    cfg, X = be["cfg"], be["X"]
+    eng = _engine(be, "bf16")
     m = cfg.llm
     dev = X.device
     g = torch.Generator(device=dev)

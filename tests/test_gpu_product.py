@@ -127,7 +127,7 @@ def test_detector_simple_test_submission_and_infer_tool(tmp_path):
         assert np.array_equal(tr["pan_results"], res["pan_results"])
 
 
-@pytest.mark.parametrize("dtype", ["bf16"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "mixed"])
 def test_c5_geometry_batch_of_eight_images(dtype):
     """BASELINE config 5's geometry (1000x1333 -> pad 1024x1344, L = 336) x 8 images through simple_test_batch:
     the selected pairs of all images decode together; every image must give what its own simple_test gives."""

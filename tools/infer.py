@@ -81,28 +81,15 @@ def image_metas(a, names):
     return metas
 
 
-def run(a, head=None):
+def run_local(a, head, world, rank, dev):
+    """This rank's share of the images (dealt round-robin, dist.shard_images) through the detector.
+    Returns (image names, [(image index, result)], seconds)."""
     from openpsg_amd.detector import OpenSeeDRelationV2, PrecomputedSegmenter, SyntheticSegmenter
-    from openpsg_amd.dist import gather_image_results, shard_images
-    from openpsg_amd.results import write_submission
+    from openpsg_amd.dist import shard_images
     if not hasattr(a, "size_given"):
         a.size_given = True
-    # one process per GPU (torch.distributed.run): whole images are dealt round-robin to the ranks
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    own_group = False
-    if world > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo")                   # host objects only; no device collective on this path
-            own_group = True
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    if head is None:
-        head = build_head(a, dev)
-    seg = SyntheticSegmenter(a.objects, seed=0, device=str(dev)) if a.segmenter == "synthetic" else \
-        PrecomputedSegmenter(a.seg_dir, device=str(dev))
+    seg = SyntheticSegmenter(a.objects, seed=0, device=str(dev), seed_from_filename=True) \
+        if a.segmenter == "synthetic" else PrecomputedSegmenter(a.seg_dir, device=str(dev))
     det = OpenSeeDRelationV2(relation_head=head, segmenter=seg)
     if a.segmenter == "synthetic" and not a.list:
         names = [f"{i}.jpg" for i in range(a.images)]
@@ -119,18 +106,55 @@ def run(a, head=None):
             outs = det.simple_test_batch([None] * len(idx), [[all_metas[i]] for i in idx])
         local_results += [(i, o[0]) for i, o in zip(idx, outs)]
     torch.cuda.synchronize()
-    dt = time.time() - t0
+    return names, local_results, time.time() - t0
+
+
+def finish(a, names, results, world, dt):
+    from openpsg_amd.results import write_submission
+    path = write_submission(results, a.out, keep_scores=a.keep_scores, names=names if a.keep_scores else None)
+    n_rel = sum(len(r["rel_results"]["relation"]) for r in results)
+    print(f"{len(names)} images on {world} GPU(s) in {dt:.2f}s ({len(names) / dt:.2f} img/s), {n_rel} relations "
+          f"-> {path}")
+    return path
+
+
+def run(a, head=None):
+    from openpsg_amd.dist import gather_image_results
+    # one process per GPU (torch.distributed.run): whole images are dealt round-robin to the ranks
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    own_group = False
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")                   # host objects only; no device collective on this path
+            own_group = True
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if head is None:
+        head = build_head(a, dev)
+    names, local_results, dt = run_local(a, head, world, rank, dev)
     results = gather_image_results(local_results, len(names))
-    path = None
-    if rank == 0:
-        path = write_submission(results, a.out, keep_scores=a.keep_scores, names=names if a.keep_scores else None)
-        n_rel = sum(len(r["rel_results"]["relation"]) for r in results)
-        print(f"{len(names)} images on {world} GPU(s) in {dt:.2f}s ({len(names) / dt:.2f} img/s), {n_rel} relations "
-              f"-> {path}")
+    path = finish(a, names, results, world, dt) if rank == 0 else None
     if own_group:
         import torch.distributed as dist
         dist.destroy_process_group()
     return results, path
+
+
+def run_fake_world(a, head, world, dev="cuda:0"):
+    """The same job over `world` ranks of ONE process, one after the other on one GPU (SURVEY 4 "fake world"): what
+    `torch.distributed.run --nproc-per-node world tools/infer.py` computes, without the processes."""
+    from openpsg_amd.dist import merge_image_results
+    dev = torch.device(dev)
+    parts, dt, names = [], 0.0, None
+    for rank in range(world):
+        names, local_results, t = run_local(a, head, world, rank, dev)
+        parts.append(local_results)
+        dt = max(dt, t)
+    results = merge_image_results(parts, len(names))
+    return results, finish(a, names, results, world, dt)
 
 
 def main():
