@@ -49,14 +49,14 @@ class SyntheticSegmenter:
         """seed_from_filename: image `<k>.jpg` always gets scene seed + k, whichever rank processes it and in whatever
         order (images dealt to several ranks, tools/infer.py); otherwise the seed advances by one per call."""
         self.num_objects, self.seed, self.device = num_objects, seed, device
-        self.seed_from_filename = seed_from_filename
+        self.base_seed, self.seed_from_filename = seed, seed_from_filename
 
     def __call__(self, img, img_meta):
         pad = img_meta["pad_shape"][:2]
         seed = self.seed
         stem = os.path.splitext(os.path.basename(str(img_meta.get("filename", ""))))[0]
         if self.seed_from_filename and stem.isdigit():
-            seed = self.seed + int(stem)
+            seed = self.base_seed + int(stem)
         s = make_scene(pad, self.num_objects, seed=seed, ori_hw=img_meta["ori_shape"][:2],
                        img_hw=img_meta["img_shape"][:2], device=self.device)
         self.seed += 1

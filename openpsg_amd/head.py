@@ -698,12 +698,14 @@ class RelationTransformerHeadV4(nn.Module):
         K, nv = sel.numel(), q.num_query
         if "pending" in rq and "hidden" not in rq:
             # selection phase done (forward_pairs_cls): last layer in full for the K chosen pairs only.  Several
-            # chunks: every chunk computes all K slots (foreign pairs as its pair 0) and keeps its own - no host sync
+            # chunks: every chunk computes all K slots (foreign pairs as its first pair) and keeps its own - no host sync
             pf = torch.zeros((K, nv, q.hidden), device=self.device, dtype=self.act_dtype) if zero_foreign else None
             for c0, c1, st, off in rq["pending"]:
                 local = sel.to(torch.int64) - c0
                 mine = (local >= 0) & (local < c1 - c0)
-                pos = torch.where(mine, local + off, torch.zeros_like(local)).to(torch.int32)
+                # foreign slots are computed as this chunk's FIRST pair (a valid pair of the same image: in a pass over
+                # several images position 0 belongs to another image, whose pair ids can exceed this image's N^2)
+                pos = torch.where(mine, local + off, torch.full_like(local, off)).to(torch.int32)
                 hk = self.rq_engine.pair_hidden(st, pos)
                 pc = hk.view(K, q.q_rows, q.hidden)[:, 1:]
                 pf = pc if pf is None else torch.where(mine[:, None, None], pc, pf)
@@ -735,7 +737,7 @@ class RelationTransformerHeadV4(nn.Module):
             c0, c1, st, off = r["pending"][0]
             local = sel.to(torch.int64) - c0
             mine = (local >= 0) & (local < c1 - c0)
-            pos.append(torch.where(mine, local + off, torch.zeros_like(local)))
+            pos.append(torch.where(mine, local + off, torch.full_like(local, off)))   # foreign: the image's own first pair
             mine_all.append(mine)
             segs.append((k0, sel.numel(), st["kv"], st["bits"], st["num_objects"]))
             k0 += sel.numel()
