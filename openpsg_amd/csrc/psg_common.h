@@ -27,6 +27,9 @@ struct psg_opts {
   int xattn_waves = 8;          // LDS-DMA cross-attention: waves per workgroup (8 or 10)
   int xattn_dma = 1;            // cross-attention: LDS-DMA kernel (psg_xattn_dma.hip) when its LDS image fits
   int ln_half_wave = 1;         // add + LayerNorm on 16-bit rows: half a wave per row, 16-byte accesses
+  int xattn_dynamic = 1;        // LDS-DMA cross-attention: a workgroup's waves draw their tiles from an LDS counter
+  int xattn_poll = 0;           // LDS-DMA cross-attention: a unit's Q tile is awaited by polling a sentinel in its LDS slot
+                                // instead of a vmcnt count (which also waits for the previous unit's stores to retire)
 };
 
 struct psg_ctx {

@@ -30,7 +30,8 @@ static const OptName kOpts[] = {
     {"selfattn_scalar", &psg_opts::selfattn_scalar},   {"decode_attn_1wave", &psg_opts::decode_attn_1wave},
     {"xattn_dma", &psg_opts::xattn_dma},               {"xattn_waves", &psg_opts::xattn_waves},
     {"dense_gemm_var", &psg_opts::dense_gemm_var},     {"qformer_own_gemm", &psg_opts::qformer_own_gemm},
-    {"ln_half_wave", &psg_opts::ln_half_wave},
+    {"ln_half_wave", &psg_opts::ln_half_wave},         {"xattn_poll", &psg_opts::xattn_poll},
+    {"xattn_dynamic", &psg_opts::xattn_dynamic},
 };
 
 // "8x1x3" (waves x K blocks x ring slots) is accepted for skinny_dma next to a plain integer

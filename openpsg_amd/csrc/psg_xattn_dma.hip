@@ -55,6 +55,9 @@ __device__ __forceinline__ uint32_t xd_lds_read32(uint32_t a) {
 __device__ __forceinline__ void xd_lds_write64(uint32_t a, xd_u32x2 v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
+__device__ __forceinline__ void xd_lds_write32(uint32_t a, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
 template <int N_>
 __device__ __forceinline__ void xd_vmwait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
@@ -65,7 +68,7 @@ __global__ void __launch_bounds__(XD_WAVES * 64, (XD_WAVES + 3) / 4)
 cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                       const uint64_t* __restrict__ bits, int words, const int32_t* __restrict__ pair_index, int N,
                       int64_t R, int L, int nq, int heads, int policy, uint16_t* __restrict__ out,
-                      long long* __restrict__ trace) {
+                      long long* __restrict__ trace, int poll, int dyn) {
   // trace != nullptr (psg_set_trace_buffer(PSG_TRACE_CROSS_ATTN), debugging only): 32 stamps per wave:
   // [0] start, [1] K/V staged, [2] = [1], [3 + i] end of unit i, [31] unit count
   long long* tr = trace ? trace + ((int64_t)blockIdx.x * XD_WAVES + (threadIdx.x >> 6)) * 32 : nullptr;
@@ -121,8 +124,17 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
   };
   // DMA of one unit into slot s: 4 x (8 rows x 128 B), piece (pc ^ r8) of row 8 i + r8 lands in slot position pc
   // of that row; + the pair ids of rows 0..31 (lanes 32..63 repeat them)
+  // poll mode: the unit's arrival is read off its LDS slot - the pair-id words (the LAST of the five DMAs; loads land in
+  // order) are set to a sentinel no pair id can take before the DMAs are issued, and the consumer spins on them.  A
+  // vmcnt count cannot tell the Q tile of unit u from the context stores of unit u - 1 that sit behind it in the same
+  // queue (gfx9 counts loads and stores together, and stores retire only when L2 has them): waiting "until at most
+  // the DMAs of unit u + 1 are outstanding" made every unit wait for the previous unit's stores to retire.
   auto issue = [&](int64_t tile, int s) {
     unsigned char* dst = my_slots + s * XD_SLOT;
+    if (poll) {
+      xd_lds_write32(slot_lds0 + (uint32_t)(s * XD_SLOT) + 4096u + (uint32_t)(lane * 4), 0xffffffffu);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the sentinel is in LDS before a DMA can overwrite it
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int64_t row, pair;
@@ -150,6 +162,27 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
   const int64_t cls_rem = NCLS % W;
   const int64_t my_cls = NCLS / W + (w < cls_rem ? 1 : 0);
   const int64_t A = W - cls_rem;                                   // waves taking part in the skipped rounds
+  // Dynamic deal inside the workgroup (dyn): the unit cost varies with the pair's mask (active key tiles), so with the
+  // static deal the slowest of the 2016 waves ends ~20 % after the mean.  Queues in global memory do not pay here (a
+  // returning atomic on 12 hot words: 20 us per pull with 2016 pullers, measured), but most of the spread is BETWEEN THE
+  // WAVES OF ONE WORKGROUP: the workgroup owns the tiles g, g + G, g + 2G, ... of its head (cls tiles first) and its
+  // eight waves draw the next one from an LDS counter (ds_add_rtn: ~100 ns, no memory traffic).
+  const int64_t ncls_g = dyn ? (NCLS > g ? (NCLS - g + G - 1) / G : 0) : 0;
+  uint32_t* cursor = reinterpret_cast<uint32_t*>(slots + (size_t)XD_WAVES * 2 * XD_SLOT);   // 16 bytes behind the slots
+  const uint32_t cursor_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cursor;
+  auto tile_of = [&](int64_t n) -> int64_t {                       // n-th tile of this workgroup; -1: none
+    if (n < ncls_g) return g + n * G;
+    const int64_t idx = g + (n - ncls_g) * G;
+    return idx < ntile - NCLS ? NCLS + idx : -1;
+  };
+  auto draw = [&]() -> int64_t {
+    uint32_t r = 0;
+    if (lane == 0) {
+      const uint32_t one = 1u;
+      asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(cursor_addr), "v"(one) : "memory");
+    }
+    return tile_of((int64_t)__builtin_amdgcn_readfirstlane(r));
+  };
   auto tile_at = [&](int64_t n) -> int64_t {                       // -1: no such unit
     if (n < my_cls) return w + n * W;                               // cls tiles come first (ids [0, NCLS))
     const int64_t kk = n - my_cls;
@@ -197,7 +230,9 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
     const int e = tid + i * (XD_WAVES * 64);
     if (e < nbw) bitreg[i] = bits[e];
   }
-  const int64_t t_u0 = tile_at(0), t_u1 = tile_at(1);
+  // (dyn: the first two units of a wave are fixed - they are requested before the first barrier; the cursor starts behind them)
+  const int64_t t_u0 = dyn ? tile_of(wid) : tile_at(0), t_u1 = dyn ? tile_of(XD_WAVES + wid) : tile_at(1);
+  if (dyn && tid == 0) *cursor = 2 * XD_WAVES;
   if (t_u0 >= 0) issue(t_u0, 0);
   if (t_u1 >= 0) issue(t_u1, 1);
 #pragma unroll
@@ -230,16 +265,22 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
     }
   }
   __syncthreads();
-  if (tid < 64) {                                       // pad keys hold zeros: sum over all Lpad slots
-    float sum = 0.f;
-    const uint16_t* vr = reinterpret_cast<const uint16_t*>(vt_lds + tid * VS);
-    for (int kk = 0; kk < Lpad; kk += 8) {
-      const uint4 x = *reinterpret_cast<const uint4*>(vr + kk);
-      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+  {                                                     // mean of V_h over the keys (pad keys hold zeros): 8 lanes per
+    const int d = tid >> 3, part = tid & 7;             // dim, each summing every 8th 16-byte piece of the V^T row
+    if (d < 64) {
+      float sum = 0.f;
+      const uint16_t* vr = reinterpret_cast<const uint16_t*>(vt_lds + d * VS);
+      for (int kk = part * 8; kk < Lpad; kk += 64) {
+        const uint4 x = *reinterpret_cast<const uint4*>(vr + kk);
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sum += E::to_f32((uint16_t)(xs[e] & 0xffffu)) + E::to_f32((uint16_t)(xs[e] >> 16));
+        for (int e = 0; e < 4; ++e) sum += E::to_f32((uint16_t)(xs[e] & 0xffffu)) + E::to_f32((uint16_t)(xs[e] >> 16));
+      }
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      sum += __shfl_xor(sum, 4);
+      if (part == 0) reinterpret_cast<float*>(mean_lds)[d] = sum / (float)L;
     }
-    reinterpret_cast<float*>(mean_lds)[tid] = sum / (float)L;
   }
   __syncthreads();
 
@@ -441,11 +482,22 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
   // retires the previous unit's 4 stores, which is conservative and correct.
   int64_t t = t_u0, t1 = t_u1;
   for (int u = 0; t >= 0; ++u) {
-    if (t1 >= 0) xd_vmwait<5>();
-    else xd_vmwait<0>();
+    if (poll) {
+      const uint32_t pa = slot_lds0 + (uint32_t)((u & 1) * XD_SLOT) + 4096u + (uint32_t)(lane * 4);
+      for (int spin = 0; spin < (1 << 22); ++spin) {          // bounded: a lost DMA must not hang the GPU
+        const uint32_t got = xd_lds_read32(pa);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (__all(got != 0xffffffffu)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    } else if (t1 >= 0) {
+      xd_vmwait<5>();
+    } else {
+      xd_vmwait<0>();
+    }
     if (aligned && t >= NCLS) run_unit(t, u & 1, std::true_type{});
     else run_unit(t, u & 1, std::false_type{});
-    const int64_t t2 = tile_at(u + 2);
+    const int64_t t2 = dyn ? (t1 >= 0 ? draw() : -1) : tile_at(u + 2);
     if (t2 >= 0) issue(t2, u & 1);
     if (tr && lane == 0) {
       if (u < 28) tr[3 + u] = __builtin_readcyclecounter();
@@ -459,7 +511,7 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
 static size_t xd_lds_bytes(int N, int words, int L, int waves) {
   const int Lpad = (L + 31) & ~31;
   return (size_t)Lpad * XD_KSTRIDE + (size_t)64 * (Lpad * 2 + 16) + 256 + (((size_t)N * words * 8 + 15) & ~(size_t)15) +
-         (size_t)waves * 2 * XD_SLOT;
+         (size_t)waves * 2 * XD_SLOT + 16;
 }
 
 // smallest LDS footprint of the kernel family (8 waves); the dispatcher compares it with the 160 KiB of a CU
@@ -482,6 +534,7 @@ static int xd_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, 
   const int64_t maxG = (ntile + waves - 1) / waves;
   if (G > maxG) G = maxG;
   if (G < 1) G = 1;
+  const int dyn = (nq == 33 && ctx->opt.xattn_dynamic && ntile >= 4 * G * waves) ? 1 : 0;   // short launches stay static
   const int64_t trace_n = G * heads * waves * 32;
   long long* trace = (ctx->trace_kind == PSG_TRACE_CROSS_ATTN && ctx->trace_words >= trace_n) ? ctx->trace : nullptr;
 #define XDLAUNCH(NC_, W_)                                                                                          \
@@ -494,7 +547,7 @@ static int xd_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, 
     }                                                                                                              \
     cross_attn_dma_kernel<E, NC_, W_><<<(unsigned)(G * heads), W_ * 64, lds, st>>>(                                   \
         (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads,   \
-        policy, (uint16_t*)out, trace);                                                                            \
+        policy, (uint16_t*)out, trace, ctx->opt.xattn_poll, dyn);                                                  \
   } while (0)
   if (waves == 10) {
     if (NC == 1) XDLAUNCH(1, 10);
