@@ -55,7 +55,7 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  * library was built with; a binding compares it with the PSG_ABI_VERSION of the header it was written against
  * (openpsg_amd/_lib.py does, at load time) instead of passing shifted arguments silently.
  *   100  round 1        200  round 2 (psg_skinny_gemm / psg_rope_kvwrite gained, psg_qformer_cross_attn lost an argument)
- *   300  round 3 (psg_rmsnorm: resid_dtype) */
+ *   300  round 3 (psg_rmsnorm: resid_dtype; psg_train_* gradient kernels added) */
 #define PSG_ABI_VERSION 300
 int psg_version(void);
 const char* psg_last_error(void);
@@ -317,6 +317,12 @@ int psg_masked_mean_pool_workspace(psg_ctx*, int C, int Hf, int Wf, int N, int64
 int psg_masked_mean_pool(psg_ctx*, const float* feat, int C, int Hf, int Wf, const int32_t* pan, int H0,
                          int W0, int img_h, int img_w, int pad_h, int pad_w, const int32_t* object_ids,
                          int N, float* out, int32_t* workspace, int64_t workspace_bytes, void* stream);
+/* split-mean variant, `_mask_pooling(output_size > 1)` (openseed_relation.py:175-200): the object's pixels in row-major
+ * order cut into `output_size` contiguous chunks (the first count mod output_size one longer), one mean per chunk; fewer
+ * pixels than chunks: the pixel list repeats; no pixels: zeros.  out [N][output_size][C]; same workspace. */
+int psg_masked_split_mean_pool(psg_ctx*, const float* feat, int C, int Hf, int Wf, const int32_t* pan, int H0,
+                               int W0, int img_h, int img_w, int pad_h, int pad_w, const int32_t* object_ids, int N,
+                               int output_size, float* out, int32_t* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- 8f rank 3: training branch of the head (forward arithmetic of the losses).
  * psg_train_object_bitmasks: V4:371-399 prepare_train.  thing_masks uint8 [n_thing][H][W] (padded ground-truth
@@ -333,6 +339,40 @@ int psg_bce_with_logits(psg_ctx*, const float* logit, const float* label, int n,
                         void* stream);
 int psg_cross_entropy_rows(psg_ctx*, const void* logits, int64_t rows, int vocab, const int32_t* labels, float* loss,
                            int dtype, void* stream);
+
+/* ---- SURVEY 8f rank 3, gradient path (V4:327-351, 463-482; the reference back-propagates both losses, LLM frozen,
+ * CFG:65): fp32 row / attention kernels of the training branch with their exact adjoints.  Batches are tiny (<= 32
+ * sampled pairs, <= 4 LLM pairs); dense projections and weight gradients go through the library GEMM.
+ * attention: q [B][Sq][H*D], k / v [Bk][Sk][H*D] (Bk == B, or 1 = shared by every sequence: the image's cross-attention
+ * K/V), keep uint8 [B][Mq][Sk] (Mq == Sq, or 1 = one key mask for all query rows), p [B][H][Sq][Sk] saved by the forward;
+ * an all-masked row is a uniform softmax (additive finfo.min).  The backward ACCUMULATES into dk / dv / dgamma / dbeta
+ * (caller zeroes them). */
+int psg_train_layernorm_fwd(psg_ctx*, const float* x, const float* gamma, const float* beta, float eps, int64_t rows,
+                            int hidden, float* y, float* mean, float* rstd, void* stream);
+int psg_train_layernorm_bwd(psg_ctx*, const float* x, const float* dy, const float* gamma, const float* mean,
+                            const float* rstd, int64_t rows, int hidden, float* dx, float* dgamma, float* dbeta,
+                            void* stream);
+int psg_train_rmsnorm_fwd(psg_ctx*, const float* x, const float* w, float eps, int64_t rows, int hidden, float* y,
+                          float* rstd, void* stream);
+int psg_train_rmsnorm_bwd(psg_ctx*, const float* x, const float* dy, const float* w, const float* rstd, int64_t rows,
+                          int hidden, float* dx, void* stream);
+int psg_train_attn_fwd(psg_ctx*, const float* q, const float* k, const float* v, const uint8_t* keep, int B, int Bk,
+                       int H, int Sq, int Sk, int D, int Mq, float scale, float* p, float* out, void* stream);
+int psg_train_attn_bwd(psg_ctx*, const float* q, const float* k, const float* v, const float* p, const float* dout,
+                       int B, int Bk, int H, int Sq, int Sk, int D, float scale, float* dq, float* dk, float* dv,
+                       void* stream);
+int psg_train_gelu_fwd(psg_ctx*, const float* x, int64_t n, float* y, void* stream);
+int psg_train_gelu_bwd(psg_ctx*, const float* x, const float* dy, int64_t n, float* dx, void* stream);
+int psg_train_silu_mul_fwd(psg_ctx*, const float* gate_up, int64_t rows, int inter, float* y, void* stream);
+int psg_train_silu_mul_bwd(psg_ctx*, const float* gate_up, const float* dy, int64_t rows, int inter, float* dgate_up,
+                           void* stream);
+/* half-split rotary on [rows][heads*head_dim] with per-row table index `pos`; sign = -1 is the adjoint */
+int psg_train_rope(psg_ctx*, const float* x, const int32_t* pos, const float* rope_cos, const float* rope_sin,
+                   int table_rows, int64_t rows, int heads, int head_dim, float sign, float* y, void* stream);
+int psg_train_ce_bwd(psg_ctx*, const float* logits, int64_t rows, int vocab, const int32_t* labels, const float* dloss,
+                     float* dlogits, void* stream);
+int psg_train_bce_bwd(psg_ctx*, const float* logit, const float* label, int n, float weight, const float* dloss,
+                      float* dlogit, void* stream);
 
 /* ---- 8f: bilinear relation scorer of the closed-set heads (relation_transformer_head_v2.py:204-209):
  * pred[b][r][s][o] = sum_c sub[b][s][r*C + c] * obj[b][o][r*C + c], i.e. einsum('nrsc,nroc->nrso') on the

@@ -76,8 +76,22 @@ SIGNATURES = {
     "psg_reduce_partials": [_vp, _vp, _i, _i64, _vp, _i, _vp],
     "psg_masked_mean_pool_workspace": [_vp, _i, _i, _i, _i, C.POINTER(_i64)],
     "psg_masked_mean_pool": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i64, _vp],
+    "psg_masked_split_mean_pool": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i64, _vp],
     "psg_bilinear_scores": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "psg_dense_gemm": [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp],
+    "psg_train_layernorm_fwd": [_vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp, _vp],
+    "psg_train_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp],
+    "psg_train_rmsnorm_fwd": [_vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp],
+    "psg_train_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp],
+    "psg_train_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    "psg_train_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "psg_train_gelu_fwd": [_vp, _vp, _i64, _vp, _vp],
+    "psg_train_gelu_bwd": [_vp, _vp, _vp, _i64, _vp, _vp],
+    "psg_train_silu_mul_fwd": [_vp, _vp, _i64, _i, _vp, _vp],
+    "psg_train_silu_mul_bwd": [_vp, _vp, _vp, _i64, _i, _vp, _vp],
+    "psg_train_rope": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp],
+    "psg_train_ce_bwd": [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp],
+    "psg_train_bce_bwd": [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
     "psg_greedy_step": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
 }
 

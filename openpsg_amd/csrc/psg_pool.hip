@@ -163,6 +163,79 @@ extern "C" int psg_masked_mean_pool(psg_ctx* ctx, const float* feat, int C, int 
   return PSG_OK;
 }
 
+// Split-mean variant (`_mask_pooling(output_size > 1)`, openseed_relation.py:175-200): the object's masked pixels, in
+// row-major order, are cut into `k` contiguous chunks (the first m mod k one pixel longer) and each chunk is averaged:
+// out[n][c] = mean of chunk c.  An object with fewer pixels than chunks repeats its pixel list (chunk c = pixel c mod m),
+// an object without pixels gives zeros.  Same slot / index passes; one wave per (object, chunk, 4 channels) sums its
+// chunk in list order - deterministic.
+__global__ void __launch_bounds__(256) pool_split_kernel(const float* __restrict__ feat, int C, int HW,
+                                                         const int32_t* __restrict__ cnt, const int32_t* __restrict__ list,
+                                                         int N, int k, float* __restrict__ out) {
+  const int64_t unit = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int cq_n = C / 4;
+  if (unit >= (int64_t)N * k * cq_n) return;
+  const int cq = (int)(unit % cq_n);
+  const int ch_i = (int)((unit / cq_n) % k);
+  const int n = (int)(unit / ((int64_t)cq_n * k));
+  const int m = cnt[n];
+  float* o = out + ((int64_t)n * k + ch_i) * C + 4 * cq;
+  if (m <= 0) {                                                 // wave-uniform
+    if (lane < 4) o[lane] = 0.f;
+    return;
+  }
+  int start, size;
+  if (m < k) {                                                  // the pixel list repeated up to k entries, one per chunk
+    start = ch_i % m;
+    size = 1;
+  } else {
+    const int base = m / k, rem = m % k;
+    start = ch_i * base + min(ch_i, rem);
+    size = base + (ch_i < rem ? 1 : 0);
+  }
+  const int32_t* lp = list + (int64_t)n * HW + start;
+  const float* f0 = feat + (int64_t)(4 * cq) * HW;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < size; i += 64) {
+    const int px = lp[i];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) a[ch] += f0[(int64_t)ch * HW + px];
+  }
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    const float sv = wave_sum(a[ch]);
+    if (lane == 0) o[ch] = sv / (float)size;
+  }
+}
+
+extern "C" int psg_masked_split_mean_pool(psg_ctx* ctx, const float* feat, int C, int Hf, int Wf, const int32_t* pan,
+                                          int H0, int W0, int img_h, int img_w, int pad_h, int pad_w,
+                                          const int32_t* object_ids, int N, int output_size, float* out,
+                                          int32_t* workspace, int64_t workspace_bytes, void* stream) {
+  PSG_REQUIRE(ctx && feat && pan && object_ids && out && workspace, PSG_ERR_INVALID,
+              "psg_masked_split_mean_pool: NULL argument");
+  PSG_REQUIRE(C > 0 && C % 4 == 0 && Hf > 0 && Wf > 0 && N > 0 && H0 > 0 && W0 > 0 && img_h > 0 && img_w > 0 &&
+                  pad_h >= img_h && pad_w >= img_w && output_size >= 1,
+              PSG_ERR_INVALID, "psg_masked_split_mean_pool: C=%d (multiple of 4) Hf=%d Wf=%d N=%d output_size=%d", C, Hf,
+              Wf, N, output_size);
+  const int HW = Hf * Wf;
+  PSG_REQUIRE(workspace_bytes >= pool_ws_ints(HW, N, C) * (int64_t)sizeof(int32_t), PSG_ERR_INVALID,
+              "psg_masked_split_mean_pool: workspace too small (psg_masked_mean_pool_workspace)");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* cnt = workspace;
+  int32_t* slot = workspace + N;
+  int32_t* list = slot + HW;
+  pool_slot_kernel<<<(HW + 255) / 256, 256, 0, st>>>(pan, H0, W0, img_h, img_w, pad_h, pad_w, Hf, Wf, object_ids, N,
+                                                    slot);
+  PSG_CHECK_LAUNCH("psg_masked_split_mean_pool(slot)");
+  pool_index_kernel<<<N, 1024, 0, st>>>(slot, HW, cnt, list);
+  PSG_CHECK_LAUNCH("psg_masked_split_mean_pool(index)");
+  const int64_t waves = (int64_t)N * output_size * (C / 4);
+  pool_split_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(feat, C, HW, cnt, list, N, output_size, out);
+  PSG_CHECK_LAUNCH("psg_masked_split_mean_pool(split)");
+  return PSG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // SURVEY 8f rank 4, second half: the bilinear relation scorer of the closed-set heads
 // (kings_sgg/models/relation_heads/relation_transformer_head_v2.py:204-209, same form in v1 / v3):

@@ -10,8 +10,8 @@ names so a reference checkpoint loads with `strict=False`
 Differences that are deliberate and documented:
   * V4:355-356 raises UnboundLocalError in the default 'binary' mode as committed; this head
     implements the intended contract: rel_pred = LLM triples, rel_score = 1 each (SURVEY 0.3);
-  * the training branch computes the reference's two losses (forward arithmetic, `forward_train`); gradients are
-    not implemented (SURVEY 8f rank 3);
+  * the training branch computes the reference's two losses (`forward_train`: values through the inference kernels;
+    `forward_train_grad`: fp32, with the gradient graph - openpsg_amd/train_graph.py; SURVEY 8f rank 3);
   * all arithmetic runs in libpsg_hip.so / hipBLASLt on the GPU; there is no CPU path.
 """
 from __future__ import annotations
@@ -19,6 +19,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 from ._lib import PsgHipError
@@ -196,6 +197,7 @@ class RelationTransformerHeadV4(nn.Module):
         self.llm_tokenizer.pad_token = self.llm_tokenizer.unk_token        # V4:105
         self.last = {}
         self._gather_cache = {}
+        self._proj_stale = False
         self.train(False)                                                   # eval by default, as init_detector leaves it
 
     # ---- weights ---------------------------------------------------------------------------------
@@ -339,12 +341,14 @@ class RelationTransformerHeadV4(nn.Module):
 
     def forward(self, inputs, is_generation=None):
         if self.training:
+            if self.act_dtype == torch.float32 and torch.is_grad_enabled():
+                return self.forward_train_grad(inputs)            # the losses with their gradient graph (V4:345-351)
             if not self.train_losses_without_grad:
                 raise NotImplementedError(
-                    "RelationTransformerHeadV4.forward in training mode: this build computes the reference's two losses "
-                    "(V4:327-351, 463-482) on the HIP path but has no backward, so a training loop would train nothing "
-                    "here.  Call forward_train(inputs) for the loss values, or construct the head with "
-                    "train_losses_without_grad=True to get them from forward().")
+                    "RelationTransformerHeadV4.forward in training mode: the gradient path runs in fp32 with autograd "
+                    "enabled (dtype='fp32'); in a 16-bit head or under no_grad only the loss VALUES are available, and a "
+                    "training loop summing them would train nothing.  Call forward_train(inputs) for the values, or "
+                    "construct the head with train_losses_without_grad=True to get them from forward().")
             return self.forward_train(inputs)
         feat, meta, info, obj_ids, names = self._unpack(inputs)
         N = len(obj_ids)
@@ -374,14 +378,11 @@ class RelationTransformerHeadV4(nn.Module):
             sn = neg[torch.randint(0, nn_, (bs * k // (k + 1),))]
         return torch.cat([sp, sn], dim=0)
 
-    @torch.no_grad()
-    def forward_train(self, inputs, sampled=None, selected=None):
-        """V4:114-133, 176-196, 218-228, 260-341, 360-406: the two losses of the training branch, computed by the
-        HIP path - `binary_rel_cls_loss` (BCE-with-logits x rel_cls_loss_weight over the sampled pairs) and
-        `rel_llm_loss` (teacher-forced next-token cross entropy over the label tokens, mean over the selected pairs).
-        This is the FORWARD arithmetic (loss values, e.g. for validation or for checking a checkpoint against the
-        reference); gradients are not implemented - the kernels have no backward.  `sampled` / `selected` replace
-        the random draws (V4:173 `qformer_sampler`, V4:222-228 `random.sample`)."""
+    def _train_prepare(self, inputs, sampled=None, selected=None):
+        """Host side of the training branch (V4:114-133, 218-228, 260-285, 360-406): relation targets, ground-truth object
+        masks on the patch grid (HIP, bit-exact), the sampled pairs and their BERT prompts, the LLM selection with its
+        prompt / label token grids.  `sampled` / `selected` replace the random draws (V4:173 `qformer_sampler`,
+        V4:222-228 `random.sample`).  Returns a dict shared by the loss-only and the gradient paths."""
         import random
         dev = self.device
         feat = inputs['mask_features']
@@ -395,11 +396,8 @@ class RelationTransformerHeadV4(nn.Module):
             target[ii, jj, rc] = 1
         binary = (target.sum(2) > 0).float().reshape(-1)
         label_index = torch.nonzero(target, as_tuple=False)
-        eng = self.rq_engine
         q = self.cfg.qformer
         # prepare_train (V4:360-406)
-        patches = eng.patch_embed(feat.to(torch.float32))
-        kv = eng.cross_kv(patches)
         gt_masks = inputs['gt_masks'][0]
         tm = gt_masks.to_tensor(torch.uint8, dev) if hasattr(gt_masks, "to_tensor") else gt_masks.to(dev, torch.uint8)
         sem = inputs['gt_semantic_seg'][0].to(dev).reshape(feat.shape[-2] * 4, feat.shape[-1] * 4).to(torch.int32)
@@ -408,7 +406,7 @@ class RelationTransformerHeadV4(nn.Module):
         tidx = torch.tensor(np.cumsum([1 if x['is_thing'] else 0 for x in info]) - 1, dtype=torch.int32, device=dev)
         gh, gw = feat.shape[-2] // self.cfg.patch_size, feat.shape[-1] // self.cfg.patch_size
         bits = ops.train_object_bitmasks(tm.contiguous(), sem.contiguous(), is_thing, cat, tidx.clamp(min=0), (gh, gw))
-        # sampled pairs through the Q-Former (V4:172-186); prompts are padded over ALL pairs (V4:146-150)
+        # sampled pairs (V4:172-186); prompts are padded over ALL pairs (V4:146-150)
         if sampled is None:
             sampled = self.qformer_sampler(target)
         sampled = torch.as_tensor(sampled, dtype=torch.int64)
@@ -421,9 +419,6 @@ class RelationTransformerHeadV4(nn.Module):
             tok = rows[uidx[p // N] * U + uidx[p % N]]
             ids[r, :len(tok)] = tok
             msk[r, :len(tok)] = 1
-        hidden, logit, _ = eng.forward_pairs(kv, bits, N, sampled.to(dev, torch.int32), torch.from_numpy(ids).to(dev),
-                                             torch.from_numpy(msk).to(dev))
-        bce = ops.bce_with_logits(logit, binary[sampled].to(dev), self.rel_cls_loss_weight)  # V4:186-196, 463-482
         # LLM selection (V4:221-228)
         if selected is None:
             selected = [int(x[0]) * N + int(x[1]) for x in label_index.tolist()]
@@ -432,13 +427,8 @@ class RelationTransformerHeadV4(nn.Module):
                 selected = random.sample(list(range(N * N)), min(N * N, self.max_llm_forward_num))
         selected = [int(x) for x in selected]
         K = len(selected)
-        # pair features of the selected pairs; pairs the sampler skipped stay zero (V4:177, 186)
         nv = q.num_query
         where = {int(p): r for r, p in enumerate(sampled.tolist())}
-        grow = torch.tensor([[where[si] * q.q_rows + 1 + t if si in where else -1 for t in range(nv)] for si in selected],
-                            dtype=torch.int32, device=dev).reshape(-1)
-        pf = torch.empty((K * nv, q.hidden), device=dev, dtype=self.act_dtype)
-        ops.gather_rows(hidden, grow, pf)
         # prompts (left padded, V4:262) and labels ' {name} </s>' per predicate (right padded, V4:267-281)
         tl = target.reshape(-1, self.num_relation_classes).tolist()
         labels = ["".join(" {} </s>".format(self.relation_classes[r]) for r, e in enumerate(tl[si]) if e)
@@ -471,20 +461,109 @@ class RelationTransformerHeadV4(nn.Module):
         for i in range(K):
             cids[i, :len(seqs[i])] = seqs[i]
             rpos[i, :len(rope[i])] = rope[i]
-        llm = self.llm_engine
-        X = llm.build_inputs(pf, torch.from_numpy(cids).to(dev), None)
-        seq_len = torch.tensor([nv + len(s_) for s_ in seqs], dtype=torch.int32, device=dev)
-        flat = torch.tensor([i * S + r for i, r in want_rows], dtype=torch.int32, device=dev)
-        logits = llm.teacher_forcing_logits(X, seq_len, torch.from_numpy(rpos.reshape(-1)).to(dev), flat)
-        rl = ops.cross_entropy_rows(logits.contiguous(), torch.tensor(want_lab, dtype=torch.int32, device=dev))
+        return dict(feat=feat, N=N, names=names, binary=binary, bits=bits, sampled=sampled, selected=selected, where=where,
+                    ids=torch.from_numpy(ids).to(dev), msk=torch.from_numpy(msk).to(dev), K=K, S=S,
+                    cids=torch.from_numpy(cids).to(dev), rpos=torch.from_numpy(rpos).to(dev),
+                    seq_len=torch.tensor([nv + len(s_) for s_ in seqs], dtype=torch.int32, device=dev),
+                    flat_rows=torch.tensor([i * S + r for i, r in want_rows], dtype=torch.int32, device=dev),
+                    want_lab=torch.tensor(want_lab, dtype=torch.int32, device=dev), counts=counts)
+
+    @staticmethod
+    def _mean_per_pair(rl, counts):
         per_pair, o = [], 0
         for c in counts:                                         # CrossEntropyLoss(reduction='mean') per pair (V4:339)
             per_pair.append(rl[o:o + c].mean() if c else rl.new_tensor(float("nan")))
             o += c
+        return per_pair
+
+    @torch.no_grad()
+    def forward_train(self, inputs, sampled=None, selected=None):
+        """V4:114-133, 176-196, 218-228, 260-341, 360-406: the two losses of the training branch, computed by the
+        inference kernels - `binary_rel_cls_loss` (BCE-with-logits x rel_cls_loss_weight over the sampled pairs) and
+        `rel_llm_loss` (teacher-forced next-token cross entropy over the label tokens, mean over the selected pairs).
+        Loss VALUES only (validation, checking a checkpoint against the reference; any activation dtype); the losses
+        with their gradients come from `forward_train_grad`."""
+        dev = self.device
+        t = self._train_prepare(inputs, sampled, selected)
+        eng = self.rq_engine
+        q = self.cfg.qformer
+        N, K, S = t["N"], t["K"], t["S"]
+        patches = eng.patch_embed(t["feat"].to(torch.float32))
+        kv = eng.cross_kv(patches)
+        hidden, logit, _ = eng.forward_pairs(kv, t["bits"], N, t["sampled"].to(dev, torch.int32), t["ids"], t["msk"])
+        bce = ops.bce_with_logits(logit, t["binary"][t["sampled"]].to(dev), self.rel_cls_loss_weight)  # V4:186-196, 463-482
+        # pair features of the selected pairs; pairs the sampler skipped stay zero (V4:177, 186)
+        nv = q.num_query
+        where = t["where"]
+        grow = torch.tensor([[where[si] * q.q_rows + 1 + v if si in where else -1 for v in range(nv)]
+                             for si in t["selected"]], dtype=torch.int32, device=dev).reshape(-1)
+        pf = torch.empty((K * nv, q.hidden), device=dev, dtype=self.act_dtype)
+        ops.gather_rows(hidden, grow, pf)
+        llm = self.llm_engine
+        X = llm.build_inputs(pf, t["cids"], None)
+        logits = llm.teacher_forcing_logits(X, t["seq_len"], t["rpos"].reshape(-1), t["flat_rows"])
+        rl = ops.cross_entropy_rows(logits.contiguous(), t["want_lab"])
+        per_pair = self._mean_per_pair(rl, t["counts"])
         llm_loss = torch.stack(per_pair).mean()                                              # V4:350-351
-        self.last = dict(sampled=sampled, selected=selected, bits=bits, bce_logit=logit, llm_logits=logits,
+        self.last = dict(sampled=t["sampled"], selected=t["selected"], bits=t["bits"], bce_logit=logit, llm_logits=logits,
                          llm_row_loss=rl, llm_pair_loss=per_pair)
         return dict(binary_rel_cls_loss=bce, rel_llm_loss=llm_loss)
+
+    def forward_train_grad(self, inputs, sampled=None, selected=None):
+        """The training branch WITH its gradient graph (V4:327-351, 463-482; tools/train.py:239-246 back-propagates the
+        sum of the two losses): the same arithmetic through `openpsg_amd/train_graph.py` - torch.autograd nodes whose
+        forward / backward are the fp32 kernels of csrc/psg_train_bwd.hip, library GEMMs for the projections.  Gradients
+        reach patch_embed, the Q-Former, relation_query / rel_cls_query, binary_rel_cls_pred and language_projection;
+        the LLM is frozen (CFG:65) and only passes the gradient through.  fp32 heads only."""
+        from . import train_graph as G
+        if self.act_dtype != torch.float32:
+            raise PsgHipError("forward_train_grad: the gradient path runs in fp32 (construct the head with dtype='fp32')")
+        dev = self.device
+        q = self.cfg.qformer
+        with torch.enable_grad():
+            P = dict(self.named_parameters())
+            if not all(p.requires_grad for p in P.values()):
+                raise PsgHipError("forward_train_grad: parameters are frozen; call head.train() first")
+            t = self._train_prepare(inputs, sampled, selected)
+            N, K, S = t["N"], t["K"], t["S"]
+            feat = t["feat"].to(torch.float32)
+            patches = G.PatchEmbedFn.apply(feat, P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], self.cfg.patch_size)
+            # object masks of the sampled pairs from the packed bits (V4:400-405)
+            L = patches.shape[0]
+            sh = torch.arange(64, device=dev, dtype=torch.int64)
+            om = ((t["bits"][:, :, None] >> sh) & 1).reshape(N, -1)[:, :L].to(torch.uint8)
+            sp = t["sampled"].to(dev)
+            keep = om[sp // N] | om[sp % N]
+            h = G.qformer_pairs(P, self.cfg, patches, t["ids"].to(torch.int64), t["msk"], keep)
+            out_s = h[:, :q.q_rows]                                                          # V4:185
+            logit = F.linear(out_s[:, 0], P["binary_rel_cls_pred.weight"], P["binary_rel_cls_pred.bias"]).squeeze(1)
+            bce = G.BceFn.apply(logit, t["binary"][t["sampled"]].to(dev), self.rel_cls_loss_weight)
+            # pair features of the selected pairs; pairs the sampler skipped stay zero (V4:177, 186)
+            nv = q.num_query
+            pfs = [out_s[t["where"][si], 1:] if si in t["where"] else out_s.new_zeros((nv, q.hidden)) for si in t["selected"]]
+            vis = F.linear(torch.stack(pfs), P["language_projection.weight"], P["language_projection.bias"])   # V4:294
+            llm = self.llm_engine
+            cids = t["cids"].to(torch.int64)
+            tokv = llm.embed[cids.clamp(min=0)] * (cids >= 0)[..., None].to(torch.float32)  # frozen embeddings (V4:296)
+            X = torch.cat([vis, tokv], dim=1)
+            logits = G.llama_teacher_forcing(llm, self.cfg, X, t["seq_len"], t["rpos"], t["flat_rows"].to(torch.int64))
+            rl = G.CrossEntropyRowsFn.apply(logits, t["want_lab"])
+            per_pair = self._mean_per_pair(rl, t["counts"])
+            llm_loss = torch.stack(per_pair).mean()                                          # V4:350-351
+        self.last = dict(sampled=t["sampled"], selected=t["selected"], bits=t["bits"], bce_logit=logit.detach(),
+                         llm_logits=logits.detach(), llm_row_loss=rl.detach(), llm_pair_loss=[x.detach() for x in per_pair])
+        return dict(binary_rel_cls_loss=bce, rel_llm_loss=llm_loss)
+
+    def train(self, mode: bool = True):
+        """Training mode makes the head's own parameters trainable (the fp32 masters under the reference's names; the
+        packed engine copies are rebuilt from them when the head returns to eval); the LLM stays frozen (CFG:65)."""
+        super().train(mode)
+        for p in self.parameters():
+            p.requires_grad_(bool(mode) and self.act_dtype == torch.float32)
+        if not mode:
+            self._rq_engine = None
+            self._proj_stale = True
+        return self
 
     def forward_batch(self, batch):
         """Throughput mode for several images (the reference handles one image per call, V4:112): the

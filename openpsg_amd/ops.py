@@ -458,6 +458,24 @@ def masked_mean_pool(feat, pan, img_hw, pad_hw, object_ids):
     return out
 
 
+def masked_split_mean_pool(feat, pan, img_hw, pad_hw, object_ids, output_size):
+    """`_mask_pooling(output_size > 1)` of the v1 detector (openseed_relation.py:175-200): per object, its masked pixels in
+    row-major order cut into `output_size` chunks, one mean per chunk -> [N, output_size, C] fp32."""
+    import ctypes
+    lib, ctx, st = _env(feat)
+    _, Cc, Hf, Wf = feat.shape
+    N = object_ids.numel()
+    nbytes = ctypes.c_int64(0)
+    check(lib.psg_masked_mean_pool_workspace(ctx, Cc, Hf, Wf, N, ctypes.byref(nbytes)), "psg_masked_mean_pool_workspace")
+    ws = torch.empty(nbytes.value // 4, device=feat.device, dtype=torch.int32)
+    out = torch.empty((N, int(output_size), Cc), device=feat.device, dtype=torch.float32)
+    check(lib.psg_masked_split_mean_pool(ctx, _p(feat, torch.float32), Cc, Hf, Wf, _p(pan, torch.int32, "pan_results"),
+                                         pan.shape[0], pan.shape[1], int(img_hw[0]), int(img_hw[1]), int(pad_hw[0]),
+                                         int(pad_hw[1]), _p(object_ids, torch.int32), N, int(output_size), _p(out), _p(ws),
+                                         nbytes.value, st), "psg_masked_split_mean_pool")
+    return out
+
+
 def bilinear_scores(sub, obj, num_relations):
     """einsum('nrsc,nroc->nrso') of the closed-set heads (relation_transformer_head_v2.py:204-209).
     sub / obj [B, N, R*C] fp32 (the Linear outputs before the reference's reshape + permute) -> [B, R, N, N] fp32."""

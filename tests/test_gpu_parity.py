@@ -725,6 +725,47 @@ def test_masked_mean_pool_vs_reference_formula(geo):
     assert torch.equal(got, again)                                  # deterministic
 
 
+@pytest.mark.parametrize("output_size", [1, 4, 7])
+def test_masked_split_mean_pool_vs_reference_formula(output_size):
+    """`_mask_pooling(feature, mask, output_size)` (openseed_relation.py:175-200), restated per object in fp64: pixels in
+    row-major order, torch.split into output_size chunks (the first n mod k one longer), chunk means; an object with fewer
+    pixels than chunks repeats its pixels; an object without pixels gives zeros."""
+    import numpy as np
+    import torch.nn.functional as F
+    from openpsg_amd import ops
+    from openpsg_amd.synthetic import make_scene
+    pad, ori, img, N = (768, 1024), (720, 960), (750, 1000), 12
+    sc = make_scene(pad, N, seed=9, ori_hw=ori, img_hw=img, void_id=0, force_id0=True, tiny_object=True, device="cuda:0")
+    feat, pan, meta = sc["mask_features"], sc["pan_results"], sc["img_meta"]
+    ids = torch.tensor([int(i) for i in sc["object_id_list"]], dtype=torch.int32, device="cuda:0")
+    got = ops.masked_split_mean_pool(feat, pan, meta["img_shape"][:2], meta["pad_shape"][:2], ids, output_size)
+    masks = torch.stack([(pan == i) for i in ids.tolist()]).float()[None]
+    m = F.interpolate(masks, size=meta["img_shape"][:2])
+    m = F.pad(m, (0, meta["pad_shape"][1] - meta["img_shape"][1], 0, meta["pad_shape"][0] - meta["img_shape"][0]))
+    m = F.interpolate(m, size=feat.shape[-2:])[0]
+    f = feat[0].double()
+    small = 0
+    for n in range(N):
+        mask = m[n:n + 1]
+        if mask.sum() <= 0:                                       # openseed_relation.py:182-183
+            want = f.new_zeros((output_size, f.shape[0]))
+        else:
+            feats = f[:, (mask >= 0.5)[0]]
+            if feats.shape[1] < output_size:
+                small += 1
+                feats = torch.cat([feats] * int(np.ceil(output_size / feats.shape[1])), dim=1)[:, :output_size]
+            split = [feats.shape[1] // output_size] * output_size
+            for idx in range(feats.shape[1] - sum(split)):
+                split[idx] += 1
+            want = torch.cat([x.mean(dim=1)[None] for x in torch.split(feats, split, dim=1)], dim=0)
+        err = (got[n].double() - want).abs().max().item()
+        assert err < 1e-4, (n, err)
+    print(f"split-mean pool, output_size {output_size}: objects with fewer pixels than chunks: {small}")
+    if output_size == 1:
+        mean = ops.masked_mean_pool(feat, pan, meta["img_shape"][:2], meta["pad_shape"][:2], ids)
+        assert (got[:, 0] - mean).abs().max().item() < 1e-5
+
+
 def test_head_state_dict_matches_reference_and_loads_partial_checkpoint():
     """Drop-in checkpoint contract: same parameter names/shapes as the reference module; a partial
     checkpoint (no language_model.*, part_checkpoint_hook.py:96-116) loads with strict=False."""

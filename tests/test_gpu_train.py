@@ -47,16 +47,19 @@ def test_training_losses_fp32_vs_reference(case):
     print(f"{case}: |logit| {e_logit:.2e}, |bce loss| {e_bce:.2e} of {float(g['binary_rel_cls_loss']):.3f}, "
           f"|llm loss| {e_llm:.2e} of {float(g['rel_llm_loss']):.3f}")
     assert e_logit < 1e-3 and e_bce < 5e-3 and e_llm < 1e-3
-    # forward() in training mode: raises by default (no backward: an mmdet-style loop must not sum these losses and
-    # train nothing); with the explicit opt-in it is the same call, drawing from the same generators as the reference
-    with pytest.raises(NotImplementedError):
-        head(_to_dev(inputs))
+    # forward() in training mode under no_grad: raises by default (loss values without a graph: an mmdet-style loop must
+    # not sum them and train nothing); with the explicit opt-in it is the same call, drawing from the same generators
+    # as the reference.  (With autograd enabled an fp32 head returns the losses WITH their graph: tests below.)
+    with torch.no_grad():
+        with pytest.raises(NotImplementedError):
+            head(_to_dev(inputs))
     head.train_losses_without_grad = True
     import random
     seeds = {"T1_train_512_n7": 5, "T2_train_768x1024_n9": 6}
     torch.manual_seed(seeds[case])
     random.seed(seeds[case])
-    out2 = head(_to_dev(inputs))
+    with torch.no_grad():
+        out2 = head(_to_dev(inputs))
     assert head.last["sampled"].tolist() == g["sampled"].tolist() and head.last["selected"] == g["selected"].tolist()
     assert abs(float(out2["rel_llm_loss"]) - float(out["rel_llm_loss"])) < 1e-6
 
@@ -114,3 +117,82 @@ def test_loss_kernels_vs_torch():
         got = ops.cross_entropy_rows(lg, lab)
         want = torch.nn.functional.cross_entropy(lg.double(), lab.long(), reduction="none", ignore_index=-100)
         assert (got.double() - want).abs().max().item() < 2e-4 and float(got[3]) == 0.0
+
+
+@pytest.mark.parametrize("case", TRAIN)
+def test_training_gradients_vs_autograd_on_the_oracle(case):
+    """SURVEY 8f rank 3, the gradient path (V4:327-351, 463-482; tools/train.py:239-246 back-propagates the sum of the two
+    losses, LLM frozen, CFG:65): d(binary_rel_cls_loss + rel_llm_loss) / d(every trainable tensor) from the HIP kernels of
+    csrc/psg_train_bwd.hip against torch.autograd through the CPU oracle, same draws."""
+    from openpsg_amd.categories import relation_categories
+    from oracle import psg_oracle as O
+    g, cfg, w, inputs = H.load_train_case(case)
+    head = _head(cfg, w, "fp32")
+    head.train(True)
+    out = head.forward_train_grad(_to_dev(inputs), sampled=g["sampled"], selected=g["selected"].tolist())
+    assert abs(float(out["binary_rel_cls_loss"].detach()) - float(g["binary_rel_cls_loss"])) < 5e-3
+    assert abs(float(out["rel_llm_loss"].detach()) - float(g["rel_llm_loss"])) < 1e-3
+    (out["binary_rel_cls_loss"] + out["rel_llm_loss"]).backward()
+    torch.cuda.synchronize()
+    # the oracle: same function, torch.autograd on the CPU (a many-core host oversubscribes torch's CPU kernels)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    trainable = [k for k in w if not k.startswith("language_model.")]
+    wr = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in w.items()}
+    meta = inputs["img_metas"][0]
+    ids, tmask, llm_prompt, llm_label = H.train_prompts(inputs)
+    gtm = inputs["gt_masks"][0].to_tensor(torch.float32, "cpu")
+    o = O.train_forward(wr, cfg, inputs["mask_features"], meta["masks_info"], meta["gt_rels"][0], gtm,
+                        inputs["gt_semantic_seg"][0], ids, tmask, llm_prompt, llm_label, relation_categories,
+                        sampled=g["sampled"], selected=g["selected"].tolist())
+    og = torch.autograd.grad(o["binary_rel_cls_loss"] + o["rel_llm_loss"], [wr[k] for k in trainable], allow_unused=True)
+    mine = dict(head.named_parameters())
+    worst, checked = 0.0, 0
+    for k, ref in zip(trainable, og):
+        got = mine[k].grad
+        got = torch.zeros_like(mine[k]).cpu() if got is None else got.cpu()
+        ref = torch.zeros_like(got) if ref is None else ref
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        if scale > 0:
+            checked += 1
+            if scale > 1e-4:                                    # (tensors whose true gradient is zero hold rounding noise)
+                worst = max(worst, err / scale)
+        # 2e-3 of the tensor's own gradient scale + the fp32 noise floor (the key biases have an EXACT zero gradient -
+        # softmax ignores a per-query constant - so both sides hold rounding noise of ~1e-6 there)
+        assert err <= 2e-3 * scale + 5e-6, f"{k}: max |grad - autograd| = {err:.3e} at gradient scale {scale:.3e}"
+    print(f"{case}: {checked} tensors with a non-zero gradient, worst relative deviation {worst:.2e}")
+    assert checked >= 60                                        # patch_embed, both Q-Former layers, queries, heads, projection
+    # gradients reached every trainable group, the frozen LLM has none
+    for k in ("patch_embed.proj.weight", "relation_query", "rel_cls_query", "binary_rel_cls_pred.weight",
+              "language_projection.weight", "relation_qformer.embeddings.word_embeddings.weight",
+              "relation_qformer.encoder.layer.0.crossattention.attention.key.weight"):
+        assert mine[k].grad is not None and float(mine[k].grad.abs().max()) > 0, k
+    assert not any(t.requires_grad for t in (head.llm_engine.lm_head, head.llm_engine.layers[0]["wqkv"]))
+
+
+def test_training_steps_through_forward_reduce_the_loss():
+    """An mmdet-style loop on the drop-in head: forward() in training mode returns the two losses with their graph, their
+    sum is back-propagated, AdamW (CFG:150-156: lr 1e-4, clip 0.01 replaced by a plain step here) updates the fp32
+    masters - the summed loss on the same draws goes down, and the head serves inference again after eval()."""
+    g, cfg, w, inputs = H.load_train_case(TRAIN[0])
+    head = _head(cfg, w, "fp32")
+    head.train(True)
+    opt = torch.optim.AdamW([p for p in head.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.0)
+    dev_in = _to_dev(inputs)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        out = head.forward_train_grad(dev_in, sampled=g["sampled"], selected=g["selected"].tolist())
+        total = out["binary_rel_cls_loss"] + out["rel_llm_loss"]
+        total.backward()
+        opt.step()
+        losses.append(float(total.detach()))
+    print("summed loss over 4 AdamW steps:", [round(x, 4) for x in losses])
+    assert losses[-1] < losses[0]
+    import random
+    torch.manual_seed(1)
+    random.seed(1)
+    out = head(dev_in)                                          # forward() in training mode: graph attached
+    assert out["rel_llm_loss"].requires_grad and out["binary_rel_cls_loss"].requires_grad
+    head.eval()
+    assert not any(p.requires_grad for p in head.parameters())
