@@ -137,7 +137,19 @@ class OpenSeeDRelationV2(nn.Module):
              for (results, feat), metas in zip(segs, img_metas_list)])
         return [[self._pack(results[0], out)] for (results, _), out in zip(segs, outs)]
 
+    def forward_train(self, img, img_metas, gt_bboxes=None, gt_labels=None, gt_masks=None, gt_semantic_seg=None,
+                      gt_bboxes_ignore=None, **kwargs):
+        """DET2:145-168: the (frozen) segmenter's mask features + the ground truth go to the relation head, whose two
+        losses come back with their gradient graph (fp32 head; openpsg_amd/train_graph.py).  The segmenter's own losses
+        are empty: it is frozen (DET2:72-79) and not part of this build."""
+        with torch.no_grad():
+            _, mask_features = self.forward_openseed(img, img_metas, mode='train')
+        losses = {}
+        losses.update(self.relation_head(dict(mask_features=mask_features, img_metas=img_metas, gt_labels=gt_labels,
+                                              gt_masks=gt_masks, gt_semantic_seg=gt_semantic_seg)))
+        return losses
+
     def forward(self, img=None, img_metas=None, return_loss=False, **kwargs):
         if return_loss:
-            raise NotImplementedError("training (DET2:145-168) is out of scope of this build")
+            return self.forward_train(img, img_metas, **kwargs)
         return self.simple_test(img, img_metas, **kwargs)

@@ -196,3 +196,27 @@ def test_training_steps_through_forward_reduce_the_loss():
     assert out["rel_llm_loss"].requires_grad and out["binary_rel_cls_loss"].requires_grad
     head.eval()
     assert not any(p.requires_grad for p in head.parameters())
+
+
+def test_detector_forward_train_returns_losses_with_gradients():
+    """DET2:145-168 through the drop-in detector: `forward(return_loss=True, ...)` hands the frozen segmenter's mask
+    features and the ground truth to the head and returns its two losses, graph attached."""
+    import random
+    from openpsg_amd.detector import OpenSeeDRelationV2
+    g, cfg, w, inputs = H.load_train_case(TRAIN[0])
+    head = _head(cfg, w, "fp32")
+    dev_in = _to_dev(inputs)
+
+    class FixedSegmenter:                                       # stands for OpenSeeD's (frozen) feature extractor
+        def __call__(self, img, meta):
+            return torch.zeros((4, 4), dtype=torch.int32, device="cuda:0"), [], dev_in["mask_features"]
+    det = OpenSeeDRelationV2(relation_head=head, segmenter=FixedSegmenter())
+    det.train(True)
+    torch.manual_seed(5)
+    random.seed(5)
+    losses = det(img=None, img_metas=dev_in["img_metas"], return_loss=True, gt_labels=None, gt_masks=dev_in["gt_masks"],
+                 gt_semantic_seg=dev_in["gt_semantic_seg"])
+    assert set(losses) == {"binary_rel_cls_loss", "rel_llm_loss"}
+    assert abs(float(losses["rel_llm_loss"].detach()) - float(g["rel_llm_loss"])) < 1e-3       # same draws as the capture
+    sum(losses.values()).backward()
+    assert float(head.language_projection.weight.grad.abs().max()) > 0
