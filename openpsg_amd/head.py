@@ -649,8 +649,12 @@ class RelationTransformerHeadV4(nn.Module):
             ph = np.arange(c0, c1, dtype=np.int64)
             uniq_h, inv_h = np.unique(uidx[ph // N] * U + uidx[ph % N], return_inverse=True)
             uniq = torch.from_numpy(uniq_h).to(self.device)
+            # (ids, mask) of the distinct prompts, every pair's row in that table, and - names-only index arithmetic the
+            # engine would otherwise redo on the device for every image - the 33 query rows of each pair's prompt block
+            nq = self.cfg.qformer.q_rows
+            rows33 = (inv_h.astype(np.int64)[:, None] * nq + np.arange(nq)[None, :]).reshape(-1).astype(np.int32)
             prompts = (tbl_d[uniq].contiguous(), msk_d[uniq].contiguous(),
-                       torch.from_numpy(inv_h.astype(np.int32)).to(self.device))
+                       torch.from_numpy(inv_h.astype(np.int32)).to(self.device), torch.from_numpy(rows33).to(self.device))
             ent = self._gather_cache[gk] = (pidx.to(torch.int32), tbl_d[trow].contiguous(), msk_d[trow].contiguous(),
                                             prompts)
         return ent

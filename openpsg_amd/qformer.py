@@ -205,8 +205,9 @@ class RelationQueryEngine:
         rows only as keys / values, so the cls row of all P pairs is computed here with the full K/V and rows 1..32
         are computed afterwards for the chosen pairs (`pair_hidden`) - identical results, the last layer's query-row
         work shrinks from 33 rows to 1 for all but the selected pairs.
-        prompts = (ids_u int32 [U, T], mask_u uint8 [U, T], inv int32 [P]): the distinct prompts of these pairs and
-        each pair's row in that table (ids == ids_u[inv]); lets the prompt-only work run on U rows instead of P.
+        prompts = (ids_u int32 [U, T], mask_u uint8 [U, T], inv int32 [P][, rows int32 [P*33]]): the distinct prompts of
+        these pairs and each pair's row in that table (ids == ids_u[inv]); lets the prompt-only work run on U rows instead
+        of P.  rows (optional, cached by the caller) = inv[p] * 33 + r, the query rows of each pair's prompt block.
         Returns (state, exist_logit [P], exist_prob [P]); state feeds `pair_hidden`."""
         q = self.cfg.qformer
         nq, H = q.q_rows, q.hidden
@@ -270,7 +271,7 @@ class RelationQueryEngine:
         cross-attention at all: their layer-0 output - the last layer's text keys / values - is per prompt too."""
         q = self.cfg.qformer
         nq, H = q.q_rows, q.hidden
-        ids_u, mask_u, inv = prompts
+        ids_u, mask_u, inv = prompts[:3]
         U, T = ids_u.shape
         P = inv.numel()
         RQu = U * nq
@@ -300,7 +301,10 @@ class RelationQueryEngine:
         # gathered per pair - the cross-attention kernel streams its Q tiles by DMA and takes no index), the residual
         # of the output LayerNorm is read from the prompt's block through the index
         qx_u = F.linear(A[:RQu], L["wq_x"], L["bq_x"])
-        rows = (inv.to(torch.int64)[:, None] * nq + torch.arange(nq, device=self.device)[None, :]).reshape(-1).to(torch.int32)
+        if len(prompts) > 3:                                              # cached with the prompt table (names only)
+            rows = prompts[3]
+        else:
+            rows = (inv.to(torch.int64)[:, None] * nq + torch.arange(nq, device=self.device)[None, :]).reshape(-1).to(torch.int32)
         qx = torch.empty((P * nq, H), device=self.device, dtype=self.dtype)
         ops.gather_rows(qx_u, rows, qx)
         cx = self._cross(0, qx, nq, kv, bits, num_objects, pair_index, None)
