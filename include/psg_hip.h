@@ -55,7 +55,8 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  * library was built with; a binding compares it with the PSG_ABI_VERSION of the header it was written against
  * (openpsg_amd/_lib.py does, at load time) instead of passing shifted arguments silently.
  *   100  round 1        200  round 2 (psg_skinny_gemm / psg_rope_kvwrite gained, psg_qformer_cross_attn lost an argument)
- *   300  round 3 (psg_rmsnorm: resid_dtype; psg_train_* gradient kernels added) */
+ *   300  round 3 (psg_rmsnorm: resid_dtype; psg_train_* gradient kernels, psg_add_layernorm_res32,
+ *        psg_masked_split_mean_pool added) */
 #define PSG_ABI_VERSION 300
 int psg_version(void);
 const char* psg_last_error(void);
@@ -120,6 +121,12 @@ int psg_add_layernorm_periodic(psg_ctx*, const void* x, const void* residual_tab
 int psg_add_layernorm_indexed(psg_ctx*, const void* x, const void* residual_table, const int32_t* block_index, int group,
                               const float* bias, const float* gamma, const float* beta, float eps, int64_t rows,
                               int hidden, void* out, int dtype, void* stream);
+/* mixed mode (16-bit GEMM operands, fp32 residual stream): x = 16-bit projection output, residual = fp32 (plain:
+ * res_period 0; periodic: res_period = table rows; indexed: res_period = group, res_index = block per group); the result is
+ * written as fp32 (out32: the next residual, never rounded to 16 bits) and / or 16-bit (out16: the next operand). */
+int psg_add_layernorm_res32(psg_ctx*, const void* x, const float* residual, int res_period, const int32_t* res_index,
+                            const float* bias, const float* gamma, const float* beta, float eps, int64_t rows,
+                            int hidden, void* out16, float* out32, int dtype, void* stream);
 
 /* ---- BertIntermediate activation, HF-IB:563-577: out = gelu_erf(x + bias); bias may be NULL. */
 int psg_bias_gelu(psg_ctx*, const void* x, const float* bias, int64_t rows, int cols, void* out,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "psg_add_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _i, _vp],
     "psg_add_layernorm_periodic": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _i64, _i, _vp, _i, _vp],
     "psg_add_layernorm_indexed": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _i64, _i, _vp, _i, _vp],
+    "psg_add_layernorm_res32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _i, _vp],
     "psg_bias_gelu": [_vp, _vp, _vp, _i64, _i, _vp, _i, _vp],
     "psg_qformer_self_attn": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "psg_qformer_self_attn_cls": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp],

@@ -210,6 +210,74 @@ __global__ void __launch_bounds__(256) add_layernorm16_kernel(const uint16_t* __
   }
 }
 
+// Mixed mode (16-bit GEMM operands, fp32 residual stream): x is the 16-bit output of a projection, the residual is the
+// fp32 copy of the previous LayerNorm's output, and the result is written twice - fp32 (the next residual, never
+// rounded to 16 bits) and 16-bit (the next projection's operand).  A wave per row of 768; the residual row follows the
+// same plain / periodic / indexed rules as add_layernorm_kernel.
+template <typename E>
+__global__ void __launch_bounds__(256) add_layernorm_res32_kernel(const uint16_t* __restrict__ x, const float* __restrict__ res,
+                                                                  const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps, int64_t rows,
+                                                                  uint16_t* __restrict__ out16, float* __restrict__ out32,
+                                                                  int res_period, const int32_t* __restrict__ res_index) {
+  constexpr int H = 768;
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  int64_t rrow = res_period > 0 ? row % res_period : row;
+  if (res_index) rrow += (int64_t)res_index[row / res_period] * res_period;
+  float v[3][4];
+  uint2 xw[3];
+  float4 rw[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int col = c * 256 + lane * 4;
+    xw[c] = *reinterpret_cast<const uint2*>(x + row * H + col);
+    if (res) rw[c] = *reinterpret_cast<const float4*>(res + rrow * H + col);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int col = c * 256 + lane * 4;
+    v[c][0] = E::to_f32((uint16_t)(xw[c].x & 0xffffu));
+    v[c][1] = E::to_f32((uint16_t)(xw[c].x >> 16));
+    v[c][2] = E::to_f32((uint16_t)(xw[c].y & 0xffffu));
+    v[c][3] = E::to_f32((uint16_t)(xw[c].y >> 16));
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + col);
+      v[c][0] += b.x; v[c][1] += b.y; v[c][2] += b.z; v[c][3] += b.w;
+    }
+    if (res) {
+      v[c][0] += rw[c].x; v[c][1] += rw[c].y; v[c][2] += rw[c].z; v[c][3] += rw[c].w;
+    }
+  }
+  ln_row<3>(v, H, eps, gamma, beta, lane);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int col = c * 256 + lane * 4;
+    if (out32) *reinterpret_cast<float4*>(out32 + row * H + col) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+    if (out16)
+      *reinterpret_cast<uint2*>(out16 + row * H + col) = make_uint2(E::pack(v[c][0], v[c][1]), E::pack(v[c][2], v[c][3]));
+  }
+}
+
+extern "C" int psg_add_layernorm_res32(psg_ctx* ctx, const void* x, const float* residual, int res_period,
+                                       const int32_t* res_index, const float* bias, const float* gamma, const float* beta,
+                                       float eps, int64_t rows, int hidden, void* out16, float* out32, int dtype,
+                                       void* stream) {
+  PSG_REQUIRE(ctx && x && gamma && beta && (out16 || out32), PSG_ERR_INVALID, "psg_add_layernorm_res32: NULL argument");
+  PSG_REQUIRE(hidden == 768, PSG_ERR_UNSUPPORTED, "psg_add_layernorm_res32: hidden=%d (kernel is built for 768)", hidden);
+  PSG_REQUIRE(res_period >= 0 && (!res_index || (res_period > 0 && rows % res_period == 0)), PSG_ERR_INVALID,
+              "psg_add_layernorm_res32: res_period=%d rows=%lld", res_period, (long long)rows);
+  if (rows == 0) return PSG_OK;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  PSG_DISPATCH_E16(dtype, "psg_add_layernorm_res32",
+                   (add_layernorm_res32_kernel<E><<<grid, 256, 0, (hipStream_t)stream>>>(
+                       (const uint16_t*)x, residual, bias, gamma, beta, eps, rows, (uint16_t*)out16, out32, res_period,
+                       res_index)));
+  PSG_CHECK_LAUNCH("psg_add_layernorm_res32");
+  return PSG_OK;
+}
+
 static int add_layernorm_launch(const char* who, psg_ctx* ctx, const void* x, const void* residual, int res_period,
                                 const int32_t* res_index, const float* bias, const float* gamma, const float* beta, float eps, int64_t rows,
                                 int hidden, void* out, int dtype, void* stream) {

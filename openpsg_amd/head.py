@@ -33,6 +33,7 @@ from .weights import head_shapes, llm_shapes
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
            "fp16": torch.float16, "float16": torch.float16, "half": torch.float16, "mixed": torch.float16,
+           "mixed_q32": torch.float16,
            torch.bfloat16: torch.bfloat16, torch.float32: torch.float32, torch.float16: torch.float16}
 
 
@@ -96,8 +97,13 @@ class RelationTransformerHeadV4(nn.Module):
                  dtype="bf16",                 # activation/weight dtype of the GPU path: 'bf16' | 'fp16' (both on the
                                                # matrix cores) | 'fp32' (verification mode) | 'mixed' = fp16 GEMM
                                                # operands with residual_dtype='fp32'
-                 residual_dtype=None,          # storage type of the residual streams: None = `dtype` (what HF keeps
-                                               # for a model cast to 16 bits) | 'fp32' (never rounded to 16 bits)
+                 residual_dtype=None,          # storage type of the Llama residual stream: None = `dtype` (what HF keeps for
+                                               # a model cast to 16 bits) | 'fp32' (never rounded to 16 bits; at 32 layers
+                                               # 15 % closer to the fp32 engine for +0.2 % time, tests/test_gpu_llm7b.py)
+                 qformer_residual_dtype=None,  # the same for the Q-Former's LayerNorm chain (every LayerNorm then reads an
+                                               # fp32 residual and writes fp32 + 16-bit copies).  Built and measured: no
+                                               # accuracy gain on the five goldens or the bench scene (two post-LN layers
+                                               # of O(1) values), relation query +0.28 ms - so 'mixed' leaves it off
                  device=None,                  # None -> RelationTransformerHeadV4.default_device
                  qformer_vocab_size=30522,
                  llm_config: LlamaConfig | None = None,
@@ -153,11 +159,16 @@ class RelationTransformerHeadV4(nn.Module):
         self.cls_first = bool(cls_first)
         self.train_losses_without_grad = bool(train_losses_without_grad)
         self.act_dtype = _DTYPES[dtype]
-        if residual_dtype is None and dtype == "mixed":
+        if residual_dtype is None and dtype in ("mixed", "mixed_q32"):
             residual_dtype = "fp32"
+        if qformer_residual_dtype is None and dtype == "mixed_q32":    # 'mixed' + the Q-Former's residual chain in fp32
+            qformer_residual_dtype = "fp32"
         self.resid_dtype = self.act_dtype if residual_dtype is None else _DTYPES[residual_dtype]
         if self.resid_dtype not in (self.act_dtype, torch.float32):
             raise PsgHipError(f"residual_dtype must be the activation dtype or 'fp32', got {residual_dtype!r}")
+        self.q_resid_dtype = self.act_dtype if qformer_residual_dtype is None else _DTYPES[qformer_residual_dtype]
+        if self.q_resid_dtype not in (self.act_dtype, torch.float32):
+            raise PsgHipError(f"qformer_residual_dtype must be the activation dtype or 'fp32', got {qformer_residual_dtype!r}")
         self.device = torch.device(self.default_device if device is None else device)
         if tokenizers is None:
             tokenizers = self.default_tokenizers
@@ -254,7 +265,8 @@ class RelationTransformerHeadV4(nn.Module):
     def rq_engine(self) -> RelationQueryEngine:
         if self._rq_engine is None:
             w = {k: v.data for k, v in self.named_parameters()}
-            self._rq_engine = RelationQueryEngine(w, self.cfg, self.device, self.act_dtype, self.xattn_variant)
+            self._rq_engine = RelationQueryEngine(w, self.cfg, self.device, self.act_dtype, self.xattn_variant,
+                                                  resid_dtype=self.q_resid_dtype)
             self._proj_stale = True              # language_projection may have been (re)loaded: see llm_engine
         return self._rq_engine
 

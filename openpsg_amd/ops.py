@@ -145,6 +145,27 @@ def add_layernorm_indexed(x, residual_table, block_index, group, bias, gamma, be
     return out
 
 
+def add_layernorm_res32(x, residual32, bias, gamma, beta, eps, out16=None, out32=None, period=0, index=None,
+                        want16=True, want32=True):
+    """Mixed mode: LayerNorm(x (16-bit) + bias + residual32 (fp32; plain, `period`-periodic table, or table blocks chosen
+    by `index` per group of `period` rows)) -> (16-bit copy in place of x unless out16 is given, fp32 copy)."""
+    lib, ctx, st = _env(x)
+    rows, hidden = x.shape
+    if want16 and out16 is None:
+        out16 = x
+    if want32 and out32 is None:
+        out32 = torch.empty((rows, hidden), device=x.device, dtype=torch.float32)
+    if residual32 is not None:
+        assert residual32.dtype == torch.float32 and residual32.shape[1] == hidden
+        assert period > 0 or residual32.shape[0] == rows
+    check(lib.psg_add_layernorm_res32(ctx, _p(x), _p(residual32, torch.float32, "residual"), int(period),
+                                      _p(index, torch.int32, "index"), _p(bias, torch.float32), _p(gamma, torch.float32),
+                                      _p(beta, torch.float32), float(eps), rows, hidden,
+                                      _p(out16, x.dtype) if want16 else None, _p(out32, torch.float32) if want32 else None,
+                                      _dt(x), st), "psg_add_layernorm_res32")
+    return (out16 if want16 else None), (out32 if want32 else None)
+
+
 def bias_gelu(x, bias=None, out=None):
     lib, ctx, st = _env(x)
     out = x if out is None else out

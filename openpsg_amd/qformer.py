@@ -29,10 +29,14 @@ from .config import PSGConfig
 
 
 class RelationQueryEngine:
-    def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, xattn_variant=None):
+    def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, xattn_variant=None, resid_dtype=None):
+        """resid_dtype=torch.float32 with a 16-bit `dtype` = mixed mode: the projections keep 16-bit operands, but every
+        LayerNorm reads its residual in fp32 and writes its result twice - fp32 (the next residual: the residual stream is
+        never rounded to 16 bits) and 16-bit (the next projection's operand); psg_add_layernorm_res32."""
         if dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise PsgHipError(f"activation dtype must be float32, bfloat16 or float16, got {dtype}")
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.res32 = resid_dtype == torch.float32 and dtype != torch.float32
         self.xattn_variant = xattn_variant
         q = cfg.qformer
         f32 = lambda k: weights[k].to(device=self.device, dtype=torch.float32).contiguous()  # noqa: E731
@@ -105,8 +109,10 @@ class RelationQueryEngine:
         return [(F.linear(pa, L["wk_x"], L["bk_x"]), F.linear(pa, L["wv_x"], L["bv_x"])) for L in self.layers]
 
     # ---- A6 + A7: Q-Former over a list of pairs ---------------------------------------------------
+    # Activations travel as (X, X32): X in the activation dtype (the projections' operand), X32 its fp32 twin in mixed mode
+    # (the residual of the next LayerNorm), else None.
     def _embed(self, ids):
-        """HF-IB:728-757 for P pairs.  Returns (X [P*(33+T), 768], shared0): with shared0 the embedded query rows are
+        """HF-IB:728-757 for P pairs.  Returns (X [P*(33+T), 768], X32, shared0): with shared0 the embedded query rows are
         ONE [33, 768] block for all pairs (learned tokens through the embedding LayerNorm; 16-bit modes): layer 0
         projects it once and uses it as a periodic residual, so rows [33, P*33) of X stay unwritten."""
         q = self.cfg.qformer
@@ -114,14 +120,38 @@ class RelationQueryEngine:
         P, T = ids.shape
         R, RQ = P * (nq + T), P * nq
         X = torch.empty((R, H), device=self.device, dtype=self.dtype)
+        X32 = torch.empty((R, H), device=self.device, dtype=torch.float32) if self.res32 else None
+        first = X32 if self.res32 else X
         shared0 = (len(self.layers) > 1 and T > 0 and self.dtype != torch.float32 and self.share_query_qkv)
         if shared0:
             ops.qformer_embed_split(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
-                                    q.ln_eps, X[:nq], X[RQ:])
+                                    q.ln_eps, first[:nq], first[RQ:])
+            if self.res32:
+                X[:nq].copy_(X32[:nq])
+                X[RQ:].copy_(X32[RQ:])
         else:
             ops.qformer_embed(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
-                              q.ln_eps, X)
-        return X, shared0
+                              q.ln_eps, first)
+            if self.res32:
+                X.copy_(X32)
+        return X, X32, shared0
+
+    def _ln(self, x, r16, r32, bias, ln, out16=None, period=0, index=None, want32=True):
+        """LayerNorm(x + bias + residual) -> (result in the activation dtype - in place of x unless out16 is given -,
+        fp32 twin or None).  period / index: residual rows from a periodic table / from table blocks chosen per group."""
+        eps = self.cfg.qformer.ln_eps
+        if self.res32:
+            return ops.add_layernorm_res32(x, r32, bias, ln[0], ln[1], eps, out16=out16, period=period, index=index,
+                                           want32=want32)
+        if index is not None:
+            return ops.add_layernorm_indexed(x, r16, index, period, bias, ln[0], ln[1], eps, out=out16), None
+        if period:
+            return ops.add_layernorm_periodic(x, r16, bias, ln[0], ln[1], eps, out=out16), None
+        return ops.add_layernorm(x, r16, bias, ln[0], ln[1], eps, out=out16), None
+
+    @staticmethod
+    def _s(t, a, b=None):
+        return None if t is None else (t[a:] if b is None else t[a:b])
 
     def _cross(self, li, qx, nq, kv, bits, num_objects, pair_index, segments):
         """Masked cross-attention of `nq` rows per pair (33, or 1 = the cls row alone) against the image's patches."""
@@ -136,8 +166,10 @@ class RelationQueryEngine:
                                    empty_policy=self.empty_policy, variant=self.xattn_variant)
         return cx
 
-    def _layer(self, li, X, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0=False, hidden_out=None):
-        """One Q-Former layer (HF-IB:446-596) over P pairs; the last layer computes the query rows only."""
+    def _layer(self, li, X, X32, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0=False,
+               hidden_out=None):
+        """One Q-Former layer (HF-IB:446-596) over P pairs; the last layer computes the query rows only.
+        Returns (Xn, Xn32)."""
         q = self.cfg.qformer
         nq, H = q.q_rows, q.hidden
         R, RQ = P * (nq + T), P * nq
@@ -155,32 +187,43 @@ class RelationQueryEngine:
         del qkv
         ra = RQ if last else R
         A = F.linear(ctx[:ra], L["wo"])
+        A32 = torch.empty((ra, H), device=self.device, dtype=torch.float32) if self.res32 else None
         if li == 0 and shared0:
-            ops.add_layernorm_periodic(A[:RQ], X[:nq], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
-            ops.add_layernorm(A[RQ:], X[RQ:], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+            self._ln_into(A[:RQ], X[:nq], self._s(X32, 0, nq), L["bo"], L["ln_a"], self._s(A32, 0, RQ), period=nq)
+            self._ln_into(A[RQ:], X[RQ:], self._s(X32, RQ), L["bo"], L["ln_a"], self._s(A32, RQ))
         else:
-            ops.add_layernorm(A, X[:ra], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+            self._ln_into(A, X[:ra], self._s(X32, 0, ra), L["bo"], L["ln_a"], A32)
         del ctx
         qx = F.linear(A[:RQ], L["wq_x"], L["bq_x"])
         cx = self._cross(li, qx, nq, kv, bits, num_objects, pair_index, segments)
         Cq = F.linear(cx, L["wo_x"])
-        ops.add_layernorm(Cq, A[:RQ], L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
+        _, Cq32 = self._ln(Cq, A[:RQ], self._s(A32, 0, RQ), L["bo_x"], L["ln_x"])
         del qx, cx
         if last and hidden_out is not None:
             assert hidden_out.shape == (RQ, H) and hidden_out.dtype == self.dtype and hidden_out.is_contiguous()
             Xn = hidden_out
         else:
             Xn = torch.empty((RQ if last else R, H), device=self.device, dtype=self.dtype)
+        Xn32 = torch.empty((Xn.shape[0], H), device=self.device, dtype=torch.float32) if self.res32 else None
         iq = self._ffn1(Cq, L["w1q"], L["b1q"])
         hq = F.linear(iq, L["w2q"])
-        ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps, out=Xn[:RQ])
+        self._ln_into(hq, Cq, Cq32, L["b2q"], L["ln_q"], self._s(Xn32, 0, RQ), out16=Xn[:RQ])
         del iq, hq
         if not last and T > 0:
             it = self._ffn1(A[RQ:], L["w1t"], L["b1t"])
             ht = F.linear(it, L["w2t"])
-            ops.add_layernorm(ht, A[RQ:], L["b2t"], L["ln_t"][0], L["ln_t"][1], q.ln_eps, out=Xn[RQ:])
+            self._ln_into(ht, A[RQ:], self._s(A32, RQ), L["b2t"], L["ln_t"], self._s(Xn32, RQ), out16=Xn[RQ:])
             del it, ht
-        return Xn
+        return Xn, Xn32
+
+    def _ln_into(self, x, r16, r32, bias, ln, out32, out16=None, period=0, index=None):
+        """_ln writing its fp32 twin into a caller-owned slice (mixed mode); returns (16-bit result, out32)."""
+        eps = self.cfg.qformer.ln_eps
+        if self.res32:
+            o16, _ = ops.add_layernorm_res32(x, r32, bias, ln[0], ln[1], eps, out16=out16, out32=out32, period=period,
+                                             index=index)
+            return o16, out32
+        return self._ln(x, r16, None, bias, ln, out16=out16, period=period, index=index)
 
     def forward_pairs(self, kv, bits, num_objects, pair_index, ids, text_mask, hidden_out=None, segments=None):
         """pair_index int32 [P] (p = i*N + j), ids int32 [P,T], text_mask uint8 [P,T].
@@ -189,11 +232,11 @@ class RelationQueryEngine:
         segments: [(first pair, pair count, kv, bits, num_objects)] - the pairs come from several images (pair
         sharding); everything but the cross-attention runs over all of them at once."""
         P, T = ids.shape
-        X, shared0 = self._embed(ids)
+        X, X32, shared0 = self._embed(ids)
         for li in range(len(self.layers)):
-            X = self._layer(li, X, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0,
-                            hidden_out if li == len(self.layers) - 1 else None)
-        logit, prob = ops.exist_head(X, self.exist_w, self.exist_b, P, self.cfg.qformer.q_rows)
+            X, X32 = self._layer(li, X, X32, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0,
+                                 hidden_out if li == len(self.layers) - 1 else None)
+        logit, prob = ops.exist_head(X32 if X32 is not None else X, self.exist_w, self.exist_b, P, self.cfg.qformer.q_rows)
         return X, logit, prob
 
     def forward_pairs_cls(self, kv, bits, num_objects, pair_index, ids, text_mask, segments=None, prompts=None):
@@ -220,22 +263,24 @@ class RelationQueryEngine:
         if (prompts is not None and segments is None and nl == 2 and T > 0 and in_space and self.dedup_prompts
                 and prompts[0].shape[0] <= 0.9 * P):
             return self._forward_pairs_cls_dedup(kv, bits, num_objects, pair_index, text_mask, prompts)
-        X, shared0 = self._embed(ids)
+        X, X32, shared0 = self._embed(ids)
         for li in range(nl - 1):
-            X = self._layer(li, X, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0)
-        logit, prob = self._cls_phase(X[:RQ], X[RQ:], None, text_mask, P, T, kv, bits, num_objects, pair_index, segments,
-                                      in_space, X)
-        state = dict(X=X, P=P, T=T, text_mask=text_mask, pair_index=pair_index, kv=kv, bits=bits,
+            X, X32 = self._layer(li, X, X32, P, T, text_mask, pair_index, kv, bits, num_objects, segments, shared0)
+        logit, prob = self._cls_phase(X[:RQ], self._s(X32, 0, RQ), X[RQ:], None, text_mask, P, T, kv, bits, num_objects,
+                                      pair_index, segments, in_space, X)
+        state = dict(X=X, X32=X32, P=P, T=T, text_mask=text_mask, pair_index=pair_index, kv=kv, bits=bits,
                      num_objects=num_objects, segments=segments)
         return state, logit, prob
 
-    def _cls_phase(self, Xq, Xt, text_index, mask, P, T, kv, bits, num_objects, pair_index, segments, in_space, X=None):
-        """Last layer for the cls row of every pair.  Xq [P*33, H] query rows entering the layer; Xt: text rows, block
-        text_index[p] (None: block p) per pair, `mask` indexed the same way.  X: the two as one tensor (K | V form)."""
+    def _cls_phase(self, Xq, Xq32, Xt, text_index, mask, P, T, kv, bits, num_objects, pair_index, segments, in_space, X=None):
+        """Last layer for the cls row of every pair.  Xq [P*33, H] query rows entering the layer (Xq32: fp32 twin); Xt:
+        text rows, block text_index[p] (None: block p) per pair, `mask` indexed the same way.  X: the two as one tensor
+        (K | V form)."""
         q = self.cfg.qformer
         nq, H = q.q_rows, q.hidden
         li, L = len(self.layers) - 1, self.layers[-1]
         x_cls = Xq.view(P, nq, H)[:, 0].contiguous()                         # [P, H] residual of the cls rows
+        x_cls32 = Xq32.view(P, nq, H)[:, 0].contiguous() if Xq32 is not None else None
         q_cls = F.linear(x_cls, L["wqkv"][:H], L["bqkv"][:H])              # queries of the cls rows only
         hd = H // q.heads
         if in_space:
@@ -254,15 +299,15 @@ class RelationQueryEngine:
             ctx = ops.qformer_self_attn_cls(q_cls, kvs, mask, P, T, nq, q.heads)
             del kvs
         A = F.linear(ctx, L["wo"])
-        ops.add_layernorm(A, x_cls, L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+        _, A32 = self._ln(A, x_cls, x_cls32, L["bo"], L["ln_a"])
         qx = F.linear(A, L["wq_x"], L["bq_x"])
         cx = self._cross(li, qx, 1, kv, bits, num_objects, pair_index, segments)
         Cq = F.linear(cx, L["wo_x"])
-        ops.add_layernorm(Cq, A, L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
+        _, Cq32 = self._ln(Cq, A, A32, L["bo_x"], L["ln_x"])
         iq = self._ffn1(Cq, L["w1q"], L["b1q"])
         hq = F.linear(iq, L["w2q"])
-        Xc = ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps)
-        return ops.exist_head(Xc, self.exist_w, self.exist_b, P, 1)
+        Xc, Xc32 = self._ln(hq, Cq, Cq32, L["b2q"], L["ln_q"])
+        return ops.exist_head(Xc32 if Xc32 is not None else Xc, self.exist_w, self.exist_b, P, 1)
 
     def _forward_pairs_cls_dedup(self, kv, bits, num_objects, pair_index, text_mask, prompts):
         """forward_pairs_cls with the prompt-only work done per DISTINCT prompt (two layers).  Layer 0's input is the
@@ -276,7 +321,7 @@ class RelationQueryEngine:
         P = inv.numel()
         RQu = U * nq
         L = self.layers[0]
-        Xu, shared0 = self._embed(ids_u)
+        Xu, Xu32, shared0 = self._embed(ids_u)
         ctx = torch.empty((U * (nq + T), H), device=self.device, dtype=self.dtype)
         if shared0:
             qkv_q = F.linear(Xu[:nq], L["wqkv"], L["bqkv"])
@@ -287,15 +332,16 @@ class RelationQueryEngine:
             ops.qformer_self_attn(qkv, mask_u, U, T, nq, q.heads, False, ctx)
         del qkv
         A = F.linear(ctx, L["wo"])
+        A32 = torch.empty((A.shape[0], H), device=self.device, dtype=torch.float32) if self.res32 else None
         if shared0:
-            ops.add_layernorm_periodic(A[:RQu], Xu[:nq], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
-            ops.add_layernorm(A[RQu:], Xu[RQu:], L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+            self._ln_into(A[:RQu], Xu[:nq], self._s(Xu32, 0, nq), L["bo"], L["ln_a"], self._s(A32, 0, RQu), period=nq)
+            self._ln_into(A[RQu:], Xu[RQu:], self._s(Xu32, RQu), L["bo"], L["ln_a"], self._s(A32, RQu))
         else:
-            ops.add_layernorm(A, Xu, L["bo"], L["ln_a"][0], L["ln_a"][1], q.ln_eps)
+            self._ln_into(A, Xu, Xu32, L["bo"], L["ln_a"], A32)
         del ctx
         it = self._ffn1(A[RQu:], L["w1t"], L["b1t"])                        # text rows: straight to their layer-0 output
         ht = F.linear(it, L["w2t"])
-        Xt_u = ops.add_layernorm(ht, A[RQu:], L["b2t"], L["ln_t"][0], L["ln_t"][1], q.ln_eps)
+        Xt_u, Xt_u32 = self._ln(ht, A[RQu:], self._s(A32, RQu), L["b2t"], L["ln_t"])
         del it, ht
         # the pair enters at the cross-attention: its queries are its prompt's 33 projected rows (projected per prompt,
         # gathered per pair - the cross-attention kernel streams its Q tiles by DMA and takes no index), the residual
@@ -309,15 +355,15 @@ class RelationQueryEngine:
         ops.gather_rows(qx_u, rows, qx)
         cx = self._cross(0, qx, nq, kv, bits, num_objects, pair_index, None)
         Cq = F.linear(cx, L["wo_x"])
-        ops.add_layernorm_indexed(Cq, A[:RQu], inv, nq, L["bo_x"], L["ln_x"][0], L["ln_x"][1], q.ln_eps)
+        _, Cq32 = self._ln(Cq, A[:RQu], self._s(A32, 0, RQu), L["bo_x"], L["ln_x"], period=nq, index=inv)
         del qx, cx, qx_u
         iq = self._ffn1(Cq, L["w1q"], L["b1q"])
         hq = F.linear(iq, L["w2q"])
-        Xq = ops.add_layernorm(hq, Cq, L["b2q"], L["ln_q"][0], L["ln_q"][1], q.ln_eps)
+        Xq, Xq32 = self._ln(hq, Cq, Cq32, L["b2q"], L["ln_q"])
         del iq, hq, Cq
-        logit, prob = self._cls_phase(Xq, Xt_u, inv, mask_u, P, T, kv, bits, num_objects, pair_index, None, True)
-        state = dict(Xq=Xq, Xt_u=Xt_u, inv=inv, P=P, T=T, text_mask=text_mask, pair_index=pair_index, kv=kv, bits=bits,
-                     num_objects=num_objects, segments=None)
+        logit, prob = self._cls_phase(Xq, Xq32, Xt_u, inv, mask_u, P, T, kv, bits, num_objects, pair_index, None, True)
+        state = dict(Xq=Xq, Xq32=Xq32, Xt_u=Xt_u, Xt_u32=Xt_u32, inv=inv, P=P, T=T, text_mask=text_mask,
+                     pair_index=pair_index, kv=kv, bits=bits, num_objects=num_objects, segments=None)
         return state, logit, prob
 
     def pair_hidden(self, state, sel, segments=None):
@@ -333,18 +379,24 @@ class RelationQueryEngine:
         K = s64.numel()
         ar = torch.arange(nq, device=self.device)
         rows = [(s64[:, None] * nq + ar[None, :]).reshape(-1)]
+        Xs32 = None
         if "Xt_u" in state:                                                  # text rows live in the per-prompt table
             trows = (state["inv"].to(torch.int64).index_select(0, s64)[:, None] * T
                      + torch.arange(T, device=self.device)[None, :]).reshape(-1)
             Xs = torch.cat([state["Xq"].index_select(0, rows[0]), state["Xt_u"].index_select(0, trows)])
+            if state.get("Xq32") is not None:
+                Xs32 = torch.cat([state["Xq32"].index_select(0, rows[0]), state["Xt_u32"].index_select(0, trows)])
         else:
             if T > 0:
                 rows.append((P * nq + s64[:, None] * T + torch.arange(T, device=self.device)[None, :]).reshape(-1))
-            Xs = state["X"].index_select(0, torch.cat(rows))                # [K*(33+T), 768]: query rows, then text rows
+            allrows = torch.cat(rows)
+            Xs = state["X"].index_select(0, allrows)                        # [K*(33+T), 768]: query rows, then text rows
+            if state.get("X32") is not None:
+                Xs32 = state["X32"].index_select(0, allrows)
         tm = state["text_mask"].index_select(0, s64) if T > 0 else state["text_mask"]
         pi = state["pair_index"].index_select(0, s64)
-        return self._layer(len(self.layers) - 1, Xs, K, T, tm, pi, state["kv"], state["bits"], state["num_objects"],
-                           segments)
+        return self._layer(len(self.layers) - 1, Xs, Xs32, K, T, tm, pi, state["kv"], state["bits"], state["num_objects"],
+                           segments)[0]
 
     def _bmm_f32(self, a, b, b32):
         """fp32 result of a batched product of activation-dtype operands (exact products, fp32 accumulation): the

@@ -309,18 +309,27 @@ def test_rope_kvwrite_split_inputs_vs_fp32_torch(splits):
         assert torch.isnan(kcc[kk, :, int(lens[kk]):]).all()
 
 
-# ---- fp16 activation mode (BASELINE config 5) -------------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["G1_c1_512_n10", "G5_c5geo_1024x1344_n8"])
-def test_fp16_mode_vs_reference(case):
-    """The same matrix-core kernels with the fp16 MFMA opcodes: 11 mantissa bits instead of bf16's 8, so the fp16
-    path must sit closer to the fp32 reference than the bf16 path does on the same case."""
+# ---- fp16 / mixed modes (BASELINE config 5 names fp16; mixed = the bench headline) -----------------------------------------
+_MODE_TABLE = {}
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fp16_and_mixed_modes_vs_reference(case):
+    """The same matrix-core kernels with the fp16 MFMA opcodes (11 mantissa bits instead of bf16's 8), and the mixed mode
+    (fp16 operands, fp32 Llama residual stream) that bench.py reports as its headline.  With the reference's selection
+    injected, on every golden: existence logits within 0.03 of the reference (bf16: 0.06-0.2), the reference's top-20
+    reproduced, most selected pairs decoding the reference's exact token sequence - next to what rounding the WEIGHTS to
+    fp16 costs alone (fp32 oracle on fp16-rounded weights: the floor of any implementation with 16-bit weights)."""
+    from oracle import psg_oracle as O
     g, cfg, w, scene = H.load_case(case)
     dev = _dev()
     ids = [int(i) for i in scene["object_id_list"]]
     names = H.object_names(scene)
+    suppress = bool(g["suppress_eos"])
+    sel = g["selected"].tolist()
     res = {}
-    for dt in ("fp16", "bf16"):
-        head = _head(cfg, w, dt, suppress_eos=bool(g["suppress_eos"]))
+    for dt in ("fp16", "mixed", "mixed_q32", "bf16"):
+        head = _head(cfg, w, dt, suppress_eos=suppress)
         rq = head.run_relation_query(scene["mask_features"].to(dev), scene["img_meta"], ids, names,
                                      scene["pan_results"].to(dev))
         dec = head.decode_selected(rq, names, selected=torch.from_numpy(g["selected"].astype(np.int32)).to(dev))
@@ -332,14 +341,37 @@ def test_fp16_mode_vs_reference(case):
         for i in range(toks.shape[0]):
             want = g["gen_tokens"][i]
             exact += [int(t) for t in toks[i] if t >= 0] == want[want >= 0].tolist()
-        overlap = len(set(rq["selected"].cpu().tolist()) & set(g["selected"].tolist()))
-        res[dt] = (e_logit, e_first, exact, overlap)
-        assert rq["hidden"].dtype == (torch.float16 if dt == "fp16" else torch.bfloat16)
-    print(f"{case}: max |existence logit - reference| fp16 {res['fp16'][0]:.3e} / bf16 {res['bf16'][0]:.3e}; first-step "
-          f"logits fp16 {res['fp16'][1]:.3e} / bf16 {res['bf16'][1]:.3e}; pairs with the reference's exact tokens fp16 "
-          f"{res['fp16'][2]}/20 / bf16 {res['bf16'][2]}/20; top-20 overlap fp16 {res['fp16'][3]} / bf16 {res['bf16'][3]}")
-    assert res["fp16"][0] < max(0.5 * res["bf16"][0], 0.03) and res["fp16"][1] < max(0.5 * res["bf16"][1], 0.1)
-    assert res["fp16"][2] >= res["bf16"][2] and res["fp16"][3] >= 19
+        overlap = len(set(rq["selected"].cpu().tolist()) & set(sel))
+        res[dt] = (float(e_logit), e_first, exact, overlap)
+        assert rq["hidden"].dtype == (torch.bfloat16 if dt == "bf16" else torch.float16)
+        assert (head.rq_engine.res32, head.llm_engine.resid_dtype == torch.float32) == \
+            {"fp16": (False, False), "bf16": (False, False), "mixed": (False, True), "mixed_q32": (True, True)}[dt]
+        del head, rq, dec
+        torch.cuda.empty_cache()
+    # the floor: fp32 arithmetic on fp16-rounded weights
+    wr = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in w.items()}
+    lw, gens_w = _oracle_run(O, wr, cfg, scene, sel, suppress)
+    f_logit = float(np.abs(lw - g["exist_logit"]).max())
+    f_exact = 0
+    for i in range(len(sel)):
+        want = g["gen_tokens"][i]
+        f_exact += gens_w[i][0] == want[want >= 0].tolist()
+    _MODE_TABLE[case] = (res, f_logit, f_exact)
+    print(f"{case}: max |existence logit - reference|: fp16 {res['fp16'][0]:.3e} / mixed {res['mixed'][0]:.3e} / mixed + fp32 "
+          f"Q-Former residual {res['mixed_q32'][0]:.3e} / bf16 {res['bf16'][0]:.3e} (fp16 weight rounding alone {f_logit:.3e}); "
+          f"first-step logits fp16 {res['fp16'][1]:.3e} / mixed {res['mixed'][1]:.3e} / mixed_q32 {res['mixed_q32'][1]:.3e} / "
+          f"bf16 {res['bf16'][1]:.3e}; pairs with the reference's exact tokens fp16 {res['fp16'][2]}/20, mixed "
+          f"{res['mixed'][2]}/20, mixed_q32 {res['mixed_q32'][2]}/20, bf16 {res['bf16'][2]}/20 (fp16 weight rounding alone "
+          f"{f_exact}/20); top-20 overlap fp16 {res['fp16'][3]}, mixed {res['mixed'][3]}, mixed_q32 {res['mixed_q32'][3]}, "
+          f"bf16 {res['bf16'][3]}")
+    for dt in ("fp16", "mixed", "mixed_q32"):
+        assert res[dt][0] < 0.03, f"{dt}: existence logits {res[dt][0]} from the reference"
+        assert res[dt][0] < max(0.5 * res["bf16"][0], 0.03) and res[dt][1] < max(0.5 * res["bf16"][1], 0.1)
+        # the reference's top-20 (one near-tie at the cut of G5 is the only difference measured on the five goldens)
+        assert res[dt][3] >= min(20, len(g["exist_logit"])) - 1
+        assert res[dt][2] >= res["bf16"][2]
+        # measured 15-19 of 20 against 17-19 for weight rounding alone
+        assert res[dt][2] >= min(15, f_exact - 3), f"{dt}: {res[dt][2]}/20 exact sequences, weight-rounding floor {f_exact}/20"
 
 
 @pytest.mark.parametrize("M,N,K", [(20, 4096, 4096), (7, 32000, 4096), (32, 768, 2752)])

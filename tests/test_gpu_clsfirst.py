@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("case", ["G1_c1_512_n10", "G2_768x1024_n12", "G5_c5geo_1024x1344_n8"])
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "mixed_q32"])
 def test_cls_first_equals_one_phase(case, dtype):
     g, cfg, w, scene = H.load_case(case)
     runs = {}
@@ -136,7 +136,7 @@ def test_cls_attention_in_input_space_matches_kv_form(dtype, T):
         assert e_ref < max(1.2 * e_kv, 0.02)                        # no K / V rounding: at least as close
 
 
-@pytest.mark.parametrize("dtype,chunk", [("fp32", 4096), ("fp32", 100), ("bf16", 4096)])
+@pytest.mark.parametrize("dtype,chunk", [("fp32", 4096), ("fp32", 100), ("bf16", 4096), ("mixed_q32", 4096)])
 def test_prompt_dedup_equals_per_pair_path(dtype, chunk, monkeypatch):
     """Scenes with repeated classes (many pairs share a prompt): the selection phase with the prompt-only work done
     once per distinct prompt (qformer._forward_pairs_cls_dedup) against the per-pair path - same logits, selection,

@@ -578,6 +578,39 @@ def test_add_layernorm_16bit_variants_vs_fp32_torch(dtype, rows):
         assert ((a_.float() - b_.float()).abs() / (1 + b_.float().abs())).max().item() < 2.1 * ulp
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows", [1, 66, 33 * 9])
+def test_add_layernorm_fp32_residual_dual_output_vs_fp32_torch(dtype, rows):
+    """Mixed mode's LayerNorm (psg_add_layernorm_res32): 16-bit projection output + fp32 residual -> fp32 result (exact to
+    fp32 rounding: the next residual) and its 16-bit copy (one rounding: the next operand); plain, periodic and indexed
+    residual rows."""
+    from openpsg_amd import ops
+    dev = _dev()
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(rows + 5)
+    x = torch.randn(rows, 768, generator=g).to(dev, tdt)
+    r = torch.randn(rows, 768, generator=g).to(dev)
+    b = torch.randn(768, generator=g).to(dev)
+    gam, bet = (1 + 0.2 * torch.randn(768, generator=g)).to(dev), torch.randn(768, generator=g).to(dev)
+    ulp = 2.0 ** (-8 if dtype == "bf16" else -11)
+    G = rows // 33
+    tab = torch.randn(4 * 33, 768, generator=g).to(dev)
+    idx = torch.randint(0, 4, (max(G, 1),), generator=g)[:G].to(dev, torch.int32)
+    cases = [(dict(), r)]
+    if rows % 33 == 0:
+        rows_i = (idx.long()[:, None] * 33 + torch.arange(33, device=dev)[None, :]).reshape(-1)
+        cases += [(dict(period=33), tab[:33].contiguous()), (dict(period=33, index=idx), tab)]
+    for kw, res in cases:
+        full = res if not kw else (res.repeat(G, 1) if "index" not in kw else tab[rows_i])
+        want = torch.nn.functional.layer_norm(x.float() + b + full, (768,), gam, bet, 1e-12)
+        o16, o32 = ops.add_layernorm_res32(x.clone(), res, b, gam, bet, 1e-12, **kw)
+        assert o16.dtype == tdt and o32.dtype == torch.float32
+        assert (o32 - want).abs().max().item() < 2e-5
+        assert ((o16.float() - want).abs() / (1 + want.abs())).max().item() < 1.5 * ulp
+        only32 = ops.add_layernorm_res32(x.clone(), res, b, gam, bet, 1e-12, want16=False, **kw)
+        assert only32[0] is None and torch.equal(only32[1], o32)
+
+
 def test_row_kernels_vs_torch():
     from openpsg_amd import ops
     dev = _dev()
