@@ -522,8 +522,14 @@ static int xd_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, 
                      const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy, void* out,
                      hipStream_t st) {
   const int Lpad = (L + 31) & ~31;
-  // 8 waves per CU; option xattn_waves = 10 takes ten when the K/V image leaves room for ten slot pairs (L <= 256)
-  const int waves = (ctx->opt.xattn_waves == 10 && xd_lds_bytes(N, words, L, 10) <= 160 * 1024) ? 10 : 8;
+  // 8 waves per CU, ten for launches with few tiles per wave when the K/V image leaves room for ten slot pairs
+  // (L <= 256): with the tiles drawn from the LDS counter, BASELINE C2 (2579 tiles per head, 15 per wave) runs 6 % faster
+  // with ten (more Q streams in flight through the staging phase and the tail), C4 (61 per wave) 3 % slower.
+  // Option xattn_waves: 8 = this rule, 10 = always ten, 0 = always eight.
+  const int64_t ntile0 = nq == 33 ? (int64_t)P + (P + 31) / 32 : ((int64_t)P * nq + 31) / 32;
+  const int64_t per_wave8 = ntile0 / (((int64_t)ctx->num_cu / heads > 0 ? (int64_t)ctx->num_cu / heads : 1) * 8);
+  const bool want10 = ctx->opt.xattn_waves == 10 || (ctx->opt.xattn_waves == 8 && per_wave8 < 32 && per_wave8 >= 4);
+  const int waves = (want10 && xd_lds_bytes(N, words, L, 10) <= 160 * 1024) ? 10 : 8;
   const size_t lds = xd_lds_bytes(N, words, L, waves);
   const int NC = (Lpad / 32 + 3) / 4;
   PSG_REQUIRE(lds <= 160 * 1024 && NC >= 1 && NC <= 3, PSG_ERR_UNSUPPORTED,
