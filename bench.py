@@ -76,7 +76,10 @@ def parse():
                     help="last Q-Former layer for all 33 rows of every pair (A/B against the default cls-first path)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the one-image strong-scaling figure")
     ap.add_argument("--pair-chunk", type=int, default=0, help="pairs per Q-Former pass (0: the head's default)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.dtype is None:
+        a.dtype = "mixed" if a.workload == "full" else "bf16"
+    return a
 
 
 def self_launch(a):
@@ -403,8 +406,6 @@ def time_steps(step, warmup, steps):
 
 def main():
     a = parse()
-    if a.dtype is None:
-        a.dtype = "mixed" if a.workload == "full" else "bf16"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)                                                 # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))

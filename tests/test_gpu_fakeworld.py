@@ -98,7 +98,7 @@ def test_one_c4_image_sharded_mixed_mode_is_within_rounding(c4):
         assert torch.equal(outs[r]["selected"], outs[0]["selected"]) and torch.equal(outs[r]["tokens"], outs[0]["tokens"])
 
 
-@pytest.mark.parametrize("world,selector", [(4, "topk"), (4, "threshold"), (2, "topk")])
+@pytest.mark.parametrize("world,selector", [(4, "topk"), (4, "threshold"), (2, "topk"), (8, "topk")])
 def test_step_with_unequal_images_over_fake_ranks(world, selector):
     """`step`: R images per step, every image's pairs sharded over all R ranks.  The images differ in object count
     (different shard lengths, different K under the threshold selector) and in size (different patch counts)."""
@@ -106,7 +106,8 @@ def test_step_with_unequal_images_over_fake_ranks(world, selector):
     from openpsg_amd.synthetic import make_scene
     kw = dict(pair_selector="threshold", exclude_diagonal=True, max_selected=24) if selector == "threshold" else {}
     head = _mk_head("fp32", 50, **kw)
-    geo = [((1024, 1024), 50), ((768, 1024), 23), ((512, 512), 9), ((1024, 1344), 31)][:world]
+    geo = ([((1024, 1024), 50), ((768, 1024), 23), ((512, 512), 9), ((1024, 1344), 31)] +
+           [((1024, 1024), 50)] * 4)[:world]                       # world 8: bench.py's weak-scaling step (N = 50 images) too
     scenes = [make_scene(hw, n, seed=60 + m, device="cuda:0", tiny_object=True) for m, (hw, n) in enumerate(geo)]
     if selector == "threshold":
         # a threshold in the middle of each image's scores gives a data-dependent K; use one between the 7th and 8th
