@@ -63,6 +63,11 @@ class LlamaDecodeEngine:
                 wdown=act(weights[p + "mlp.down_proj.weight"]),
                 ln1=f32(p + "input_layernorm.weight"), ln2=f32(p + "post_attention_layernorm.weight")))
         self.use_skinny = True
+        # greedy argmax over the fp32 split-K sums of the lm_head, NOT over their 16-bit rounding: HF computes the logits of
+        # a model cast to 16 bits in 16 bits, but the reference runs the LLM in fp32 (V4:99-100), and a 16-bit logit has
+        # an ulp of 0.008-0.016 (fp16) / 0.06 (bf16) at |x| ~ 8-16 - wider than many top-2 margins of a 32000-way
+        # argmax, so rounding first turns near-ties into ties that the lower index wins
+        self.exact_argmax = True
         # row operations that run as the PROLOGUE of the projection that consumes them (one launch instead of two;
         # psg_skinny_gemm_fused).  Built for "rmsnorm", bit-identical, and OFF by default: measured 26.6 vs 25.6 us
         # per (RMSNorm + q/k/v projection), 75.2 vs 74.0 ms per image - the in-launch hand-off (write-through
@@ -314,7 +319,8 @@ class LlamaDecodeEngine:
         dec_pos = (seq_len - 1).contiguous()                                           # greedy_step does += 1
         dec_pair = torch.arange(K, device=dev, dtype=torch.int32)
         sup = m.eos if suppress_eos else -1
-        ops.greedy_step(logits, 0, max_new, m.eos, sup, tokens, done, next_ids, dec_pos, dtype=self.dtype)
+        ops.greedy_step(logits, 0, max_new, m.eos, sup, tokens, done, next_ids, dec_pos,
+                        dtype=torch.float32 if self.exact_argmax else self.dtype)
         x = torch.empty((K, D), device=dev, dtype=self.resid_dtype)   # residual stream of the decode rows
         return dict(kc=kc, vc=vc, ctx_len=ctx_len, tokens=tokens, done=done, next_ids=next_ids, dec_pos=dec_pos,
                     dec_pair=dec_pair, sup=sup, x=x, max_new=max_new, first_logits=first_logits)
@@ -334,4 +340,4 @@ class LlamaDecodeEngine:
                 h = self._forward(st["x"], st["dec_pair"], st["dec_pos"], st["kc"], st["vc"], st["ctx_len"], decode=True)
                 logits = self.linear(h, self.lm_head)
             ops.greedy_step(logits, step, st["max_new"], m.eos, st["sup"], st["tokens"], st["done"], st["next_ids"],
-                            st["dec_pos"], dtype=self.dtype)
+                            st["dec_pos"], dtype=torch.float32 if self.exact_argmax else self.dtype)
