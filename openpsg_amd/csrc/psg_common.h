@@ -27,6 +27,13 @@ struct psg_opts {
   int xattn_waves = 8;          // LDS-DMA cross-attention: waves per workgroup (8 or 10)
   int xattn_dma = 1;            // cross-attention: LDS-DMA kernel (psg_xattn_dma.hip) when its LDS image fits
   int ln_half_wave = 1;         // add + LayerNorm on 16-bit rows: half a wave per row, 16-byte accesses
+  // host-side variants of the engines (read by openpsg_amd/qformer.py / llm.py through psg_get_option: one mechanism,
+  // per context, for every A/B switch - none is a process-wide environment toggle of the Python layer)
+  int qformer_share_qkv = 1;    // layer 0: ONE Q/K/V projection of the 33 learned query rows for all pairs
+  int qformer_cls_input_space = 1;  // selection phase of the last layer in the input space (psg_qformer_cls_attn_input)
+  int qformer_dedup_prompts = 1;    // prompt-only work of the two-layer Q-Former once per distinct prompt
+  int llm_fuse_rmsnorm = 0;     // decode step: RMSNorm as the prologue of the projection it feeds (psg_skinny_gemm_fused)
+  int prefill_attn_scalar = 0;  // prompt pass: scalar cache-attention kernel instead of the matrix-core one
   int xattn_dynamic = 1;        // LDS-DMA cross-attention: a workgroup's waves draw their tiles from an LDS counter
   int xattn_poll = 0;           // LDS-DMA cross-attention: a unit's Q tile is awaited by polling a sentinel in its LDS slot
                                 // instead of a vmcnt count (which also waits for the previous unit's stores to retire)

@@ -32,6 +32,10 @@ static const OptName kOpts[] = {
     {"dense_gemm_var", &psg_opts::dense_gemm_var},     {"qformer_own_gemm", &psg_opts::qformer_own_gemm},
     {"ln_half_wave", &psg_opts::ln_half_wave},         {"xattn_poll", &psg_opts::xattn_poll},
     {"xattn_dynamic", &psg_opts::xattn_dynamic},
+    {"qformer_share_qkv", &psg_opts::qformer_share_qkv},
+    {"qformer_cls_input_space", &psg_opts::qformer_cls_input_space},
+    {"qformer_dedup_prompts", &psg_opts::qformer_dedup_prompts},
+    {"llm_fuse_rmsnorm", &psg_opts::llm_fuse_rmsnorm}, {"prefill_attn_scalar", &psg_opts::prefill_attn_scalar},
 };
 
 // "8x1x3" (waves x K blocks x ring slots) is accepted for skinny_dma next to a plain integer

@@ -21,7 +21,6 @@ gate and the greedy step are HIP kernels.
 from __future__ import annotations
 
 import collections
-import os
 
 import torch
 import torch.nn.functional as F
@@ -72,7 +71,10 @@ class LlamaDecodeEngine:
         # psg_skinny_gemm_fused).  Built for "rmsnorm", bit-identical, and OFF by default: measured 26.6 vs 25.6 us
         # per (RMSNorm + q/k/v projection), 75.2 vs 74.0 ms per image - the in-launch hand-off (write-through
         # publish, counter, poll, x staged after it) costs what the separate launch costs
-        self.fuse_rowops = frozenset(os.environ.get("PSG_FUSE_ROWOPS", "none").replace(",", " ").split()) - {"none"}
+        from . import _lib
+        dev_i = self.device.index or 0
+        self.fuse_rowops = frozenset({"rmsnorm"}) if _lib.get_option(dev_i, "llm_fuse_rmsnorm") else frozenset()
+        self.prefill_attn_scalar = bool(_lib.get_option(dev_i, "prefill_attn_scalar"))
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
         self.early_exit_chunk = 4        # natural-EOS decode: steps per graph between "all pairs done?" checks
         self.last_replays = 0
@@ -112,7 +114,7 @@ class LlamaDecodeEngine:
         att = torch.empty_like(n)
         act = torch.empty((rows, m.inter), device=self.device, dtype=self.dtype)
         mfma_prefill = (prefill_shape is not None and self.dtype in (torch.bfloat16, torch.float16) and m.head_dim == 128
-                        and prefill_shape[1] <= 64 and os.environ.get("PSG_PREFILL_ATTN_SCALAR") != "1")
+                        and prefill_shape[1] <= 64 and not self.prefill_attn_scalar)
         for l, L in enumerate(self.layers):
             qkv = self.linear(n, L["wqkv"])
             if decode:

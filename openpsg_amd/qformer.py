@@ -18,8 +18,6 @@ Dense projections go through torch (`F.linear` -> hipBLASLt); everything else is
 """
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.nn.functional as F
 
@@ -81,14 +79,15 @@ class RelationQueryEngine:
                 L["wv32t"] = L["wqkv"][2 * H:].float().view(q.heads, hd, H).transpose(1, 2).contiguous()
             self.layers.append(L)
         self.empty_policy = PSG_EMPTY_UNIFORM if cfg.empty_row_policy == "uniform" else PSG_EMPTY_UNMASKED
-        self.share_query_qkv = os.environ.get("PSG_SHARE_QUERY_QKV", "1") != "0"
+        opt = lambda name: bool(_lib.get_option(self.device.index or 0, name))  # noqa: E731  (options of the psg_ctx)
+        self.share_query_qkv = opt("qformer_share_qkv")
         # selection phase of the last layer: cls-row attention in the input space (no K | V projection of all rows)
-        self.cls_input_space = os.environ.get("PSG_CLS_INPUT_SPACE", "1") != "0"
+        self.cls_input_space = opt("qformer_cls_input_space")
         self._bmm_out_dtype = None       # torch.bmm(..., out_dtype=fp32) available? (probed at first use)
         # two-layer Q-Former: everything in front of layer 0's cross-attention and every text row entering the last
         # layer depend on the PROMPT (class pair) only - computed once per distinct prompt when the caller hands the
         # prompt table over (forward_pairs_cls(prompts=...)) and it has fewer rows than 0.9 x the pairs
-        self.dedup_prompts = os.environ.get("PSG_DEDUP_PROMPTS", "1") != "0"
+        self.dedup_prompts = opt("qformer_dedup_prompts")
 
     # ---- A4: prepare_inference (V4:408-435) ----------------------------------------------------
     def patch_embed(self, mask_features: torch.Tensor) -> torch.Tensor:

@@ -10,7 +10,10 @@ pinned against OUTPUTS OF THE REFERENCE ITSELF run in the build container:
 ``oracle/capture_reference.py`` stub-imports the real ``RelationTransformerHeadV4`` from
 /root/reference, drives it with HF ``InstructBlipQFormerModel`` / ``LlamaForCausalLM``
 (transformers 5.15.0, eager attention) and writes ``tests/golden/*.npz``;
-``tests/test_oracle_golden.py`` checks every function here against those captures.
+``tests/test_oracle_golden.py`` checks every function here against those captures (G1-G5: small LLMs; G6: the LLM
+at the width the reference instantiates, 4096 / 32 heads / 11008 / vocabulary 32000, 2 layers; T1-T2: the training
+branch).  The functions are plain differentiable torch, so torch.autograd through ``train_forward`` is also the
+GRADIENT oracle of the training branch (tests/test_gpu_train.py).
 
 The pinned mode is fp32.  The same functions also run with bf16 tensors (weights cast by the caller), following
 HF's own conventions for a model cast to bf16 (masks from finfo(dtype).min, softmax / RMSNorm statistics in fp32
