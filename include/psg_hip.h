@@ -188,6 +188,15 @@ int psg_topk(psg_ctx*, const float* score, int n, int k, int32_t* out_idx, float
  * idx < 0 writes zeros.  src_dtype/dst_dtype allow fp32 tables -> bf16 activations. */
 int psg_gather_rows(psg_ctx*, const void* src, int src_dtype, const int32_t* idx, int64_t n, int cols,
                     int64_t src_row_stride, void* dst, int dst_dtype, int64_t dst_row_stride, void* stream);
+/* rows of the SELECTED pairs for the second phase of the last Q-Former layer (V4:215, 235-237), in one launch: sel[s] is
+ * a global pair id; a pair of this chunk (first <= id < first + count) sits at position id - first + slot_off of the pass,
+ * any other slot is computed as the chunk's first pair and flagged mine_out[s] = 0.  out [K*(nq+T)][cols]: the K*nq query
+ * rows (xq[pos*nq + q]) then the K*T text rows (block text_index[pos], or pos, of xt); mask_out [K][T] = text_mask[pos];
+ * pair_out [K] = pair_index[pos].  Optional outputs may be NULL. */
+int psg_gather_pair_rows(psg_ctx*, const void* xq, const void* xt, const int32_t* text_index, const uint8_t* text_mask,
+                         const int32_t* pair_index, const int32_t* sel, int K, int first, int count, int slot_off,
+                         int nq, int T, int cols, void* out, uint8_t* mask_out, int32_t* pair_out, uint8_t* mine_out,
+                         int dtype, void* stream);
 
 /* ---- K12: Llama RMSNorm, HF-LL:53-67, fused with the residual add of HF-LL decoder layer:
  * if delta != NULL: resid += delta (written back); out = w * (resid * rsqrt(mean(resid^2)+eps)).

@@ -61,6 +61,7 @@ SIGNATURES = {
     "psg_exist_head": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "psg_topk": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "psg_gather_rows": [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _i, _i64, _vp],
+    "psg_gather_pair_rows": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "psg_rmsnorm": [_vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _i, _i, _vp],
     "psg_rope_kvwrite": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "psg_train_object_bitmasks": [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],

@@ -333,6 +333,69 @@ extern "C" int psg_topk(psg_ctx* ctx, const float* score, int n, int k, int32_t*
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rows of the SELECTED pairs for the second phase of the last Q-Former layer (V4:215, 235-237: pair_feature of the chosen
+// pairs only): one launch instead of the index arithmetic (arange / mul / add / where / clamp / cat / index_select: ~20
+// library launches of 5 us) that depended on the selection.  sel[s] is a global pair id; a pair this chunk owns
+// (first <= id < first + count) sits at position id - first + slot_off of the pass, any other slot is computed as the
+// chunk's own first pair (a valid pair of the same image) and flagged in mine[s] = 0.
+//   out rows [0, K*nq): query rows q of slot s = xq[pos * nq + q];  rows [K*nq, K*(nq+T)): text rows, block
+//   text_index[pos] (or pos) of xt;  mask_out[s][t] = text_mask[pos][t];  pair_out[s] = pair_index[pos].
+// ---------------------------------------------------------------------------------------------
+template <typename T_>
+__global__ void gather_pair_rows_kernel(const T_* __restrict__ xq, const T_* __restrict__ xt,
+                                        const int32_t* __restrict__ text_index, const uint8_t* __restrict__ text_mask,
+                                        const int32_t* __restrict__ pair_index, const int32_t* __restrict__ sel, int K,
+                                        int first, int count, int slot_off, int nq, int T, int cols,
+                                        T_* __restrict__ out, uint8_t* __restrict__ mask_out,
+                                        int32_t* __restrict__ pair_out, uint8_t* __restrict__ mine_out) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t nrow = (int64_t)K * (nq + T);
+  if (row >= nrow) return;
+  const bool is_q = row < (int64_t)K * nq;
+  const int s = is_q ? (int)(row / nq) : (int)((row - (int64_t)K * nq) / T);
+  const int r = is_q ? (int)(row % nq) : (int)((row - (int64_t)K * nq) % T);
+  const int id = sel[s];
+  const bool mine = id >= first && id < first + count;
+  const int pos = (mine ? id - first : 0) + slot_off;
+  const T_* src;
+  if (is_q) {
+    src = xq + ((int64_t)pos * nq + r) * cols;
+    if (r == 0 && lane == 0) {
+      if (pair_out) pair_out[s] = pair_index[pos];
+      if (mine_out) mine_out[s] = mine ? 1 : 0;
+    }
+  } else {
+    const int blk = text_index ? text_index[pos] : pos;
+    src = xt + ((int64_t)blk * T + r) * cols;
+    if (lane == 0 && mask_out) mask_out[(int64_t)s * T + r] = text_mask[(int64_t)pos * T + r];
+  }
+  for (int c = lane * 4; c < cols; c += 256) {
+    float v[4];
+    Act<T_>::ld4(src, c, v);
+    Act<T_>::st4(out, row * cols + c, v);
+  }
+}
+
+extern "C" int psg_gather_pair_rows(psg_ctx* ctx, const void* xq, const void* xt, const int32_t* text_index,
+                                    const uint8_t* text_mask, const int32_t* pair_index, const int32_t* sel, int K,
+                                    int first, int count, int slot_off, int nq, int Tt, int cols, void* out,
+                                    uint8_t* mask_out, int32_t* pair_out, uint8_t* mine_out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && xq && sel && out && (xt || Tt == 0) && (text_mask || !mask_out) && (pair_index || !pair_out),
+              PSG_ERR_INVALID, "psg_gather_pair_rows: NULL argument");
+  PSG_REQUIRE(K >= 0 && nq > 0 && Tt >= 0 && cols > 0 && cols % 4 == 0 && count > 0 && slot_off >= 0, PSG_ERR_INVALID,
+              "psg_gather_pair_rows: K=%d nq=%d T=%d cols=%d count=%d", K, nq, Tt, cols, count);
+  if (K == 0) return PSG_OK;
+  const int64_t rows = (int64_t)K * (nq + Tt);
+  PSG_DISPATCH_DTYPE(dtype, "psg_gather_pair_rows",
+                     (gather_pair_rows_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+                         (const T*)xq, (const T*)xt, text_index, text_mask, pair_index, sel, K, first, count, slot_off, nq,
+                         Tt, cols, (T*)out, mask_out, pair_out, mine_out)));
+  PSG_CHECK_LAUNCH("psg_gather_pair_rows");
+  return PSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // row gather: dst[r][:] = src[idx[r]][:]  (idx < 0 -> zeros); one wave per row, 4 elements / lane
 // ---------------------------------------------------------------------------------------------
 template <typename TS, typename TD>

@@ -796,6 +796,16 @@ class RelationTransformerHeadV4(nn.Module):
             # chunks: every chunk computes all K slots (foreign pairs as its first pair) and keeps its own - no host sync
             pf = torch.zeros((K, nv, q.hidden), device=self.device, dtype=self.act_dtype) if zero_foreign else None
             for c0, c1, st, off in rq["pending"]:
+                if st.get("segments") is None:
+                    # one kernel gathers the selected pairs' rows, masks and pair ids (foreign slots: the chunk's own
+                    # first pair, flagged) - no selection-dependent index arithmetic on the device
+                    hk, mine_u8 = self.rq_engine.pair_hidden_sel(st, sel, c0, c1 - c0, off)
+                    pc = hk.view(K, q.q_rows, q.hidden)[:, 1:]
+                    if pf is None and len(rq["pending"]) == 1:
+                        pf = pc                                            # single chunk, every pair its own
+                    else:
+                        pf = pc if pf is None else torch.where(mine_u8.bool()[:, None, None], pc, pf)
+                    continue
                 local = sel.to(torch.int64) - c0
                 mine = (local >= 0) & (local < c1 - c0)
                 # foreign slots are computed as this chunk's FIRST pair (a valid pair of the same image: in a pass over

@@ -67,6 +67,7 @@ class LlamaDecodeEngine:
         # an ulp of 0.008-0.016 (fp16) / 0.06 (bf16) at |x| ~ 8-16 - wider than many top-2 margins of a 32000-way
         # argmax, so rounding first turns near-ties into ties that the lower index wins
         self.exact_argmax = True
+        self._mm_out_dtype = None        # torch.mm(..., out_dtype=fp32) available? (probed at first use)
         # row operations that run as the PROLOGUE of the projection that consumes them (one launch instead of two;
         # psg_skinny_gemm_fused).  Built for "rmsnorm", bit-identical, and OFF by default: measured 26.6 vs 25.6 us
         # per (RMSNorm + q/k/v projection), 75.2 vs 74.0 ms per image - the in-launch hand-off (write-through
@@ -94,6 +95,23 @@ class LlamaDecodeEngine:
                 and w.shape[1] % 64 == 0 and w.shape[1] >= 256):
             return ops.skinny_gemm(x, w)          # fp32 split-K partials, reduced by the consumer kernel
         return F.linear(x, w)
+
+    def logits(self, h):
+        """lm_head.  <= 32 rows: the weight-streaming kernel (fp32 split-K partials, summed inside the greedy step);
+        more rows (several images' pairs decoded together): the library GEMM with an fp32 result, so that the greedy
+        argmax sees unrounded logits on this path too (exact_argmax)."""
+        out = self.linear(h, self.lm_head)
+        if isinstance(out, ops.Partials) or not self.exact_argmax or h.dtype == torch.float32:
+            return out
+        if self._mm_out_dtype is None:
+            try:
+                torch.mm(h[:1], self.lm_head[:16].t(), out_dtype=torch.float32)
+                self._mm_out_dtype = True
+            except (TypeError, RuntimeError):
+                self._mm_out_dtype = False
+        if self._mm_out_dtype:
+            return torch.mm(h, self.lm_head.t(), out_dtype=torch.float32)
+        return out.float()
 
     # ---- one pass over `rows` token rows -------------------------------------------------------
     def _forward(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, decode=False, prefill_shape=None, rope_pos=None,
@@ -311,10 +329,10 @@ class LlamaDecodeEngine:
         resid = X.reshape(K * maxlen, D).to(self.resid_dtype, copy=True)
         last_rows = (torch.arange(K, device=dev, dtype=torch.int32) * maxlen + seq_len - 1).contiguous()
         h_last = self._forward(resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape=(K, maxlen), keep_rows=last_rows)
-        logits = self.linear(h_last, self.lm_head)
+        logits = self.logits(h_last)
         first_logits = None
         if return_first_logits:
-            first_logits = logits.reduce(self.dtype) if isinstance(logits, ops.Partials) else logits.clone()
+            first_logits = logits.reduce(self.dtype) if isinstance(logits, ops.Partials) else logits.to(self.dtype)
         tokens = torch.full((K, max_new), -1, device=dev, dtype=torch.int32)
         done = torch.zeros(K, device=dev, dtype=torch.int32)
         next_ids = torch.zeros(K, device=dev, dtype=torch.int32)
@@ -340,6 +358,6 @@ class LlamaDecodeEngine:
                 logits = self._decode_step_fused(st, sync[(step - lo) * per_step:(step - lo + 1) * per_step])
             else:
                 h = self._forward(st["x"], st["dec_pair"], st["dec_pos"], st["kc"], st["vc"], st["ctx_len"], decode=True)
-                logits = self.linear(h, self.lm_head)
+                logits = self.logits(h)
             ops.greedy_step(logits, step, st["max_new"], m.eos, st["sup"], st["tokens"], st["done"], st["next_ids"],
                             st["dec_pos"], dtype=torch.float32 if self.exact_argmax else self.dtype)

@@ -279,6 +279,25 @@ def gather_rows(src, idx, dst):
     return dst
 
 
+def gather_pair_rows(xq, xt, text_index, text_mask, pair_index, sel, first, count, slot_off, nq, T, want_aux=True):
+    """Rows of the selected pairs (global ids `sel`, int32 [K]) out of a selection-phase pass: see psg_gather_pair_rows.
+    Returns (rows [K*(nq+T), cols], text mask [K, T] uint8, pair ids [K] int32, mine [K] uint8) - the last three None
+    when want_aux is False (a second table of the same pass, e.g. the fp32 twins)."""
+    lib, ctx, st = _env(xq)
+    K = sel.numel()
+    cols = xq.shape[1]
+    out = torch.empty((K * (nq + T), cols), device=xq.device, dtype=xq.dtype)
+    tm = torch.empty((K, T), device=xq.device, dtype=torch.uint8) if want_aux else None
+    pi = torch.empty(K, device=xq.device, dtype=torch.int32) if want_aux else None
+    mine = torch.empty(K, device=xq.device, dtype=torch.uint8) if want_aux else None
+    check(lib.psg_gather_pair_rows(ctx, _p(xq), _p(xt, xq.dtype) if T > 0 else None, _p(text_index, torch.int32, "text_index"),
+                                   _p(text_mask, torch.uint8, "text_mask") if want_aux and T > 0 else None,
+                                   _p(pair_index, torch.int32, "pair_index") if want_aux else None,
+                                   _p(sel, torch.int32, "sel"), K, int(first), int(count), int(slot_off), int(nq), int(T), cols,
+                                   _p(out), _p(tm) if T > 0 else None, _p(pi), _p(mine), _dt(xq), st), "psg_gather_pair_rows")
+    return out, tm, pi, mine
+
+
 class Partials:
     """fp32 split-K slices [S, rows, cols] written by `skinny_gemm`; the consumer kernels
     (rmsnorm, rope_kvwrite, silu_mul, greedy_step) sum them while loading."""

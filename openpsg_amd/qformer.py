@@ -397,6 +397,34 @@ class RelationQueryEngine:
         return self._layer(len(self.layers) - 1, Xs, Xs32, K, T, tm, pi, state["kv"], state["bits"], state["num_objects"],
                            segments)[0]
 
+    def pair_hidden_sel(self, state, sel, first, count, slot_off=0):
+        """`pair_hidden` for GLOBAL pair ids of a single-image pass: the rows of the selected pairs, their text masks and
+        pair ids come out of ONE gather kernel (psg_gather_pair_rows) instead of ~20 index-arithmetic launches.
+        sel int32 [K]; the chunk holds the pairs [first, first + count) at positions slot_off.. of the pass; slots of pairs
+        outside it are computed as the chunk's first pair.  Returns (hidden [K*33, 768], mine uint8 [K])."""
+        q = self.cfg.qformer
+        nq = q.q_rows
+        P, T = state["P"], state["T"]
+        assert state["segments"] is None
+        if "Xt_u" in state:                                                  # text rows live in the per-prompt table
+            xq, xt, tix = state["Xq"], state["Xt_u"], state["inv"]
+            xq32, xt32 = state.get("Xq32"), state.get("Xt_u32")
+        else:
+            X, X32 = state["X"], state.get("X32")
+            xq, xt, tix = X[:P * nq], X[P * nq:], None
+            xq32, xt32 = (None, None) if X32 is None else (X32[:P * nq], X32[P * nq:])
+        sel = sel.to(torch.int32).contiguous()
+        Xs, tm, pi, mine = ops.gather_pair_rows(xq, xt, tix, state["text_mask"], state["pair_index"], sel, first, count,
+                                                slot_off, nq, T)
+        Xs32 = None
+        if xq32 is not None:
+            Xs32 = ops.gather_pair_rows(xq32, xt32, tix, None, None, sel, first, count, slot_off, nq, T, want_aux=False)[0]
+        if T == 0:
+            tm = state["text_mask"]
+        hk = self._layer(len(self.layers) - 1, Xs, Xs32, sel.numel(), T, tm, pi, state["kv"], state["bits"],
+                         state["num_objects"], None)[0]
+        return hk, mine
+
     def _bmm_f32(self, a, b, b32):
         """fp32 result of a batched product of activation-dtype operands (exact products, fp32 accumulation): the
         library's 16-bit-in / fp32-out batched GEMM where this PyTorch has it, else the fp32 GEMM on widened copies."""
