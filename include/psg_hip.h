@@ -55,7 +55,8 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  * library was built with; a binding compares it with the PSG_ABI_VERSION of the header it was written against
  * (openpsg_amd/_lib.py does, at load time) instead of passing shifted arguments silently.
  *   100  round 1        200  round 2 (psg_skinny_gemm / psg_rope_kvwrite gained, psg_qformer_cross_attn lost an argument)
- *   300  round 3 (psg_rmsnorm: resid_dtype; psg_train_* gradient kernels, psg_add_layernorm_res32,
+ *   300  round 3 (psg_rmsnorm: resid_dtype; psg_greedy_step: embedding row of the chosen token;
+ *        psg_train_* gradient kernels, psg_add_layernorm_res32, psg_gather_pair_rows,
  *        psg_masked_split_mean_pool added) */
 #define PSG_ABI_VERSION 300
 int psg_version(void);
@@ -318,10 +319,12 @@ int psg_dense_gemm(psg_ctx*, const void* x, const void* w, const float* bias, in
  * logits [K][vocab] (dtype); token = argmax (first maximal index); suppress_token >= 0 is
  * excluded.  For each pair k not yet done: tokens[k][step] = token, done[k] |= (token == eos),
  * next_ids[k] = token, tok_pos[k] += 1.  Finished pairs write -1 and keep decoding harmlessly.
- * splits > 0: logits is fp32 split-K partials [splits][K][vocab] (summed before the argmax). */
+ * splits > 0: logits is fp32 split-K partials [splits][K][vocab] (summed before the argmax).
+ * x_out (may be NULL) [K][hidden] (x_dtype): receives embed[token] (V4:296 / HF embed_tokens of the next step's input) -
+ * the embedding gather of the next decode step folded into this launch. */
 int psg_greedy_step(psg_ctx*, const void* logits, int splits, int K, int vocab, int step, int max_new,
-                    int eos, int suppress_token, int32_t* tokens, int32_t* done, int32_t* next_ids,
-                    int32_t* tok_pos, int dtype, void* stream);
+                    int eos, int suppress_token, int32_t* tokens, int32_t* done, int32_t* next_ids, int32_t* tok_pos,
+                    const void* embed, int embed_dtype, int hidden, void* x_out, int x_dtype, int dtype, void* stream);
 
 /* ---- masked-mean object pooling of the v1-v3 detectors
  * (kings_sgg/models/detectors/openseed_relation.py:453-468):

@@ -94,7 +94,7 @@ SIGNATURES = {
     "psg_train_rope": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp],
     "psg_train_ce_bwd": [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp],
     "psg_train_bce_bwd": [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
-    "psg_greedy_step": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "psg_greedy_step": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
 }
 
 _lib = None

@@ -792,14 +792,18 @@ extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int splits, int64
 }
 
 // ---- K16 greedy step: argmax over the vocabulary + per-pair bookkeeping -------------------------
-template <typename T>
+// TE / TX: element types of the embedding table and of the next step's residual rows (x_out, may be nullptr): the row of
+// the chosen token is copied there by the same workgroup - the embedding gather of the next decode step needs no launch.
+template <typename T, typename TE, typename TX>
 __global__ void __launch_bounds__(1024) greedy_step_kernel(const void* __restrict__ logits, int S, int vocab, int step,
                                                            int max_new, int eos, int suppress,
                                                            int32_t* __restrict__ tokens, int32_t* __restrict__ done,
                                                            int32_t* __restrict__ next_ids,
-                                                           int32_t* __restrict__ tok_pos) {
+                                                           int32_t* __restrict__ tok_pos, const TE* __restrict__ embed,
+                                                           int hidden, TX* __restrict__ x_out) {
   __shared__ float s_val[16];
   __shared__ int s_idx[16];
+  __shared__ int s_tok;
   const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int64_t slice = (int64_t)gridDim.x * vocab;
   float best = -INFINITY;
@@ -895,20 +899,46 @@ __global__ void __launch_bounds__(1024) greedy_step_kernel(const void* __restric
     if (!was_done && bi == eos) done[k] = 1;
     next_ids[k] = bi;
     tok_pos[k] += 1;
+    s_tok = bi;
+  }
+  if (x_out) {                                                   // kernel-uniform
+    __syncthreads();
+    const TE* src = embed + (int64_t)s_tok * hidden;
+    for (int c = tid * 4; c < hidden; c += (int)blockDim.x * 4) {
+      float v[4];
+      Act<TE>::ld4(src, c, v);
+      Act<TX>::st4(x_out, (int64_t)k * hidden + c, v);
+    }
   }
 }
 
 extern "C" int psg_greedy_step(psg_ctx* ctx, const void* logits, int splits, int K, int vocab, int step, int max_new, int eos,
                                int suppress_token, int32_t* tokens, int32_t* done, int32_t* next_ids, int32_t* tok_pos,
-                               int dtype, void* stream) {
+                               const void* embed, int embed_dtype, int hidden, void* x_out, int x_dtype, int dtype,
+                               void* stream) {
   PSG_REQUIRE(ctx && logits && tokens && done && next_ids && tok_pos, PSG_ERR_INVALID,
               "psg_greedy_step: NULL argument");
   PSG_REQUIRE(K > 0 && vocab > 0 && step >= 0 && step < max_new, PSG_ERR_INVALID,
               "psg_greedy_step: K=%d vocab=%d step=%d max_new=%d", K, vocab, step, max_new);
-  PSG_DISPATCH_DTYPE(dtype, "psg_greedy_step",
-                     (greedy_step_kernel<T><<<K, 1024, 0, (hipStream_t)stream>>>(logits, splits, vocab, step, max_new,
-                                                                               eos, suppress_token, tokens, done,
-                                                                               next_ids, tok_pos)));
+  PSG_REQUIRE(!x_out || (embed && hidden > 0 && hidden % 4 == 0), PSG_ERR_INVALID,
+              "psg_greedy_step: x_out needs the embedding table and hidden %% 4 == 0 (hidden=%d)", hidden);
+  hipStream_t st = (hipStream_t)stream;
+#define GS(TE_, TX_)                                                                                                  \
+  PSG_DISPATCH_DTYPE(dtype, "psg_greedy_step",                                                                        \
+                     (greedy_step_kernel<T, TE_, TX_><<<K, 1024, 0, st>>>(logits, splits, vocab, step, max_new, eos,   \
+                                                                         suppress_token, tokens, done, next_ids,      \
+                                                                         tok_pos, (const TE_*)embed, hidden,          \
+                                                                         (TX_*)x_out)))
+  if (!x_out || (embed_dtype == PSG_F32 && x_dtype == PSG_F32)) GS(float, float);
+  else if (embed_dtype == PSG_BF16 && x_dtype == PSG_BF16) GS(bf16_t, bf16_t);
+  else if (embed_dtype == PSG_BF16 && x_dtype == PSG_F32) GS(bf16_t, float);
+  else if (embed_dtype == PSG_F16 && x_dtype == PSG_F16) GS(f16_t, f16_t);
+  else if (embed_dtype == PSG_F16 && x_dtype == PSG_F32) GS(f16_t, float);
+  else {
+    psg_set_error("psg_greedy_step: embedding dtype %d -> residual dtype %d unsupported", embed_dtype, x_dtype);
+    return PSG_ERR_UNSUPPORTED;
+  }
+#undef GS
   PSG_CHECK_LAUNCH("psg_greedy_step");
   return PSG_OK;
 }

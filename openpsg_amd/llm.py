@@ -339,9 +339,10 @@ class LlamaDecodeEngine:
         dec_pos = (seq_len - 1).contiguous()                                           # greedy_step does += 1
         dec_pair = torch.arange(K, device=dev, dtype=torch.int32)
         sup = m.eos if suppress_eos else -1
-        ops.greedy_step(logits, 0, max_new, m.eos, sup, tokens, done, next_ids, dec_pos,
-                        dtype=torch.float32 if self.exact_argmax else self.dtype)
         x = torch.empty((K, D), device=dev, dtype=self.resid_dtype)   # residual stream of the decode rows
+        # the greedy step also writes the chosen token's embedding row into x: the next step's input, no gather launch
+        ops.greedy_step(logits, 0, max_new, m.eos, sup, tokens, done, next_ids, dec_pos,
+                        dtype=torch.float32 if self.exact_argmax else self.dtype, embed=self.embed, x_out=x)
         return dict(kc=kc, vc=vc, ctx_len=ctx_len, tokens=tokens, done=done, next_ids=next_ids, dec_pos=dec_pos,
                     dec_pair=dec_pair, sup=sup, x=x, max_new=max_new, first_logits=first_logits)
 
@@ -353,11 +354,11 @@ class LlamaDecodeEngine:
             per_step = 2 * (4 * len(self.layers) + 1)
             sync = torch.zeros((hi - lo) * per_step, device=self.device, dtype=torch.int32)
         for step in range(lo, hi):
-            ops.gather_rows(self.embed, st["next_ids"], st["x"])
             if fused:
                 logits = self._decode_step_fused(st, sync[(step - lo) * per_step:(step - lo + 1) * per_step])
             else:
                 h = self._forward(st["x"], st["dec_pair"], st["dec_pos"], st["kc"], st["vc"], st["ctx_len"], decode=True)
                 logits = self.logits(h)
             ops.greedy_step(logits, step, st["max_new"], m.eos, st["sup"], st["tokens"], st["done"], st["next_ids"],
-                            st["dec_pos"], dtype=torch.float32 if self.exact_argmax else self.dtype)
+                            st["dec_pos"], dtype=torch.float32 if self.exact_argmax else self.dtype, embed=self.embed,
+                            x_out=st["x"])

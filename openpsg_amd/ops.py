@@ -411,16 +411,24 @@ def silu_mul(gate_up, out):
     return out
 
 
-def greedy_step(logits, step, max_new, eos, suppress_token, tokens, done, next_ids, tok_pos, dtype=None):
+def greedy_step(logits, step, max_new, eos, suppress_token, tokens, done, next_ids, tok_pos, dtype=None, embed=None,
+                x_out=None):
+    """embed [vocab, hidden] + x_out [K, hidden]: the chosen token's embedding row goes to x_out in the same launch (the
+    next decode step's input; x_out may be fp32 next to a 16-bit table)."""
     lib, ctx, st = _env(tokens)
     K, vocab = logits.shape
     if isinstance(logits, Partials):
         lp, ls, dt = _p(logits.t), logits.splits, _DT[dtype or torch.bfloat16]
     else:
         lp, ls, dt = _p(logits), 0, _dt(logits)
+    if x_out is not None:
+        assert embed is not None and x_out.shape == (K, embed.shape[1])
+        ep, ed, hid, xp, xd = _p(embed), _dt(embed), embed.shape[1], _p(x_out), _dt(x_out)
+    else:
+        ep, ed, hid, xp, xd = None, 0, 0, None, 0
     check(lib.psg_greedy_step(ctx, lp, ls, K, vocab, int(step), int(max_new), int(eos), int(suppress_token),
                               _p(tokens, torch.int32), _p(done, torch.int32), _p(next_ids, torch.int32),
-                              _p(tok_pos, torch.int32), dt, st), "psg_greedy_step")
+                              _p(tok_pos, torch.int32), ep, ed, hid, xp, xd, dt, st), "psg_greedy_step")
 
 
 def skinny_gemm(x, w, splits=None) -> Partials:

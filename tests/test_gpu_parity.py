@@ -377,9 +377,14 @@ def test_greedy_step_argmax_ties_suppress_and_bookkeeping(vocab, splits, dtype):
     done[4] = 1                                                    # pair 4 finished earlier
     next_ids = torch.zeros(K, device=dev, dtype=torch.int32)
     pos = torch.arange(K, device=dev, dtype=torch.int32) + 40
-    ops.greedy_step(logits, 1, max_new, eos, 7, tokens, done, next_ids, pos, dtype=tdt)
+    # the chosen token's embedding row goes to the next step's residual rows in the same launch (16-bit or fp32 rows)
+    emb_dt = torch.float32 if tdt == torch.float32 else tdt
+    embed = torch.randn(vocab, 256, generator=g).to(dev, emb_dt)
+    x_out = torch.full((K, 256), float("nan"), device=dev, dtype=torch.float32 if splits else emb_dt)
+    ops.greedy_step(logits, 1, max_new, eos, 7, tokens, done, next_ids, pos, dtype=tdt, embed=embed, x_out=x_out)
     torch.cuda.synchronize()
     assert torch.equal(next_ids, want)
+    assert torch.equal(x_out.float(), embed[want.long()].float())
     if not splits:
         assert int(want[0]) == 100 and int(want[3]) == vocab - 1
     exp_tok = want.clone()
