@@ -534,8 +534,8 @@ class RelationTransformerHeadV4(nn.Module):
         q = self.cfg.qformer
         with torch.enable_grad():
             P = dict(self.named_parameters())
-            if not all(p.requires_grad for p in P.values()):
-                raise PsgHipError("forward_train_grad: parameters are frozen; call head.train() first")
+            if not any(p.requires_grad for p in P.values()):       # (a caller may freeze part of the head; not all of it)
+                raise PsgHipError("forward_train_grad: every parameter is frozen; call head.train() first")
             t = self._train_prepare(inputs, sampled, selected)
             N, K, S = t["N"], t["K"], t["S"]
             feat = t["feat"].to(torch.float32)
