@@ -174,6 +174,20 @@ def relation_query_flops(N, L, T, cls_first=False, selected=20):
     return N * N * (first + last) + per_image
 
 
+def relation_query_flops_executed(N, L, T, U, selected=20):
+    """What the cls-first, prompt-deduplicated relation query actually executes for one image (dense-equivalent for the
+    cross-attention contraction, whose masked key tiles are skipped): layer 0's self-attention block, text FFN and
+    cross-attention query projection once per DISTINCT prompt (U of them), the rest of layer 0 and the selection phase of
+    the last layer per pair, the full last layer for the selected pairs."""
+    S, H, F = 33 + T, 768, 3072
+    per_prompt = 2 * T * H * 3 * H + 4 * S * S * H + 2 * S * H * H + 4 * T * H * F + 2 * 33 * H * H
+    per_pair0 = 4 * 33 * L * H + 2 * 33 * H * H + 4 * 33 * H * F
+    last_cls = (2 * H * H + 2 * H * H + 4 * 12 * S * H + 2 * H * H) + 2 * H * H + (2 * H * H + 4 * L * H + 2 * H * H) + 4 * H * F
+    last_full = 2 * S * H * 3 * H + 4 * S * S * H + 2 * 33 * H * H + (2 * 33 * H * H + 4 * 33 * L * H + 2 * 33 * H * H) + 4 * 33 * H * F
+    per_image = 2 * 33 * H * 3 * H + 2 * L * 65536 * 256 + 2 * 2 * 2 * L * 256 * H
+    return U * per_prompt + N * N * (per_pair0 + last_cls) + selected * last_full + per_image
+
+
 def host_info():
     model = ""
     try:
@@ -571,10 +585,17 @@ def main():
             el = time_steps(rq_step, 2, 10) / 10
             T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
             fl = relation_query_flops(N, (a.size // 64) ** 2, T, head.cls_first, head.cfg.num_selected)
+            # algorithmic FLOPs per pair (SURVEY 8d's formula minus work nobody reads) next to what the kernels execute
+            # (the prompt-only share once per distinct prompt)
+            U = max([v[3][0].shape[0] for v in head._gather_cache.values() if len(v) > 3] or [N * N])
+            fx = relation_query_flops_executed(N, (a.size // 64) ** 2, T, U, head.cfg.num_selected) if head.cls_first else fl
             line["stages"] = {"relation_query_ms": round(el * 1e3, 3),
                               "relation_query_pairs_per_s": round(pairs_per_image / el, 1),
                               "relation_query_tflops": round(fl / el / 1e12, 1),
-                              "relation_query_mfma_frac": round(fl / el / 2.5e15, 4), "prompt_tokens": T}
+                              "relation_query_mfma_frac": round(fl / el / 2.5e15, 4),
+                              "relation_query_executed_tflops": round(fx / el / 1e12, 1),
+                              "relation_query_executed_mfma_frac": round(fx / el / 2.5e15, 4),
+                              "distinct_prompts": int(U), "prompt_tokens": T}
             if world == 1 and not force_dist and a.images_per_step == 1:
                 # the timed region repeats ONE scene (hot per-names caches); what an image with a class list never seen
                 # before costs: six other scenes, each run once (head.warm_prompts() as a deployment does at start-up)
