@@ -105,7 +105,7 @@ def setup_head(a, dev):
     from openpsg_amd.weights import make_weights_device
     cfg = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=a.llm_layers), max_object_num=a.objects)
     dtype = getattr(a, "dtype_override", None) or a.dtype
-    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    tdt = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(dtype, torch.float16)
     w = make_weights_device(cfg, 0, dev, llm_dtype=tdt, with_llm=a.workload == "full")
     head = RelationTransformerHeadV4(dtype=dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
                                      llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True,

@@ -57,8 +57,9 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *   100  round 1        200  round 2 (psg_skinny_gemm / psg_rope_kvwrite gained, psg_qformer_cross_attn lost an argument)
  *   300  round 3 (psg_rmsnorm: resid_dtype; psg_greedy_step: embedding row of the chosen token;
  *        psg_train_* gradient kernels, psg_add_layernorm_res32, psg_gather_pair_rows,
- *        psg_masked_split_mean_pool added) */
-#define PSG_ABI_VERSION 300
+ *        psg_masked_split_mean_pool added)
+ *   400  round 4 (psg_skinny_gemm_plan: dtype; psg_skinny_gemm accepts PSG_F32 = the reference's own precision) */
+#define PSG_ABI_VERSION 400
 int psg_version(void);
 const char* psg_last_error(void);
 int psg_create(int device, psg_ctx** out);
@@ -259,6 +260,8 @@ int psg_silu_mul(psg_ctx*, const void* gate_up, int splits, int64_t rows, int in
  * projections and lm_head, all bias-free Linear layers): y[M][N] = x[M][K] . w[N][K]^T with
  * M <= 32 rows (the selected pairs), 16-bit in (`dtype` = PSG_BF16 or PSG_F16) / fp32 accumulate; every weight byte is read from
  * HBM exactly once per call.  N % 16 == 0, K % 64 == 0.
+ * `dtype` = PSG_F32: x and w are fp32 (the precision the reference runs the LLM in, V4:99-100), exact fp32 arithmetic on
+ * v_mfma_f32_16x16x4_f32 (+ v_mfma_f32_4x4x1_16b_f32 for rows 16..19), K % 32 == 0 (psg_gemm_f32.hip).
  * K is split `splits` ways across workgroups (psg_skinny_gemm_plan chooses the count); the kernel
  * writes fp32 partials part[splits][M][N] and does NOT reduce them: the consumers below
  * (psg_rmsnorm, psg_rope_kvwrite, psg_silu_mul, psg_greedy_step) take a `*_splits` argument and sum
@@ -266,7 +269,7 @@ int psg_silu_mul(psg_ctx*, const void* gate_up, int splits, int64_t rows, int in
  * psg_reduce_partials materialises y for any other consumer.
  * The planner also fixes the slab height (8, 11 or 12 wavefronts x 16 rows per workgroup, option skinny_wide) so that
  * the slabs divide evenly over the compute units: a launch lasts as long as the workgroups that walk one slab more. */
-int psg_skinny_gemm_plan(psg_ctx*, int M, int N, int K, int* splits);
+int psg_skinny_gemm_plan(psg_ctx*, int M, int N, int K, int dtype, int* splits);
 int psg_skinny_gemm(psg_ctx*, const void* x, const void* w, float* part, int M, int N, int K,
                     int splits, int dtype, void* stream);
 int psg_reduce_partials(psg_ctx*, const float* part, int splits, int64_t n, void* y, int dtype,

@@ -578,9 +578,20 @@ static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
   return S;
 }
 
-extern "C" int psg_skinny_gemm_plan(psg_ctx* ctx, int M, int N, int K, int* splits) {
+// fp32 instantiation (psg_gemm_f32.hip)
+int psg_sgf_plan(const psg_ctx* ctx, int M, int N, int K);
+int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K, int splits,
+                   void* stream);
+
+extern "C" int psg_skinny_gemm_plan(psg_ctx* ctx, int M, int N, int K, int dtype, int* splits) {
   PSG_REQUIRE(ctx && splits, PSG_ERR_INVALID, "psg_skinny_gemm_plan: NULL argument");
   PSG_REQUIRE(M >= 1 && M <= 32, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm: M=%d (1..32 rows)", M);
+  if (dtype == PSG_F32) {
+    PSG_REQUIRE(N >= 16 && N % 16 == 0 && K >= 32 && K % 32 == 0, PSG_ERR_UNSUPPORTED,
+                "psg_skinny_gemm(f32): N=%d must be a multiple of 16, K=%d a multiple of 32", N, K);
+    *splits = psg_sgf_plan(ctx, M, N, K);
+    return PSG_OK;
+  }
   PSG_REQUIRE(N > 0 && N % 16 == 0 && K >= 64 && K % 64 == 0, PSG_ERR_UNSUPPORTED,
               "psg_skinny_gemm: N=%d must be a multiple of 16, K=%d a multiple of 64", N, K);
   *splits = sg_plan(ctx, M, N, K);
@@ -718,6 +729,7 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
 
 extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K,
                                int splits, int dtype, void* stream) {
+  if (dtype == PSG_F32) return psg_sgf_launch(ctx, x, w, part, M, N, K, splits, stream);
   PSG_DISPATCH_E16(dtype, "psg_skinny_gemm", return sg_launch<E>(ctx, x, w, part, M, N, K, splits, stream));
 }
 

@@ -89,10 +89,11 @@ class LlamaDecodeEngine:
         self.rope = (ang.cos().contiguous().to(self.device), ang.sin().contiguous().to(self.device))
 
     def linear(self, x, w):
-        """Bias-free projection.  Decode-step shapes (<= 32 rows, bf16 / fp16) use the hand-written
-        weight-streaming kernel; prefill and the fp32 verification mode go through hipBLASLt."""
-        if (self.use_skinny and x.dtype in (torch.bfloat16, torch.float16) and x.shape[0] <= 32 and w.shape[0] % 16 == 0
-                and w.shape[1] % 64 == 0 and w.shape[1] >= 256):
+        """Bias-free projection.  Decode-step shapes (<= 32 rows) use the hand-written weight-streaming kernel - in
+        the 16-bit modes and in the fp32 mode (the reference's own precision, V4:99-100) alike; the prompt pass goes
+        through hipBLASLt."""
+        if (self.use_skinny and x.shape[0] <= 32 and w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0
+                and w.shape[1] >= 256):
             return ops.skinny_gemm(x, w)          # fp32 split-K partials, reduced by the consumer kernel
         return F.linear(x, w)
 

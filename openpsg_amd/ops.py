@@ -432,8 +432,8 @@ def greedy_step(logits, step, max_new, eos, suppress_token, tokens, done, next_i
 
 
 def skinny_gemm(x, w, splits=None) -> Partials:
-    """Decode-step projection: fp32 split-K partials of x @ w.T (x: <= 32 rows of bf16); every
-    weight byte streams from HBM once.  Hand the result to a consumer kernel or call .reduce()."""
+    """Decode-step projection: fp32 split-K partials of x @ w.T (x: <= 32 rows of bf16 / fp16 / fp32, w of the
+    same type); every weight byte streams from HBM once.  Hand the result to a consumer kernel or call .reduce()."""
     lib, ctx, st = _env(x)
     M, K = x.shape
     N = w.shape[0]
@@ -441,11 +441,11 @@ def skinny_gemm(x, w, splits=None) -> Partials:
     if splits is None:
         import ctypes
         s = ctypes.c_int(0)
-        check(lib.psg_skinny_gemm_plan(ctx, M, N, K, ctypes.byref(s)), "psg_skinny_gemm_plan")
+        check(lib.psg_skinny_gemm_plan(ctx, M, N, K, _dt(x), ctypes.byref(s)), "psg_skinny_gemm_plan")
         splits = s.value
     part = torch.empty((splits, M, N), device=x.device, dtype=torch.float32)
-    if x.dtype not in (torch.bfloat16, torch.float16) or w.dtype != x.dtype:
-        raise PsgHipError(f"skinny_gemm: x / w must both be bf16 or fp16, got {x.dtype} / {w.dtype}")
+    if x.dtype not in _DT or w.dtype != x.dtype:
+        raise PsgHipError(f"skinny_gemm: x / w must both be bf16, fp16 or fp32, got {x.dtype} / {w.dtype}")
     check(lib.psg_skinny_gemm(ctx, _p(x, name="x"), _p(w, name="w"), _p(part), M, N, K, splits, _dt(x), st),
           "psg_skinny_gemm")
     return Partials(part)
@@ -464,7 +464,7 @@ def skinny_gemm_fused(kind, x_out, w, sync, *, inp=None, resid=None, norm_w=None
     assert w.shape[1] == K and w.dtype == x_out.dtype and sync.dtype == torch.int32 and sync.numel() >= 2
     if splits is None:
         s = ctypes.c_int(0)
-        check(lib.psg_skinny_gemm_plan(ctx, M, N, K, ctypes.byref(s)), "psg_skinny_gemm_plan")
+        check(lib.psg_skinny_gemm_plan(ctx, M, N, K, _dt(x_out), ctypes.byref(s)), "psg_skinny_gemm_plan")
         splits = s.value
     pro = Prologue()
     pro.kind = int(kind)

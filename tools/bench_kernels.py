@@ -27,15 +27,20 @@ def timeit(fn, iters=30, warm=5, flush=None):
     return ts[len(ts) // 2], ts[0]
 
 
-def skinny(M):
+def skinny(M, dtype=torch.bfloat16):
     dev = torch.device("cuda:0")
+    esz = torch.empty(0, dtype=dtype).element_size()
     shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008),
               ("lm_head", 32000, 4096)]
     tot_b, tot_s, tot_l = 0, 0.0, 0.0
+    only = os.environ.get("PSG_BENCH_SHAPES")               # e.g. "gate_up" or "qkv,o": PMC passes of one shape
+    if only:
+        shapes = [s_ for s_ in shapes if s_[0] in only.split(",")]
+    nolib = os.environ.get("PSG_BENCH_NOLIB") == "1"
     for name, N, K in shapes:
-        x = torch.randn(M, K, device=dev).bfloat16()
-        ncopy = max(2, int(800e6 / (N * K * 2)) + 1)       # rotate > MALL-size of weights: always cold
-        ws = [(torch.randn(N, K, device=dev) / K ** 0.5).bfloat16() for _ in range(ncopy)]
+        x = torch.randn(M, K, device=dev).to(dtype)
+        ncopy = max(2, int(800e6 / (N * K * esz)) + 1)     # rotate > MALL-size of weights: always cold
+        ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(dtype) for _ in range(ncopy)]
         it = [0]
 
         REP = 16                                            # back-to-back launches per timing sample
@@ -50,10 +55,10 @@ def skinny(M):
                 it[0] += 1
                 torch.nn.functional.linear(x, ws[it[0] % ncopy])
         ts, _ = timeit(run_s, iters=12, warm=2)
-        tl, _ = timeit(run_l, iters=12, warm=2)
+        tl, _ = (ts, 0) if nolib else timeit(run_l, iters=12, warm=2)
         ts, tl = ts / REP, tl / REP
-        gb = N * K * 2 / 1e9
-        print(f"skinny M={M} {name:8s} N={N:6d} K={K:6d}: {ts:8.1f} us = {gb / ts * 1e6:7.0f} GB/s | "
+        gb = N * K * esz / 1e9
+        print(f"skinny {str(dtype)[6:]} M={M} {name:8s} N={N:6d} K={K:6d}: {ts:8.1f} us = {gb / ts * 1e6:7.0f} GB/s | "
               f"hipBLASLt {tl:8.1f} us = {gb / tl * 1e6:7.0f} GB/s", flush=True)
         mult = 1 if name == "lm_head" else 32
         tot_b += gb * mult
@@ -122,6 +127,11 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if "skinny" in a.what:
         skinny(20)
+    if "skinny32" in a.what:                  # the fp32 instantiation (psg_gemm_f32.hip); skinny32_m<M> for other row counts
+        skinny(20, torch.float32)
+    for wname in a.what:
+        if wname.startswith("skinny32_m"):
+            skinny(int(wname[10:]), torch.float32)
     if "mall" in a.what:
         mall()
     if "xattn" in a.what:
