@@ -58,7 +58,8 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *   300  round 3 (psg_rmsnorm: resid_dtype; psg_greedy_step: embedding row of the chosen token;
  *        psg_train_* gradient kernels, psg_add_layernorm_res32, psg_gather_pair_rows,
  *        psg_masked_split_mean_pool added)
- *   400  round 4 (psg_skinny_gemm_plan: dtype; psg_skinny_gemm accepts PSG_F32 = the reference's own precision) */
+ *   400  round 4 (psg_skinny_gemm_plan: dtype; psg_skinny_gemm accepts PSG_F32 = the reference's own precision;
+ *        psg_train_attn_fwd / _bwd: attention-probability dropout mask) */
 #define PSG_ABI_VERSION 400
 int psg_version(void);
 const char* psg_last_error(void);
@@ -378,11 +379,14 @@ int psg_train_rmsnorm_fwd(psg_ctx*, const float* x, const float* w, float eps, i
                           float* rstd, void* stream);
 int psg_train_rmsnorm_bwd(psg_ctx*, const float* x, const float* dy, const float* w, const float* rstd, int64_t rows,
                           int hidden, float* dx, void* stream);
+/* drop (may be NULL): uint8 keep mask [B][H][Sq][Sk] of the attention-probability dropout the reference trains with
+ * (HF-IB:176-196, InstructBlipQFormerConfig.attention_probs_dropout_prob = 0.1), drop_scale = 1 / (1 - p_drop). */
 int psg_train_attn_fwd(psg_ctx*, const float* q, const float* k, const float* v, const uint8_t* keep, int B, int Bk,
-                       int H, int Sq, int Sk, int D, int Mq, float scale, float* p, float* out, void* stream);
+                       int H, int Sq, int Sk, int D, int Mq, float scale, const uint8_t* drop, float drop_scale, float* p,
+                       float* out, void* stream);
 int psg_train_attn_bwd(psg_ctx*, const float* q, const float* k, const float* v, const float* p, const float* dout,
-                       int B, int Bk, int H, int Sq, int Sk, int D, float scale, float* dq, float* dk, float* dv,
-                       void* stream);
+                       int B, int Bk, int H, int Sq, int Sk, int D, float scale, const uint8_t* drop, float drop_scale,
+                       float* dq, float* dk, float* dv, void* stream);
 int psg_train_gelu_fwd(psg_ctx*, const float* x, int64_t n, float* y, void* stream);
 int psg_train_gelu_bwd(psg_ctx*, const float* x, const float* dy, int64_t n, float* dx, void* stream);
 int psg_train_silu_mul_fwd(psg_ctx*, const float* gate_up, int64_t rows, int inter, float* y, void* stream);

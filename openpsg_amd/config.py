@@ -20,6 +20,8 @@ class QFormerConfig:
     enc_hidden: int = 256      # object_feature_size (V4:42), cross-attention K/V input width
     ln_eps: float = 1e-12
     num_query: int = 32        # relation_query rows (V4:87-88); +1 rel_cls_query row (V4:89-90)
+    hidden_dropout: float = 0.1    # InstructBlipQFormerConfig defaults, which V4:78-84 leaves untouched: active when the
+    attn_dropout: float = 0.1      # reference trains (training branch only; inference has no dropout)
 
     @property
     def head_dim(self) -> int:

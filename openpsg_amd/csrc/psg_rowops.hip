@@ -895,6 +895,9 @@ __global__ void __launch_bounds__(1024) greedy_step_kernel(const void* __restric
         bi = s_idx[w];
       }
     const int was_done = done[k];
+    // every logit NaN (an fp16 overflow upstream): bi keeps its initial 0x7fffffff - emit token 0 rather than read
+    // 2^31 * hidden elements past the embedding table
+    if (bi < 0 || bi >= vocab) bi = 0;
     tokens[(int64_t)k * max_new + step] = was_done ? -1 : bi;
     if (!was_done && bi == eos) done[k] = 1;
     next_ids[k] = bi;

@@ -151,12 +151,15 @@ extern "C" int psg_train_rmsnorm_bwd(psg_ctx* ctx, const float* x, const float* 
 // ---- attention -------------------------------------------------------------------------------------------------------
 // q [B][Sq][H*D], k / v [Bk][Sk][H*D] (Bk = B, or 1 = shared by every sequence), keep uint8 [B][Mq][Sk] (Mq = Sq, or
 // 1 = one key mask for all query rows; 1 = attend), p [B][H][Sq][Sk] (saved for the backward), out [B][Sq][H*D].
-// One wave per (b, h, query row); Sk <= 1024; D <= 128.
+// drop (may be NULL) uint8 [B][H][Sq][Sk]: attention-probability dropout (HF-IB:176-196 `self.dropout(attention_probs)`,
+// active when the reference trains): out = sum_j p_j drop_j drop_scale v_j with drop_scale = 1 / (1 - p_drop); p is saved
+// BEFORE the dropout.  One wave per (b, h, query row); Sk <= 1024; D <= 128.
 #define TR_MAXK 16   // keys per lane
 
 __global__ void __launch_bounds__(64) tr_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, const uint8_t* __restrict__ keep,
                                                          int B, int Bk, int H, int Sq, int Sk, int D, int Mq, float scale,
+                                                         const uint8_t* __restrict__ drop, float drop_scale,
                                                          float* __restrict__ p, float* __restrict__ out) {
   __shared__ float s_p[TR_MAXK * 64];
   const int lane = threadIdx.x;
@@ -194,12 +197,13 @@ __global__ void __launch_bounds__(64) tr_attn_fwd_kernel(const float* __restrict
   sum = wave_sum(sum);
   const float inv = 1.0f / sum;
   float* pr = p + (((int64_t)b * H + h) * Sq + i) * Sk;
+  const uint8_t* dr = drop ? drop + (((int64_t)b * H + h) * Sq + i) * Sk : nullptr;
 #pragma unroll
   for (int t = 0; t < TR_MAXK; ++t) {
     const int j = t * 64 + lane;
     if (j < Sk) {
       const float pv = s[t] * inv;
-      s_p[j] = pv;
+      s_p[j] = dr ? (dr[j] ? pv * drop_scale : 0.f) : pv;
       pr[j] = pv;
     }
   }
@@ -211,12 +215,14 @@ __global__ void __launch_bounds__(64) tr_attn_fwd_kernel(const float* __restrict
   }
 }
 
-// dP_j = dO . v_j; c = sum_j p_j dP_j; dS_j = p_j (dP_j - c); dq = scale sum_j dS_j k_j; dk_j += scale dS_j q;
-// dv_j += p_j dO  (dk / dv by atomics: rows of many queries - and, shared keys, of many sequences - add up)
+// dP_j = dO . v_j (x drop_j drop_scale under dropout); c = sum_j p_j dP_j; dS_j = p_j (dP_j - c); dq = scale sum_j dS_j k_j;
+// dk_j += scale dS_j q; dv_j += p_j (drop_j drop_scale) dO  (dk / dv by atomics: rows of many queries - and, shared keys, of
+// many sequences - add up)
 __global__ void __launch_bounds__(64) tr_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, const float* __restrict__ p,
                                                          const float* __restrict__ dout, int B, int Bk, int H, int Sq, int Sk,
-                                                         int D, float scale, float* __restrict__ dq, float* __restrict__ dk,
+                                                         int D, float scale, const uint8_t* __restrict__ drop,
+                                                         float drop_scale, float* __restrict__ dq, float* __restrict__ dk,
                                                          float* __restrict__ dv) {
   __shared__ float s_ds[TR_MAXK * 64];
   __shared__ float s_p[TR_MAXK * 64];
@@ -226,6 +232,7 @@ __global__ void __launch_bounds__(64) tr_attn_bwd_kernel(const float* __restrict
   const int64_t qoff = ((int64_t)b * Sq + i) * hid + h * D;
   const int64_t kvoff = (int64_t)(Bk == 1 ? 0 : b) * Sk * hid + h * D;
   const float* pr = p + (((int64_t)b * H + h) * Sq + i) * Sk;
+  const uint8_t* dr = drop ? drop + (((int64_t)b * H + h) * Sq + i) * Sk : nullptr;
   float dp[TR_MAXK];
   float c = 0.f;
 #pragma unroll
@@ -235,6 +242,7 @@ __global__ void __launch_bounds__(64) tr_attn_bwd_kernel(const float* __restrict
     if (j < Sk) {
       float acc = 0.f;
       for (int d = 0; d < D; ++d) acc += dout[qoff + d] * v[kvoff + (int64_t)j * hid + d];
+      if (dr) acc = dr[j] ? acc * drop_scale : 0.f;
       dp[t] = acc;
       c += pr[j] * acc;
     }
@@ -244,7 +252,7 @@ __global__ void __launch_bounds__(64) tr_attn_bwd_kernel(const float* __restrict
   for (int t = 0; t < TR_MAXK; ++t) {
     const int j = t * 64 + lane;
     if (j < Sk) {
-      s_p[j] = pr[j];
+      s_p[j] = dr ? (dr[j] ? pr[j] * drop_scale : 0.f) : pr[j];
       s_ds[j] = pr[j] * (dp[t] - c) * scale;
     }
   }
@@ -264,29 +272,29 @@ __global__ void __launch_bounds__(64) tr_attn_bwd_kernel(const float* __restrict
 }
 
 extern "C" int psg_train_attn_fwd(psg_ctx* ctx, const float* q, const float* k, const float* v, const uint8_t* keep, int B,
-                                  int Bk, int H, int Sq, int Sk, int D, int Mq, float scale, float* p, float* out,
-                                  void* stream) {
+                                  int Bk, int H, int Sq, int Sk, int D, int Mq, float scale, const uint8_t* drop,
+                                  float drop_scale, float* p, float* out, void* stream) {
   PSG_REQUIRE(ctx && q && k && v && keep && p && out, PSG_ERR_INVALID, "psg_train_attn_fwd: NULL argument");
   PSG_REQUIRE(B >= 0 && (Bk == B || Bk == 1) && H > 0 && Sq > 0 && Sk > 0 && Sk <= TR_MAXK * 64 && D > 0 && D <= 128 &&
                   (Mq == 1 || Mq == Sq),
               PSG_ERR_UNSUPPORTED, "psg_train_attn_fwd: B=%d Bk=%d H=%d Sq=%d Sk=%d D=%d Mq=%d", B, Bk, H, Sq, Sk, D, Mq);
   if (B == 0) return PSG_OK;
   tr_attn_fwd_kernel<<<(unsigned)(B * H * Sq), 64, 0, (hipStream_t)stream>>>(q, k, v, keep, B, Bk, H, Sq, Sk, D, Mq, scale,
-                                                                           p, out);
+                                                                           drop, drop_scale, p, out);
   PSG_CHECK_LAUNCH("psg_train_attn_fwd");
   return PSG_OK;
 }
 
 extern "C" int psg_train_attn_bwd(psg_ctx* ctx, const float* q, const float* k, const float* v, const float* p,
-                                  const float* dout, int B, int Bk, int H, int Sq, int Sk, int D, float scale, float* dq,
-                                  float* dk, float* dv, void* stream) {
+                                  const float* dout, int B, int Bk, int H, int Sq, int Sk, int D, float scale,
+                                  const uint8_t* drop, float drop_scale, float* dq, float* dk, float* dv, void* stream) {
   PSG_REQUIRE(ctx && q && k && v && p && dout && dq && dk && dv, PSG_ERR_INVALID, "psg_train_attn_bwd: NULL argument");
   PSG_REQUIRE(B >= 0 && (Bk == B || Bk == 1) && H > 0 && Sq > 0 && Sk > 0 && Sk <= TR_MAXK * 64 && D > 0 && D <= 128,
               PSG_ERR_UNSUPPORTED, "psg_train_attn_bwd: B=%d Bk=%d H=%d Sq=%d Sk=%d D=%d", B, Bk, H, Sq, Sk, D);
   if (B == 0) return PSG_OK;
   // dk / dv are accumulated: the caller hands them in zeroed
-  tr_attn_bwd_kernel<<<(unsigned)(B * H * Sq), 64, 0, (hipStream_t)stream>>>(q, k, v, p, dout, B, Bk, H, Sq, Sk, D, scale, dq,
-                                                                           dk, dv);
+  tr_attn_bwd_kernel<<<(unsigned)(B * H * Sq), 64, 0, (hipStream_t)stream>>>(q, k, v, p, dout, B, Bk, H, Sq, Sk, D, scale, drop,
+                                                                           drop_scale, dq, dk, dv);
   PSG_CHECK_LAUNCH("psg_train_attn_bwd");
   return PSG_OK;
 }
@@ -357,8 +365,8 @@ extern "C" int psg_train_silu_mul_bwd(psg_ctx* ctx, const float* gu, const float
 // x [rows][heads * head_dim], pos int32 [rows] (row of the cos / sin tables [table_rows][head_dim / 2]):
 // y = x cos + rotate_half(x) sin * sign.  sign = +1: HF-LL:130-160; sign = -1: its adjoint (the rotation by -angle).
 __global__ void tr_rope_kernel(const float* __restrict__ x, const int32_t* __restrict__ pos, const float* __restrict__ cs,
-                               const float* __restrict__ sn, int64_t rows, int heads, int head_dim, float sign,
-                               float* __restrict__ y) {
+                               const float* __restrict__ sn, int table_rows, int64_t rows, int heads, int head_dim,
+                               float sign, float* __restrict__ y) {
   const int half = head_dim / 2;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * heads * half) return;
@@ -366,7 +374,9 @@ __global__ void tr_rope_kernel(const float* __restrict__ x, const int32_t* __res
   const int h = (int)((i / half) % heads);
   const int64_t r = i / ((int64_t)half * heads);
   const int64_t base = (r * heads + h) * head_dim;
-  const float c = cs[(int64_t)pos[r] * half + d], s = sn[(int64_t)pos[r] * half + d] * sign;
+  int pr = pos[r];
+  pr = pr < 0 ? 0 : (pr >= table_rows ? table_rows - 1 : pr);  // never read outside the tables (RopeFn checks the range)
+  const float c = cs[(int64_t)pr * half + d], s = sn[(int64_t)pr * half + d] * sign;
   const float a = x[base + d], b = x[base + d + half];
   y[base + d] = a * c - b * s;                               // rotate_half(x) = [-x2, x1]
   y[base + d + half] = b * c + a * s;
@@ -379,8 +389,8 @@ extern "C" int psg_train_rope(psg_ctx* ctx, const float* x, const int32_t* pos, 
               PSG_ERR_INVALID, "psg_train_rope: bad argument");
   if (rows == 0) return PSG_OK;
   const int64_t n = rows * heads * (head_dim / 2);
-  tr_rope_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, pos, rope_cos, rope_sin, rows, heads,
-                                                                             head_dim, sign, y);
+  tr_rope_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, pos, rope_cos, rope_sin, table_rows,
+                                                                             rows, heads, head_dim, sign, y);
   PSG_CHECK_LAUNCH("psg_train_rope");
   return PSG_OK;
 }

@@ -125,6 +125,8 @@ class RelationTransformerHeadV4(nn.Module):
                  prompt_bucket=8,              # Llama prompt grid rounded up to a multiple of this (graph reuse)
                  cls_first=True,               # last Q-Former layer: cls row of every pair -> selection -> rows 1..32
                                                # of the selected pairs only (same results; qformer.forward_pairs_cls)
+                 train_dropout=True,           # the gradient path applies the Q-Former dropouts the reference trains with
+                                               # (HF defaults 0.1 / 0.1, V4:78-84); False = deterministic (oracle checks)
                  train_losses_without_grad=False,   # forward() in training mode returns the two losses WITHOUT a graph
                                                # (forward_train); off: it raises, so that an mmdet-style loop cannot sum
                                                # them and silently train nothing in this head
@@ -158,6 +160,7 @@ class RelationTransformerHeadV4(nn.Module):
         self.prompt_bucket = int(prompt_bucket)
         self.cls_first = bool(cls_first)
         self.train_losses_without_grad = bool(train_losses_without_grad)
+        self.train_dropout = bool(train_dropout)
         self.act_dtype = _DTYPES[dtype]
         if residual_dtype is None and dtype in ("mixed", "mixed_q32"):
             residual_dtype = "fp32"
@@ -183,6 +186,13 @@ class RelationTransformerHeadV4(nn.Module):
         # parameters under the reference's names (fp32 masters; the engines keep packed copies)
         for key, shape in head_shapes(self.cfg).items():
             _set_nested(self, key, torch.zeros(shape, dtype=torch.float32, device=self.device))
+        # Trainable from construction in an fp32 head (the gradient path is fp32), whatever the training flag says: an
+        # mmdet-style flow wraps the model in DistributedDataParallel BEFORE runner.train() calls model.train(), and DDP
+        # registers its reducer hooks for the parameters that require a gradient at that moment.  A caller's own
+        # freezes (requires_grad_(False) on part of the head) are never touched again.
+        for p_ in self.parameters():
+            p_.requires_grad_(self.act_dtype == torch.float32)
+        self._engine_version = None
         self._llm_weights = None
         self._rq_engine = None
         self._llm_engine = None
@@ -261,12 +271,23 @@ class RelationTransformerHeadV4(nn.Module):
                                              resid_dtype=self.resid_dtype)
         return self
 
+    def _param_version(self) -> int:
+        """Sum of the parameters' in-place version counters: every optimizer step (and any other in-place update of a
+        parameter) moves it, so packed engine copies older than the masters are detected without a hook."""
+        return sum(int(p._version) for p in self.parameters())
+
     @property
     def rq_engine(self) -> RelationQueryEngine:
+        # training mode: optimizer steps move the masters under the packed copies (eval-mode flows invalidate
+        # explicitly - load_*, train(False) - and skip the 70-tensor walk on the inference path)
+        ver = self._param_version() if self.training else self._engine_version
+        if self._rq_engine is not None and ver != self._engine_version:
+            self._rq_engine = None
         if self._rq_engine is None:
             w = {k: v.data for k, v in self.named_parameters()}
             self._rq_engine = RelationQueryEngine(w, self.cfg, self.device, self.act_dtype, self.xattn_variant,
                                                   resid_dtype=self.q_resid_dtype)
+            self._engine_version = ver
             self._proj_stale = True              # language_projection may have been (re)loaded: see llm_engine
         return self._rq_engine
 
@@ -275,6 +296,10 @@ class RelationTransformerHeadV4(nn.Module):
         if self._llm_engine is None:
             raise PsgHipError("the LLM weights are not loaded: reference checkpoints do not contain "
                               "`language_model.*` (part_checkpoint_hook.py:96-116); call load_llm_weights()")
+        if self.training:
+            ver = self._param_version()
+            if ver != getattr(self, "_proj_version", None):  # an optimizer step moved language_projection
+                self._proj_stale, self._proj_version = True, ver
         if getattr(self, "_proj_stale", False):               # language_projection was (re)loaded after the engine was built
             self._llm_engine.proj_w = self.language_projection.weight.data.to(self.act_dtype).contiguous()
             self._llm_engine.proj_b = self.language_projection.bias.data.to(self.act_dtype).contiguous()
@@ -521,12 +546,14 @@ class RelationTransformerHeadV4(nn.Module):
                          llm_row_loss=rl, llm_pair_loss=per_pair)
         return dict(binary_rel_cls_loss=bce, rel_llm_loss=llm_loss)
 
-    def forward_train_grad(self, inputs, sampled=None, selected=None):
+    def forward_train_grad(self, inputs, sampled=None, selected=None, dropout=None):
         """The training branch WITH its gradient graph (V4:327-351, 463-482; tools/train.py:239-246 back-propagates the
         sum of the two losses): the same arithmetic through `openpsg_amd/train_graph.py` - torch.autograd nodes whose
         forward / backward are the fp32 kernels of csrc/psg_train_bwd.hip, library GEMMs for the projections.  Gradients
         reach patch_embed, the Q-Former, relation_query / rel_cls_query, binary_rel_cls_pred and language_projection;
-        the LLM is frozen (CFG:65) and only passes the gradient through.  fp32 heads only."""
+        the LLM is frozen (CFG:65) and only passes the gradient through.  fp32 heads only.
+        dropout: None = `train_dropout` (on by default: the reference trains its Q-Former with HF's default dropouts
+        active, V4:78-84); False = off (what the oracle and the goldens are captured with); or a train_graph.Dropout."""
         from . import train_graph as G
         if self.act_dtype != torch.float32:
             raise PsgHipError("forward_train_grad: the gradient path runs in fp32 (construct the head with dtype='fp32')")
@@ -535,7 +562,7 @@ class RelationTransformerHeadV4(nn.Module):
         with torch.enable_grad():
             P = dict(self.named_parameters())
             if not any(p.requires_grad for p in P.values()):       # (a caller may freeze part of the head; not all of it)
-                raise PsgHipError("forward_train_grad: every parameter is frozen; call head.train() first")
+                raise PsgHipError("forward_train_grad: every parameter of the head is frozen (requires_grad False)")
             t = self._train_prepare(inputs, sampled, selected)
             N, K, S = t["N"], t["K"], t["S"]
             feat = t["feat"].to(torch.float32)
@@ -546,14 +573,23 @@ class RelationTransformerHeadV4(nn.Module):
             om = ((t["bits"][:, :, None] >> sh) & 1).reshape(N, -1)[:, :L].to(torch.uint8)
             sp = t["sampled"].to(dev)
             keep = om[sp // N] | om[sp % N]
-            h = G.qformer_pairs(P, self.cfg, patches, t["ids"].to(torch.int64), t["msk"], keep)
+            if dropout is None:
+                dropout = self.train_dropout
+            if dropout is True:
+                dropout = G.Dropout(q.hidden_dropout, q.attn_dropout)
+            h = G.qformer_pairs(P, self.cfg, patches, t["ids"].to(torch.int64), t["msk"], keep, dropout or None)
             out_s = h[:, :q.q_rows]                                                          # V4:185
             logit = F.linear(out_s[:, 0], P["binary_rel_cls_pred.weight"], P["binary_rel_cls_pred.bias"]).squeeze(1)
             bce = G.BceFn.apply(logit, t["binary"][t["sampled"]].to(dev), self.rel_cls_loss_weight)
-            # pair features of the selected pairs; pairs the sampler skipped stay zero (V4:177, 186)
+            # pair features of the selected pairs as the reference builds them (V4:177, 186): a zero table of all N*N pairs,
+            # `table[sampled] = out`.  The sampler draws WITH replacement (V4:437-461), and index_put's backward hands
+            # every duplicate row the gradient of its table entry - so a selected pair that was drawn d times sends the
+            # LLM-loss gradient into all d of its rows (the rows hold identical values, whichever lands in the table)
             nv = q.num_query
-            pfs = [out_s[t["where"][si], 1:] if si in t["where"] else out_s.new_zeros((nv, q.hidden)) for si in t["selected"]]
-            vis = F.linear(torch.stack(pfs), P["language_projection.weight"], P["language_projection.bias"])   # V4:294
+            table = out_s.new_zeros((N * N, q.q_rows, q.hidden))
+            table = table.index_put((sp.to(torch.int64),), out_s)
+            pf = table[torch.tensor(t["selected"], dtype=torch.int64, device=dev), 1:]
+            vis = F.linear(pf, P["language_projection.weight"], P["language_projection.bias"])               # V4:294
             llm = self.llm_engine
             cids = t["cids"].to(torch.int64)
             tokv = llm.embed[cids.clamp(min=0)] * (cids >= 0)[..., None].to(torch.float32)  # frozen embeddings (V4:296)
@@ -567,14 +603,13 @@ class RelationTransformerHeadV4(nn.Module):
         return dict(binary_rel_cls_loss=bce, rel_llm_loss=llm_loss)
 
     def train(self, mode: bool = True):
-        """Training mode makes the head's own parameters trainable (the fp32 masters under the reference's names; the
-        packed engine copies are rebuilt from them when the head returns to eval); the LLM stays frozen (CFG:65)."""
+        """The training flag only; `requires_grad` is NOT tied to it (set once at construction: fp32 masters are
+        trainable, a caller's freezes stay).  Either transition drops the packed engine copies, which are rebuilt from
+        the masters at their next use (the engines also notice in-place updates of the masters by themselves, see
+        `_param_version`); the LLM stays frozen (CFG:65)."""
         super().train(mode)
-        for p in self.parameters():
-            p.requires_grad_(bool(mode) and self.act_dtype == torch.float32)
-        if not mode:
-            self._rq_engine = None
-            self._proj_stale = True
+        self._rq_engine = None
+        self._proj_stale = True
         return self
 
     def forward_batch(self, batch):

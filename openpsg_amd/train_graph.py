@@ -90,10 +90,11 @@ class RMSNormFn(torch.autograd.Function):
 
 class AttnFn(torch.autograd.Function):
     """softmax(q.k * scale + additive mask) v.  q [B, Sq, H*D]; k, v [Bk, Sk, H*D] with Bk == B or 1 (shared by all
-    sequences); keep uint8 [B, Mq, Sk], Mq == Sq or 1.  An all-masked row gives a uniform softmax (additive finfo.min)."""
+    sequences); keep uint8 [B, Mq, Sk], Mq == Sq or 1.  An all-masked row gives a uniform softmax (additive finfo.min).
+    drop: None, or (uint8 keep mask [B, heads, Sq, Sk], 1 / (1 - p)) - dropout on the attention probabilities."""
 
     @staticmethod
-    def forward(ctx, q, k, v, keep, heads, scale):
+    def forward(ctx, q, k, v, keep, heads, scale, drop=None):
         q, k, v = _f32(q, "attention q"), _f32(k), _f32(v)
         keep = keep.to(torch.uint8).contiguous()
         B, Sq, hid = q.shape
@@ -101,13 +102,16 @@ class AttnFn(torch.autograd.Function):
         D = hid // heads
         Mq = keep.shape[1]
         assert keep.shape == (B, Mq, Sk) and v.shape == k.shape and Bk in (B, 1)
+        dmask, dscale = (None, 1.0) if drop is None else (drop[0].to(torch.uint8).contiguous(), float(drop[1]))
+        assert dmask is None or dmask.shape == (B, heads, Sq, Sk)
         p = torch.empty((B, heads, Sq, Sk), device=q.device, dtype=torch.float32)
         out = torch.empty_like(q)
         lib, c, st = _env(q)
         check(lib.psg_train_attn_fwd(c, q.data_ptr(), k.data_ptr(), v.data_ptr(), keep.data_ptr(), B, Bk, heads, Sq, Sk, D,
-                                     Mq, float(scale), p.data_ptr(), out.data_ptr(), st), "psg_train_attn_fwd")
+                                     Mq, float(scale), None if dmask is None else dmask.data_ptr(), dscale, p.data_ptr(),
+                                     out.data_ptr(), st), "psg_train_attn_fwd")
         ctx.save_for_backward(q, k, v, p)
-        ctx.heads, ctx.scale = heads, float(scale)
+        ctx.heads, ctx.scale, ctx.dmask, ctx.dscale = heads, float(scale), dmask, dscale
         return out
 
     @staticmethod
@@ -120,9 +124,10 @@ class AttnFn(torch.autograd.Function):
         dk, dv = torch.zeros_like(k), torch.zeros_like(v)
         lib, c, st = _env(q)
         check(lib.psg_train_attn_bwd(c, q.data_ptr(), k.data_ptr(), v.data_ptr(), p.data_ptr(), dout.data_ptr(), B, Bk,
-                                     ctx.heads, Sq, Sk, hid // ctx.heads, ctx.scale, dq.data_ptr(), dk.data_ptr(),
-                                     dv.data_ptr(), st), "psg_train_attn_bwd")
-        return dq, dk, dv, None, None, None
+                                     ctx.heads, Sq, Sk, hid // ctx.heads, ctx.scale,
+                                     None if ctx.dmask is None else ctx.dmask.data_ptr(), ctx.dscale, dq.data_ptr(),
+                                     dk.data_ptr(), dv.data_ptr(), st), "psg_train_attn_bwd")
+        return dq, dk, dv, None, None, None, None
 
 
 class GeluFn(torch.autograd.Function):
@@ -175,6 +180,8 @@ class RopeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, cos, sin, heads):
         x = _f32(x, "rope x")
+        if pos.numel() and (int(pos.max()) >= cos.shape[0] or int(pos.min()) < 0):      # training only: one read-back
+            raise PsgHipError(f"rope: position {int(pos.max())} outside the {cos.shape[0]}-row rotary table")
         ctx.save_for_backward(pos, cos, sin)
         ctx.heads = heads
         return RopeFn._run(x, pos, cos, sin, heads, 1.0)
@@ -262,11 +269,37 @@ def layer_norm(x, gamma, beta, eps):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
-def qformer_pairs(P, cfg, patches, ids, text_mask, pair_keep):
+class Dropout:
+    """The Q-Former's dropouts as the reference trains it: V4:78-84 builds InstructBlipQFormerConfig with its defaults
+    (hidden_dropout_prob = attention_probs_dropout_prob = 0.1) and tools/train.py puts the model in train() mode, so HF
+    applies dropout after the embedding LayerNorm (HF-IB:728-757), on the attention probabilities (HF-IB:176-196) and on
+    every dense output before its residual LayerNorm (HF-IB:519-530, 579-596).  Masks are drawn with torch's generator
+    of `device` (or the given one; a CPU generator + upload lets a test replay the same masks in the CPU oracle), in the
+    order the layers run."""
+
+    def __init__(self, p_hidden=0.1, p_attn=0.1, generator=None):
+        self.p_hidden, self.p_attn, self.generator = float(p_hidden), float(p_attn), generator
+
+    def _keep(self, shape, p, device):
+        gdev = device if self.generator is None else self.generator.device
+        return (torch.rand(shape, device=gdev, generator=self.generator) >= p).to(device)
+
+    def hidden(self, x):
+        if self.p_hidden <= 0:
+            return x
+        return x * (self._keep(x.shape, self.p_hidden, x.device).to(x.dtype) / (1.0 - self.p_hidden))
+
+    def attn(self, B, heads, Sq, Sk, device):
+        if self.p_attn <= 0:
+            return None
+        return self._keep((B, heads, Sq, Sk), self.p_attn, device).to(torch.uint8), 1.0 / (1.0 - self.p_attn)
+
+
+def qformer_pairs(P, cfg, patches, ids, text_mask, pair_keep, dropout: Dropout | None = None):
     """The relation Q-Former (HF-IB:446-757 as driven by V4:179-185) over B pairs, all rows of all layers (training
     keeps the text rows of the last layer out of the loss, V4:185, but computes them like the reference).
     P: parameters by reference name; patches [L, C]; ids int64 [B, T]; text_mask [B, T]; pair_keep uint8 [B, L].
-    Returns the last hidden state [B, 33 + T, 768]."""
+    dropout: None = off (the oracle comparison), or a `Dropout` plan.  Returns the last hidden state [B, 33 + T, 768]."""
     q = cfg.qformer
     nq, H, heads = q.q_rows, q.hidden, q.heads
     B, T = ids.shape
@@ -276,6 +309,10 @@ def qformer_pairs(P, cfg, patches, ids, text_mask, pair_keep):
     h = layer_norm(torch.cat([query[None].expand(B, -1, -1), emb], dim=1), P[pre + "layernorm.weight"],
                    P[pre + "layernorm.bias"], q.ln_eps)
     dev = h.device
+    dh = (lambda x: x) if dropout is None else dropout.hidden                                    # noqa: E731
+    da = (lambda *a: None) if dropout is None else dropout.attn                                  # noqa: E731
+    S, L = nq + T, patches.shape[0]
+    h = dh(h)
     self_keep = torch.cat([torch.ones((B, nq), dtype=torch.uint8, device=dev), text_mask.to(torch.uint8)], dim=1)[:, None, :]
     cross_keep = pair_keep.to(torch.uint8)[:, None, :]
     scale = (H // heads) ** -0.5
@@ -283,19 +320,20 @@ def qformer_pairs(P, cfg, patches, ids, text_mask, pair_keep):
     for l in range(q.layers):
         p = f"relation_qformer.encoder.layer.{l}."
         a = AttnFn.apply(lin(p + "attention.attention.query", h), lin(p + "attention.attention.key", h),
-                         lin(p + "attention.attention.value", h), self_keep, heads, scale)
-        a = layer_norm(lin(p + "attention.output.dense", a) + h, P[p + "attention.output.LayerNorm.weight"],
+                         lin(p + "attention.attention.value", h), self_keep, heads, scale, da(B, heads, S, S, dev))
+        a = layer_norm(dh(lin(p + "attention.output.dense", a)) + h, P[p + "attention.output.LayerNorm.weight"],
                        P[p + "attention.output.LayerNorm.bias"], q.ln_eps)
         q33 = a[:, :nq]
         kx = lin(p + "crossattention.attention.key", patches)[None]                           # shared by every pair
         vx = lin(p + "crossattention.attention.value", patches)[None]
-        c = AttnFn.apply(lin(p + "crossattention.attention.query", q33), kx, vx, cross_keep, heads, scale)
-        c = layer_norm(lin(p + "crossattention.output.dense", c) + q33, P[p + "crossattention.output.LayerNorm.weight"],
+        c = AttnFn.apply(lin(p + "crossattention.attention.query", q33), kx, vx, cross_keep, heads, scale,
+                         da(B, heads, nq, L, dev))
+        c = layer_norm(dh(lin(p + "crossattention.output.dense", c)) + q33, P[p + "crossattention.output.LayerNorm.weight"],
                        P[p + "crossattention.output.LayerNorm.bias"], q.ln_eps)
-        hq = layer_norm(lin(p + "output_query.dense", GeluFn.apply(lin(p + "intermediate_query.dense", c))) + c,
+        hq = layer_norm(dh(lin(p + "output_query.dense", GeluFn.apply(lin(p + "intermediate_query.dense", c)))) + c,
                         P[p + "output_query.LayerNorm.weight"], P[p + "output_query.LayerNorm.bias"], q.ln_eps)
         at = a[:, nq:]
-        ht = layer_norm(lin(p + "output.dense", GeluFn.apply(lin(p + "intermediate.dense", at))) + at,
+        ht = layer_norm(dh(lin(p + "output.dense", GeluFn.apply(lin(p + "intermediate.dense", at)))) + at,
                         P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], q.ln_eps)
         h = torch.cat([hq, ht], dim=1)
     return h

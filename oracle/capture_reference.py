@@ -15,7 +15,11 @@ tests/golden/.  Recipe:
      `head(inputs)`; catch the UnboundLocalError the committed binary branch raises at V4:355
       - every capture is complete by then.
 
-Usage:  python oracle/capture_reference.py            (writes tests/golden/G*.npz, T*.npz and the state-dict schema)
+Rows f2 / f4: the commented-out threshold selector (V4:230-234), `_mask_pooling` / the masked-mean block of
+the v1-v3 detectors and the v2 bilinear scorer are captured by exec'ing the reference's OWN source lines, read from
+/root/reference at capture time (F2_*.npz, F4_*.npz).
+
+Usage:  python oracle/capture_reference.py            (writes tests/golden/G*.npz, T*.npz, F*.npz and the state-dict schema)
         python oracle/capture_reference.py G6 T1     (only the cases whose names start with one of the arguments)
 """
 from __future__ import annotations
@@ -394,6 +398,132 @@ def capture_train_case(mod, name):
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+# ---- rows f2 / f4 of SURVEY 8: the threshold selector and the masked pooling / bilinear scorer of the v1-v3 detectors -----
+def _reference_lines(rel_path, first, last, must_contain, uncomment=False):
+    """Source lines [first, last] (1-based) of a reference file, dedented, as ONE code string that is exec'd here, in the
+    build container, with prepared locals - the reference's own text runs, nothing of it is stored in the repository.
+    `must_contain` pins the line numbers to the statements they are meant to be.  uncomment: the lines are a
+    commented-out block (V4:230-234); the leading '# ' is stripped."""
+    import textwrap
+    lines = open(os.path.join(REF, rel_path)).read().splitlines()[first - 1:last]
+    if uncomment:
+        lines = [ln.replace("# ", "", 1) for ln in lines]
+    code = textwrap.dedent("\n".join(lines))
+    for needle in must_contain:
+        assert needle in code, f"{rel_path}:{first}-{last} no longer holds {needle!r}"
+    return code
+
+
+def import_reference_v1_detector():
+    """`kings_sgg/models/detectors/openseed_relation.py` with its un-installed imports stubbed: only the self-free
+    `_mask_pooling` is called."""
+    import_reference_head()
+    _stub("dbm")
+    _stub("mmdet.models.detectors.base", BaseDetector=object)
+    _stub("detectron2")
+    _stub("detectron2.data", MetadataCatalog=None)
+    _stub("detectron2.utils")
+    _stub("detectron2.utils.colormap", random_color=None)
+    _stub("openseed", build_model=None)
+    _stub("openseed.BaseModel", BaseModel=None)
+    mod = importlib.import_module("kings_sgg.models.detectors.openseed_relation")
+    assert mod.__file__.startswith(REF), mod.__file__
+    return mod
+
+
+def capture_threshold_selector():
+    """F2: the commented-out selector V4:230-234, uncommented and executed as written, on seeded probability vectors
+    (no hit, fewer hits than max_llm_forward_num, more, exact ties across the threshold and at the top-k cut).  A
+    SINGLE hit makes the reference's `.squeeze().tolist()` return an int and `len()` raise TypeError, fewer pairs than
+    max_llm_forward_num make its topk raise: both recorded (the build tops up / clamps instead)."""
+    code = _reference_lines("kings_sgg/models/relation_heads/relation_transformer_head_v4.py", 230, 234,
+                            ["torch.nonzero(", "self.pair_selector_threshold", "more_selected_idxes", "set(selected_idxes) |"],
+                            uncomment=True)
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for name, n, mlf, thr, maker in [
+            ("no_hit", 36, 4, 0.5, lambda: torch.rand(36, generator=g) * 0.45),
+            ("few_hits", 100, 8, 0.5, lambda: torch.cat([torch.rand(97, generator=g) * 0.4, torch.tensor([0.9, 0.7, 0.6])])[torch.randperm(100, generator=g)]),
+            ("many_hits", 100, 4, 0.5, lambda: torch.rand(100, generator=g)),
+            ("ties", 64, 6, 0.5, lambda: (torch.randint(0, 8, (64,), generator=g).float() / 8.0)),
+            ("all_hits", 16, 20, 0.25, lambda: 0.5 + torch.rand(16, generator=g) * 0.5),
+            ("one_hit", 25, 3, 0.5, lambda: torch.cat([torch.rand(24, generator=g) * 0.4, torch.tensor([0.8])]))]:
+        prob = maker().float()
+        loc = dict(torch=torch, rel_cls_pred=prob[:, None].clone(), qformer_batch_size=n,
+                   self=types.SimpleNamespace(pair_selector_threshold=thr, max_llm_forward_num=mlf))
+        err = ""
+        try:
+            exec(code, loc)                                           # noqa: S102 - the reference's own five lines
+            sel = sorted(int(i) for i in loc["selected_idxes"])
+        except (TypeError, RuntimeError) as e:                        # the single-hit quirk; topk(k > N*N)
+            err, sel = f"{type(e).__name__}: {e}", []
+        cases.append((name, prob.numpy(), mlf, thr, np.asarray(sel, dtype=np.int64), err))
+        print(f"F2 {name}: n={n} hits={(prob > thr).sum().item()} selected={len(sel)} {err}")
+    out = {"num_cases": np.int64(len(cases))}
+    for k, (name, prob, mlf, thr, sel, err) in enumerate(cases):
+        out.update({f"c{k}_name": np.str_(name), f"c{k}_prob": prob, f"c{k}_max_llm_forward_num": np.int64(mlf),
+                    f"c{k}_threshold": np.float32(thr), f"c{k}_selected_sorted": sel, f"c{k}_error": np.str_(err)})
+    np.savez_compressed(os.path.join(REPO, "tests", "golden", "F2_threshold_selector.npz"), **out)
+
+
+def capture_pooling_and_scorer():
+    """F4: (a) `OpenSeeDRelation._mask_pooling(None, feature, mask, k)` for k in {1, 4, 7} on seeded features and masks
+    (an empty mask, a 2-pixel mask with fewer pixels than chunks, ragged and full masks);
+    (b) the masked-mean block openseed_relation.py:453-468, executed as written: nearest resize to the image size, zero
+    pad, nearest resize to the feature map, (feat * m).sum / (m.sum + 1e-8);
+    (c) the bilinear scorer relation_transformer_head_v2.py:208-213: two Linear layers, reshape + permute, einsum."""
+    import torch.nn.functional as F
+    mod = import_reference_v1_detector()
+    pool = mod.OpenSeeDRelation._mask_pooling
+    g = torch.Generator().manual_seed(404)
+    C, h, w = 24, 20, 28
+    feature = torch.randn(C, h, w, generator=g)
+    masks = torch.zeros(6, 1, h, w)
+    masks[1, 0, 3, 5] = masks[1, 0, 9, 2] = 1.0                       # two pixels: fewer than 4 / 7 chunks
+    masks[2, 0, 2:9, 4:17] = 1.0
+    masks[3, 0] = (torch.rand(h, w, generator=g) > 0.7).float()        # ragged
+    masks[4, 0] = 1.0                                                 # everything
+    masks[5, 0, 10:13, 0:5] = 0.6                                     # soft values >= 0.5 count, as (mask >= 0.5)
+    out = dict(pool_feature=feature.numpy(), pool_masks=masks.numpy())
+    for k in (1, 4, 7):
+        with torch.no_grad():
+            out[f"pool_k{k}"] = np.stack([pool(None, feature, masks[i], k).numpy() for i in range(masks.shape[0])])
+    # (b) the masked-mean block with the locals its enclosing method has at that point
+    code = _reference_lines("kings_sgg/models/detectors/openseed_relation.py", 453, 468,
+                            ["mask_tensor = torch.stack(mask_list)[None]", "F.interpolate(mask_tensor, size=(h_img, w_img))",
+                             "F.pad(mask_tensor", "mask_tensor.sum(dim=[2, 3]) + 1e-8"])
+    scene = make_scene((256, 320), 7, seed=12, ori_hw=(200, 260), img_hw=(240, 312), void_id=133, tiny_object=True)
+    feat = torch.randn(1, C, 64, 80, generator=g)
+    ids = [int(i) for i in scene["object_id_list"]]
+    loc = dict(torch=torch, F=F, mask_list=[scene["pan_results"] == i for i in ids], dtype=torch.float32,
+               resize_height=240, resize_width=312, pad_height=256, pad_width=320, feature_map=feat)
+    with torch.no_grad():
+        exec(code, loc)                                               # noqa: S102
+    out.update(mean_feature_map=feat.numpy(), mean_pan=scene["pan_results"].numpy().astype(np.int32),
+               mean_ids=np.asarray(ids, dtype=np.int32), mean_shapes=np.asarray([[200, 260], [240, 312], [256, 320]]),
+               mean_object_embedding=loc["object_embedding"][0].numpy())
+    # (c) the scorer
+    code = _reference_lines("kings_sgg/models/relation_heads/relation_transformer_head_v2.py", 208, 213,
+                            ["self.object_vision_only_sub_pred(object_embedding)", "'nrsc,nroc->nrso'"])
+    B, N, R, Co, Ci = 2, 9, 5, 12, 16
+    sub_l, obj_l = nn.Linear(Ci, R * Co), nn.Linear(Ci, R * Co)
+    with torch.no_grad():
+        for lin in (sub_l, obj_l):
+            lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.3)
+            lin.bias.copy_(torch.randn(lin.bias.shape, generator=g) * 0.1)
+    emb = torch.randn(B, N, Ci, generator=g)
+    loc = dict(torch=torch, object_embedding=emb, batch_size=B, object_num=N,
+               self=types.SimpleNamespace(object_vision_only_sub_pred=sub_l, object_vision_only_obj_pred=obj_l,
+                                          num_relation_classes=R, output_feature_size=Co))
+    with torch.no_grad():
+        exec(code, loc)                                               # noqa: S102
+        out.update(score_sub=sub_l(emb).numpy(), score_obj=obj_l(emb).numpy(), score_R=np.int64(R),
+                   score_pred=loc["object_vision_only_pred"].numpy())
+    np.savez_compressed(os.path.join(REPO, "tests", "golden", "F4_pooling_scorer.npz"), **out)
+    print("F4: pooled", {k: out[f'pool_k{k}'].shape for k in (1, 4, 7)}, "mean", out["mean_object_embedding"].shape,
+          "scores", out["score_pred"].shape)
+
+
 def main(only=()):
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -404,6 +534,10 @@ def main(only=()):
         capture_state_dict_keys(mod)
     if want("G3_mask_grid"):
         capture_mask_grid_case(mod)
+    if want("F2_threshold_selector"):
+        capture_threshold_selector()
+    if want("F4_pooling_scorer"):
+        capture_pooling_and_scorer()
     scene_cases = [
         # G5 = the C5 geometry (480x640 -> 1000x1333 -> pad 1024x1344, L = 16*21 = 336, not a multiple of 32/64)
         ("G5_c5geo_1024x1344_n8",

@@ -31,7 +31,9 @@ both third-party and absent from /root/reference; the reference pins no version,
   qformer self/cross att HF-IB:446-515 (eager: 176-196), output blocks 519-530
   qformer FFN            HF-IB:563-596, 664-672
   existence head         V4:206-209
-  selector               V4:235-237
+  selector               V4:235-237; threshold selector V4:230-234 (commented out in the reference; select_threshold)
+  masked pooling (f4)    openseed_relation.py:175-200 (_mask_pooling), :453-468 (masked mean);
+                         bilinear scorer relation_transformer_head_v2.py:208-213
   llm inputs             V4:294-301
   llama forward          HF-LL:53-67 (RMSNorm), 130-160 (rotary), 191-214 (eager attention), 163-177 (MLP)
   greedy generate        V4:305-312 (HF generate, num_beams=1, do_sample forced False)
@@ -112,7 +114,7 @@ def _ln(w, prefix, x, eps):
     return F.layer_norm(x, (x.shape[-1],), w[prefix + ".weight"], w[prefix + ".bias"], eps)
 
 
-def _mha(q, k, v, add_mask, heads):
+def _mha(q, k, v, add_mask, heads, drop=None):
     """q [B,Sq,D], k/v [B or 1,Sk,D], add_mask broadcastable to [B,1,Sq,Sk] (HF-IB:176-196)."""
     B, Sq, D = q.shape
     hd = D // heads
@@ -122,6 +124,8 @@ def _mha(q, k, v, add_mask, heads):
     s = torch.matmul(qh, kh.transpose(-1, -2)) * (hd ** -0.5)
     s = s + add_mask.to(s.dtype)
     p = torch.softmax(s, dim=-1)
+    if drop is not None:                                   # HF-IB:176-196: dropout on the attention probabilities (training)
+        p = p * drop
     o = torch.matmul(p, vh)
     return o.transpose(1, 2).reshape(B, Sq, D)
 
@@ -138,8 +142,13 @@ def qformer_embeddings(w, cfg, input_ids):
 
 
 def qformer_forward(w, cfg, input_ids, text_mask, patches, pmask, chunk: int = 256,
-                    return_layers: bool = False):
+                    return_layers: bool = False, dropout=None):
     """Relation Q-Former for B pairs.
+
+    dropout: None (eval; every golden is captured with dropout off), or an object with `hidden(x)` and
+    `attn(B, heads, Sq, Sk, device) -> (keep mask, scale)` - the dropouts HF applies when the reference TRAINS
+    (InstructBlipQFormerConfig defaults 0.1 / 0.1, V4:78-84): after the embedding LayerNorm, on the attention
+    probabilities, on every dense output before its residual LayerNorm; drawn in the order the layers run.
 
     input_ids [B,T] int64, text_mask [B,T] {0,1}, patches [L, enc_hidden] (shared by every pair:
     V4:168 only `expand`s), pmask bool [B, L] (V4:170 expands it over the 33 query rows).
@@ -154,6 +163,14 @@ def qformer_forward(w, cfg, input_ids, text_mask, patches, pmask, chunk: int = 2
         pm = pmask[s0:s0 + chunk]
         B = ids.shape[0]
         h = qformer_embeddings(w, cfg, ids)
+        dh = (lambda x: x) if dropout is None else dropout.hidden                          # noqa: E731
+
+        def da(Sq, Sk):
+            if dropout is None:
+                return None
+            m = dropout.attn(B, q.heads, Sq, Sk, h.device)
+            return None if m is None else m[0].to(h.dtype) * m[1]
+        h = dh(h)
         self_mask = torch.cat([torch.ones(B, nq), tm.float()], dim=1)            # V4:158-159
         fmin = torch.finfo(h.dtype).min                    # == FMIN in fp32, the pinned mode (HF: finfo(dtype).min)
         add_self = ((1.0 - self_mask) * fmin)[:, None, None, :]
@@ -166,22 +183,22 @@ def qformer_forward(w, cfg, input_ids, text_mask, patches, pmask, chunk: int = 2
             p = f"relation_qformer.encoder.layer.{l}."
             # self attention over all S tokens
             a = _mha(_lin(w, p + "attention.attention.query", h), _lin(w, p + "attention.attention.key", h),
-                     _lin(w, p + "attention.attention.value", h), add_self, q.heads)
-            a = _ln(w, p + "attention.output.LayerNorm", _lin(w, p + "attention.output.dense", a) + h, q.ln_eps)
+                     _lin(w, p + "attention.attention.value", h), add_self, q.heads, da(h.shape[1], h.shape[1]))
+            a = _ln(w, p + "attention.output.LayerNorm", dh(_lin(w, p + "attention.output.dense", a)) + h, q.ln_eps)
             # cross attention for the 33 query rows; K/V are the same for every pair
             q33 = a[:, :nq]
             kx = _lin(w, p + "crossattention.attention.key", patches)[None]
             vx = _lin(w, p + "crossattention.attention.value", patches)[None]
-            c = _mha(_lin(w, p + "crossattention.attention.query", q33), kx, vx, add_cross, q.heads)
+            c = _mha(_lin(w, p + "crossattention.attention.query", q33), kx, vx, add_cross, q.heads, da(nq, patches.shape[0]))
             c = _ln(w, p + "crossattention.output.LayerNorm",
-                    _lin(w, p + "crossattention.output.dense", c) + q33, q.ln_eps)
+                    dh(_lin(w, p + "crossattention.output.dense", c)) + q33, q.ln_eps)
             # feed forward: query rows / text rows use different weights (HF-IB:664-672)
             hq = _ln(w, p + "output_query.LayerNorm",
-                     _lin(w, p + "output_query.dense", F.gelu(_lin(w, p + "intermediate_query.dense", c))) + c,
+                     dh(_lin(w, p + "output_query.dense", F.gelu(_lin(w, p + "intermediate_query.dense", c)))) + c,
                      q.ln_eps)
             at = a[:, nq:]
             ht = _ln(w, p + "output.LayerNorm",
-                     _lin(w, p + "output.dense", F.gelu(_lin(w, p + "intermediate.dense", at))) + at, q.ln_eps)
+                     dh(_lin(w, p + "output.dense", F.gelu(_lin(w, p + "intermediate.dense", at)))) + at, q.ln_eps)
             h = torch.cat([hq, ht], dim=1)
             if return_layers:
                 dump.append(dict(self_out=a, cross_out=c, hidden=h))
@@ -204,6 +221,60 @@ def select_topk(prob: torch.Tensor, k: int = 20):
     build fixes 'lower pair index first' (stable sort)."""
     order = torch.sort(prob, descending=True, stable=True).indices
     return order[:k].tolist()
+
+
+def select_threshold(prob: torch.Tensor, threshold: float, max_llm_forward_num: int):
+    """V4:230-234 (commented out in the reference), literally: the pairs with p > threshold, united with the
+    top-max_llm_forward_num by score when there are fewer of them than max(max_llm_forward_num, N*N) - N*N pairs always
+    exist, so the union is always taken - as a SET; returned sorted by pair index.  Pinned on
+    tests/golden/F2_threshold_selector.npz (the five lines, uncommented and exec'd).  Two inputs the literal lines crash
+    on are given the evident meaning instead: a single hit (`.squeeze().tolist()` yields an int) is a one-element set,
+    and top-k is clamped to the number of pairs."""
+    p = prob.reshape(-1)
+    selected = set(torch.nonzero(p > threshold, as_tuple=False).reshape(-1).tolist())
+    if len(selected) < max(max_llm_forward_num, p.numel()):
+        selected |= set(p.topk(min(max_llm_forward_num, p.numel())).indices.tolist())
+    return sorted(selected)
+
+
+def mask_pooling(feature: torch.Tensor, mask: torch.Tensor, output_size: int = 1) -> torch.Tensor:
+    """openseed_relation.py:175-200.  feature [C, h, w], mask [1, h, w] -> [output_size, C]: the masked pixels
+    (mask >= 0.5) in row-major order are cut into output_size chunks (the first n mod k one longer), one mean per
+    chunk; fewer pixels than chunks: the pixel list is repeated; no pixel (mask.sum() <= 0): zeros."""
+    if float(mask.sum()) <= 0:
+        return feature.new_zeros((output_size, feature.shape[0]))
+    feats = feature[:, (mask >= 0.5)[0]]
+    n = feats.shape[1]
+    if n < output_size:
+        feats = feats.repeat(1, -(-output_size // n))[:, :output_size]
+        n = output_size
+    base, extra = divmod(n, output_size)
+    out, pos = [], 0
+    for c in range(output_size):
+        ln = base + (1 if c < extra else 0)
+        out.append(feats[:, pos:pos + ln].mean(dim=1))
+        pos += ln
+    return torch.stack(out)
+
+
+def masked_mean_objects(feature_map: torch.Tensor, pan: torch.Tensor, object_ids, img_hw, pad_hw) -> torch.Tensor:
+    """openseed_relation.py:453-468.  Per-object masks of the id map -> nearest resize to the image size -> zero pad to
+    the padded size -> nearest resize to the feature map (ATen legacy 'nearest', float32 scale) ->
+    (feat * m).sum / (m.sum + 1e-8).  feature_map [1, C, h, w] -> [N, C]."""
+    m = torch.stack([pan == int(i) for i in object_ids])[None].to(feature_map.dtype)
+    m = F.interpolate(m, size=(int(img_hw[0]), int(img_hw[1])))
+    m = F.pad(m, (0, int(pad_hw[1]) - int(img_hw[1]), 0, int(pad_hw[0]) - int(img_hw[0])))
+    m = F.interpolate(m, size=feature_map.shape[-2:])[0][:, None]
+    return (feature_map * m).sum(dim=[2, 3]) / (m.sum(dim=[2, 3]) + 1e-8)
+
+
+def bilinear_scores(sub: torch.Tensor, obj: torch.Tensor, num_relations: int) -> torch.Tensor:
+    """relation_transformer_head_v2.py:208-213.  sub / obj [B, N, R*C] (the two Linear outputs) -> reshape [B, N, R, C],
+    permute to [B, R, N, C], einsum('nrsc,nroc->nrso') -> [B, R, N, N]."""
+    B, N, RC = sub.shape
+    s = sub.reshape(B, N, num_relations, RC // num_relations).permute(0, 2, 1, 3)
+    o = obj.reshape(B, N, num_relations, RC // num_relations).permute(0, 2, 1, 3)
+    return torch.matmul(s, o.transpose(-1, -2))
 
 
 def relation_query(w, cfg, mask_features, img_meta, object_ids, pan, input_ids, text_mask):
@@ -432,8 +503,8 @@ def llm_teacher_forcing_loss(w, cfg, pair_feature_si, prompt_ids, prompt_mask, l
 
 def train_forward(w, cfg, mask_features, masks_info, gt_rels, gt_thing_masks, gt_semantic_seg, input_ids, text_mask,
                   llm_prompt, llm_label, relation_classes, sampled=None, selected=None, batch_size=32,
-                  neg_over_pos=3, loss_weight=50.0, max_llm_forward_num=4):
-    """The training branch end to end (dropout off).  input_ids / text_mask: BERT prompts of ALL N^2 pairs
+                  neg_over_pos=3, loss_weight=50.0, max_llm_forward_num=4, dropout=None):
+    """The training branch end to end (dropout off unless a `dropout` plan is given, see qformer_forward).  input_ids / text_mask: BERT prompts of ALL N^2 pairs
     (V4:146-152); llm_prompt / llm_label: callables(list of pair indices / list of label strings) -> (ids, mask),
     left- / right-padded (V4:262-281).  `sampled` / `selected` replace the random draws (V4:173, 222-228)."""
     import random
@@ -447,7 +518,8 @@ def train_forward(w, cfg, mask_features, masks_info, gt_rels, gt_thing_masks, gt
     if sampled is None:
         sampled = qformer_sampler(target, batch_size, neg_over_pos)
     sampled = torch.as_tensor(sampled, dtype=torch.long)
-    out_s = qformer_forward(w, cfg, input_ids[sampled], text_mask[sampled], patches, pm[sampled])
+    out_s = qformer_forward(w, cfg, input_ids[sampled], text_mask[sampled], patches, pm[sampled], chunk=1 << 30,
+                            dropout=dropout)
     logit, _ = existence_head(w, out_s)
     bce = existence_loss(logit, binary[sampled], loss_weight)
     qout = torch.zeros(n * n, out_s.shape[1], out_s.shape[2])        # V4:177, 186: unsampled pairs stay zero

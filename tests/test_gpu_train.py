@@ -13,11 +13,12 @@ pytestmark = pytest.mark.gpu
 TRAIN = ["T1_train_512_n7", "T2_train_768x1024_n9"]
 
 
-def _head(cfg, w, dtype):
+def _head(cfg, w, dtype, train_dropout=False):
+    """train_dropout False: the goldens and the oracle are captured with dropout off (the dropout path has its own tests)."""
     from openpsg_amd.head import RelationTransformerHeadV4
     h = RelationTransformerHeadV4(dtype=dtype, device="cuda:0", qformer_vocab_size=cfg.qformer.vocab,
                                   llm_config=cfg.llm, llm_feature_size=cfg.llm.hidden, tokenizers="word",
-                                  max_object_num=cfg.max_object_num)
+                                  max_object_num=cfg.max_object_num, train_dropout=train_dropout)
     h.load_weights(w)
     return h
 
@@ -129,7 +130,7 @@ def test_training_gradients_vs_autograd_on_the_oracle(case):
     g, cfg, w, inputs = H.load_train_case(case)
     head = _head(cfg, w, "fp32")
     head.train(True)
-    out = head.forward_train_grad(_to_dev(inputs), sampled=g["sampled"], selected=g["selected"].tolist())
+    out = head.forward_train_grad(_to_dev(inputs), sampled=g["sampled"], selected=g["selected"].tolist(), dropout=False)
     assert abs(float(out["binary_rel_cls_loss"].detach()) - float(g["binary_rel_cls_loss"])) < 5e-3
     assert abs(float(out["rel_llm_loss"].detach()) - float(g["rel_llm_loss"])) < 1e-3
     (out["binary_rel_cls_loss"] + out["rel_llm_loss"]).backward()
@@ -195,7 +196,7 @@ def test_training_steps_through_forward_reduce_the_loss():
     out = head(dev_in)                                          # forward() in training mode: graph attached
     assert out["rel_llm_loss"].requires_grad and out["binary_rel_cls_loss"].requires_grad
     head.eval()
-    assert not any(p.requires_grad for p in head.parameters())
+    assert all(p.requires_grad for p in head.parameters())     # requires_grad is not tied to the training flag
 
 
 def test_detector_forward_train_returns_losses_with_gradients():
@@ -220,3 +221,110 @@ def test_detector_forward_train_returns_losses_with_gradients():
     assert abs(float(losses["rel_llm_loss"].detach()) - float(g["rel_llm_loss"])) < 1e-3       # same draws as the capture
     sum(losses.values()).backward()
     assert float(head.language_projection.weight.grad.abs().max()) > 0
+
+
+def _oracle_grads(g, cfg, w, inputs, sampled, selected, dropout=None):
+    """d(sum of the two losses) / d(every trainable tensor) by torch.autograd through the CPU oracle."""
+    from openpsg_amd.categories import relation_categories
+    from oracle import psg_oracle as O
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    trainable = [k for k in w if not k.startswith("language_model.")]
+    wr = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in w.items()}
+    meta = inputs["img_metas"][0]
+    ids, tmask, llm_prompt, llm_label = H.train_prompts(inputs)
+    gtm = inputs["gt_masks"][0].to_tensor(torch.float32, "cpu")
+    o = O.train_forward(wr, cfg, inputs["mask_features"], meta["masks_info"], meta["gt_rels"][0], gtm,
+                        inputs["gt_semantic_seg"][0], ids, tmask, llm_prompt, llm_label, relation_categories,
+                        sampled=sampled, selected=selected, dropout=dropout)
+    og = torch.autograd.grad(o["binary_rel_cls_loss"] + o["rel_llm_loss"], [wr[k] for k in trainable], allow_unused=True)
+    return o, dict(zip(trainable, og))
+
+
+def _compare_grads(head, og, tol=2e-3):
+    mine = dict(head.named_parameters())
+    checked = 0
+    for k, ref in og.items():
+        got = mine[k].grad
+        got = torch.zeros_like(mine[k]).cpu() if got is None else got.cpu()
+        ref = torch.zeros_like(got) if ref is None else ref
+        scale, err = float(ref.abs().max()), float((got - ref).abs().max())
+        checked += scale > 0
+        assert err <= tol * scale + 5e-6, f"{k}: max |grad - autograd| = {err:.3e} at gradient scale {scale:.3e}"
+    return checked
+
+
+def test_selected_pair_drawn_twice_by_the_sampler_gets_the_gradient_in_both_rows():
+    """The sampler draws with replacement (V4:437-461) and the reference scatters `qformer_outputs[sampled] = out`
+    (V4:186): index_put's backward hands EVERY duplicate row the gradient of its table entry.  A selected pair drawn
+    twice must therefore send the LLM-loss gradient into both of its Q-Former rows - against autograd on the oracle,
+    which scatters the same way."""
+    g, cfg, w, inputs = H.load_train_case(TRAIN[0])
+    sampled = [int(x) for x in g["sampled"]]
+    selected = [int(x) for x in g["selected"]]
+    dup = next(s for s in selected if s in sampled)
+    j = next(i for i, s in enumerate(sampled) if s not in selected)          # overwrite a draw nobody selected
+    sampled[j] = dup
+    assert sampled.count(dup) >= 2
+    head = _head(cfg, w, "fp32")
+    head.train(True)
+    out = head.forward_train_grad(_to_dev(inputs), sampled=np.asarray(sampled), selected=selected)
+    (out["binary_rel_cls_loss"] + out["rel_llm_loss"]).backward()
+    torch.cuda.synchronize()
+    o, og = _oracle_grads(g, cfg, w, inputs, np.asarray(sampled), selected)
+    assert abs(float(out["rel_llm_loss"].detach()) - float(o["rel_llm_loss"])) < 1e-3
+    assert _compare_grads(head, og) >= 60
+
+
+def test_training_dropout_matches_the_oracle_on_the_same_masks():
+    """The Q-Former dropouts the reference trains with (InstructBlipQFormerConfig defaults 0.1 / 0.1, V4:78-84; after
+    the embedding LayerNorm, on the attention probabilities, on every dense output): the HIP gradient path and the CPU
+    oracle draw their masks from CPU generators with the same seed, in the same order - losses and gradients agree;
+    dropout changes the losses; the default plan (torch's device generator) is reproducible under torch.manual_seed."""
+    from openpsg_amd import train_graph as G
+    g, cfg, w, inputs = H.load_train_case(TRAIN[0])
+    head = _head(cfg, w, "fp32", train_dropout=True)
+    head.train(True)
+    dev_in = _to_dev(inputs)
+    sel = g["selected"].tolist()
+    plan = lambda: G.Dropout(cfg.qformer.hidden_dropout, cfg.qformer.attn_dropout, generator=torch.Generator().manual_seed(11))  # noqa: E731
+    out = head.forward_train_grad(dev_in, sampled=g["sampled"], selected=sel, dropout=plan())
+    (out["binary_rel_cls_loss"] + out["rel_llm_loss"]).backward()
+    torch.cuda.synchronize()
+    o, og = _oracle_grads(g, cfg, w, inputs, g["sampled"], sel, dropout=plan())
+    assert abs(float(out["binary_rel_cls_loss"].detach()) - float(o["binary_rel_cls_loss"])) < 5e-3
+    assert abs(float(out["rel_llm_loss"].detach()) - float(o["rel_llm_loss"])) < 1e-3
+    assert _compare_grads(head, og, tol=3e-3) >= 60
+    plain = head.forward_train_grad(dev_in, sampled=g["sampled"], selected=sel, dropout=False)
+    assert abs(float(plain["binary_rel_cls_loss"].detach()) - float(out["binary_rel_cls_loss"].detach())) > 1e-3
+    torch.manual_seed(3)
+    a = head.forward_train_grad(dev_in, sampled=g["sampled"], selected=sel)            # default: train_dropout plan
+    torch.manual_seed(3)
+    b = head.forward_train_grad(dev_in, sampled=g["sampled"], selected=sel)
+    assert float(a["rel_llm_loss"].detach()) == float(b["rel_llm_loss"].detach())
+    assert abs(float(a["binary_rel_cls_loss"].detach()) - float(plain["binary_rel_cls_loss"].detach())) > 1e-3
+
+
+def test_requires_grad_is_set_at_construction_and_engines_follow_the_masters():
+    """(1) A freshly built fp32 head is trainable BEFORE train() is called (DistributedDataParallel wraps the model
+    first), a 16-bit head is not; (2) a caller's freeze survives train(True); (3) in training mode the loss VALUES of
+    forward_train come from the masters as they are after an optimizer step, not from packed copies built before it."""
+    g, cfg, w, inputs = H.load_train_case(TRAIN[0])
+    head = _head(cfg, w, "fp32")
+    assert not head.training and all(p.requires_grad for p in head.parameters())
+    assert not any(p.requires_grad for p in _head(cfg, w, "bf16").parameters())
+    head.patch_embed.proj.weight.requires_grad_(False)
+    head.train(True)
+    assert not head.patch_embed.proj.weight.requires_grad and head.relation_query.requires_grad
+    dev_in = _to_dev(inputs)
+    sel = g["selected"].tolist()
+    before = head.forward_train(dev_in, sampled=g["sampled"], selected=sel)         # builds the packed engines
+    opt = torch.optim.SGD([p for p in head.parameters() if p.requires_grad], lr=5e-3)
+    out = head.forward_train_grad(dev_in, sampled=g["sampled"], selected=sel)
+    (out["binary_rel_cls_loss"] + out["rel_llm_loss"]).backward()
+    assert head.patch_embed.proj.weight.grad is None
+    opt.step()
+    after_vals = head.forward_train(dev_in, sampled=g["sampled"], selected=sel)     # inference kernels, fresh copies
+    after_grad = head.forward_train_grad(dev_in, sampled=g["sampled"], selected=sel)
+    assert abs(float(after_vals["binary_rel_cls_loss"]) - float(before["binary_rel_cls_loss"])) > 1e-4
+    assert abs(float(after_vals["binary_rel_cls_loss"]) - float(after_grad["binary_rel_cls_loss"].detach())) < 5e-3
+    assert abs(float(after_vals["rel_llm_loss"]) - float(after_grad["rel_llm_loss"].detach())) < 2e-3

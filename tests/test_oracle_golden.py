@@ -117,3 +117,36 @@ def test_training_branch_vs_reference(case):
     torch.manual_seed(seeds[case])
     assert O.qformer_sampler(target).tolist() == g["sampled"].tolist()
     assert len(g["sampled"]) == 4 * len({(a, b) for a, b, _ in meta["gt_rels"][0]})      # positives + 3x negatives
+
+
+def test_threshold_selector_vs_reference_lines():
+    """f2: oracle.select_threshold against the reference's commented-out V4:230-234, uncommented and exec'd at capture
+    time (tests/golden/F2_threshold_selector.npz).  Cases where the literal lines raise are recorded as such."""
+    g = dict(np.load(H.GOLDEN + "/F2_threshold_selector.npz"))
+    seen_error = 0
+    for k in range(int(g["num_cases"])):
+        prob = torch.from_numpy(g[f"c{k}_prob"])
+        got = O.select_threshold(prob, float(g[f"c{k}_threshold"]), int(g[f"c{k}_max_llm_forward_num"]))
+        if str(g[f"c{k}_error"]):
+            seen_error += 1                                       # the reference crashes here; the oracle's stated meaning
+            hits = set((prob > float(g[f"c{k}_threshold"])).nonzero().flatten().tolist())
+            assert hits <= set(got) and len(got) == max(len(hits), min(int(g[f"c{k}_max_llm_forward_num"]), prob.numel()))
+            continue
+        assert got == g[f"c{k}_selected_sorted"].tolist(), str(g[f"c{k}_name"])
+    assert seen_error == 2
+
+
+def test_pooling_and_scorer_vs_reference():
+    """f4: oracle.mask_pooling / masked_mean_objects / bilinear_scores against `_mask_pooling`, the masked-mean block and
+    the einsum scorer of the reference itself (tests/golden/F4_pooling_scorer.npz)."""
+    g = dict(np.load(H.GOLDEN + "/F4_pooling_scorer.npz"))
+    feature, masks = torch.from_numpy(g["pool_feature"]), torch.from_numpy(g["pool_masks"])
+    for k in (1, 4, 7):
+        got = torch.stack([O.mask_pooling(feature, masks[i], k) for i in range(masks.shape[0])])
+        np.testing.assert_allclose(got.numpy(), g[f"pool_k{k}"], atol=1e-6)
+    assert not g["pool_k4"][0].any() and np.abs(g["pool_k4"][1]).sum() > 0      # empty mask -> zeros; 2 pixels -> repeated
+    ori, img, pad = g["mean_shapes"]
+    got = O.masked_mean_objects(torch.from_numpy(g["mean_feature_map"]), torch.from_numpy(g["mean_pan"]), g["mean_ids"], img, pad)
+    np.testing.assert_allclose(got.numpy(), g["mean_object_embedding"], atol=1e-6)
+    got = O.bilinear_scores(torch.from_numpy(g["score_sub"]), torch.from_numpy(g["score_obj"]), int(g["score_R"]))
+    np.testing.assert_allclose(got.numpy(), g["score_pred"], atol=1e-5)
