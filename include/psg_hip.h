@@ -59,7 +59,7 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *        psg_train_* gradient kernels, psg_add_layernorm_res32, psg_gather_pair_rows,
  *        psg_masked_split_mean_pool added)
  *   400  round 4 (psg_skinny_gemm_plan: dtype; psg_skinny_gemm accepts PSG_F32 = the reference's own precision;
- *        psg_train_attn_fwd / _bwd: attention-probability dropout mask) */
+ *        psg_train_attn_fwd / _bwd: attention-probability dropout mask; psg_split_f16x3, psg_scale_rows_cols added) */
 #define PSG_ABI_VERSION 400
 int psg_version(void);
 const char* psg_last_error(void);
@@ -311,6 +311,17 @@ typedef struct psg_prologue {
 } psg_prologue;
 int psg_skinny_gemm_fused(psg_ctx*, const psg_prologue* pro, void* x, const void* w, float* part, int M, int N, int K,
                           int splits, int dtype, void* stream);
+
+/* ---- fp32-grade products on the 16-bit matrix cores (prompt pass of the reference-precision mode, V4:99-100 with
+ * HF-LL:163-177): an fp32 row, scaled by a power of two so that its largest magnitude lies in [2^13, 2^14), is written as
+ * three fp16 K segments - order 0 (activations): [hi | hi | lo], order 1 (weights): [hi | lo | hi], hi = fp16(v),
+ * lo = fp16(v - hi) - so that ONE fp16 GEMM over K' = 3K computes xh.wh + xh.wl + xl.wh with fp32 accumulation
+ * (error ~3 * 2^-22 per product; psg_split.hip).  inv_scale[row] = the power of two that undoes the row's scaling;
+ * psg_scale_rows_cols applies y[m][n] *= row_scale[m] * col_scale[n] in place (exact). */
+int psg_split_f16x3(psg_ctx*, const float* x, int64_t rows, int K, int64_t row_stride, int order, void* out,
+                    float* inv_scale, void* stream);
+int psg_scale_rows_cols(psg_ctx*, float* y, int64_t rows, int N, const float* row_scale, const float* col_scale,
+                        void* stream);
 
 /* ---- Q-Former dense projections with fused epilogue (HF-IB:563-596 intermediate(_query): Linear + exact-erf GELU):
  * out[M][N] = epilogue(x[M][K] . w[N][K]^T + bias[N]); x / w / out bf16 or fp16 row-major, bias fp32 (may be NULL),

@@ -85,6 +85,8 @@ SIGNATURES = {
     "psg_train_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp],
     "psg_train_rmsnorm_fwd": [_vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp],
     "psg_train_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp],
+    "psg_split_f16x3": [_vp, _vp, _i64, _i, _i64, _i, _vp, _vp, _vp],
+    "psg_scale_rows_cols": [_vp, _vp, _i64, _i, _vp, _vp, _vp],
     "psg_train_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _vp, _vp],
     "psg_train_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _vp, _vp, _vp],
     "psg_train_gelu_fwd": [_vp, _vp, _i64, _vp, _vp],

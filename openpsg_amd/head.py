@@ -33,7 +33,7 @@ from .weights import head_shapes, llm_shapes
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
            "fp16": torch.float16, "float16": torch.float16, "half": torch.float16, "mixed": torch.float16,
-           "mixed_q32": torch.float16,
+           "mixed_q32": torch.float16, "fp32s": torch.float32,
            torch.bfloat16: torch.bfloat16, torch.float32: torch.float32, torch.float16: torch.float16}
 
 
@@ -95,8 +95,9 @@ class RelationTransformerHeadV4(nn.Module):
                  max_object_num=30,
                  # ---- build-specific, keyword only --------------------------------------------------
                  dtype="bf16",                 # activation/weight dtype of the GPU path: 'bf16' | 'fp16' (both on the
-                                               # matrix cores) | 'fp32' (verification mode) | 'mixed' = fp16 GEMM
-                                               # operands with residual_dtype='fp32'
+                                               # matrix cores) | 'fp32' (the reference's own precision, exact fp32
+                                               # everywhere) | 'fp32s' (fp32 with split-fp16 prompt-pass products)
+                                               # | 'mixed' = fp16 GEMM operands with residual_dtype='fp32'
                  residual_dtype=None,          # storage type of the Llama residual stream: None = `dtype` (what HF keeps for
                                                # a model cast to 16 bits) | 'fp32' (never rounded to 16 bits; at 32 layers
                                                # 15 % closer to the fp32 engine for +0.2 % time, tests/test_gpu_llm7b.py)
@@ -162,6 +163,10 @@ class RelationTransformerHeadV4(nn.Module):
         self.train_losses_without_grad = bool(train_losses_without_grad)
         self.train_dropout = bool(train_dropout)
         self.act_dtype = _DTYPES[dtype]
+        # 'fp32s' = the fp32 mode with the prompt pass's projections as split-fp16 products on the 16-bit matrix cores
+        # (x.w = xh.wh + xh.wl + xl.wh, fp32 accumulation, ~7e-7 per product instead of fp32's 6e-8; llm.py, psg_split.hip):
+        # everything else - Q-Former, decode steps, KV cache, attention - is the fp32 mode's own exact-fp32 arithmetic
+        self.prefill_split = dtype == "fp32s"
         if residual_dtype is None and dtype in ("mixed", "mixed_q32"):
             residual_dtype = "fp32"
         if qformer_residual_dtype is None and dtype == "mixed_q32":    # 'mixed' + the Q-Former's residual chain in fp32
@@ -268,7 +273,7 @@ class RelationTransformerHeadV4(nn.Module):
         w["language_projection.weight"] = self.language_projection.weight.data
         w["language_projection.bias"] = self.language_projection.bias.data
         self._llm_engine = LlamaDecodeEngine(w, self.cfg, self.device, self.act_dtype, n_layers=n_layers,
-                                             resid_dtype=self.resid_dtype)
+                                             resid_dtype=self.resid_dtype, prefill_split=self.prefill_split)
         return self
 
     def _param_version(self) -> int:

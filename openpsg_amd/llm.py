@@ -31,8 +31,11 @@ from .config import PSGConfig
 
 
 class LlamaDecodeEngine:
-    def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, n_layers=None, resid_dtype=None):
-        """resid_dtype: storage type of the residual stream; None = `dtype` (what HF keeps for a model cast to 16
+    def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, n_layers=None, resid_dtype=None,
+                 prefill_split=False):
+        """prefill_split (fp32 engines): the prompt pass's projections as split-fp16 products on the 16-bit matrix cores,
+        `linear_split` below; the decode steps stay exact fp32 (psg_gemm_f32.hip).
+        resid_dtype: storage type of the residual stream; None = `dtype` (what HF keeps for a model cast to 16
         bits), torch.float32 with a 16-bit `dtype` = mixed mode (16-bit GEMM operands, the residual stream - the sum
         of 2 x layers updates - never rounded to 16 bits; costs 160 KB more traffic per decode row kernel)."""
         if dtype not in (torch.float32, torch.bfloat16, torch.float16):
@@ -62,6 +65,13 @@ class LlamaDecodeEngine:
                 wdown=act(weights[p + "mlp.down_proj.weight"]),
                 ln1=f32(p + "input_layernorm.weight"), ln2=f32(p + "post_attention_layernorm.weight")))
         self.use_skinny = True
+        self.prefill_split = bool(prefill_split) and dtype == torch.float32
+        if self.prefill_split:
+            # [wh | wl | wh] fp16 + the per-row power of two that undoes the row scaling, per projection (3 x 2 bytes per
+            # weight next to the fp32 copy the decode steps stream: 40 GB + 27 GB for Llama-2-7B, of 288 GB)
+            for L in self.layers:
+                for k in ("wqkv", "wo", "wgu", "wdown"):
+                    L[k + "_s"] = ops.split_f16x3(L[k], weights=True)
         # greedy argmax over the fp32 split-K sums of the lm_head, NOT over their 16-bit rounding: HF computes the logits of
         # a model cast to 16 bits in 16 bits, but the reference runs the LLM in fp32 (V4:99-100), and a 16-bit logit has
         # an ulp of 0.008-0.016 (fp16) / 0.06 (bf16) at |x| ~ 8-16 - wider than many top-2 margins of a 32000-way
@@ -88,13 +98,24 @@ class LlamaDecodeEngine:
         ang = torch.arange(4096, dtype=torch.float32)[:, None] * inv_freq[None, :]
         self.rope = (ang.cos().contiguous().to(self.device), ang.sin().contiguous().to(self.device))
 
-    def linear(self, x, w):
+    def linear_split(self, x, ws):
+        """x [rows, K] fp32 @ w.T as ONE fp16 matrix-core GEMM over 3K: [xh | xh | xl] . [wh | wl | wh]^T with fp32
+        accumulation, rows and columns rescaled by their powers of two afterwards (exact).  Products of fp16 values
+        are exact in fp32, so what is lost against an fp32 GEMM is the xl.wl term and the split residuals: ~7e-7
+        relative per product (fp32 rounds each product to 6e-8), at 3/16 of the fp32 matrix time."""
+        a3, inv_r = ops.split_f16x3(x)
+        y = torch.mm(a3, ws[0].t(), out_dtype=torch.float32)
+        return ops.scale_rows_cols(y, inv_r, ws[1])
+
+    def linear(self, x, w, ws=None):
         """Bias-free projection.  Decode-step shapes (<= 32 rows) use the hand-written weight-streaming kernel - in
         the 16-bit modes and in the fp32 mode (the reference's own precision, V4:99-100) alike; the prompt pass goes
         through hipBLASLt."""
         if (self.use_skinny and x.shape[0] <= 32 and w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0
                 and w.shape[1] >= 256):
             return ops.skinny_gemm(x, w)          # fp32 split-K partials, reduced by the consumer kernel
+        if ws is not None and x.dtype == torch.float32:
+            return self.linear_split(x, ws)
         return F.linear(x, w)
 
     def logits(self, h):
@@ -135,7 +156,7 @@ class LlamaDecodeEngine:
         mfma_prefill = (prefill_shape is not None and self.dtype in (torch.bfloat16, torch.float16) and m.head_dim == 128
                         and prefill_shape[1] <= 64 and not self.prefill_attn_scalar)
         for l, L in enumerate(self.layers):
-            qkv = self.linear(n, L["wqkv"])
+            qkv = self.linear(n, L["wqkv"], L.get("wqkv_s"))
             if decode:
                 ops.decode_attn(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, kc[l], vc[l], att)
             elif mfma_prefill and isinstance(qkv, torch.Tensor) and rope_pos is None:
@@ -158,11 +179,11 @@ class LlamaDecodeEngine:
                 att, resid = att_k, resid_k
                 n = torch.empty_like(att)
                 act = torch.empty((k, m.inter), device=self.device, dtype=self.dtype)
-            o = self.linear(att, L["wo"])
+            o = self.linear(att, L["wo"], L.get("wo_s"))
             ops.rmsnorm(resid, o, L["ln2"], m.rms_eps, n)                      # resid += o ; n = norm(resid)
-            gu = self.linear(n, L["wgu"])
+            gu = self.linear(n, L["wgu"], L.get("wgu_s"))
             ops.silu_mul(gu, act)
-            d = self.linear(act, L["wdown"])
+            d = self.linear(act, L["wdown"], L.get("wdown_s"))
             nxt = self.layers[l + 1]["ln1"] if l + 1 < len(self.layers) else self.final_norm
             ops.rmsnorm(resid, d, nxt, m.rms_eps, n)                           # resid += d ; n = norm(resid)
         return n

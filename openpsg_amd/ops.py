@@ -583,3 +583,26 @@ def dense_gemm(x, w, bias=None, gelu=False, out=None):
     check(lib.psg_dense_gemm(ctx, _p(x, name="x"), _p(w, name="w"), _p(bias, torch.float32, "bias"), 1 if gelu else 0,
                              _p(out, x.dtype), M, N, K, _dt(x), st), "psg_dense_gemm")
     return out
+
+
+def split_f16x3(x, weights=False):
+    """fp32 rows -> three fp16 K segments for an fp32-grade product on the 16-bit matrix cores (psg_split_f16x3):
+    activations [hi | hi | lo], weights [hi | lo | hi].  Returns (fp16 [rows, 3K], inv_scale fp32 [rows])."""
+    lib, ctx, st = _env(x)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    rows, K = x.shape
+    out = torch.empty((rows, 3 * K), device=x.device, dtype=torch.float16)
+    inv = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(lib.psg_split_f16x3(ctx, x.data_ptr(), rows, K, x.stride(0), 1 if weights else 0, _p(out), _p(inv), st),
+          "psg_split_f16x3")
+    return out, inv
+
+
+def scale_rows_cols(y, row_scale, col_scale):
+    """y[m][n] *= row_scale[m] * col_scale[n] in place (fp32)."""
+    lib, ctx, st = _env(y)
+    rows, N = y.shape
+    assert row_scale.numel() == rows and col_scale.numel() == N
+    check(lib.psg_scale_rows_cols(ctx, _p(y, torch.float32, "y"), rows, N, _p(row_scale, torch.float32),
+                                  _p(col_scale, torch.float32), st), "psg_scale_rows_cols")
+    return y

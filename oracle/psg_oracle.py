@@ -229,11 +229,13 @@ def select_threshold(prob: torch.Tensor, threshold: float, max_llm_forward_num: 
     exist, so the union is always taken - as a SET; returned sorted by pair index.  Pinned on
     tests/golden/F2_threshold_selector.npz (the five lines, uncommented and exec'd).  Two inputs the literal lines crash
     on are given the evident meaning instead: a single hit (`.squeeze().tolist()` yields an int) is a one-element set,
-    and top-k is clamped to the number of pairs."""
+    and top-k is clamped to the number of pairs.  Ties at the top-k cut: torch.topk's order among equal scores is
+    unspecified; as in select_topk the build fixes 'lower pair index first' (stable sort)."""
     p = prob.reshape(-1)
     selected = set(torch.nonzero(p > threshold, as_tuple=False).reshape(-1).tolist())
     if len(selected) < max(max_llm_forward_num, p.numel()):
-        selected |= set(p.topk(min(max_llm_forward_num, p.numel())).indices.tolist())
+        order = torch.sort(p, descending=True, stable=True).indices
+        selected |= set(order[:min(max_llm_forward_num, p.numel())].tolist())
     return sorted(selected)
 
 

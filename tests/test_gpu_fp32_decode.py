@@ -92,3 +92,68 @@ def test_fp32_engine_decode_uses_the_streaming_kernel_and_matches_library_path()
         outs[skinny] = (toks.cpu(), fl.float().cpu())
     assert (outs[True][1] - outs[False][1]).abs().max().item() < 1e-4
     assert torch.equal(outs[True][0], outs[False][0])
+
+
+# ---- the prompt pass of the reference-precision mode as split-fp16 products ('fp32s', psg_split.hip) -------------------
+@pytest.mark.parametrize("M,N,K,spread", [(980, 4096, 4096, 1.0), (257, 768, 2752, 1.0), (64, 512, 256, 1e-4), (333, 1024, 1024, 1e3)])
+def test_split_f16x3_product_is_fp32_grade(M, N, K, spread):
+    """[xh | xh | xl] . [wh | wl | wh]^T with fp32 accumulation against an fp64 product: within 1.5e-6 * sum|x w| per
+    output (3 * 2^-22 = 7e-7 per product + fp32 accumulation), i.e. the fp32 class - the library SGEMM sits at ~3e-7 on
+    the same data, a plain fp16 GEMM at 5e-4.  `spread`: rows / columns of very different magnitude (1e-4 .. 1e3)
+    exercise the per-row power-of-two scaling."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g) * torch.logspace(0, float(np.log10(spread)), M)[:, None]
+    w = torch.randn(N, K, generator=g) / K ** 0.5 * torch.logspace(0, float(np.log10(spread)), N)[:, None]
+    x, w = x.to(dev), w.to(dev)
+    a3, inv_r = ops.split_f16x3(x)
+    b3, inv_c = ops.split_f16x3(w, weights=True)
+    assert a3.shape == (M, 3 * K) and torch.equal(a3[:, :K], a3[:, K:2 * K]) and torch.equal(b3[:, :K], b3[:, 2 * K:])
+    assert bool(torch.isfinite(a3.float()).all()) and float(a3.float().abs().max()) < 16384.5
+    y = ops.scale_rows_cols(torch.mm(a3, b3.t(), out_dtype=torch.float32), inv_r, inv_c)
+    ref = x.double() @ w.double().t()
+    bound = (x.double().abs() @ w.double().abs().t()) + 1e-300
+    rel = ((y.double() - ref).abs() / bound).max().item()
+    lib = ((torch.nn.functional.linear(x, w).double() - ref).abs() / bound).max().item()
+    h16 = ((torch.nn.functional.linear(x.half(), w.half()).double() - ref).abs() / bound).max().item()
+    print(f"M={M} N={N} K={K} spread={spread}: split-fp16 {rel:.2e}, library SGEMM {lib:.2e}, plain fp16 GEMM {h16:.2e} "
+          f"(x sum|x w|)")
+    assert rel < 1.5e-6
+
+
+import numpy as np  # noqa: E402
+
+from tests import helpers as H  # noqa: E402
+
+CASES = ["G1_c1_512_n10", "G2_768x1024_n12", "G4_llm_wide_n6", "G5_c5geo_1024x1344_n8", "G6_llm_7b_width_n6"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fp32s_mode_meets_the_fp32_bar_on_the_reference_goldens(case):
+    """dtype='fp32s' (fp32 everywhere, the prompt pass's projections as split-fp16 products) against the captures of the
+    real reference head: existence logits within 1e-3, selection identical, every greedy token of every selected pair
+    identical, first-step top-8 logits within 1e-3 - the same assertions as the exact-fp32 mode (test_gpu_parity.py)."""
+    from openpsg_amd.head import RelationTransformerHeadV4
+    g, cfg, w, scene = H.load_case(case)
+    head = RelationTransformerHeadV4(dtype="fp32s", device="cuda:0", qformer_vocab_size=cfg.qformer.vocab,
+                                     llm_config=cfg.llm, llm_feature_size=cfg.llm.hidden, tokenizers="word",
+                                     max_object_num=cfg.max_object_num, on_parse_error="skip",
+                                     suppress_eos=bool(g["suppress_eos"]))
+    head.load_weights(w)
+    assert head.llm_engine.prefill_split
+    dev = _dev()
+    head(dict(mask_features=scene["mask_features"].to(dev), img_metas=[scene["img_meta"]],
+              object_info=[dict(object_id_list=scene["object_id_list"], pan_results=scene["pan_results"].to(dev))]))
+    last = head.last
+    assert np.abs(last["exist_logit"].cpu().numpy() - g["exist_logit"]).max() < 1e-3
+    assert last["selected"].cpu().tolist() == g["selected"].tolist()
+    toks = last["tokens_host"]
+    fl = last["first_logits"].float().cpu().numpy()
+    worst = 0.0
+    for i in range(toks.shape[0]):
+        want = g["gen_tokens"][i]
+        assert [int(t) for t in toks[i] if t >= 0] == want[want >= 0].tolist(), f"pair #{i}: greedy tokens differ"
+        worst = max(worst, float(np.abs(fl[i][g["gen_top8_idx"][i]] - g["gen_top8_val"][i]).max()))
+    print(f"{case}: fp32s first-step top-8 logits within {worst:.2e} of the reference")
+    assert worst < 1e-3

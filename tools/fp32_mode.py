@@ -4,7 +4,8 @@
     rocprofv3 --kernel-trace --stats -d /tmp/p -- python tools/fp32_mode.py 3 1
 
 Same scene, head construction and step as bench.py's `parity_grade` leg (V4:99-100 loads the LLM without a dtype:
-fp32 is the reference's own arithmetic).  PSG_F32_SKINNY=0 sends the decode projections back to the library SGEMM.
+fp32 is the reference's own arithmetic).  PSG_F32_SKINNY=0 sends the decode projections back to the library SGEMM; PSG_MODE=fp32s runs the prompt pass's
+projections as split-fp16 products (psg_split.hip).
 """
 import json
 import os
@@ -25,7 +26,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     a = bench.parse.__globals__["argparse"].Namespace(objects=50, size=1024, llm_layers=int(os.environ.get("PSG_LAYERS", "32")),
-                                                       workload="full", dtype="fp32", one_phase=False, pair_chunk=0,
+                                                       workload="full", dtype=os.environ.get("PSG_MODE", "fp32"), one_phase=False, pair_chunk=0,
                                                        categories=133)
     head = bench.setup_head(a, dev)
     if os.environ.get("PSG_F32_SKINNY") == "0":
@@ -33,7 +34,7 @@ def main():
     scene = make_scene((a.size, a.size), a.objects, seed=0, device=str(dev), num_categories=a.categories)
     inputs = bench.scene_inputs(scene)
     el = bench.time_steps(lambda: head(inputs), warmup, steps) / steps
-    print(json.dumps({"mode": "fp32", "ms_per_step": round(el * 1e3, 3), "pairs_per_s": round(50 * 49 / el, 1),
+    print(json.dumps({"mode": a.dtype, "ms_per_step": round(el * 1e3, 3), "pairs_per_s": round(50 * 49 / el, 1),
                       "steps": steps, "skinny": bool(head.llm_engine.use_skinny)}), flush=True)
 
 
