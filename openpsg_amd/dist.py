@@ -14,8 +14,10 @@ shard naturally.  One process per GPU; a job is R images for R ranks (weak scali
      rank m (exactly one non-zero contributor per row, so the sum is exact);
   5. rank m decodes image m's K pairs (LLM weights replicated) and token ids are ALL-GATHERED.
 
-`step_one_image` is the STRONG-scaling form (one image for all ranks, BASELINE C4): rank 0 broadcasts its
-patches, every rank runs its pair shard, probabilities are all-gathered, the selected pair features are
+`step_one_image` is the STRONG-scaling form (one image for all ranks, BASELINE C4): rank 0 - where the segmenter
+ran - broadcasts the image's constants in ONE int32 message: object ids [N], object bitmasks [N, ceil(L/64)] and the
+patch embedding [L, 256] (~260 KB instead of the 67 MB feature map).  The other ranks never see the image:
+names and prompt ids follow from the object ids.  Every rank runs its pair shard, probabilities are all-gathered, the selected pair features are
 all-reduced (one non-zero contributor per row) and the K decodes are DEALT round-robin to the ranks (SURVEY 8e
 item 3; LLM weights replicated), token ids all-gathered.  What dealing can and cannot buy: a decode step streams
 all 13.5 GB of Llama weights for 1 row as for 20, so only the compute-bound prompt pass and the relation query
@@ -59,12 +61,13 @@ def merge_image_results(parts, num_images: int):
     return out
 
 
-def gather_image_results(indexed_results, num_images: int, group=None):
+def gather_image_results(indexed_results, num_images: int, group=None, always_collective=False):
     """Every rank hands in [(image index, result)] for its share; every rank gets the full list in
-    image order.  Results are host objects (numpy maps, python lists), so this is an object gather."""
+    image order.  Results are host objects (numpy maps, python lists), so this is an object gather.
+    always_collective: run the object gather at world size 1 too (first-run insurance for the RCCL path)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (always_collective and dist.is_initialized()):
         parts = [indexed_results]
     else:
         parts = [None] * world
@@ -93,7 +96,21 @@ class HipBackend:
     def patch_embed(self, scene):
         return self.head.rq_engine.patch_embed(scene["mask_features"].to(torch.float32))
 
-    def query_shard(self, scene, patches, p0, p1):
+    def image_constants(self, scene):
+        """(object ids int32 [N], bitmasks int64 [N, W], patches fp32 [L, C]) of an image this rank holds."""
+        ids = self._ids(scene)
+        patches, bits = self.head.image_constants(scene["mask_features"], scene["img_meta"], ids, scene["pan_results"])
+        return torch.tensor(ids, dtype=torch.int32, device=self.device), bits, patches
+
+    def scene_from_ids(self, ids):
+        """What a rank that received an image's constants knows of it: the object ids (names, prompts, decode)."""
+        return dict(object_id_list=[int(i) for i in ids.tolist()])
+
+    def query_shard(self, scene, patches, p0, p1, bits=None):
+        if bits is not None:                          # constants of another rank: the image itself is not here
+            rq = self.head.run_relation_query(None, None, self._ids(scene), self._names(scene), None, pair_range=(p0, p1),
+                                              patches=patches, bits=bits)
+            return (rq if "pending" in rq else rq["hidden"]), rq["exist_prob"]
         rq = self.head.run_relation_query(scene["mask_features"], scene["img_meta"], self._ids(scene), self._names(scene),
                                           scene["pan_results"], pair_range=(p0, p1), patches=patches)
         # cls-first head: the "hidden" handle is the pending selection-phase state (rows 1..32 are computed for the
@@ -235,17 +252,21 @@ class PairShardedPipeline:
         dist.reduce_scatter_tensor(recv.view(-1), send.contiguous().view(-1), op=dist.ReduceOp.SUM, group=self.group)
         return recv
 
+    _BCAST_DTYPES = (torch.float32, torch.int32, torch.int64, torch.float16, torch.bfloat16, torch.uint8)
+
     def _broadcast(self, t, src, device):
+        """Two phases: shape + dtype (8 int64), then the payload."""
         g_src = dist.get_global_rank(self.group, src) if self.group is not None else src
         meta = torch.zeros(8, dtype=torch.int64, device=device)
         if self.rank == src:
             meta[0] = t.dim()
             for i, d in enumerate(t.shape):
                 meta[1 + i] = d
+            meta[7] = self._BCAST_DTYPES.index(t.dtype)
         dist.broadcast(meta, src=g_src, group=self.group)
         if self.rank != src:
-            shape = [int(x) for x in meta[1:1 + int(meta[0])].tolist()]
-            t = torch.empty(shape, device=device, dtype=torch.float32)
+            m = meta.tolist()
+            t = torch.empty([int(x) for x in m[1:1 + int(m[0])]], device=device, dtype=self._BCAST_DTYPES[int(m[7])])
         dist.broadcast(t, src=g_src, group=self.group)
         return t
 
@@ -281,22 +302,53 @@ class PairShardedPipeline:
         Returns dict with per-image lists: existence probabilities, selections and (if decoding) token ids."""
         return self._drive(self.step_gen(scenes))
 
+    def _device(self, scene):
+        if scene is not None and scene.get("mask_features") is not None:
+            return scene["mask_features"].device
+        return self.be.device
+
     @staticmethod
-    def _device(scene):
-        return scene["mask_features"].device
+    def pack_constants(ids, bits, patches):
+        """One int32 message: [N, W, L, C | ids (N) | bitmask words (2 N W) | patches (L C, fp32 bit patterns)]."""
+        N, W = bits.shape
+        L, C = patches.shape
+        head = torch.tensor([N, W, L, C], dtype=torch.int32, device=patches.device)
+        return torch.cat([head, ids.to(torch.int32).reshape(-1), bits.contiguous().view(torch.int32).reshape(-1),
+                          patches.contiguous().view(torch.int32).reshape(-1)])
+
+    @staticmethod
+    def unpack_constants(msg):
+        N, W, L, C = (int(v) for v in msg[:4].tolist())
+        o = 4
+        ids = msg[o:o + N].clone()
+        o += N
+        bits = msg[o:o + 2 * N * W].clone().view(torch.int64).reshape(N, W)
+        o += 2 * N * W
+        patches = msg[o:o + L * C].clone().view(torch.float32).reshape(L, C)
+        return ids, bits, patches
 
     # ---- the pipelines, as generators yielding ("collective", tensor, ...) requests --------------------------------
     def step_one_image_gen(self, scene, deal_decodes=True):
+        """scene: the image's inputs on rank 0 (where the segmenter ran); ignored - may be None - on every other rank,
+        which works from rank 0's broadcast alone."""
         be, R, r = self.be, self.world, self.rank
+        dev = self._device(scene)
+        # 1. the image's constants from the rank that holds it: object ids, object bitmasks, patches - one message of
+        #    ~260 KB instead of the 67 MB feature map and the full-resolution id map
+        if hasattr(be, "image_constants"):
+            msg = self.pack_constants(*be.image_constants(scene)) if r == 0 else None
+            msg = yield ("broadcast", msg, 0, dev)
+            ids, bits, patches = self.unpack_constants(msg)
+            scene = scene if r == 0 else be.scene_from_ids(ids)
+        else:                                                       # backends without mask kernels (the CPU test oracle)
+            bits = None
+            patches = be.patch_embed(scene) if r == 0 else None
+            patches = yield ("broadcast", patches, 0, dev)
         N = be.num_objects(scene)
         B = N * N
-        dev = self._device(scene)
-        # 1. patches from the rank that holds the feature map (rank 0) - 256 KB instead of 67 MB
-        patches = be.patch_embed(scene) if r == 0 else None
-        patches = yield ("broadcast", patches, 0, dev)
         # 2. my pair shard; 3. probabilities everywhere, identical selection everywhere
         p0, p1, shard = shard_range(B, R, r)
-        hidden, prob = be.query_shard(scene, patches, p0, p1)
+        hidden, prob = be.query_shard(scene, patches, p0, p1) if bits is None else be.query_shard(scene, patches, p0, p1, bits)
         prob_pad = torch.full((shard,), -1.0, device=patches.device, dtype=torch.float32)
         prob_pad[:p1 - p0] = prob
         probs = (yield ("all_gather", prob_pad)).reshape(-1)[:B].contiguous()

@@ -660,17 +660,30 @@ class RelationTransformerHeadV4(nn.Module):
             k0 = k1
         return results
 
-    def _prepare_image(self, feat, meta, obj_ids, names, pan, patches=None):
-        """A4 + A5 for one image: shared cross-attention K/V, object bitmasks, prompt-id table (cached per names)."""
+    def image_constants(self, feat, meta, obj_ids, pan):
+        """What the rank that holds an image's segmenter outputs hands to the other ranks: the patch
+        embedding [L, C] fp32 (V4:410; 256 KB instead of the 67 MB feature map) and the object bitmasks
+        [N, ceil(L/64)] (V4:416-429).  With the object ids - from which every rank derives the names and looks the
+        prompt ids up in its own per-class-pair tables (V4:146-152) - that is all `run_relation_query` needs."""
+        eng = self.rq_engine
+        patches = eng.patch_embed(feat.to(torch.float32))
+        ids_dev = torch.tensor(obj_ids, dtype=torch.int32, device=self.device)
+        pan_dev = pan.to(device=self.device, dtype=torch.int32).contiguous()
+        return patches, eng.object_bitmasks(pan_dev, meta, ids_dev, feat.shape[-2:])
+
+    def _prepare_image(self, feat, meta, obj_ids, names, pan, patches=None, bits=None):
+        """A4 + A5 for one image: shared cross-attention K/V, object bitmasks, prompt-id table (cached per names).
+        bits given (another rank computed them, `image_constants`): `feat`, `meta` and `pan` are not touched."""
         eng = self.rq_engine
         dev = self.device
         N = len(obj_ids)
         if patches is None:
             patches = eng.patch_embed(feat.to(torch.float32))
         kv = eng.cross_kv(patches)
-        ids_dev = torch.tensor(obj_ids, dtype=torch.int32, device=dev)
-        pan_dev = pan.to(device=dev, dtype=torch.int32).contiguous()
-        bits = eng.object_bitmasks(pan_dev, meta, ids_dev, feat.shape[-2:])
+        if bits is None:
+            ids_dev = torch.tensor(obj_ids, dtype=torch.int32, device=dev)
+            pan_dev = pan.to(device=dev, dtype=torch.int32).contiguous()
+            bits = eng.object_bitmasks(pan_dev, meta, ids_dev, feat.shape[-2:])
         # BERT prompts: [U*U, T] table gathered per pair on the device (cached per set of names)
         ck = ("q", tuple(names))
         if ck not in self._table_cache:
@@ -711,14 +724,15 @@ class RelationTransformerHeadV4(nn.Module):
                                             prompts)
         return ent
 
-    def run_relation_query(self, feat, meta, obj_ids, names, pan, pair_range=None, patches=None):
+    def run_relation_query(self, feat, meta, obj_ids, names, pan, pair_range=None, patches=None, bits=None):
         """A4-A8 on the GPU.  pair_range=(p0,p1) restricts the Q-Former to a shard of the pairs;
-        `patches` [L,C] fp32 skips the patch embedding (pair sharding: another rank computed it)."""
+        `patches` [L,C] fp32 skips the patch embedding (pair sharding: another rank computed it); with `bits` as well
+        (`image_constants` of that rank) feat / meta / pan may be None: this rank never sees the image."""
         eng = self.rq_engine
         dev = self.device
         N = len(obj_ids)
         B = N * N
-        patches, kv, bits, ck = self._prepare_image(feat, meta, obj_ids, names, pan, patches)
+        patches, kv, bits, ck = self._prepare_image(feat, meta, obj_ids, names, pan, patches, bits)
         uidx = self._table_cache[ck][0].tolist()
         p0, p1 = (0, B) if pair_range is None else pair_range
         q = self.cfg.qformer

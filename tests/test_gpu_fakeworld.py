@@ -59,15 +59,16 @@ def c4():
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_one_c4_image_sharded_over_fake_ranks_fp32(c4, world):
-    """BASELINE C4 (100 masks, 10 000 pairs) through step_one_image: patches broadcast, pair shards, identical top-20,
-    features all-reduced, the 20 decodes dealt round-robin (K = 10 / 5 / 3-or-2 per rank), tokens re-assembled."""
+    """BASELINE C4 (100 masks, 10 000 pairs) through step_one_image: the image's constants (object ids, bitmasks, patches)
+    broadcast by rank 0 - ranks != 0 get NO scene -, pair shards, identical top-20, features all-reduced, the 20 decodes
+    dealt round-robin (K = 10 / 5 / 3-or-2 per rank), tokens re-assembled."""
     from openpsg_amd.dist import HipBackend, LoopbackWorld
     scene, heads = c4
     head, ref = heads["fp32"]
-    nan_scene = dict(scene, mask_features=torch.full_like(scene["mask_features"], float("nan")))
     fw = LoopbackWorld(world)
     pipes = fw.pipelines(HipBackend(head))
-    outs = fw.run([p.step_one_image_gen(scene if r == 0 else nan_scene) for r, p in enumerate(pipes)])
+    # SURVEY 8e: only rank 0 holds the image; every other rank works from its broadcast (object ids, bitmasks, patches)
+    outs = fw.run([p.step_one_image_gen(scene if r == 0 else None) for r, p in enumerate(pipes)])
     torch.cuda.synchronize()
     d = (outs[0]["exist_prob"] - ref["prob"]).abs().max().item()
     print(f"world {world}: max |prob - single GPU| = {d:.2e}")
@@ -165,3 +166,21 @@ def test_infer_tool_image_dealing_through_the_fake_world(tmp_path):
             assert a_["rel_results"] == b_["rel_results"] and np.array_equal(a_["pan_results"], b_["pan_results"])
         ja, jb = outs[1][1], outs[world][1]
         assert [x["relations"] for x in ja] == [x["relations"] for x in jb]
+
+
+def test_image_constants_message_round_trip():
+    """The one-message broadcast of SURVEY 8e: object ids, bitmask words and patches survive the int32 packing bit for
+    bit, and a rank that received them alone reproduces rank 0's pair shard exactly."""
+    from openpsg_amd.dist import HipBackend, PairShardedPipeline
+    from openpsg_amd.synthetic import make_scene
+    head = _mk_head("fp32", 30)
+    scene = make_scene((768, 1024), 13, seed=3, ori_hw=(720, 960), img_hw=(750, 1000), device="cuda:0", tiny_object=True)
+    be = HipBackend(head)
+    ids, bits, patches = be.image_constants(scene)
+    msg = PairShardedPipeline.pack_constants(ids, bits, patches)
+    assert msg.dtype == torch.int32 and msg.numel() == 4 + ids.numel() + 2 * bits.numel() + patches.numel()
+    ids2, bits2, patches2 = PairShardedPipeline.unpack_constants(msg.clone())
+    assert torch.equal(ids2, ids) and torch.equal(bits2, bits) and torch.equal(patches2, patches)
+    here = be.query_shard(scene, patches, 40, 120)
+    there = be.query_shard(be.scene_from_ids(ids2), patches2, 40, 120, bits2)
+    assert torch.equal(here[1], there[1])
