@@ -329,6 +329,14 @@ int psg_scale_rows_cols(psg_ctx*, float* y, int64_t rows, int N, const float* ro
 enum psg_epilogue { PSG_EPI_NONE = 0, PSG_EPI_GELU = 1 };
 int psg_dense_gemm(psg_ctx*, const void* x, const void* w, const float* bias, int epilogue, void* out, int64_t M,
                    int N, int K, int dtype, void* stream);
+/* The same kernel with an fp32 output (out_dtype = PSG_F32) and per-row / per-column scales applied to the accumulator
+ * before the bias: out[m][n] = epilogue(acc[m][n] * row_scale[m] * col_scale[n] + bias[n]) - the second half of the
+ * split-fp16 product of the fp32s mode (psg_split_f16x3 operands, K' = 3K).  Every output element is one k-ordered
+ * accumulation over the whole K (no split-K): a row's result does not depend on M, so a pair shard
+ * reproduces the full pass bit for bit.  out_dtype = dtype: as psg_dense_gemm (scales must be NULL). */
+int psg_dense_gemm_ex(psg_ctx*, const void* x, const void* w, const float* bias, int epilogue, void* out, int64_t M,
+                      int N, int K, int dtype, int out_dtype, const float* row_scale, const float* col_scale,
+                      void* stream);
 
 /* ---- K16: greedy step (HF generate, num_beams=1, do_sample=False; V4:305-312).
  * logits [K][vocab] (dtype); token = argmax (first maximal index); suppress_token >= 0 is

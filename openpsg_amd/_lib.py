@@ -81,6 +81,7 @@ SIGNATURES = {
     "psg_masked_split_mean_pool": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i64, _vp],
     "psg_bilinear_scores": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "psg_dense_gemm": [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp],
+    "psg_dense_gemm_ex": [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp],
     "psg_train_layernorm_fwd": [_vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp, _vp],
     "psg_train_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp],
     "psg_train_rmsnorm_fwd": [_vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp],

@@ -24,7 +24,7 @@ struct psg_opts {
   int selfattn_scalar = 0;      // Q-Former self-attention: scalar checker kernel even in bf16
   int decode_attn_1wave = 0;    // decode attention: one wave per (pair, head) instead of a workgroup
   int dense_gemm_var = 0;       // psg_dense_gemm ablation builds (1: no MFMA, 2: no staging); 0 = the real kernel
-  int qformer_own_gemm = 1;     // Q-Former FFN1: psg_dense_gemm with fused bias + GELU instead of library GEMM + psg_bias_gelu
+  int qformer_own_gemm = 1;     // 1: Q-Former FFN1 on psg_dense_gemm (fused bias + GELU); 2: EVERY Q-Former projection on it (row-count invariant: bit-exact pair sharding); 0: library GEMMs
   int xattn_waves = 8;          // LDS-DMA cross-attention: 8 = ten waves for launches with < 32 tiles per wave, else eight; 10 = always ten; 0 = always eight
   int xattn_dma = 1;            // cross-attention: LDS-DMA kernel (psg_xattn_dma.hip) when its LDS image fits
   int ln_half_wave = 1;         // add + LayerNorm on 16-bit rows: half a wave per row, 16-byte accesses

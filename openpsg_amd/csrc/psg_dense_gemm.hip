@@ -60,23 +60,35 @@ __device__ __forceinline__ dg_u32x4 dg_lds_read128(uint32_t a) {
   return v;
 }
 
-template <typename E, int GELU, int VAR>   // VAR (ablation builds): 0 normal, 1 no MFMA, 2 no staging after the first K tile
+// VAR (ablation builds): 0 normal, 1 no MFMA, 2 no staging after the first K tile.  OUT32: fp32 output
+// out32[m][n] = epilogue(acc * row_scale[m] * col_scale[n] + bias[n]) - the split-fp16 products of the fp32s mode
+// (psg_split.hip: the scales are the powers of two that undo the operands' row scaling).
+// Every output element is ONE k-ordered accumulation over the whole K (no split-K, tiles walk K front to back), so a
+// row's result does not depend on M or on the tile it falls into: a pair shard reproduces the rows of the
+// full pass bit for bit.
+template <typename E, int GELU, int VAR, int OUT32 = 0>
 __global__ void __launch_bounds__(512, 2)
 dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
-                  uint16_t* __restrict__ out, int M, int N, int K) {
+                  uint16_t* __restrict__ out, int M, int N, int K, const float* __restrict__ row_scale,
+                  const float* __restrict__ col_scale) {
   using v8 = typename E::v8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][A 32 KiB | B 32 KiB]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int NB = N / DG_BN, MB = (M + DG_BM - 1) / DG_BM;
-  const int MB8 = (MB + 7) / 8 * 8;
+  const int MB8 = MB >= 8 ? (MB + 7) / 8 * 8 : MB;         // fewer than 8 row blocks: plain numbering (no idle XCD slots)
   const int ntile = MB8 * NB;
   const int wm = wid >> 2, wn = wid & 3;                   // wave tile: rows [128 wm, +128), cols [64 wn, +64)
   // persistent workgroups (one per CU) walk tiles b, b + grid, ...  XCD-aware numbering: tile t lives on XCD
   // t % 8 (= the XCD of its workgroup as long as the grid is a multiple of 8); the NB column tiles of a row block
   // share an XCD, whose L2 then serves the x tile to all of them
   auto tile_mn = [&](int t, int& mb, int& nb) {
+    if (MB < 8) {                                          // row blocks innermost: the MB tiles of a column block
+      mb = t % MB;                                         // are neighbours (they share the w tile through L2)
+      nb = t / MB;
+      return;
+    }
     const int xcd = t & 7, idx = t >> 3;
     mb = (idx / NB) * 8 + xcd;
     nb = idx % NB;
@@ -223,6 +235,35 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
       for (int q = 0; q < 4; ++q)
         bv[j][q] = bias ? *reinterpret_cast<const float4*>(bias + n0 + wn * 64 + j * 32 + 8 * q + 4 * hi)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (OUT32) {
+      float* out32 = reinterpret_cast<float*>(out);
+      float4 cs[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          cs[j][q] = col_scale ? *reinterpret_cast<const float4*>(col_scale + n0 + wn * 64 + j * 32 + 8 * q + 4 * hi)
+                               : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 128 + i * 32 + l31;
+        const float rs = (row_scale && m < M) ? row_scale[m] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v[4] = {acc[i][j][4 * q] * (rs * cs[j][q].x) + bv[j][q].x, acc[i][j][4 * q + 1] * (rs * cs[j][q].y) + bv[j][q].y,
+                          acc[i][j][4 * q + 2] * (rs * cs[j][q].z) + bv[j][q].z, acc[i][j][4 * q + 3] * (rs * cs[j][q].w) + bv[j][q].w};
+            if (GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = dg_gelu(v[e]);
+            }
+            if (m < M)
+              *reinterpret_cast<float4*>(out32 + (int64_t)m * N + n0 + wn * 64 + j * 32 + 8 * q + 4 * hi) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+          }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm * 128 + i * 32 + l31;
@@ -255,6 +296,7 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
         }
       }
     }
+    }
     if (!has_next) return;
     t = tn;
     mb = mbn;
@@ -262,9 +304,22 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
   }
 }
 
+extern "C" int psg_dense_gemm_ex(psg_ctx* ctx, const void* x, const void* w, const float* bias, int epilogue, void* out,
+                                 int64_t M, int N, int K, int dtype, int out_dtype, const float* row_scale,
+                                 const float* col_scale, void* stream);
 extern "C" int psg_dense_gemm(psg_ctx* ctx, const void* x, const void* w, const float* bias, int epilogue, void* out,
                               int64_t M, int N, int K, int dtype, void* stream) {
+  return psg_dense_gemm_ex(ctx, x, w, bias, epilogue, out, M, N, K, dtype, dtype, nullptr, nullptr, stream);
+}
+
+extern "C" int psg_dense_gemm_ex(psg_ctx* ctx, const void* x, const void* w, const float* bias, int epilogue, void* out,
+                                 int64_t M, int N, int K, int dtype, int out_dtype, const float* row_scale,
+                                 const float* col_scale, void* stream) {
   PSG_REQUIRE(ctx && x && w && out, PSG_ERR_INVALID, "psg_dense_gemm: NULL argument");
+  PSG_REQUIRE(out_dtype == dtype || out_dtype == PSG_F32, PSG_ERR_UNSUPPORTED,
+              "psg_dense_gemm: output dtype %d (the operand dtype %d or fp32)", out_dtype, dtype);
+  PSG_REQUIRE(out_dtype == PSG_F32 || (!row_scale && !col_scale), PSG_ERR_UNSUPPORTED,
+              "psg_dense_gemm: row / column scales need the fp32 output");
   PSG_REQUIRE(M >= 0 && N > 0 && K > 0 && M < (1ll << 31), PSG_ERR_INVALID, "psg_dense_gemm: M=%lld N=%d K=%d",
               (long long)M, N, K);
   PSG_REQUIRE(N % DG_BN == 0 && K % DG_BK == 0, PSG_ERR_UNSUPPORTED,
@@ -273,26 +328,30 @@ extern "C" int psg_dense_gemm(psg_ctx* ctx, const void* x, const void* w, const 
               epilogue);
   if (M == 0) return PSG_OK;
   const int NB = N / DG_BN, MB = (int)((M + DG_BM - 1) / DG_BM);
-  const int MB8 = (MB + 7) / 8 * 8;
+  const int MB8 = MB >= 8 ? (MB + 7) / 8 * 8 : MB;
   int grid_i = ctx->num_cu / 8 * 8;                          // persistent: one workgroup per CU, a multiple of 8 (XCD map)
   if (grid_i > MB8 * NB) grid_i = MB8 * NB;
   const unsigned grid = (unsigned)grid_i;
   const size_t lds = 2 * 65536;
-#define DGL(G, V)                                                                                                    \
+#define DGL(G, V, O)                                                                                                 \
   do {                                                                                                              \
-    hipError_t e = hipFuncSetAttribute((const void*)dense_gemm_kernel<E, G, V>,                                        \
+    hipError_t e = hipFuncSetAttribute((const void*)dense_gemm_kernel<E, G, V, O>,                                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     if (e != hipSuccess) {                                                                                          \
       psg_set_error("psg_dense_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));                               \
       return PSG_ERR_HIP;                                                                                           \
     }                                                                                                               \
-    dense_gemm_kernel<E, G, V><<<grid, 512, lds, (hipStream_t)stream>>>((const uint16_t*)x, (const uint16_t*)w, bias, \
-                                                                     (uint16_t*)out, (int)M, N, K);                 \
+    dense_gemm_kernel<E, G, V, O><<<grid, 512, lds, (hipStream_t)stream>>>(                                            \
+        (const uint16_t*)x, (const uint16_t*)w, bias, (uint16_t*)out, (int)M, N, K, row_scale, col_scale);          \
   } while (0)
   const int var = ctx->opt.dense_gemm_var;
-  PSG_DISPATCH_E16(dtype, "psg_dense_gemm",
-                   if (var == 1) DGL(0, 1); else if (var == 2) DGL(0, 2); else if (epilogue == PSG_EPI_GELU) DGL(1, 0);
-                   else DGL(0, 0));
+  if (out_dtype == PSG_F32 && dtype != PSG_F32) {
+    PSG_DISPATCH_E16(dtype, "psg_dense_gemm", if (epilogue == PSG_EPI_GELU) DGL(1, 0, 1); else DGL(0, 0, 1));
+  } else {
+    PSG_DISPATCH_E16(dtype, "psg_dense_gemm",
+                     if (var == 1) DGL(0, 1, 0); else if (var == 2) DGL(0, 2, 0); else if (epilogue == PSG_EPI_GELU) DGL(1, 0, 0);
+                     else DGL(0, 0, 0));
+  }
 #undef DGL
   PSG_CHECK_LAUNCH("psg_dense_gemm");
   return PSG_OK;

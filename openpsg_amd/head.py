@@ -291,7 +291,7 @@ class RelationTransformerHeadV4(nn.Module):
         if self._rq_engine is None:
             w = {k: v.data for k, v in self.named_parameters()}
             self._rq_engine = RelationQueryEngine(w, self.cfg, self.device, self.act_dtype, self.xattn_variant,
-                                                  resid_dtype=self.q_resid_dtype)
+                                                  resid_dtype=self.q_resid_dtype, split=self.prefill_split)
             self._engine_version = ver
             self._proj_stale = True              # language_projection may have been (re)loaded: see llm_engine
         return self._rq_engine

@@ -573,15 +573,19 @@ def cross_entropy_rows(logits, labels):
     return loss
 
 
-def dense_gemm(x, w, bias=None, gelu=False, out=None):
-    """out = [gelu](x @ w.T + bias) in one pass (bf16 / fp16; N % 256 == 0, K % 64 == 0)."""
+def dense_gemm(x, w, bias=None, gelu=False, out=None, out_dtype=None, row_scale=None, col_scale=None):
+    """out = [gelu](x @ w.T [* row_scale[:, None] * col_scale[None, :]] + bias) in one pass (bf16 / fp16 operands;
+    N % 256 == 0, K % 64 == 0).  out_dtype=torch.float32: fp32 result (needed for the scales: the split-fp16 products of
+    the fp32s mode).  Row-count invariant: a row's result does not depend on how many other rows the call has."""
     lib, ctx, st = _env(x)
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and w.dtype == x.dtype
-    out = torch.empty((M, N), device=x.device, dtype=x.dtype) if out is None else out
-    check(lib.psg_dense_gemm(ctx, _p(x, name="x"), _p(w, name="w"), _p(bias, torch.float32, "bias"), 1 if gelu else 0,
-                             _p(out, x.dtype), M, N, K, _dt(x), st), "psg_dense_gemm")
+    odt = x.dtype if out_dtype is None else out_dtype
+    out = torch.empty((M, N), device=x.device, dtype=odt) if out is None else out
+    check(lib.psg_dense_gemm_ex(ctx, _p(x, name="x"), _p(w, name="w"), _p(bias, torch.float32, "bias"), 1 if gelu else 0,
+                                _p(out, odt), M, N, K, _dt(x), _DT[odt], _p(row_scale, torch.float32, "row_scale"),
+                                _p(col_scale, torch.float32, "col_scale"), st), "psg_dense_gemm")
     return out
 
 

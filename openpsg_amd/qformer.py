@@ -27,14 +27,19 @@ from .config import PSGConfig
 
 
 class RelationQueryEngine:
-    def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, xattn_variant=None, resid_dtype=None):
-        """resid_dtype=torch.float32 with a 16-bit `dtype` = mixed mode: the projections keep 16-bit operands, but every
+    def __init__(self, weights: dict, cfg: PSGConfig, device, dtype=torch.bfloat16, xattn_variant=None, resid_dtype=None,
+                 split=False):
+        """split (fp32 engines, head dtype 'fp32s'): every projection as a split-fp16 product, see `_lin`.
+        resid_dtype=torch.float32 with a 16-bit `dtype` = mixed mode: the projections keep 16-bit operands, but every
         LayerNorm reads its residual in fp32 and writes its result twice - fp32 (the next residual: the residual stream is
         never rounded to 16 bits) and 16-bit (the next projection's operand); psg_add_layernorm_res32."""
         if dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise PsgHipError(f"activation dtype must be float32, bfloat16 or float16, got {dtype}")
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.res32 = resid_dtype == torch.float32 and dtype != torch.float32
+        self.split = bool(split) and dtype == torch.float32
+        self._split_w, self._bias32 = {}, {}
+        self.own_gemm = int(_lib.get_option(self.device.index or 0, "qformer_own_gemm"))
         self.xattn_variant = xattn_variant
         q = cfg.qformer
         f32 = lambda k: weights[k].to(device=self.device, dtype=torch.float32).contiguous()  # noqa: E731
@@ -82,7 +87,9 @@ class RelationQueryEngine:
         opt = lambda name: bool(_lib.get_option(self.device.index or 0, name))  # noqa: E731  (options of the psg_ctx)
         self.share_query_qkv = opt("qformer_share_qkv")
         # selection phase of the last layer: cls-row attention in the input space (no K | V projection of all rows)
-        self.cls_input_space = opt("qformer_cls_input_space")
+        # (its two small batched products are library calls whose kernel choice follows the pair count: the row-count
+        # invariant modes - split, qformer_own_gemm = 2 - project K | V through `_lin` instead)
+        self.cls_input_space = opt("qformer_cls_input_space") and not (self.split or self.own_gemm >= 2)
         self._bmm_out_dtype = None       # torch.bmm(..., out_dtype=fp32) available? (probed at first use)
         # two-layer Q-Former: everything in front of layer 0's cross-attention and every text row entering the last
         # layer depend on the PROMPT (class pair) only - computed once per distinct prompt when the caller hands the
@@ -105,7 +112,7 @@ class RelationQueryEngine:
     def cross_kv(self, patches: torch.Tensor):
         """Shared cross-attention K/V, one pair of [L,768] tensors per layer (HF-IB:465-466)."""
         pa = patches.to(self.dtype)
-        return [(F.linear(pa, L["wk_x"], L["bk_x"]), F.linear(pa, L["wv_x"], L["bv_x"])) for L in self.layers]
+        return [(self._lin(pa, L["wk_x"], L["bk_x"]), self._lin(pa, L["wv_x"], L["bv_x"])) for L in self.layers]
 
     # ---- A6 + A7: Q-Former over a list of pairs ---------------------------------------------------
     # Activations travel as (X, X32): X in the activation dtype (the projections' operand), X32 its fp32 twin in mixed mode
@@ -177,15 +184,15 @@ class RelationQueryEngine:
         ctx = torch.empty((R, H), device=self.device, dtype=self.dtype)
         if li == 0 and shared0:
             # the query rows entering layer 0 are identical for every pair: project the first pair's 33 rows once
-            qkv_q = F.linear(X[:nq], L["wqkv"], L["bqkv"])
-            qkv = F.linear(X[RQ:], L["wqkv"], L["bqkv"])
+            qkv_q = self._lin(X[:nq], L["wqkv"], L["bqkv"])
+            qkv = self._lin(X[RQ:], L["wqkv"], L["bqkv"])
             ops.qformer_self_attn_shared(qkv_q, qkv, text_mask, P, T, nq, q.heads, ctx)
         else:
-            qkv = F.linear(X, L["wqkv"], L["bqkv"])
+            qkv = self._lin(X, L["wqkv"], L["bqkv"])
             ops.qformer_self_attn(qkv, text_mask, P, T, nq, q.heads, last, ctx)
         del qkv
         ra = RQ if last else R
-        A = F.linear(ctx[:ra], L["wo"])
+        A = self._lin(ctx[:ra], L["wo"])
         A32 = torch.empty((ra, H), device=self.device, dtype=torch.float32) if self.res32 else None
         if li == 0 and shared0:
             self._ln_into(A[:RQ], X[:nq], self._s(X32, 0, nq), L["bo"], L["ln_a"], self._s(A32, 0, RQ), period=nq)
@@ -193,9 +200,9 @@ class RelationQueryEngine:
         else:
             self._ln_into(A, X[:ra], self._s(X32, 0, ra), L["bo"], L["ln_a"], A32)
         del ctx
-        qx = F.linear(A[:RQ], L["wq_x"], L["bq_x"])
+        qx = self._lin(A[:RQ], L["wq_x"], L["bq_x"])
         cx = self._cross(li, qx, nq, kv, bits, num_objects, pair_index, segments)
-        Cq = F.linear(cx, L["wo_x"])
+        Cq = self._lin(cx, L["wo_x"])
         _, Cq32 = self._ln(Cq, A[:RQ], self._s(A32, 0, RQ), L["bo_x"], L["ln_x"])
         del qx, cx
         if last and hidden_out is not None:
@@ -205,12 +212,12 @@ class RelationQueryEngine:
             Xn = torch.empty((RQ if last else R, H), device=self.device, dtype=self.dtype)
         Xn32 = torch.empty((Xn.shape[0], H), device=self.device, dtype=torch.float32) if self.res32 else None
         iq = self._ffn1(Cq, L["w1q"], L["b1q"])
-        hq = F.linear(iq, L["w2q"])
+        hq = self._lin(iq, L["w2q"])
         self._ln_into(hq, Cq, Cq32, L["b2q"], L["ln_q"], self._s(Xn32, 0, RQ), out16=Xn[:RQ])
         del iq, hq
         if not last and T > 0:
             it = self._ffn1(A[RQ:], L["w1t"], L["b1t"])
-            ht = F.linear(it, L["w2t"])
+            ht = self._lin(it, L["w2t"])
             self._ln_into(ht, A[RQ:], self._s(A32, RQ), L["b2t"], L["ln_t"], self._s(Xn32, RQ), out16=Xn[RQ:])
             del it, ht
         return Xn, Xn32
@@ -280,7 +287,7 @@ class RelationQueryEngine:
         li, L = len(self.layers) - 1, self.layers[-1]
         x_cls = Xq.view(P, nq, H)[:, 0].contiguous()                         # [P, H] residual of the cls rows
         x_cls32 = Xq32.view(P, nq, H)[:, 0].contiguous() if Xq32 is not None else None
-        q_cls = F.linear(x_cls, L["wqkv"][:H], L["bqkv"][:H])              # queries of the cls rows only
+        q_cls = self._lin(x_cls, L["wqkv"][:H], L["bqkv"][:H])              # queries of the cls rows only
         hd = H // q.heads
         if in_space:
             # keys / values never materialised: the cls queries go back through W_k (g_h = W_k,h^T q_h), the kernel
@@ -294,17 +301,17 @@ class RelationQueryEngine:
             del g, xbar
         else:
             assert X is not None
-            kvs = F.linear(X, L["wqkv"][H:], L["bqkv"][H:])                 # keys | values of every row
+            kvs = self._lin(X, L["wqkv"][H:], L["bqkv"][H:])                 # keys | values of every row
             ctx = ops.qformer_self_attn_cls(q_cls, kvs, mask, P, T, nq, q.heads)
             del kvs
-        A = F.linear(ctx, L["wo"])
+        A = self._lin(ctx, L["wo"])
         _, A32 = self._ln(A, x_cls, x_cls32, L["bo"], L["ln_a"])
-        qx = F.linear(A, L["wq_x"], L["bq_x"])
+        qx = self._lin(A, L["wq_x"], L["bq_x"])
         cx = self._cross(li, qx, 1, kv, bits, num_objects, pair_index, segments)
-        Cq = F.linear(cx, L["wo_x"])
+        Cq = self._lin(cx, L["wo_x"])
         _, Cq32 = self._ln(Cq, A, A32, L["bo_x"], L["ln_x"])
         iq = self._ffn1(Cq, L["w1q"], L["b1q"])
-        hq = F.linear(iq, L["w2q"])
+        hq = self._lin(iq, L["w2q"])
         Xc, Xc32 = self._ln(hq, Cq, Cq32, L["b2q"], L["ln_q"])
         return ops.exist_head(Xc32 if Xc32 is not None else Xc, self.exist_w, self.exist_b, P, 1)
 
@@ -323,14 +330,14 @@ class RelationQueryEngine:
         Xu, Xu32, shared0 = self._embed(ids_u)
         ctx = torch.empty((U * (nq + T), H), device=self.device, dtype=self.dtype)
         if shared0:
-            qkv_q = F.linear(Xu[:nq], L["wqkv"], L["bqkv"])
-            qkv = F.linear(Xu[RQu:], L["wqkv"], L["bqkv"])
+            qkv_q = self._lin(Xu[:nq], L["wqkv"], L["bqkv"])
+            qkv = self._lin(Xu[RQu:], L["wqkv"], L["bqkv"])
             ops.qformer_self_attn_shared(qkv_q, qkv, mask_u, U, T, nq, q.heads, ctx)
         else:
-            qkv = F.linear(Xu, L["wqkv"], L["bqkv"])
+            qkv = self._lin(Xu, L["wqkv"], L["bqkv"])
             ops.qformer_self_attn(qkv, mask_u, U, T, nq, q.heads, False, ctx)
         del qkv
-        A = F.linear(ctx, L["wo"])
+        A = self._lin(ctx, L["wo"])
         A32 = torch.empty((A.shape[0], H), device=self.device, dtype=torch.float32) if self.res32 else None
         if shared0:
             self._ln_into(A[:RQu], Xu[:nq], self._s(Xu32, 0, nq), L["bo"], L["ln_a"], self._s(A32, 0, RQu), period=nq)
@@ -339,13 +346,13 @@ class RelationQueryEngine:
             self._ln_into(A, Xu, Xu32, L["bo"], L["ln_a"], A32)
         del ctx
         it = self._ffn1(A[RQu:], L["w1t"], L["b1t"])                        # text rows: straight to their layer-0 output
-        ht = F.linear(it, L["w2t"])
+        ht = self._lin(it, L["w2t"])
         Xt_u, Xt_u32 = self._ln(ht, A[RQu:], self._s(A32, RQu), L["b2t"], L["ln_t"])
         del it, ht
         # the pair enters at the cross-attention: its queries are its prompt's 33 projected rows (projected per prompt,
         # gathered per pair - the cross-attention kernel streams its Q tiles by DMA and takes no index), the residual
         # of the output LayerNorm is read from the prompt's block through the index
-        qx_u = F.linear(A[:RQu], L["wq_x"], L["bq_x"])
+        qx_u = self._lin(A[:RQu], L["wq_x"], L["bq_x"])
         if len(prompts) > 3:                                              # cached with the prompt table (names only)
             rows = prompts[3]
         else:
@@ -353,11 +360,11 @@ class RelationQueryEngine:
         qx = torch.empty((P * nq, H), device=self.device, dtype=self.dtype)
         ops.gather_rows(qx_u, rows, qx)
         cx = self._cross(0, qx, nq, kv, bits, num_objects, pair_index, None)
-        Cq = F.linear(cx, L["wo_x"])
+        Cq = self._lin(cx, L["wo_x"])
         _, Cq32 = self._ln(Cq, A[:RQu], self._s(A32, 0, RQu), L["bo_x"], L["ln_x"], period=nq, index=inv)
         del qx, cx, qx_u
         iq = self._ffn1(Cq, L["w1q"], L["b1q"])
-        hq = F.linear(iq, L["w2q"])
+        hq = self._lin(iq, L["w2q"])
         Xq, Xq32 = self._ln(hq, Cq, Cq32, L["b2q"], L["ln_q"])
         del iq, hq, Cq
         logit, prob = self._cls_phase(Xq, Xq32, Xt_u, inv, mask_u, P, T, kv, bits, num_objects, pair_index, None, True)
@@ -440,12 +447,47 @@ class RelationQueryEngine:
             return torch.bmm(a, b, out_dtype=torch.float32)
         return torch.bmm(a.float(), b32)
 
+    def _lin(self, x, w, b=None, gelu=False):
+        """Linear layer of the Q-Former (HF-IB: every `nn.Linear` on the path), optionally with the exact-erf GELU.
+          * split mode (head dtype 'fp32s'): fp32 in / out as a split-fp16 product on the 16-bit matrix cores -
+            [xh | xh | xl] . [wh | wl | wh]^T through psg_dense_gemm with fp32 accumulation, the operands' power-of-two
+            row scales undone in its epilogue (psg_split.hip; ~7e-7 per product, the class of the library SGEMM).  The
+            kernel walks the whole K per output tile, so a row's result does not depend on the row count of the call:
+            a pair shard reproduces the full pass bit for bit (SURVEY 8e);
+          * 16-bit modes with context option qformer_own_gemm = 2: psg_dense_gemm for every projection (the same
+            row-count invariance; 1 = only the two FFN1 projections, where the fused GELU saves a pass);
+          * otherwise the library GEMM."""
+        N, K = w.shape
+        fits = N % 256 == 0 and K % 64 == 0 and x.shape[0] > 0
+        if self.split and fits and x.dtype == torch.float32:
+            key = (w.data_ptr(), N, K)
+            ws = self._split_w.get(key)
+            if ws is None:
+                ws = self._split_w[key] = ops.split_f16x3(w, weights=True)
+            a3, inv_r = ops.split_f16x3(x)
+            return ops.dense_gemm(a3, ws[0], b, gelu=gelu, out_dtype=torch.float32, row_scale=inv_r, col_scale=ws[1])
+        if self.own_gemm >= 2 and fits and x.dtype != torch.float32 and x.is_contiguous():
+            if b is not None and b.dtype != torch.float32:
+                key = (b.data_ptr(), N)
+                b32 = self._bias32.get(key)
+                if b32 is None:
+                    b32 = self._bias32[key] = b.float().contiguous()
+                b = b32
+            return ops.dense_gemm(x, w, b, gelu=gelu)
+        if gelu:
+            y = F.linear(x, w)
+            ops.bias_gelu(y, b)
+            return y
+        return F.linear(x, w, b)
+
     def _ffn1(self, x, w, b):
         """intermediate(_query): Linear + exact-erf GELU (HF-IB:563-577).  16-bit modes: one pass through
         psg_dense_gemm (own MFMA GEMM with the bias + GELU epilogue fused; context option qformer_own_gemm);
         fp32 verification mode and odd shapes: library GEMM + psg_bias_gelu."""
+        if self.split or self.own_gemm >= 2:
+            return self._lin(x, w, b, gelu=True)
         if (self.dtype != torch.float32 and w.shape[0] % 256 == 0 and w.shape[1] % 64 == 0 and x.shape[0] >= 256
-                and _lib.get_option(self.device.index or 0, "qformer_own_gemm")):
+                and self.own_gemm):
             return ops.dense_gemm(x, w, b, gelu=True)
         y = F.linear(x, w)
         ops.bias_gelu(y, b)

@@ -157,3 +157,31 @@ def test_fp32s_mode_meets_the_fp32_bar_on_the_reference_goldens(case):
         worst = max(worst, float(np.abs(fl[i][g["gen_top8_idx"][i]] - g["gen_top8_val"][i]).max()))
     print(f"{case}: fp32s first-step top-8 logits within {worst:.2e} of the reference")
     assert worst < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(2500 * 3, 768, 768, False), (980, 4096, 4096, False), (515, 3072, 768, True), (33, 2304, 768, False)])
+def test_dense_gemm_fp32_output_with_split_scales(M, N, K, gelu):
+    """psg_dense_gemm_ex: fp16 split operands in, fp32 out, power-of-two scales and the bias applied in the epilogue -
+    the Q-Former's Linear layers in the fp32s mode - against fp64; and row-count invariance, bit for bit."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    a3, inv_r = ops.split_f16x3(x)
+    b3, inv_c = ops.split_f16x3(w, weights=True)
+    y = ops.dense_gemm(a3, b3, b, gelu=gelu, out_dtype=torch.float32, row_scale=inv_r, col_scale=inv_c)
+    ref = x.double() @ w.double().t() + b.double()
+    bound = (x.double().abs() @ w.double().abs().t()) + b.double().abs() + 1e-300
+    if gelu:
+        err = (y.double() - torch.nn.functional.gelu(ref)).abs().max().item()
+        assert err < 2e-5                                             # the kernel's exact-erf GELU is the A-S 7.1.26 form (1.5e-7) 
+    else:
+        rel = ((y.double() - ref).abs() / bound).max().item()
+        print(f"M={M} N={N} K={K}: {rel:.2e} x sum|x w|")
+        assert rel < 1.5e-6
+    for m2 in (1, min(M, 257)):
+        a2, r2 = ops.split_f16x3(x[:m2].contiguous())
+        y2 = ops.dense_gemm(a2, b3, b, gelu=gelu, out_dtype=torch.float32, row_scale=r2, col_scale=inv_c)
+        assert torch.equal(y2, y[:m2])
