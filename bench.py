@@ -355,7 +355,7 @@ def parity_block(a, dev, scene, oracle_part, headline_ms):
         full = a.workload == "full" and oracle_part["decodes"] is not None
         ocfg = oracle_part["cfg"]
         k = min(20, n)
-        for dt in ("fp32", "bf16", "fp16", "mixed"):
+        for dt in ("fp32", "fp32s", "bf16", "fp16", "mixed"):
             kw = dict(llm_config=ocfg.llm, llm_truncate_num=oracle_part["n_layers"], suppress_eos=True) if full else {}
             h = RelationTransformerHeadV4(dtype=dt, device=str(dev), tokenizers="word", max_object_num=N,
                                           on_parse_error="skip", **kw)
@@ -378,7 +378,6 @@ def parity_block(a, dev, scene, oracle_part, headline_ms):
         h = RelationTransformerHeadV4(dtype="fp32", device=str(dev), tokenizers="word", max_object_num=N,
                                       llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True)
         h.load_weights(w32)
-        del w32
         inputs = scene_inputs(scene)
         el = time_steps(lambda: h(inputs), 1, 3) / 3
         out.update(fp32_mode_ms_per_step=round(el * 1e3, 2), fp32_mode_pairs_per_s=round(N * (N - 1) / el, 1),
@@ -399,8 +398,22 @@ def parity_block(a, dev, scene, oracle_part, headline_ms):
                                  "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(bpl),
                                  "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": nl,
                                  "bytes_per_decode_step": int(bpl * nl), "traffic": None}
-        out["_parity_grade"] = grade
         del h
+        torch.cuda.empty_cache()
+        # the same path with the prompt pass's and the Q-Former's projections as split-fp16 products ('fp32s': fp32-grade,
+        # ~7e-7 per product; decode steps, attention, KV cache and every row operation stay exact fp32)
+        h = RelationTransformerHeadV4(dtype="fp32s", device=str(dev), tokenizers="word", max_object_num=N,
+                                      llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True)
+        h.load_weights(w32)
+        del w32
+        els = time_steps(lambda: h(inputs), 1, 3) / 3
+        grade["fp32s"] = dict(mode="fp32 with split-fp16 products (x.w = xh.wh + xh.wl + xl.wh on the 16-bit matrix cores, "
+                                   "fp32 accumulation) in the prompt pass and the Q-Former; decode steps exact fp32",
+                              ms_per_step=round(els * 1e3, 2), pairs_per_s=round(N * (N - 1) / els, 1), steps=3,
+                              max_logit_err_vs_oracle=modes.get("fp32s", {}).get("max_logit_err_vs_oracle"),
+                              top20_overlap=modes.get("fp32s", {}).get("top20_overlap"),
+                              decode_7b_width_2_layers=modes.get("fp32s", {}).get("decode_7b_width_2_layers"))
+        out["_parity_grade"] = grade
         torch.cuda.empty_cache()
         # the full path in the other 16-bit modes (same scene, same step, their own 32-layer engine)
         for dt in ("bf16", "fp16", "mixed"):
@@ -628,6 +641,36 @@ def main():
                     line["stages"]["new_scene_ms_per_image"] = round((time.perf_counter() - t0) / len(fresh) * 1e3, 3)
                 except Exception as e:  # noqa: BLE001
                     line["stages"]["new_scene_ms_per_image"] = f"failed: {e}"
+        if world == 1 and not force_dist and a.images_per_step == 1 and a.workload == "full" and not a.no_roofline:
+            # BASELINE config C2 (relation-query transformer only, bf16) as an object of the SAME line, so that the driver's
+            # default run records it: its own bf16 head (no LLM), the stage timed as `--workload rq` times it
+            try:
+                import copy
+                b = copy.copy(a)
+                b.workload, b.dtype_override = "rq", "bf16"
+                h2 = setup_head(b, dev)
+
+                def rq2():
+                    rq = h2.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_, scene["pan_results"])
+                    h2.selected_pair_features(rq)
+                    return rq["selected"].cpu()
+                k2 = max(10, a.steps)
+                el2 = time_steps(rq2, 3, k2) / k2
+                T2 = max(v[2].shape[1] for k_, v in h2._table_cache.items() if k_[0] == "q")
+                fl2 = relation_query_flops(N, (a.size // 64) ** 2, T2, h2.cls_first, h2.cfg.num_selected)
+                U2 = max([v[3][0].shape[0] for v in h2._gather_cache.values() if len(v) > 3] or [N * N])
+                fx2 = relation_query_flops_executed(N, (a.size // 64) ** 2, T2, U2, h2.cfg.num_selected) if h2.cls_first else fl2
+                line["c2"] = {"workload": "C2: 1024x1024, 50 masks, relation-query transformer only, 1xMI355X bf16",
+                              "value": round(pairs_per_image / el2, 1), "unit": "pairs/s", "ms_per_step": round(el2 * 1e3, 3),
+                              "steps": k2, "dtype": "bf16",
+                              "roofline": {"bound": "mfma", "achieved": round(fl2 / el2 / 1e12, 1), "peak": 2500.0,
+                                           "unit": "TFLOP/s", "frac": round(fl2 / el2 / 2.5e15, 4),
+                                           "executed_tflops": round(fx2 / el2 / 1e12, 1),
+                                           "executed_frac": round(fx2 / el2 / 2.5e15, 4), "flops_per_step": int(fl2)}}
+                del h2
+                torch.cuda.empty_cache()
+            except Exception as exc:                                   # never lose the headline line
+                line["c2"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         if (not a.no_batched and a.workload == "full" and world == 1 and not force_dist
                 and a.images_per_step == 1):
             # secondary figure, not `value`: four such images per step, their 80 selected pairs decoded together
