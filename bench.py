@@ -398,6 +398,11 @@ def parity_block(a, dev, scene, oracle_part, headline_ms):
                                  "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(bpl),
                                  "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": nl,
                                  "bytes_per_decode_step": int(bpl * nl), "traffic": None}
+            pmc32 = os.path.join(REPO, "profiles", "pmc_skinny_gemm_f32.json")
+            if os.path.exists(pmc32):
+                grade["roofline"]["traffic"] = json.load(open(pmc32)).get("hbm_bytes_per_launch")
+                grade["roofline"]["traffic_source"] = ("profiles/pmc_skinny_gemm_f32.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                       "passes of this kernel; not re-measured in this run)")
         del h
         torch.cuda.empty_cache()
         # the same path with the prompt pass's and the Q-Former's projections as split-fp16 products ('fp32s': fp32-grade,

@@ -22,6 +22,14 @@ python tools/prof_summary.py "$(db /tmp/p_rq)" "$OUT/${TAG}_bench_rq_kernel_stat
 run /tmp/p_fetch --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch -- python tools/bench_kernels.py skinny
 run /tmp/p_write --pmc WRITE_SIZE --kernel-trace -d /tmp/p_write -- python tools/bench_kernels.py skinny
 python tools/pmc_summary.py "$(db /tmp/p_fetch)" "$(db /tmp/p_write)" "$OUT/pmc_skinny_gemm.json" > /dev/null
+# 3b. the fp32 instantiation (psg_gemm_f32.hip): traffic, wave-state counters, per-image tables of both fp32 modes
+run /tmp/p_fetch32 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch32 -- env PSG_BENCH_NOLIB=1 python tools/bench_kernels.py skinny32
+run /tmp/p_write32 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_write32 -- env PSG_BENCH_NOLIB=1 python tools/bench_kernels.py skinny32
+python tools/pmc_summary.py "$(db /tmp/p_fetch32)" "$(db /tmp/p_write32)" "$OUT/pmc_skinny_gemm_f32.json" 4 > /dev/null
+PSG_BENCH_SHAPES=gate_up PSG_BENCH_NOLIB=1 bash tools/pmc_cmd.sh skinny_gemm_f32 "$OUT/${TAG}_f32_decode_gemm_pmc_gateup.txt" python tools/bench_kernels.py skinny32 > /dev/null
+PSG_BENCH_NOLIB=1 python tools/bench_kernels.py skinny32 skinny32_m4 skinny32_m16 skinny32_m32 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_f32_decode_gemm_bench.txt"
+bash tools/fp32_profile.sh "$OUT/${TAG}_fp32_per_image_kernels.csv" > /dev/null
+PSG_MODE=fp32s bash tools/fp32_profile.sh "$OUT/${TAG}_fp32s_per_image_kernels.csv" > /dev/null
 # 4. cross-attention (LDS-DMA kernel), N = 50 and N = 100: four PMC passes each
 for n in 50 100; do
   f="$OUT/${TAG}_xattn_pmc_n$n.txt"

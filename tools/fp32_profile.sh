@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-image kernel time of the fp32 (reference-precision) mode: two rocprofv3 kernel traces of tools/fp32_mode.py that
-# differ only in the number of timed steps (tools/per_image_diff.py divides the difference by the extra steps).
+# differ only in the number of timed steps; PSG_MODE=fp32s profiles the split-fp16 variant (tools/per_image_diff.py divides the difference by the extra steps).
 #   tools/fp32_profile.sh [out.csv]        (run on the MI355X box from the repo root)
 set -u
 OUT=${1:-gpurun_out/r04_fp32_per_image_kernels.csv}

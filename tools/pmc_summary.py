@@ -32,21 +32,23 @@ def runs(db, counter):
     return [sum(r) / len(r) for r in out], rows[0][1] if rows else ""
 
 
-def main(fetch_db, write_db, out=None):
+def main(fetch_db, write_db, out=None, esz=2):
+    """esz: bytes per weight element (2: the 16-bit kernel, `bench_kernels.py skinny`; 4: the fp32 kernel, `skinny32`)."""
+    esz = int(esz)
     f, _ = runs(fetch_db, "FETCH_SIZE")
     w, _ = runs(write_db, "WRITE_SIZE")
     per, tot_a, tot_h = {}, 0.0, 0.0
     for (name, N, K), fk, wk in zip(SHAPES, f, w):
-        alg = N * K * 2
+        alg = N * K * esz
         hbm = 2 * fk * 1024 + wk * 1024
         per[name] = dict(algorithmic_bytes=alg, fetch_size_kb=round(fk, 1), write_size_kb=round(wk, 1),
                          hbm_bytes=int(hbm), ratio=round(hbm / alg, 3))
         mult = 1 if name == "lm_head" else 32
         tot_a += alg * mult
         tot_h += hbm * mult
-    res = dict(kernel="skinny_gemm_dma_kernel<8, 1, 3, 2>",
+    res = dict(kernel="skinny_gemm_dma_kernel<8, 1, 3, 2>" if esz == 2 else "skinny_gemm_f32_kernel (psg_gemm_f32.hip)",
                method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/bench_kernels.py "
-                      "skinny (M=20); hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction per "
+                      + ("skinny" if esz == 2 else "skinny32") + " (M=20); hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction per "
                       "MI355X_MICROARCH.md); summarised by tools/pmc_summary.py",
                per_shape=per, launches_per_decode_step=129, hbm_bytes_per_launch=int(tot_h / 129),
                algorithmic_bytes_per_launch=int(tot_a / 129), ratio=round(tot_h / tot_a, 3))
@@ -57,4 +59,4 @@ def main(fetch_db, write_db, out=None):
 
 
 if __name__ == "__main__":
-    print(main(*sys.argv[1:4]))
+    print(main(*sys.argv[1:5]))
