@@ -20,6 +20,7 @@ struct psg_opts {
   int skinny_nt = 1;            // non-temporal weight DMAs
   int skinny_xdma = 1;          // x slice staged by LDS-DMA as well
   int skinny_f32_slots = 3;     // fp32 weight-streaming kernel (psg_gemm_f32.hip): 2 KB blocks per wave's DMA ring (3 or 5)
+  int skinny_f32_waves = 0;     // fp32 kernel: forced slab height in wavefronts (8, 11, 12, 16); 0 = the planner's choice
   int skinny_wide = 1;          // 11-wave (176-row) slabs where they save a round of slabs (gate/up projection)
   int selfattn_scalar = 0;      // Q-Former self-attention: scalar checker kernel even in bf16
   int decode_attn_1wave = 0;    // decode attention: one wave per (pair, head) instead of a workgroup

@@ -300,11 +300,19 @@ int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int 
   // slab height against round quantisation, as in the 16-bit kernel (gate/up: 172 slabs of 128 rows over 32 column
   // groups = 6 rounds, 126 slabs of 176 rows = 4 rounds of 1.375x the rows: 8 % less)
   int wv = 8;
-  if (ctx->opt.skinny_wide) {
-    for (int cand : {11, 12})
-      if ((double)sgf_round_cost(ctx, N, splits, cand) < 0.95 * sgf_round_cost(ctx, N, splits, wv) &&
-          sgf_lds(M, K, splits, cand, slots) <= 160 * 1024)
-        wv = cand;
+  const int forced_wv = ctx->opt.skinny_f32_waves;
+  if (forced_wv == 8 || forced_wv == 11 || forced_wv == 12 || forced_wv == 16) {
+    wv = forced_wv;
+  } else if (ctx->opt.skinny_wide) {
+    const int g = ctx->num_cu / splits > 0 ? ctx->num_cu / splits : 1;
+    for (int cand : {11, 12}) {
+      if (sgf_lds(M, K, splits, cand, slots) > 160 * 1024) continue;
+      const int cc = sgf_round_cost(ctx, N, splits, cand), cw = sgf_round_cost(ctx, N, splits, wv);
+      // cheaper walk - or the same walk in fewer, evenly filled rounds (q/k/v: 3 rounds of 128 rows -> 2 of 192: one slab
+      // epilogue less and 12 waves' worth of DMAs in flight; measured 46.9 -> 43.1 us)
+      const int ns = (N + 16 * cand - 1) / (16 * cand);
+      if ((double)cc < 0.95 * cw || (cc == cw && ns % g == 0)) wv = cand;
+    }
   }
   const size_t lds = sgf_lds(M, K, splits, wv, slots);
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm(f32): %zu B of LDS; use more splits", lds);
@@ -347,6 +355,7 @@ int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int 
   } while (0)
   if (wv == 8) SGF_W(8);
   else if (wv == 11) SGF_W(11);
+  else if (wv == 16) SGF_W(16);
   else SGF_W(12);
 #undef SGF_W
 #undef SGF_L
