@@ -37,6 +37,27 @@ _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.flo
            torch.bfloat16: torch.bfloat16, torch.float32: torch.float32, torch.float16: torch.float16}
 
 
+class _Pending:
+    """An image submitted with `head.submit`: its kernels are enqueued on `stream`; `result()` is the only host wait."""
+
+    def __init__(self, head, stream, rq, out, num_objects):
+        self.head, self.stream, self.rq, self.out, self.N = head, stream, rq, out, num_objects
+
+    def result(self):
+        if self.rq is None:
+            return dict(rel_pred=[], rel_score=[])
+        h, out = self.head, self.out
+        with torch.cuda.stream(self.stream):
+            sel = self.rq["selected"]
+            out["tokens_host"] = out["tokens"].cpu().numpy()               # waits for this stream's work only
+            out["selected_host"] = sel.cpu().numpy()
+        self.rq.update(out)
+        h.last = self.rq
+        rel_pred, rel_score = h.parse(out["tokens_host"], out["selected_host"], self.N)
+        self.rq = self.out = None
+        return dict(rel_pred=rel_pred, rel_score=rel_score)
+
+
 def _set_nested(root: nn.Module, dotted: str, tensor: torch.Tensor):
     parts = dotted.split(".")
     mod = root
@@ -223,6 +244,14 @@ class RelationTransformerHeadV4(nn.Module):
         self.llm_tokenizer.pad_token = self.llm_tokenizer.unk_token        # V4:105
         self.last = {}
         self._gather_cache = {}
+        self._slot_streams = {}
+        self._decode_done = None
+        # submit(): image k+1's decode steps wait for image k's (its relation query and prompt pass do not).  Measured A/B
+        # at BASELINE C3, two slots: serialised 67.4 ms per image = no gain over one image at a time; free-running 56.6.
+        # What overlaps is decode beside decode: the latency-bound row kernels and the fixed start / tail of every
+        # weight-streaming launch of one image run under the other image's streaming - not prompt pass beside decode
+        # (a decode launch holds every CU's LDS; a library GEMM workgroup cannot move in next to it)
+        self.serialize_decodes = False
         self._proj_stale = False
         self.train(False)                                                   # eval by default, as init_detector leaves it
 
@@ -404,6 +433,44 @@ class RelationTransformerHeadV4(nn.Module):
         self.last = rq
         rel_pred, rel_score = self.parse(out["tokens_host"], out["selected_host"], N) if is_generation else ([], [])
         return dict(rel_pred=rel_pred, rel_score=rel_score)
+
+    # ---- two images in flight -------------------------------------------------------------------------------------------
+    def submit(self, inputs, slot=0):
+        """`forward` without its final host synchronisation: everything is enqueued on the slot's own HIP stream and a
+        handle is returned; `handle.result()` waits for that stream only, copies the token ids back and parses them
+        (same dict as `forward`).  With two slots the caller keeps two images in flight:
+
+            pending = head.submit(image_k1, slot=(k + 1) % 2)      # relation query + prompt pass: matrix-core bound
+            result_k = previous.result()                           # image k's decode steps: HBM bound, already running
+
+        Two images' kernels then interleave on the GPU: 1.19x images per second on one MI355X at BASELINE C3 (56.6 against
+        67.4 ms per image; three in flight: 60.6), every result identical to `forward`'s.  The gain is decode beside
+        decode - an image's latency-bound row kernels (22 us per layer) and the fixed start / tail of its weight-streaming
+        launches run under the other image's streaming (A/B: `serialize_decodes`).  The reference handles one image
+        per call (V4:112); this is the same call, issued one image ahead.  A slot owns its decode graphs (KV caches,
+        static buffers) and must not be re-submitted before its pending result was taken."""
+        if self.training:
+            raise PsgHipError("submit: inference only")
+        st = self._slot_streams.get(slot)
+        if st is None:
+            st = self._slot_streams[slot] = torch.cuda.Stream(device=self.device)
+        st.wait_stream(torch.cuda.current_stream(self.device))          # the inputs were produced on the caller's stream
+        with torch.cuda.stream(st):
+            feat, meta, info, obj_ids, names = self._unpack(inputs)
+            N = len(obj_ids)
+            if N == 0:
+                return _Pending(self, st, None, None, 0)
+            rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
+            # A/B switch `serialize_decodes`: this image's decode steps wait for the previous image's
+            prev = self._decode_done
+
+            def gate():
+                if prev is not None:
+                    st.wait_event(prev)
+            out = self.decode_selected(rq, names, to_host=False, slot=slot, gate=gate if self.serialize_decodes else None)
+            self._decode_done = torch.cuda.Event()
+            self._decode_done.record(st)
+        return _Pending(self, st, rq, out, N)
 
     # ---- training branch: forward arithmetic of the losses (SURVEY 8f rank 3) -------------------------------------
     def qformer_sampler(self, relation_target):
@@ -945,7 +1012,7 @@ class RelationTransformerHeadV4(nn.Module):
         pids, plen = tbl_d[trow].contiguous(), lens_d[trow].contiguous()
         return self.llm_engine.build_inputs(pf, pids, plen), plen
 
-    def decode_selected(self, rq, names, selected=None, pair_features=None, to_host=True):
+    def decode_selected(self, rq, names, selected=None, pair_features=None, to_host=True, slot=0, gate=None):
         """A9: batched greedy decode of the selected pairs."""
         sel = rq["selected"] if selected is None else selected
         K = sel.numel()
@@ -960,7 +1027,7 @@ class RelationTransformerHeadV4(nn.Module):
                 pair_features = torch.cat([pair_features, pair_features[-nv:].repeat(4 - K % 4, 1)]).contiguous()
         X, plen = self.llm_inputs(rq, names, sel_in, pair_features)
         tokens, first_logits = self.llm_engine.generate(X, plen, suppress_eos=self.suppress_eos,
-                                                        return_first_logits=True)
+                                                        return_first_logits=True, slot=slot, gate=gate)
         tokens, first_logits, X, plen = tokens[:K], first_logits[:K], X[:K], plen[:K]
         out = dict(tokens=tokens, first_logits=first_logits, llm_inputs=X, prompt_len=plen)
         if to_host:

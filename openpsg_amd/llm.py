@@ -267,7 +267,8 @@ class LlamaDecodeEngine:
         return F.linear(h_rows, self.lm_head)
 
     @torch.no_grad()
-    def generate(self, X, prompt_len, max_new_tokens=None, suppress_eos=False, return_first_logits=False):
+    def generate(self, X, prompt_len, max_new_tokens=None, suppress_eos=False, return_first_logits=False, slot=0,
+                 gate=None):
         """Batched greedy decode.  X [K, 32+Tp, D]; prompt_len int32 [K] (# of prompt tokens).
         Returns tokens int32 [K, max_new] (device; -1 after a pair's EOS) and optionally the
         first-step logits [K, vocab].
@@ -277,13 +278,19 @@ class LlamaDecodeEngine:
           * suppress_eos (benchmark worst case): ONE graph = prefill + max_new-1 steps (~5000 launches);
           * natural EOS: the reference's per-pair `generate` stops at EOS (V4:305-312), and a relation string
             is a handful of tokens, so the steps are cut into graphs of `early_exit_chunk` steps and the
-            replay stops as soon as every pair has emitted EOS (one 4-byte read-back per chunk)."""
+            replay stops as soon as every pair has emitted EOS (one 4-byte read-back per chunk).
+        slot: graphs (with their KV caches and static buffers) are kept per slot, so that two generations - of two
+        images on two HIP streams, `head.submit` - can be in flight at once; a slot is used by one stream at a time.
+        gate: callable run between the prompt pass (+ first token) and the decode steps, which are then two graphs - the
+        caller makes the stream wait there for the previous image's decode (the prompt pass of image k+1 is matrix-core
+        work that fits beside image k's HBM-bound decode steps; two decodes side by side only share the HBM)."""
         max_new = self.cfg.max_new_tokens if max_new_tokens is None else max_new_tokens
         if not self.use_graph:
             return self._finish(self._generate_eager(X, prompt_len, max_new, suppress_eos, return_first_logits),
                                 return_first_logits)
         chunk = 0 if suppress_eos else int(self.early_exit_chunk)
-        key = (tuple(X.shape), max_new, bool(suppress_eos), bool(return_first_logits), chunk)
+        split = gate is not None and chunk <= 0 and max_new > 1
+        key = (tuple(X.shape), max_new, bool(suppress_eos), bool(return_first_logits), chunk, int(slot), split)
         ent = self._graphs.get(key)
         if ent is not None:
             self._graphs.move_to_end(key)
@@ -297,7 +304,8 @@ class LlamaDecodeEngine:
                 self._generate_eager(Xs, ps, max_new, suppress_eos, return_first_logits)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
-            bounds = [max_new] if chunk <= 0 else sorted(set(list(range(chunk, max_new, chunk)) + [max_new]))
+            bounds = ([1, max_new] if split else [max_new]) if chunk <= 0 else sorted(
+                set(list(range(chunk, max_new, chunk)) + [max_new]))
             graphs, st, lo = [], None, 0
             for hi in bounds:                                  # graph i runs steps [lo, hi); step 0 includes the prefill
                 g = torch.cuda.CUDAGraph()
@@ -308,7 +316,7 @@ class LlamaDecodeEngine:
                         all_done = st["done"].min() if chunk > 0 else None
                     else:
                         self._steps(st, lo, hi)
-                        all_done = st["done"].min()
+                        all_done = st["done"].min() if chunk > 0 else None
                 graphs.append((g, hi, all_done))
                 lo = hi
             ent = self._graphs[key] = (graphs, Xs, ps, st)
@@ -316,10 +324,12 @@ class LlamaDecodeEngine:
         Xs.copy_(X)
         ps.copy_(prompt_len)
         self.last_replays = 0
-        for g, hi, all_done in graphs:
+        for gi, (g, hi, all_done) in enumerate(graphs):
+            if gi == 1 and gate is not None:
+                gate()
             g.replay()
             self.last_replays += 1
-            if hi < max_new and int(all_done.item()) != 0:     # every pair has emitted EOS: the rest would be -1
+            if hi < max_new and all_done is not None and int(all_done.item()) != 0:     # every pair has emitted EOS: the rest would be -1
                 break
         # the graph's static buffers are overwritten by the next replay: hand out copies
         fl = st["first_logits"]

@@ -146,3 +146,42 @@ def test_c5_geometry_batch_of_eight_images(dtype):
         assert all(t[0] != t[1] for t in s["rel_results"]["relation"])      # exclude_diagonal
         n_rel += len(s["rel_results"]["relation"])
     assert n_rel >= 8 * 2 * 4                                               # at least max_llm_forward_num pairs per image
+
+
+def test_two_images_in_flight_give_the_results_of_forward():
+    """`head.submit` / `.result()`: images enqueued one ahead on two HIP streams (slot = k % 2), results taken one behind -
+    the decode graphs, KV caches and static buffers are per slot.  Every image's selection, token ids and parsed
+    triples equal `forward`'s, for scenes of different object counts and sizes, in any interleaving."""
+    import numpy as np
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_device
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=30522), llm=tiny_llm(512, 2, 1024, 512), max_object_num=50)
+    w = make_weights_device(cfg, 7, torch.device("cuda:0"), llm_dtype=torch.float32)
+    for dtype in ("fp32", "mixed"):
+        head = RelationTransformerHeadV4(dtype=dtype, device="cuda:0", llm_config=cfg.llm, llm_feature_size=512,
+                                         tokenizers="word", max_object_num=50, on_parse_error="skip", suppress_eos=True)
+        head.load_weights(w)
+        geo = [((1024, 1024), 50), ((768, 1024), 23), ((512, 512), 9), ((1024, 1024), 50), ((1024, 1344), 31), ((512, 512), 9)]
+        scenes = [make_scene(hw, n, seed=70 + m, device="cuda:0", tiny_object=True) for m, (hw, n) in enumerate(geo)]
+        ins = [dict(mask_features=s["mask_features"], img_metas=[s["img_meta"]],
+                    object_info=[dict(object_id_list=s["object_id_list"], pan_results=s["pan_results"])]) for s in scenes]
+        want = []
+        for i in ins:
+            r = head(i)
+            want.append((r, head.last["tokens_host"].copy(), head.last["selected"].cpu().numpy()))
+        got, pending = [], []
+        for k, i in enumerate(ins * 2):                               # twelve images, two in flight
+            pending.append(head.submit(i, slot=k % 2))
+            if len(pending) > 1:
+                r = pending.pop(0).result()
+                got.append((r, head.last["tokens_host"].copy(), head.last["selected_host"].copy()))
+        r = pending.pop(0).result()
+        got.append((r, head.last["tokens_host"].copy(), head.last["selected_host"].copy()))
+        assert len(got) == 2 * len(ins)
+        for k, (r, toks, sel) in enumerate(got):
+            wr, wt, ws = want[k % len(ins)]
+            assert np.array_equal(sel, ws) and np.array_equal(toks, wt) and r == wr, f"{dtype}: image {k} differs"
+        empty = head.submit(dict(ins[0], object_info=[dict(object_id_list=[], pan_results=scenes[0]["pan_results"])]), slot=0)
+        assert empty.result() == dict(rel_pred=[], rel_score=[])
