@@ -58,6 +58,31 @@ class _Pending:
         return dict(rel_pred=rel_pred, rel_score=rel_score)
 
 
+class _PendingBatch:
+    """A batch submitted with `head.submit_batch`; `result()` is the only host wait (on the batch's stream)."""
+
+    def __init__(self, head, stream, items, results, tokens):
+        self.head, self.stream, self.items, self.results, self.tokens = head, stream, items, results, tokens
+
+    def result(self):
+        h, results = self.head, self.results
+        if not self.items:
+            return results
+        with torch.cuda.stream(self.stream):
+            tokens_host = self.tokens.cpu().numpy()
+            sels = [sel.cpu().numpy() for _, _, sel, _, _ in self.items]
+        k0 = 0
+        h.last_batch = []
+        for (i, N, _, X, _), sel_host in zip(self.items, sels):
+            k1 = k0 + X.shape[0]
+            rel_pred, rel_score = h.parse(tokens_host[k0:k1], sel_host, N)
+            results[i] = dict(rel_pred=rel_pred, rel_score=rel_score)
+            h.last_batch.append(dict(tokens_host=tokens_host[k0:k1], selected_host=sel_host))
+            k0 = k1
+        self.items = self.tokens = None
+        return results
+
+
 def _set_nested(root: nn.Module, dotted: str, tensor: torch.Tensor):
     parts = dotted.split(".")
     mod = root
@@ -246,6 +271,7 @@ class RelationTransformerHeadV4(nn.Module):
         self._gather_cache = {}
         self._slot_streams = {}
         self._decode_done = None
+        self._front_done = None
         # submit(): image k+1's decode steps wait for image k's (its relation query and prompt pass do not).  Measured A/B
         # at BASELINE C3, two slots: serialised 67.4 ms per image = no gain over one image at a time; free-running 56.6.
         # What overlaps is decode beside decode: the latency-bound row kernels and the fixed start / tail of every
@@ -460,14 +486,25 @@ class RelationTransformerHeadV4(nn.Module):
             N = len(obj_ids)
             if N == 0:
                 return _Pending(self, st, None, None, 0)
+            # The front halves (relation query + prompt pass: the only part with LIBRARY GEMMs) of consecutive images are
+            # ordered by an event - free in the steady state, where image k's front half ended long before image k+1 is
+            # submitted -, so that two library GEMMs never run side by side on two streams: hipBLASLt kernels with a
+            # workspace (stream-K / split-K, picked at 40-80 rows) were seen to dead-lock the GPU that way
+            # (tools/inflight_stress.py batch).  What overlaps is image k's decode steps - own kernels only - with
+            # image k+1's front half and decode.
+            if self._front_done is not None:
+                st.wait_event(self._front_done)
             rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
-            # A/B switch `serialize_decodes`: this image's decode steps wait for the previous image's
-            prev = self._decode_done
+            prev, front_done = self._decode_done, torch.cuda.Event()
 
-            def gate():
-                if prev is not None:
+            def gate():                                         # between the prompt pass and the decode steps
+                front_done.record(st)
+                if prev is not None and self.serialize_decodes:     # A/B switch: decode steps of two images never overlap
                     st.wait_event(prev)
-            out = self.decode_selected(rq, names, to_host=False, slot=slot, gate=gate if self.serialize_decodes else None)
+            out = self.decode_selected(rq, names, to_host=False, slot=slot, gate=gate)
+            if self.llm_engine.last_replays < 2:                # the generation ran as one graph (natural-EOS chunks): no gate
+                front_done.record(st)
+            self._front_done = front_done
             self._decode_done = torch.cuda.Event()
             self._decode_done.record(st)
         return _Pending(self, st, rq, out, N)
@@ -689,43 +726,37 @@ class RelationTransformerHeadV4(nn.Module):
         relation query runs per image, then the selected pairs of ALL images are decoded in one batched
         greedy decode, so the Llama weights stream from HBM once per step for the whole batch instead
         of once per image.  Per-image results are those of forward() up to the rounding of the
-        projection GEMMs, which see a different row count (library GEMM above 32 rows)."""
+        projection GEMMs, which see a different row count (library GEMM above 32 rows).
+        (Two BATCHES in flight on two streams were tried and are not offered: above 32 rows the decode projections are
+        library GEMMs, and two of those side by side - one in a graph, one eager - hung the GPU at 40 and 80 rows;
+        tools/inflight_stress.py batch.)"""
         if self.training:
             raise NotImplementedError("training branch (V4:114-133, 360-406) is out of scope of this build")
-        items, results = [], [None] * len(batch)
-        for i, inputs in enumerate(batch):
-            feat, meta, info, obj_ids, names = self._unpack(inputs)
-            if not obj_ids:
-                results[i] = dict(rel_pred=[], rel_score=[])
-                continue
-            rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
-            X, plen = self.llm_inputs(rq, names)
-            items.append((i, len(obj_ids), rq["selected"], X, plen))
-        if not items:
-            return results
-        maxlen = max(it[3].shape[1] for it in items)
-        Xs = []
-        for _, _, _, X, _ in items:                                  # rows past a pair's length are never read
-            if X.shape[1] < maxlen:
-                X = torch.cat([X, X.new_zeros((X.shape[0], maxlen - X.shape[1], X.shape[2]))], dim=1)
-            Xs.append(X)
-        Xall, pall = torch.cat(Xs), torch.cat([it[4] for it in items])
-        if Xall.shape[0] % 4:                                        # data-dependent pair counts: keep the decode
-            extra = 4 - Xall.shape[0] % 4                            # graphs few (copies of the last pair, cut below)
-            Xall = torch.cat([Xall, Xall[-1:].expand(extra, -1, -1)])
-            pall = torch.cat([pall, pall[-1:].expand(extra)])
-        tokens = self.llm_engine.generate(Xall, pall, suppress_eos=self.suppress_eos)
-        tokens_host = tokens.cpu().numpy()
-        k0 = 0
-        self.last_batch = []
-        for i, N, sel, X, _ in items:
-            k1 = k0 + X.shape[0]
-            sel_host = sel.cpu().numpy()
-            rel_pred, rel_score = self.parse(tokens_host[k0:k1], sel_host, N)
-            results[i] = dict(rel_pred=rel_pred, rel_score=rel_score)
-            self.last_batch.append(dict(tokens_host=tokens_host[k0:k1], selected_host=sel_host))
-            k0 = k1
-        return results
+        st, gslot = torch.cuda.current_stream(self.device), 0
+        items, results, tokens = [], [None] * len(batch), None
+        with torch.cuda.stream(st):
+            for i, inputs in enumerate(batch):
+                feat, meta, info, obj_ids, names = self._unpack(inputs)
+                if not obj_ids:
+                    results[i] = dict(rel_pred=[], rel_score=[])
+                    continue
+                rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
+                X, plen = self.llm_inputs(rq, names)
+                items.append((i, len(obj_ids), rq["selected"], X, plen))
+            if items:
+                maxlen = max(it[3].shape[1] for it in items)
+                Xs = []
+                for _, _, _, X, _ in items:                              # rows past a pair's length are never read
+                    if X.shape[1] < maxlen:
+                        X = torch.cat([X, X.new_zeros((X.shape[0], maxlen - X.shape[1], X.shape[2]))], dim=1)
+                    Xs.append(X)
+                Xall, pall = torch.cat(Xs), torch.cat([it[4] for it in items])
+                if Xall.shape[0] % 4:                                    # data-dependent pair counts: keep the decode
+                    extra = 4 - Xall.shape[0] % 4                        # graphs few (copies of the last pair, cut below)
+                    Xall = torch.cat([Xall, Xall[-1:].expand(extra, -1, -1)])
+                    pall = torch.cat([pall, pall[-1:].expand(extra)])
+                tokens = self.llm_engine.generate(Xall, pall, suppress_eos=self.suppress_eos, slot=gslot)
+        return _PendingBatch(self, st, items, results, tokens).result()
 
     def image_constants(self, feat, meta, obj_ids, pan):
         """What the rank that holds an image's segmenter outputs hands to the other ranks: the patch
