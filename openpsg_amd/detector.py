@@ -128,6 +128,15 @@ class OpenSeeDRelationV2(nn.Module):
         return res
 
     @torch.no_grad()
+    def simple_test_submit(self, imgs, img_metas, slot=0):
+        """`simple_test` issued one image ahead (RelationTransformerHeadV4.submit): segmenter + head enqueued on the
+        slot's HIP stream; returns a callable whose call waits for that stream and gives simple_test's result."""
+        results, mask_features = self.forward_openseed(imgs, img_metas, mode='test')
+        pending = self.relation_head.submit(dict(mask_features=mask_features, img_metas=img_metas, object_info=results),
+                                            slot=slot)
+        return lambda: [self._pack(results[0], pending.result())]
+
+    @torch.no_grad()
     def simple_test_batch(self, imgs_list, img_metas_list, **kwargs):
         """Throughput mode: simple_test for several images whose selected pairs are decoded together
         (RelationTransformerHeadV4.forward_batch).  One entry per image, each as simple_test takes it."""

@@ -125,6 +125,13 @@ def test_detector_simple_test_submission_and_infer_tool(tmp_path):
     assert (tmp_path / "tool" / "submission" / "panseg" / "img_0.png").exists()
     for tr, res in zip(tool_results, results):
         assert np.array_equal(tr["pan_results"], res["pan_results"])
+    # and with two images in flight (--in-flight 2: head.submit through OpenSeeDRelationV2.simple_test_submit)
+    a2 = infer.parser().parse_args(["--segmenter", "precomputed", "--seg-dir", str(seg_dir), "--list", str(lst),
+                                    "--ori-size", "480", "640", "--out", str(tmp_path / "tool2"), "--keep-scores",
+                                    "--in-flight", "2"])
+    a2.size_given = False
+    _, path2 = infer.run(a2, head=head)
+    assert [t["relations"] for t in json.load(open(path2))] == [d["relations"] for d in direct]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16", "mixed"])

