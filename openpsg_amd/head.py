@@ -494,6 +494,9 @@ class RelationTransformerHeadV4(nn.Module):
             # image k+1's front half and decode.
             if self._front_done is not None:
                 st.wait_event(self._front_done)
+            if self._decode_done is not None and (self.cfg.num_selected > 32 or (
+                    self.pair_selector == "threshold" and self.max_selected > 32) or not self.llm_engine.use_skinny):
+                st.wait_event(self._decode_done)              # > 32 decode rows = library GEMMs in the decode: no overlap at all
             rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
             prev, front_done = self._decode_done, torch.cuda.Event()
 
