@@ -474,7 +474,7 @@ class RelationTransformerHeadV4(nn.Module):
         decode - an image's latency-bound row kernels (22 us per layer) and the fixed start / tail of its weight-streaming
         launches run under the other image's streaming (A/B: `serialize_decodes`).  The reference handles one image
         per call (V4:112); this is the same call, issued one image ahead.  A slot owns its decode graphs (KV caches,
-        static buffers) and must not be re-submitted before its pending result was taken."""
+        static buffers; `forward` has its own) and must not be re-submitted before its pending result was taken."""
         if self.training:
             raise PsgHipError("submit: inference only")
         st = self._slot_streams.get(slot)
@@ -504,7 +504,8 @@ class RelationTransformerHeadV4(nn.Module):
                 front_done.record(st)
                 if prev is not None and self.serialize_decodes:     # A/B switch: decode steps of two images never overlap
                     st.wait_event(prev)
-            out = self.decode_selected(rq, names, to_host=False, slot=slot, gate=gate)
+            # graph slot 0 belongs to `forward` (the caller's stream): a pending submit never shares its KV caches
+            out = self.decode_selected(rq, names, to_host=False, slot=slot + 1, gate=gate)
             if self.llm_engine.last_replays < 2:                # the generation ran as one graph (natural-EOS chunks): no gate
                 front_done.record(st)
             self._front_done = front_done

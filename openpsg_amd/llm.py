@@ -90,7 +90,7 @@ class LlamaDecodeEngine:
         self.early_exit_chunk = 4        # natural-EOS decode: steps per graph between "all pairs done?" checks
         self.last_replays = 0
         self._graphs = collections.OrderedDict()   # input shape -> captured decode graphs (LRU, at most max_graphs)
-        self.max_graphs = 6              # a graph owns its KV caches (~0.7 GB at K = 20 for Llama-2-7B)
+        self.max_graphs = 8              # a graph owns its KV caches (~0.7 GB at K = 20 for Llama-2-7B); `forward` + two submit slots
         hd = m.head_dim
         # rotary tables as HF builds them (HF-LL:115-128): inv_freq and the outer product in fp32 on the
         # host, cos/sin per position; the kernels index them by position
