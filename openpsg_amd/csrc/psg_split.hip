@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) split_f16x3_kernel(const float* __restric
   int e = (int)((__float_as_uint(mx) >> 23) & 255u) - 127;
   if (!(mx > 0.f) || e == 128) e = 13;
   int se = 127 + 13 - e;
-  se = se < 1 ? 1 : (se > 254 ? 254 : se);
+  se = se < 1 ? 1 : (se > 253 ? 253 : se);                                         // 2^-(se - 127) stays a normal number too
   const float scale = __uint_as_float((uint32_t)se << 23);
   if (tid == 0) inv_scale[row] = __uint_as_float((uint32_t)(254 - se) << 23);      // 2^-(se - 127)
   uint16_t* o0 = out + row * 3 * (int64_t)K;

@@ -498,15 +498,16 @@ class RelationTransformerHeadV4(nn.Module):
                     self.pair_selector == "threshold" and self.max_selected > 32) or not self.llm_engine.use_skinny):
                 st.wait_event(self._decode_done)              # > 32 decode rows = library GEMMs in the decode: no overlap at all
             rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
-            prev, front_done = self._decode_done, torch.cuda.Event()
+            prev, front_done, gated = self._decode_done, torch.cuda.Event(), [False]
 
             def gate():                                         # between the prompt pass and the decode steps
                 front_done.record(st)
+                gated[0] = True
                 if prev is not None and self.serialize_decodes:     # A/B switch: decode steps of two images never overlap
                     st.wait_event(prev)
             # graph slot 0 belongs to `forward` (the caller's stream): a pending submit never shares its KV caches
             out = self.decode_selected(rq, names, to_host=False, slot=slot + 1, gate=gate)
-            if self.llm_engine.last_replays < 2:                # the generation ran as one graph (natural-EOS chunks): no gate
+            if not gated[0]:                                    # eager run, or every pair ended inside the first graph
                 front_done.record(st)
             self._front_done = front_done
             self._decode_done = torch.cuda.Event()
