@@ -267,3 +267,40 @@ def test_decode_steps_are_batch_invariant_bit_for_bit(bench_engine):
         for r, i in enumerate(rows):
             assert torch.equal(q[r], q20[i]) and torch.equal(d[r], d20[i]) and torch.equal(lg[r], l20[i]), \
                 f"row {i}: batch of {nrows} differs from batch of 20"
+
+
+def test_fp32_decode_steps_are_batch_invariant_bit_for_bit(bench_engine):
+    """The same for the fp32 kernel (psg_gemm_f32.hip) at the benchmarked width: a row of a 20-row batch (rows 0..15 on
+    v_mfma_f32_16x16x1_4b, rows 16..19 on v_mfma_f32_4x4x1_16b) == that row in a batch of 1, 4, 16 or 17, bit for bit -
+    whichever instruction and whichever position it gets.  One 7B-width layer of fp32 weights (0.8 GB)."""
+    from openpsg_amd import ops
+    be = bench_engine
+    cfg = be["cfg"]
+    m = cfg.llm
+    dev = be["dev"]
+    pre = "language_model.model.layers.0."
+    w = {k: be["w"][pre + k].float() for k in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                                                "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight")}
+    wqkv = torch.cat([w["self_attn.q_proj.weight"], w["self_attn.k_proj.weight"], w["self_attn.v_proj.weight"]], 0).contiguous()
+    wgu = torch.cat([w["mlp.gate_proj.weight"], w["mlp.up_proj.weight"]], 0).contiguous()
+    wdown = w["mlp.down_proj.weight"].contiguous()
+    g = torch.Generator(device=dev)
+    g.manual_seed(12)
+    x = torch.randn((20, m.hidden), device=dev, generator=g)
+    ln = torch.ones(m.hidden, device=dev)
+    outs = {}
+    for rows in (list(range(20)), [17], [2, 5, 9, 17], list(range(16)), list(range(3, 20))):
+        ii = torch.tensor(rows, device=dev)
+        xs = x[ii].contiguous()
+        n = torch.empty_like(xs)
+        ops.rmsnorm(xs.clone(), None, ln, m.rms_eps, n)
+        qkv = ops.skinny_gemm(n, wqkv).reduce(torch.float32)
+        act = torch.empty((len(rows), m.inter), device=dev, dtype=torch.float32)
+        ops.silu_mul(ops.skinny_gemm(n, wgu), act)
+        d = ops.skinny_gemm(act, wdown).reduce(torch.float32)
+        outs[tuple(rows)] = (qkv, d)
+    torch.cuda.synchronize()
+    q20, d20 = outs[tuple(range(20))]
+    for rows, (q, d) in outs.items():
+        for r, i in enumerate(rows):
+            assert torch.equal(q[r], q20[i]) and torch.equal(d[r], d20[i]), f"row {i} in a batch of {len(rows)} differs"
