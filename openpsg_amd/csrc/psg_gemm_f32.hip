@@ -271,13 +271,16 @@ static int sgf_round_cost(const psg_ctx* ctx, int N, int splits, int wv) {
 
 // Split count of the fp32 kernel: one workgroup per CU (its LDS holds the rings, the tile and the x slice), 8 slices of
 // K where K allows it (column groups = CUs / slices), deeper only while the x slice does not fit next to the rings.
+// The count does NOT depend on M (the LDS bound is taken at 32 rows): the slices are summed in order by the consumer, so
+// a plan that followed the row count would make a pair's result depend on how many pairs share the step.
 int psg_sgf_plan(const psg_ctx* ctx, int M, int N, int K) {
+  (void)M;
   const int forced = ctx->opt.skinny_splits;
   const int KB = K >> 5;
   int S = forced > 0 ? forced : 8;
   while (S > 1 && KB / S < 4) S >>= 1;                               // at least 4 blocks (128 floats) per slice
   if (forced <= 0)
-    while (S < PSG_MAX_SPLITS && S * 2 <= KB && sgf_lds(M, K, S, 8, 3) > 156 * 1024) S *= 2;
+    while (S < PSG_MAX_SPLITS && S * 2 <= KB && sgf_lds(32, K, S, 8, 3) > 156 * 1024) S *= 2;
   if (S > KB) S = KB;
   if (S > PSG_MAX_SPLITS) S = PSG_MAX_SPLITS;
   if (S < 1) S = 1;

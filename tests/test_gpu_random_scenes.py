@@ -3,7 +3,8 @@ random padded geometries (patch counts that are not multiples of 32 or 64, non-s
 void aliased with person#0 or not, vanishing objects (empty pair masks), class lists of random size (prompt lengths,
 prompt de-duplication on / off by ratio).  Per scene: mask bits exact, existence logits 1e-3 on every pair, identical
 top-K, greedy tokens of the first selected pairs identical; the mixed mode (the benchmarked one) on the same scenes stays
-within 0.03 of the oracle's logits."""
+within 0.03 of the oracle's logits; the fp32s mode (split-fp16 products) meets the fp32 bar and decodes the fp32 head's
+tokens."""
 import numpy as np
 import pytest
 import torch
@@ -25,7 +26,7 @@ def heads():
     cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 2, 512, 512), max_object_num=30)
     w = make_weights_numpy(cfg, seed=77)
     out = {}
-    for dt in ("fp32", "mixed"):
+    for dt in ("fp32", "fp32s", "mixed"):
         h = RelationTransformerHeadV4(dtype=dt, device="cuda:0", qformer_vocab_size=512, llm_config=cfg.llm,
                                       llm_feature_size=cfg.llm.hidden, tokenizers="word", max_object_num=30,
                                       on_parse_error="skip", suppress_eos=True)
@@ -89,3 +90,13 @@ def test_random_scene_against_the_oracle(heads, seed):
     print(f"seed {seed}: pad {pad}, N = {n}, L = {L}, empty pair masks {empty}; fp32 logits {err:.1e}; mixed logits {em:.1e}; "
           f"{checked} decodes token-exact")
     assert em < 0.03, em
+    # the fp32 mode with split-fp16 products: the fp32 bar, and the fp32 head's own selection and tokens
+    hs_ = hs["fp32s"]
+    hs_(inputs)
+    torch.cuda.synchronize()
+    es = (hs_.last["exist_logit"].cpu() - rq["exist_logit"]).abs().max().item()
+    assert es < 1e-3, es
+    sel_s = hs_.last["selected"].cpu().tolist()
+    assert all(a == b or abs(float(p[a]) - float(p[b])) < 2e-6 for a, b in zip(sel_s, sel)), (sel_s, sel)
+    if sel_s == got_sel:
+        assert np.array_equal(hs_.last["tokens_host"], last["tokens_host"]), "fp32s tokens differ from the fp32 head's"
