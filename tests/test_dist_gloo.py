@@ -22,6 +22,7 @@ def _free_port():
 
 class OracleBackend:
     """Implements the five compute calls of PairShardedPipeline with oracle/psg_oracle.py."""
+    device = torch.device("cpu")
 
     def __init__(self, cfg, w, k=5, max_new=4, threshold=None):
         self.cfg, self.w, self.k, self.max_new, self.threshold = cfg, w, k, max_new, threshold
@@ -70,6 +71,44 @@ class OracleBackend:
         # returns tokens derived from the selection (checks the token all-gather)
         self.received = features.clone()
         return (selected.long()[:, None] * 10 + torch.arange(self.max_new)[None, :]).to(torch.int32)
+
+
+class ConstantsOracleBackend(OracleBackend):
+    """The same with the SURVEY 8e hand-over: rank 0 computes an image's constants (object ids, bitmasks, patches), the
+    pipeline broadcasts them as one int32 message, and every other rank works from them alone (its `scene` is None)."""
+
+    def image_constants(self, scene):
+        from oracle import psg_oracle as O
+        ids = [int(i) for i in scene["object_id_list"]]
+        fh, fw = scene["mask_features"].shape[-2:]
+        grid = O.mask_grid(scene["pan_results"], scene["img_meta"]["img_shape"], scene["img_meta"]["pad_shape"],
+                           (fh // 16, fw // 16))
+        om = O.object_masks(grid, ids)                                              # bool [N, L]
+        L = om.shape[1]
+        words = (L + 63) // 64
+        pad = torch.zeros((om.shape[0], words * 64), dtype=torch.int64)
+        pad[:, :L] = om.to(torch.int64)
+        w_ = (pad.view(-1, words, 64) << torch.arange(64, dtype=torch.int64)).sum(-1)   # bit l & 63 of word l >> 6
+        return torch.tensor(ids, dtype=torch.int32), w_.contiguous(), self.patch_embed(scene)
+
+    def scene_from_ids(self, ids):
+        return dict(object_id_list=[int(i) for i in ids.tolist()])
+
+    def query_shard(self, scene, patches, p0, p1, bits=None):
+        if bits is None:
+            return super().query_shard(scene, patches, p0, p1)
+        from oracle import psg_oracle as O
+        from tests import helpers as H
+        ids, tmask = H.qformer_prompts(scene)                                       # from the object ids alone
+        L = patches.shape[0]
+        om = ((bits[:, :, None] >> torch.arange(64, dtype=torch.int64)) & 1).reshape(bits.shape[0], -1)[:, :L].bool()
+        pm = O.pair_masks(om)
+        self.calls.append((p0, p1))
+        if p1 <= p0:
+            return torch.zeros(0, self.hidden), torch.zeros(0)
+        out = O.qformer_forward(self.w, self.cfg, ids[p0:p1], tmask[p0:p1], patches, pm[p0:p1])
+        _, prob = O.existence_head(self.w, out)
+        return out.reshape(-1, self.hidden).contiguous(), prob
 
 
 def _worker(rank, world, port, n_obj, ret, threshold=None):
@@ -149,9 +188,9 @@ def _one_image_worker(rank, world, port, n_obj, ret):
     cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 1, 512, 512))
     w = make_weights_numpy(cfg, seed=3, with_llm=False)
     scene = make_scene((256, 256), n_obj, seed=77, tiny_object=True)
-    if rank != 0:                               # only rank 0 holds the feature map; the others get the patches
-        scene = dict(scene, mask_features=torch.full_like(scene["mask_features"], float("nan")))
-    be = OracleBackend(cfg, w)
+    if rank != 0:                               # only rank 0 holds the image; the others work from its broadcast alone
+        scene = None
+    be = ConstantsOracleBackend(cfg, w)
     real_pe = be.patch_embed
     be.patch_embed = lambda sc: real_pe(sc) if rank == 0 else (_ for _ in ()).throw(AssertionError("rank > 0"))
     with torch.no_grad():
@@ -173,8 +212,9 @@ def _one_image_worker(rank, world, port, n_obj, ret):
 
 @pytest.mark.parametrize("n_obj", [4, 3])
 def test_one_image_strong_scaling_world2_gloo(n_obj):
-    """SURVEY 8e incl. item 3: one image for both ranks - patches broadcast from rank 0, pair shards, identical
-    top-K, selected features all-reduced, the K decodes dealt round-robin, tokens gathered in selection order."""
+    """SURVEY 8e incl. item 3: one image for both ranks - its constants (object ids, bitmask words, patches) broadcast
+    from rank 0 as one int32 message through gloo, rank 1 called with scene=None -, pair shards, identical top-K,
+    selected features all-reduced, the K decodes dealt round-robin, tokens gathered in selection order."""
     world = 2
     port = _free_port()
     mgr = mp.Manager()

@@ -5,7 +5,7 @@ through the same object."""
 import pytest
 import torch
 
-from tests.test_dist_gloo import OracleBackend
+from tests.test_dist_gloo import ConstantsOracleBackend, OracleBackend
 
 
 def _setup(threshold=None):
@@ -50,12 +50,11 @@ def test_loopback_one_image_dealt_decodes(world, n_obj):
     torch.set_num_threads(4)
     cfg, w = _setup()
     scene = make_scene((256, 256), n_obj, seed=77, tiny_object=True)
-    nan_scene = dict(scene, mask_features=torch.full_like(scene["mask_features"], float("nan")))
-    bes = [OracleBackend(cfg, w) for _ in range(world)]
+    bes = [ConstantsOracleBackend(cfg, w) for _ in range(world)]
     fw = LoopbackWorld(world)
     with torch.no_grad():
-        # only rank 0 holds the feature map; the others see NaN and must work from the broadcast patches
-        outs = fw.run([p.step_one_image_gen(scene if r == 0 else nan_scene) for r, p in enumerate(fw.pipelines(bes))])
+        # only rank 0 holds the image; the others get scene=None and work from the broadcast constants
+        outs = fw.run([p.step_one_image_gen(scene if r == 0 else None) for r, p in enumerate(fw.pipelines(bes))])
         B = n_obj * n_obj
         be1 = OracleBackend(cfg, w)
         h, prob = be1.query_shard(scene, be1.patch_embed(scene), 0, B)
@@ -82,3 +81,20 @@ def test_loopback_rejects_diverging_ranks():
         yield ("all_reduce", torch.zeros(1))
     with pytest.raises(RuntimeError):
         LoopbackWorld(2).run([a(), b()])
+
+
+def test_constants_message_round_trip_on_cpu():
+    """pack_constants / unpack_constants: ids, 64-bit mask words (including bit 63) and fp32 patches (including NaN and
+    -0.0 bit patterns) survive the int32 message bit for bit."""
+    from openpsg_amd.dist import PairShardedPipeline
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 133000, (7,), generator=g).to(torch.int32)
+    bits = torch.randint(-2 ** 63, 2 ** 63 - 1, (7, 5), generator=g, dtype=torch.int64)
+    bits[0, 0] = -2 ** 63                                                        # only bit 63 set
+    patches = torch.randn(21, 16, generator=g)
+    patches[3, 2], patches[4, 4] = float("nan"), -0.0
+    msg = PairShardedPipeline.pack_constants(ids, bits, patches)
+    assert msg.dtype == torch.int32 and msg.numel() == 4 + 7 + 2 * 35 + 21 * 16
+    i2, b2, p2 = PairShardedPipeline.unpack_constants(msg)
+    assert torch.equal(i2, ids) and torch.equal(b2, bits)
+    assert torch.equal(p2.view(torch.int32), patches.view(torch.int32))
