@@ -42,10 +42,14 @@ class _Pending:
 
     def __init__(self, head, stream, rq, out, num_objects):
         self.head, self.stream, self.rq, self.out, self.N = head, stream, rq, out, num_objects
+        self._result = None
 
     def result(self):
+        if self._result is not None:                                  # taken before: the same dict again
+            return self._result
         if self.rq is None:
-            return dict(rel_pred=[], rel_score=[])
+            self._result = dict(rel_pred=[], rel_score=[])
+            return self._result
         h, out = self.head, self.out
         with torch.cuda.stream(self.stream):
             sel = self.rq["selected"]
@@ -55,7 +59,8 @@ class _Pending:
         h.last = self.rq
         rel_pred, rel_score = h.parse(out["tokens_host"], out["selected_host"], self.N)
         self.rq = self.out = None
-        return dict(rel_pred=rel_pred, rel_score=rel_score)
+        self._result = dict(rel_pred=rel_pred, rel_score=rel_score)
+        return self._result
 
 
 class _PendingBatch:

@@ -40,6 +40,18 @@ for kmul in (1, 3):
                 us = bench(lambda i: torch.nn.functional.linear(x, ws[i % 3]))
             elif v == "lib32":
                 us = bench(lambda i: torch.mm(x, ws[i % 3].t(), out_dtype=torch.float32))
+            elif v == "rb32":                                        # the same through rocBLAS
+                torch.backends.cuda.preferred_blas_library("cublas")
+                try:
+                    us = bench(lambda i: torch.mm(x, ws[i % 3].t(), out_dtype=torch.float32))
+                finally:
+                    torch.backends.cuda.preferred_blas_library("cublaslt")
+            elif v == "rb":
+                torch.backends.cuda.preferred_blas_library("cublas")
+                try:
+                    us = bench(lambda i: torch.nn.functional.linear(x, ws[i % 3]))
+                finally:
+                    torch.backends.cuda.preferred_blas_library("cublaslt")
             elif v == "own":
                 us = bench(lambda i: ops.dense_gemm(x, ws[i % 3], out=out))
             elif v == "sk":
