@@ -60,7 +60,7 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *        psg_masked_split_mean_pool added)
  *   400  round 4 (psg_skinny_gemm_plan: dtype; psg_skinny_gemm accepts PSG_F32 = the reference's own precision;
  *        psg_train_attn_fwd / _bwd: attention-probability dropout mask; psg_split_f16x3, psg_scale_rows_cols added) */
-#define PSG_ABI_VERSION 400
+#define PSG_ABI_VERSION 401
 int psg_version(void);
 const char* psg_last_error(void);
 int psg_create(int device, psg_ctx** out);
@@ -325,8 +325,8 @@ int psg_scale_rows_cols(psg_ctx*, float* y, int64_t rows, int N, const float* ro
 
 /* ---- Q-Former dense projections with fused epilogue (HF-IB:563-596 intermediate(_query): Linear + exact-erf GELU):
  * out[M][N] = epilogue(x[M][K] . w[N][K]^T + bias[N]); x / w / out bf16 or fp16 row-major, bias fp32 (may be NULL),
- * fp32 accumulate.  N % 256 == 0, K % 64 == 0.  One pass instead of a library GEMM + psg_bias_gelu. */
-enum psg_epilogue { PSG_EPI_NONE = 0, PSG_EPI_GELU = 1 };
+ * fp32 accumulate.  N % 16 == 0, K % 64 == 0.  One pass instead of a library GEMM + psg_bias_gelu. */
+enum psg_epilogue { PSG_EPI_NONE = 0, PSG_EPI_GELU = 1, PSG_EPI_SWIGLU = 2 };
 int psg_dense_gemm(psg_ctx*, const void* x, const void* w, const float* bias, int epilogue, void* out, int64_t M,
                    int N, int K, int dtype, void* stream);
 /* The same kernel with an fp32 output (out_dtype = PSG_F32) and per-row / per-column scales applied to the accumulator
@@ -337,6 +337,19 @@ int psg_dense_gemm(psg_ctx*, const void* x, const void* w, const float* bias, in
 int psg_dense_gemm_ex(psg_ctx*, const void* x, const void* w, const float* bias, int epilogue, void* out, int64_t M,
                       int N, int K, int dtype, int out_dtype, const float* row_scale, const float* col_scale,
                       void* stream);
+/* The same kernel with the output tile chosen by the caller - the Llama prompt pass (HF-LL:163-177; ~980 rows = 4 row
+ * blocks of 256) needs tiles that fill the 256 CUs in whole rounds: PSG_TILE_AUTO picks the geometry with the fewest
+ * rounds x tile area for [M, N].  Geometries other than 256 x 256 take the plain and the SwiGLU epilogue with 16-bit
+ * output.  PSG_EPI_SWIGLU (Llama MLP): w is the gate / up weight with its rows interleaved in groups of 8 by
+ * psg_interleave_gate_up ([2 inter][K] -> w[16 p + r] = gate[8 p + r], w[16 p + 8 + r] = up[8 p + r], r < 8), N = 2 inter,
+ * and out is [M][inter] = silu(gate) * up with the roundings of the separate kernels (GEMM output, act_fn(gate),
+ * product: psg_silu_mul); bias must be NULL.  Results do not depend on the tile (one k-ordered accumulation each). */
+enum psg_tile { PSG_TILE_AUTO = 0, PSG_TILE_256x256 = 1, PSG_TILE_256x192 = 2, PSG_TILE_256x128 = 3, PSG_TILE_256x64 = 4,
+                PSG_TILE_128x128 = 5 };
+int psg_dense_gemm_tiled(psg_ctx*, const void* x, const void* w, const float* bias, int epilogue, void* out, int64_t M,
+                         int N, int K, int dtype, int out_dtype, const float* row_scale, const float* col_scale, int tile,
+                         void* stream);
+int psg_interleave_gate_up(psg_ctx*, const void* gate_up, void* out, int inter, int K, void* stream);
 
 /* ---- K16: greedy step (HF generate, num_beams=1, do_sample=False; V4:305-312).
  * logits [K][vocab] (dtype); token = argmax (first maximal index); suppress_token >= 0 is

@@ -27,8 +27,6 @@
 // workgroups that share a panel) was measured slower: the shared bursts are L2 hits.
 #include "psg_common.h"
 
-#define DG_BM 256
-#define DG_BN 256
 #define DG_BK 64
 
 // exact-erf GELU, Abramowitz-Stegun 7.1.26 (same arithmetic as bias_gelu_rows_bf16_kernel in psg_rowops.hip; the
@@ -50,6 +48,10 @@ template <int N_>
 __device__ __forceinline__ void dg_vmwait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
+template <int N_>
+__device__ __forceinline__ void dg_lgkmwait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_) : "memory");
+}
 __device__ __forceinline__ void dg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // Fragment reads are inline asm: next to a pending LDS-DMA hipcc makes every ds_read it generates itself wait
 // vmcnt(0) first (the DMA is an LDS write that may alias), which would serialise the prefetch behind the reads.
@@ -65,62 +67,82 @@ __device__ __forceinline__ dg_u32x4 dg_lds_read128(uint32_t a) {
 // (psg_split.hip: the scales are the powers of two that undo the operands' row scaling).
 // Every output element is ONE k-ordered accumulation over the whole K (no split-K, tiles walk K front to back), so a
 // row's result does not depend on M or on the tile it falls into: a pair shard reproduces the rows of the
-// full pass bit for bit.
-template <typename E, int GELU, int VAR, int OUT32 = 0>
-__global__ void __launch_bounds__(512, 2)
+// full pass bit for bit - whatever the tile geometry.
+//
+// Tile geometry <WM, WN, TI, TJ>: WM x WN waves, each TI x TJ accumulator tiles of 32 x 32 ->
+// BM = 32 WM TI rows of x by BN = 32 WN TJ rows of w.  256 x 256 (2, 4, 4, 2) is the Q-Former's tile; the Llama prompt
+// pass (M ~ 980 rows = 4 row blocks, HF-LL:163-177) picks the width per shape so that the tiles fill the 256 CUs in
+// whole rounds (psg_dense_gemm_tiled).  N need not be a multiple of BN: w rows past N are clamped in the staging and
+// never stored.
+//
+// EPI = PSG_EPI_SWIGLU (Llama MLP, HF-LL:163-177): w holds gate and up rows interleaved in groups of 8
+// (w[16 p + r] = gate[8 p + r], w[16 p + 8 + r] = up[8 p + r], r < 8: psg_interleave_gate_up), so a lane's accumulator
+// chunks alternate gate / up of the SAME 4 columns; out[m][8 p + r] = silu(gate) * up, N / 2 columns, with the
+// roundings of the separate kernels (GEMM output, act_fn(gate), product: psg_silu_mul).
+template <typename E, int EPI, int VAR, int OUT32, int WM, int WN, int TI, int TJ>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 2 : 1))
 dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
                   uint16_t* __restrict__ out, int M, int N, int K, const float* __restrict__ row_scale,
                   const float* __restrict__ col_scale) {
   using v8 = typename E::v8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][A 32 KiB | B 32 KiB]
+  constexpr int NW = WM * WN, BM = WM * TI * 32, BN = WN * TJ * 32;
+  constexpr int A_BYTES = BM * 128, BUF_BYTES = (BM + BN) * 128;        // one K tile: [A: BM rows | B: BN rows] x 128 B
+  constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;                      // staging instructions per wave
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA instructions per wave");
+  constexpr bool GELU = EPI == PSG_EPI_GELU, SWIGLU = EPI == PSG_EPI_SWIGLU;
+  static_assert(!(SWIGLU && OUT32), "the SwiGLU epilogue writes the 16-bit activation");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][A | B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const int NB = N / DG_BN, MB = (M + DG_BM - 1) / DG_BM;
-  const int MB8 = MB >= 8 ? (MB + 7) / 8 * 8 : MB;         // fewer than 8 row blocks: plain numbering (no idle XCD slots)
-  const int ntile = MB8 * NB;
-  const int wm = wid >> 2, wn = wid & 3;                   // wave tile: rows [128 wm, +128), cols [64 wn, +64)
+  const int NB = (N + BN - 1) / BN, MB = (M + BM - 1) / BM;
+  const int MB8 = (MB + 7) / 8 * 8, NB8 = (NB + 7) / 8 * 8;
+  const int ntile = MB >= 8 ? MB8 * NB : MB * NB8;
+  const int wm = wid / WN, wn = wid % WN;                  // wave tile: rows [32 TI wm, +32 TI), cols [32 TJ wn, +32 TJ)
   // persistent workgroups (one per CU) walk tiles b, b + grid, ...  XCD-aware numbering: tile t lives on XCD
-  // t % 8 (= the XCD of its workgroup as long as the grid is a multiple of 8); the NB column tiles of a row block
-  // share an XCD, whose L2 then serves the x tile to all of them
+  // t % 8 (= the XCD of its workgroup as long as the grid is a multiple of 8).  8 or more row blocks: the NB column
+  // tiles of a row block share an XCD, whose L2 then serves the x tile to all of them.  Fewer (the prompt pass): the
+  // MB row blocks of a column block share an XCD and run side by side - the w tile comes from HBM once.
   auto tile_mn = [&](int t, int& mb, int& nb) {
-    if (MB < 8) {                                          // row blocks innermost: the MB tiles of a column block
-      mb = t % MB;                                         // are neighbours (they share the w tile through L2)
-      nb = t / MB;
+    const int xcd = t & 7, idx = t >> 3;
+    if (MB < 8) {
+      mb = idx % MB;
+      nb = (idx / MB) * 8 + xcd;
       return;
     }
-    const int xcd = t & 7, idx = t >> 3;
     mb = (idx / NB) * 8 + xcd;
     nb = idx % NB;
   };
 
   // staging: one instruction = 8 rows x 128 B; lane -> row 8 g + (lane >> 3), 16-byte slot lane & 7, which holds
   // source piece slot ^ swz(row), swz(row) = (row >> 1) & 7 (conflict-free for the 32 x 32 x 16 fragment reads: a
-  // ds_read_b128 lane group sees 16 rows whose even / odd members get 8 distinct slots each).  A 256 x 64 tile =
-  // 32 instructions, 4 per wave; rows past M are clamped (never stored)
+  // ds_read_b128 lane group sees 16 rows whose even / odd members get 8 distinct slots each).  Rows past M / N are
+  // clamped (never stored)
   const int srow = lane >> 3, sslot = lane & 7;
   auto stage_x = [&](int m0, int kt, int buf) {
-    unsigned char* ab = smem + buf * 65536;
+    unsigned char* ab = smem + buf * BUF_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (wid * 4 + i) * 8 + srow;               // 0..255
+    for (int i = 0; i < AI; ++i) {
+      const int r = (wid * AI + i) * 8 + srow;
       const int piece = sslot ^ ((r >> 1) & 7);
       int gr = m0 + r;
       gr = gr < M ? gr : M - 1;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(x + (int64_t)gr * K + kt * DG_BK + piece * 8),
-          (__attribute__((address_space(3))) void*)(ab + (wid * 4 + i) * 1024), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(ab + (wid * AI + i) * 1024), 16, 0, 0);
     }
   };
   auto stage_w = [&](int n0, int kt, int buf) {
-    unsigned char* ab = smem + buf * 65536;
+    unsigned char* ab = smem + buf * BUF_BYTES + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (wid * 4 + i) * 8 + srow;
+    for (int i = 0; i < BI; ++i) {
+      const int r = (wid * BI + i) * 8 + srow;
       const int piece = sslot ^ ((r >> 1) & 7);
+      int gr = n0 + r;
+      gr = gr < N ? gr : N - 1;
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(w + (int64_t)(n0 + r) * K + kt * DG_BK + piece * 8),
-          (__attribute__((address_space(3))) void*)(ab + 32768 + (wid * 4 + i) * 1024), 16, 0, 0);
+          (const __attribute__((address_space(1))) void*)(w + (int64_t)gr * K + kt * DG_BK + piece * 8),
+          (__attribute__((address_space(3))) void*)(ab + (wid * BI + i) * 1024), 16, 0, 0);
     }
   };
 
@@ -131,23 +153,23 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
   for (;; t += gridDim.x) {
     if (t >= ntile) return;
     tile_mn(t, mb, nb);
-    if (mb < MB) break;
+    if (mb < MB && nb < NB) break;
   }
   int par = 0;                                              // LDS buffer of the K tile about to be consumed
-  stage_x(mb * DG_BM, 0, 0);
-  stage_w(nb * DG_BN, 0, 0);
-  // per-lane fragment row offsets (bytes) and swizzles: A rows 128 wm + 32 i + l31, B rows 64 wn + 32 j + l31
-  uint32_t arow[4], brow[2], aswz[4], bswz[2];
+  stage_x(mb * BM, 0, 0);
+  stage_w(nb * BN, 0, 0);
+  // per-lane fragment row offsets (bytes) and swizzles: A rows 32 TI wm + 32 i + l31, B rows 32 TJ wn + 32 j + l31
+  uint32_t arow[TI], brow[TJ], aswz[TI], bswz[TJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wm * 128 + i * 32 + l31;
+  for (int i = 0; i < TI; ++i) {
+    const int r = wm * (TI * 32) + i * 32 + l31;
     arow[i] = (uint32_t)(r * 128);
     aswz[i] = (uint32_t)((r >> 1) & 7);
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = wn * 64 + j * 32 + l31;
-    brow[j] = (uint32_t)(32768 + r * 128);
+  for (int j = 0; j < TJ; ++j) {
+    const int r = wn * (TJ * 32) + j * 32 + l31;
+    brow[j] = (uint32_t)(A_BYTES + r * 128);
     bswz[j] = (uint32_t)((r >> 1) & 7);
   }
   union Frag {
@@ -155,42 +177,42 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
     v8 v;
   };
   for (;;) {
-    const int m0 = mb * DG_BM, n0 = nb * DG_BN;
+    const int m0 = mb * BM, n0 = nb * BN;
     // next real tile (its first K tile is requested during this tile's last K step: in flight during the epilogue)
     int tn = t + gridDim.x, mbn = 0, nbn = 0;
     for (; tn < ntile; tn += gridDim.x) {
       tile_mn(tn, mbn, nbn);
-      if (mbn < MB) break;
+      if (mbn < MB && nbn < NB) break;
     }
     const bool has_next = tn < ntile;
 
-    psg_f32x16 acc[4][2];
+    psg_f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = (psg_f32x16){0};
+      for (int j = 0; j < TJ; ++j) acc[i][j] = (psg_f32x16){0};
 
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = par;
       par ^= 1;
       const bool more_k = kt + 1 < nk;
       const bool pf = VAR != 2 && (more_k || has_next);
-      const int pm0 = more_k ? m0 : mbn * DG_BM, pn0 = more_k ? n0 : nbn * DG_BN, pkt = more_k ? kt + 1 : 0;
+      const int pm0 = more_k ? m0 : mbn * BM, pn0 = more_k ? n0 : nbn * BN, pkt = more_k ? kt + 1 : 0;
       dg_vmwait<0>();                                       // tile kt landed (requested during the previous K step)
       dg_lds_barrier();                                     // every wave's part of tile kt is in LDS; nobody reads buf ^ 1 any more
-      const uint32_t base = smem_lds + (uint32_t)(buf * 65536);
-      // four sub-steps of 16 in k, 8 MFMAs (32 x 32 x 16) each; the 6 fragment reads of sub-step s+1 are issued
-      // before the MFMAs of sub-step s; the DMAs of the next K tile are issued beside sub-steps 0 and 1
-      Frag af[2][4], bf[2][2];
-      auto read_frags = [&](int sub, Frag (&a_)[4], Frag (&b_)[2]) {
+      const uint32_t base = smem_lds + (uint32_t)(buf * BUF_BYTES);
+      // four sub-steps of 16 in k, TI x TJ MFMAs (32 x 32 x 16) each; the TI + TJ fragment reads of sub-step s+1 are
+      // issued before the MFMAs of sub-step s; the DMAs of the next K tile are issued beside sub-steps 0 and 1
+      Frag af[2][TI], bf[2][TJ];
+      auto read_frags = [&](int sub, Frag (&a_)[TI], Frag (&b_)[TJ]) {
         const uint32_t piece = (uint32_t)(2 * sub + hi);    // 16-byte piece (8 elements) of the 128-byte row
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b_[j].u = dg_lds_read128(base + brow[j] + ((piece ^ bswz[j]) << 4));
+        for (int j = 0; j < TJ; ++j) b_[j].u = dg_lds_read128(base + brow[j] + ((piece ^ bswz[j]) << 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_[i].u = dg_lds_read128(base + arow[i] + ((piece ^ aswz[i]) << 4));
+        for (int i = 0; i < TI; ++i) a_[i].u = dg_lds_read128(base + arow[i] + ((piece ^ aswz[i]) << 4));
       };
 #define DG_MMA(AF, BF)                                                                            \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) {    \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) {  \
     if (VAR == 1) {                                                                               \
       asm volatile("" ::"v"(BF[j].u), "v"(AF[i].u));                                              \
     } else {                                                                                      \
@@ -200,22 +222,22 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
       read_frags(0, af[0], bf[0]);
       read_frags(1, af[1], bf[1]);
       if (pf) stage_x(pm0, pkt, buf ^ 1);
-      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      dg_lgkmwait<TI + TJ>();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
       DG_MMA(af[0], bf[0])
       __builtin_amdgcn_sched_barrier(0);
       read_frags(2, af[0], bf[0]);
       if (pf) stage_w(pn0, pkt, buf ^ 1);
-      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      dg_lgkmwait<TI + TJ>();
       __builtin_amdgcn_sched_barrier(0);
       DG_MMA(af[1], bf[1])
       __builtin_amdgcn_sched_barrier(0);
       read_frags(3, af[1], bf[1]);
-      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      dg_lgkmwait<TI + TJ>();
       __builtin_amdgcn_sched_barrier(0);
       DG_MMA(af[0], bf[0])
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dg_lgkmwait<0>();
       __builtin_amdgcn_sched_barrier(0);
       DG_MMA(af[1], bf[1])
       __builtin_amdgcn_s_setprio(0);
@@ -224,32 +246,65 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
       // every wave reaches only after its own lgkmcnt(0) above, i.e. after its last read of this buffer
     }
 
-    // epilogue.  acc[i][j][reg] = C[m][n] with m = m0 + 128 wm + 32 i + l31 and
-    // n = n0 + 64 wn + 32 j + 8 (reg >> 2) + 4 hi + (reg & 3): the two half-waves hold alternating 4-column chunks of
+    // epilogue.  acc[i][j][reg] = C[m][n] with m = m0 + 32 TI wm + 32 i + l31 and
+    // n = n0 + 32 TJ wn + 32 j + 8 (reg >> 2) + 4 hi + (reg & 3): the two half-waves hold alternating 4-column chunks of
     // a row, so one v_permlane32_swap per pair of chunks gives every lane 8 consecutive columns = one 16-byte store
     // (lanes 0-31: columns 16 q .. +7, lanes 32-63: columns 16 q + 8 .. +15)
-    float4 bv[2][4];
+    const int cw = n0 + wn * (TJ * 32);                      // first column of the wave tile
+    if constexpr (SWIGLU) {
+      const int No = N >> 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < TI; ++i) {
+        const int m = m0 + wm * (TI * 32) + i * 32 + l31;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        bv[j][q] = bias ? *reinterpret_cast<const float4*>(bias + n0 + wn * 64 + j * 32 + 8 * q + 4 * hi)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < TJ; ++j) {
+          uint32_t pk[2][2];                                 // [16-group p][2 words] = 4 output columns at 8 p + 4 hi
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            uint16_t h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float g = E::to_f32(E::from_f32(acc[i][j][8 * p + e]));         // the GEMM's 16-bit output
+              const float u = E::to_f32(E::from_f32(acc[i][j][8 * p + 4 + e]));
+              const float sg = E::to_f32(E::from_f32(g / (1.0f + expf(-g))));       // HF rounds act_fn(gate)
+              h[e] = E::from_f32(sg * u);
+            }
+            pk[p][0] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+            pk[p][1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+          }
+          auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+          auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+          const int nin = cw + j * 32 + 16 * hi;             // the 16 interleaved columns this lane's 8 outputs come from
+          if (m < M && nin + 16 <= N)
+            *reinterpret_cast<uint4*>(out + (int64_t)m * No + (nin >> 1)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+      }
+    } else {
+    float4 bv[TJ][4];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = cw + j * 32 + 8 * q + 4 * hi;
+        bv[j][q] = (bias && n + 4 <= N) ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     if constexpr (OUT32) {
       float* out32 = reinterpret_cast<float*>(out);
-      float4 cs[2][4];
+      float4 cs[TJ][4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          cs[j][q] = col_scale ? *reinterpret_cast<const float4*>(col_scale + n0 + wn * 64 + j * 32 + 8 * q + 4 * hi)
-                               : make_float4(1.f, 1.f, 1.f, 1.f);
+        for (int q = 0; q < 4; ++q) {
+          const int n = cw + j * 32 + 8 * q + 4 * hi;
+          cs[j][q] = (col_scale && n + 4 <= N) ? *reinterpret_cast<const float4*>(col_scale + n)
+                                               : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 128 + i * 32 + l31;
+      for (int i = 0; i < TI; ++i) {
+        const int m = m0 + wm * (TI * 32) + i * 32 + l31;
         const float rs = (row_scale && m < M) ? row_scale[m] : 1.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float v[4] = {acc[i][j][4 * q] * (rs * cs[j][q].x) + bv[j][q].x, acc[i][j][4 * q + 1] * (rs * cs[j][q].y) + bv[j][q].y,
@@ -258,17 +313,17 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = dg_gelu(v[e]);
             }
-            if (m < M)
-              *reinterpret_cast<float4*>(out32 + (int64_t)m * N + n0 + wn * 64 + j * 32 + 8 * q + 4 * hi) =
-                  make_float4(v[0], v[1], v[2], v[3]);
+            const int n = cw + j * 32 + 8 * q + 4 * hi;
+            if (m < M && n + 4 <= N)
+              *reinterpret_cast<float4*>(out32 + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
           }
       }
     } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 128 + i * 32 + l31;
+    for (int i = 0; i < TI; ++i) {
+      const int m = m0 + wm * (TI * 32) + i * 32 + l31;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < TJ; ++j) {
         uint32_t pk[4][2];                                   // [chunk q][2 words] = 4 columns at 8 q + 4 hi
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -289,12 +344,12 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
           auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
           // lanes 0-31 now hold [own chunk 2q2 | upper's chunk 2q2] = columns 16 q2 + 0..7;
           // lanes 32-63 hold [lower's chunk 2q2+1 | own chunk 2q2+1] = columns 16 q2 + 8..15
-          if (m < M) {
-            const int n = n0 + wn * 64 + j * 32 + 16 * q2 + 8 * hi;
+          const int n = cw + j * 32 + 16 * q2 + 8 * hi;
+          if (m < M && n + 8 <= N)
             *reinterpret_cast<uint4*>(out + (int64_t)m * N + n) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-          }
         }
       }
+    }
     }
     }
     if (!has_next) return;
@@ -304,17 +359,75 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
   }
 }
 
-extern "C" int psg_dense_gemm_ex(psg_ctx* ctx, const void* x, const void* w, const float* bias, int epilogue, void* out,
-                                 int64_t M, int N, int K, int dtype, int out_dtype, const float* row_scale,
-                                 const float* col_scale, void* stream);
-extern "C" int psg_dense_gemm(psg_ctx* ctx, const void* x, const void* w, const float* bias, int epilogue, void* out,
-                              int64_t M, int N, int K, int dtype, void* stream) {
-  return psg_dense_gemm_ex(ctx, x, w, bias, epilogue, out, M, N, K, dtype, dtype, nullptr, nullptr, stream);
+// Tile geometries: code = 100 BM/32... kept small on purpose (every entry is 2 element types x its epilogues)
+struct dg_geom {
+  int id, wm, wn, ti, tj;
+};
+static const dg_geom DG_GEOMS[] = {
+    {PSG_TILE_256x256, 2, 4, 4, 2}, {PSG_TILE_256x192, 4, 2, 2, 3}, {PSG_TILE_256x128, 4, 2, 2, 2},
+    {PSG_TILE_256x64, 8, 1, 1, 2},  {PSG_TILE_128x128, 2, 2, 2, 2},
+};
+
+template <typename E, int EPI, int VAR, int OUT32, int WM, int WN, int TI, int TJ>
+static int dg_launch(psg_ctx* ctx, const void* x, const void* w, const float* bias, void* out, int64_t M, int N, int K,
+                     const float* row_scale, const float* col_scale, void* stream) {
+  constexpr int BM = WM * TI * 32, BN = WN * TJ * 32;
+  const int NB = (N + BN - 1) / BN, MB = (int)((M + BM - 1) / BM);
+  const int ntile = MB >= 8 ? (MB + 7) / 8 * 8 * NB : MB * ((NB + 7) / 8 * 8);
+  int grid_i = ctx->num_cu / 8 * 8;                          // persistent: one workgroup per CU, a multiple of 8 (XCD map)
+  if (grid_i > ntile) grid_i = ntile;
+  const size_t lds = 2 * (size_t)(BM + BN) * 128;
+  auto k = dense_gemm_kernel<E, EPI, VAR, OUT32, WM, WN, TI, TJ>;
+  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) {
+    psg_set_error("psg_dense_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return PSG_ERR_HIP;
+  }
+  k<<<(unsigned)grid_i, WM * WN * 64, lds, (hipStream_t)stream>>>((const uint16_t*)x, (const uint16_t*)w, bias,
+                                                                   (uint16_t*)out, (int)M, N, K, row_scale, col_scale);
+  PSG_CHECK_LAUNCH("psg_dense_gemm");
+  return PSG_OK;
 }
 
+// tile that fills the CUs best for [M, N]: cost = rounds x tile area, ties to the larger tile (less operand traffic)
+static int dg_auto_tile(const psg_ctx* ctx, int64_t M, int N) {
+  int best = PSG_TILE_256x256;
+  double best_cost = 1e300;
+  const int cus = ctx->num_cu / 8 * 8;
+  for (const dg_geom& g : DG_GEOMS) {
+    if (g.id == PSG_TILE_128x128) continue;                  // 4-wave tile: explicit requests only
+    const int BM = g.wm * g.ti * 32, BN = g.wn * g.tj * 32;
+    const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int64_t rounds = (tiles + cus - 1) / cus;
+    // narrow tiles read more LDS per MFMA: measured per-round time ~ area x {1, 1.04, 1.1, 1.5}
+    const double pen = BN >= 256 ? 1.0 : BN >= 192 ? 1.04 : BN >= 128 ? 1.1 : 1.5;
+    const double cost = (double)rounds * BM * BN * pen;
+    if (cost < best_cost * 0.999) {
+      best_cost = cost;
+      best = g.id;
+    }
+  }
+  return best;
+}
+
+extern "C" int psg_dense_gemm_tiled(psg_ctx* ctx, const void* x, const void* w, const float* bias, int epilogue,
+                                    void* out, int64_t M, int N, int K, int dtype, int out_dtype, const float* row_scale,
+                                    const float* col_scale, int tile, void* stream);
 extern "C" int psg_dense_gemm_ex(psg_ctx* ctx, const void* x, const void* w, const float* bias, int epilogue, void* out,
                                  int64_t M, int N, int K, int dtype, int out_dtype, const float* row_scale,
                                  const float* col_scale, void* stream) {
+  return psg_dense_gemm_tiled(ctx, x, w, bias, epilogue, out, M, N, K, dtype, out_dtype, row_scale, col_scale,
+                              PSG_TILE_256x256, stream);
+}
+extern "C" int psg_dense_gemm(psg_ctx* ctx, const void* x, const void* w, const float* bias, int epilogue, void* out,
+                              int64_t M, int N, int K, int dtype, void* stream) {
+  return psg_dense_gemm_tiled(ctx, x, w, bias, epilogue, out, M, N, K, dtype, dtype, nullptr, nullptr,
+                              PSG_TILE_256x256, stream);
+}
+
+extern "C" int psg_dense_gemm_tiled(psg_ctx* ctx, const void* x, const void* w, const float* bias, int epilogue,
+                                    void* out, int64_t M, int N, int K, int dtype, int out_dtype, const float* row_scale,
+                                    const float* col_scale, int tile, void* stream) {
   PSG_REQUIRE(ctx && x && w && out, PSG_ERR_INVALID, "psg_dense_gemm: NULL argument");
   PSG_REQUIRE(out_dtype == dtype || out_dtype == PSG_F32, PSG_ERR_UNSUPPORTED,
               "psg_dense_gemm: output dtype %d (the operand dtype %d or fp32)", out_dtype, dtype);
@@ -322,37 +435,66 @@ extern "C" int psg_dense_gemm_ex(psg_ctx* ctx, const void* x, const void* w, con
               "psg_dense_gemm: row / column scales need the fp32 output");
   PSG_REQUIRE(M >= 0 && N > 0 && K > 0 && M < (1ll << 31), PSG_ERR_INVALID, "psg_dense_gemm: M=%lld N=%d K=%d",
               (long long)M, N, K);
-  PSG_REQUIRE(N % DG_BN == 0 && K % DG_BK == 0, PSG_ERR_UNSUPPORTED,
-              "psg_dense_gemm: N=%d must be a multiple of %d and K=%d of %d", N, DG_BN, K, DG_BK);
-  PSG_REQUIRE(epilogue == PSG_EPI_NONE || epilogue == PSG_EPI_GELU, PSG_ERR_INVALID, "psg_dense_gemm: epilogue=%d",
-              epilogue);
+  PSG_REQUIRE(N % 16 == 0 && K % DG_BK == 0, PSG_ERR_UNSUPPORTED,
+              "psg_dense_gemm: N=%d must be a multiple of 16 and K=%d of %d", N, K, DG_BK);
+  PSG_REQUIRE(epilogue == PSG_EPI_NONE || epilogue == PSG_EPI_GELU || epilogue == PSG_EPI_SWIGLU, PSG_ERR_INVALID,
+              "psg_dense_gemm: epilogue=%d", epilogue);
+  PSG_REQUIRE(epilogue != PSG_EPI_SWIGLU || (out_dtype == dtype && !bias), PSG_ERR_UNSUPPORTED,
+              "psg_dense_gemm: the SwiGLU epilogue takes no bias and writes the operand dtype");
   if (M == 0) return PSG_OK;
-  const int NB = N / DG_BN, MB = (int)((M + DG_BM - 1) / DG_BM);
-  const int MB8 = MB >= 8 ? (MB + 7) / 8 * 8 : MB;
-  int grid_i = ctx->num_cu / 8 * 8;                          // persistent: one workgroup per CU, a multiple of 8 (XCD map)
-  if (grid_i > MB8 * NB) grid_i = MB8 * NB;
-  const unsigned grid = (unsigned)grid_i;
-  const size_t lds = 2 * 65536;
-#define DGL(G, V, O)                                                                                                 \
-  do {                                                                                                              \
-    hipError_t e = hipFuncSetAttribute((const void*)dense_gemm_kernel<E, G, V, O>,                                     \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-    if (e != hipSuccess) {                                                                                          \
-      psg_set_error("psg_dense_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));                               \
-      return PSG_ERR_HIP;                                                                                           \
-    }                                                                                                               \
-    dense_gemm_kernel<E, G, V, O><<<grid, 512, lds, (hipStream_t)stream>>>(                                            \
-        (const uint16_t*)x, (const uint16_t*)w, bias, (uint16_t*)out, (int)M, N, K, row_scale, col_scale);          \
-  } while (0)
+  if (tile == PSG_TILE_AUTO) tile = dg_auto_tile(ctx, M, N);
   const int var = ctx->opt.dense_gemm_var;
-  if (out_dtype == PSG_F32 && dtype != PSG_F32) {
-    PSG_DISPATCH_E16(dtype, "psg_dense_gemm", if (epilogue == PSG_EPI_GELU) DGL(1, 0, 1); else DGL(0, 0, 1));
-  } else {
-    PSG_DISPATCH_E16(dtype, "psg_dense_gemm",
-                     if (var == 1) DGL(0, 1, 0); else if (var == 2) DGL(0, 2, 0); else if (epilogue == PSG_EPI_GELU) DGL(1, 0, 0);
-                     else DGL(0, 0, 0));
+  const bool o32 = out_dtype == PSG_F32 && dtype != PSG_F32;
+  PSG_REQUIRE(tile == PSG_TILE_256x256 || (!o32 && epilogue != PSG_EPI_GELU && var == 0), PSG_ERR_UNSUPPORTED,
+              "psg_dense_gemm: tile %d is built for the plain and SwiGLU epilogues with 16-bit output", tile);
+#define DGL(EPI, V, O, WM, WN, TI, TJ) \
+  return dg_launch<E, EPI, V, O, WM, WN, TI, TJ>(ctx, x, w, bias, out, M, N, K, row_scale, col_scale, stream)
+#define DG_TILE(WM, WN, TI, TJ)                                                        \
+  PSG_DISPATCH_E16(dtype, "psg_dense_gemm", if (epilogue == PSG_EPI_SWIGLU) DGL(PSG_EPI_SWIGLU, 0, 0, WM, WN, TI, TJ); \
+                   else DGL(PSG_EPI_NONE, 0, 0, WM, WN, TI, TJ))
+  switch (tile) {
+    case PSG_TILE_256x256:
+      if (o32) {
+        PSG_REQUIRE(epilogue != PSG_EPI_SWIGLU, PSG_ERR_UNSUPPORTED, "psg_dense_gemm: SwiGLU with fp32 output");
+        PSG_DISPATCH_E16(dtype, "psg_dense_gemm",
+                         if (epilogue == PSG_EPI_GELU) DGL(PSG_EPI_GELU, 0, 1, 2, 4, 4, 2); else DGL(PSG_EPI_NONE, 0, 1, 2, 4, 4, 2));
+      } else {
+        PSG_DISPATCH_E16(dtype, "psg_dense_gemm",
+                         if (var == 1) DGL(PSG_EPI_NONE, 1, 0, 2, 4, 4, 2); else if (var == 2) DGL(PSG_EPI_NONE, 2, 0, 2, 4, 4, 2);
+                         else if (epilogue == PSG_EPI_GELU) DGL(PSG_EPI_GELU, 0, 0, 2, 4, 4, 2);
+                         else if (epilogue == PSG_EPI_SWIGLU) DGL(PSG_EPI_SWIGLU, 0, 0, 2, 4, 4, 2);
+                         else DGL(PSG_EPI_NONE, 0, 0, 2, 4, 4, 2));
+      }
+      break;
+    case PSG_TILE_256x192: DG_TILE(4, 2, 2, 3); break;
+    case PSG_TILE_256x128: DG_TILE(4, 2, 2, 2); break;
+    case PSG_TILE_256x64: DG_TILE(8, 1, 1, 2); break;
+    case PSG_TILE_128x128: DG_TILE(2, 2, 2, 2); break;
+    default: break;
   }
+#undef DG_TILE
 #undef DGL
-  PSG_CHECK_LAUNCH("psg_dense_gemm");
+  psg_set_error("psg_dense_gemm: unknown tile %d", tile);
+  return PSG_ERR_INVALID;
+}
+
+// ---- gate / up interleave for the SwiGLU epilogue ---------------------------------------------------------------------
+// out[16 p + r] = gate_up[8 p + r], out[16 p + 8 + r] = gate_up[inter + 8 p + r] (r < 8): rows of K 16-bit elements
+__global__ void __launch_bounds__(256) interleave_gate_up_kernel(const uint16_t* __restrict__ gu, uint16_t* __restrict__ out,
+                                                                 int inter, int K) {
+  const int orow = blockIdx.x;                               // 0 .. 2 inter
+  const int p = orow >> 4, r = orow & 15;
+  const int srow = r < 8 ? 8 * p + r : inter + 8 * p + (r - 8);
+  const uint4* s = reinterpret_cast<const uint4*>(gu + (int64_t)srow * K);
+  uint4* d = reinterpret_cast<uint4*>(out + (int64_t)orow * K);
+  for (int c = threadIdx.x; c < K / 8; c += 256) d[c] = s[c];
+}
+
+extern "C" int psg_interleave_gate_up(psg_ctx* ctx, const void* gate_up, void* out, int inter, int K, void* stream) {
+  PSG_REQUIRE(ctx && gate_up && out, PSG_ERR_INVALID, "psg_interleave_gate_up: NULL argument");
+  PSG_REQUIRE(inter > 0 && inter % 8 == 0 && K > 0 && K % 8 == 0, PSG_ERR_UNSUPPORTED,
+              "psg_interleave_gate_up: inter=%d and K=%d must be multiples of 8", inter, K);
+  interleave_gate_up_kernel<<<2 * inter, 256, 0, (hipStream_t)stream>>>((const uint16_t*)gate_up, (uint16_t*)out, inter, K);
+  PSG_CHECK_LAUNCH("psg_interleave_gate_up");
   return PSG_OK;
 }

@@ -573,19 +573,38 @@ def cross_entropy_rows(logits, labels):
     return loss
 
 
-def dense_gemm(x, w, bias=None, gelu=False, out=None, out_dtype=None, row_scale=None, col_scale=None):
+TILES = {"auto": 0, "256x256": 1, "256x192": 2, "256x128": 3, "256x64": 4, "128x128": 5}      # enum psg_tile
+
+
+def dense_gemm(x, w, bias=None, gelu=False, out=None, out_dtype=None, row_scale=None, col_scale=None, tile="256x256",
+               swiglu=False):
     """out = [gelu](x @ w.T [* row_scale[:, None] * col_scale[None, :]] + bias) in one pass (bf16 / fp16 operands;
-    N % 256 == 0, K % 64 == 0).  out_dtype=torch.float32: fp32 result (needed for the scales: the split-fp16 products of
-    the fp32s mode).  Row-count invariant: a row's result does not depend on how many other rows the call has."""
+    N % 16 == 0, K % 64 == 0).  out_dtype=torch.float32: fp32 result (needed for the scales: the split-fp16 products of
+    the fp32s mode).  Row-count invariant: a row's result does not depend on how many other rows the call has, nor on
+    the tile ("auto": the geometry that fills the CUs in the fewest rounds for [M, N]).
+    swiglu=True: w is a gate / up weight interleaved by `interleave_gate_up`; out [M, N / 2] = silu(gate) * up."""
     lib, ctx, st = _env(x)
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and w.dtype == x.dtype
     odt = x.dtype if out_dtype is None else out_dtype
-    out = torch.empty((M, N), device=x.device, dtype=odt) if out is None else out
-    check(lib.psg_dense_gemm_ex(ctx, _p(x, name="x"), _p(w, name="w"), _p(bias, torch.float32, "bias"), 1 if gelu else 0,
-                                _p(out, odt), M, N, K, _dt(x), _DT[odt], _p(row_scale, torch.float32, "row_scale"),
-                                _p(col_scale, torch.float32, "col_scale"), st), "psg_dense_gemm")
+    out = torch.empty((M, N // 2 if swiglu else N), device=x.device, dtype=odt) if out is None else out
+    assert out.shape == (M, N // 2 if swiglu else N)
+    assert not (swiglu and gelu)
+    check(lib.psg_dense_gemm_tiled(ctx, _p(x, name="x"), _p(w, name="w"), _p(bias, torch.float32, "bias"),
+                                   2 if swiglu else 1 if gelu else 0, _p(out, odt), M, N, K, _dt(x), _DT[odt],
+                                   _p(row_scale, torch.float32, "row_scale"), _p(col_scale, torch.float32, "col_scale"),
+                                   TILES[tile], st), "psg_dense_gemm")
+    return out
+
+
+def interleave_gate_up(w_gate_up):
+    """[2 inter, K] (gate rows, then up rows) -> the row order the SwiGLU epilogue of `dense_gemm` reads: groups of 16
+    rows = 8 gate rows, then the 8 up rows of the same columns."""
+    lib, ctx, st = _env(w_gate_up)
+    n2, K = w_gate_up.shape
+    out = torch.empty_like(w_gate_up)
+    check(lib.psg_interleave_gate_up(ctx, _p(w_gate_up, name="gate_up"), _p(out), n2 // 2, K, st), "psg_interleave_gate_up")
     return out
 
 

@@ -54,6 +54,18 @@ for kmul in (1, 3):
                     torch.backends.cuda.preferred_blas_library("cublaslt")
             elif v == "own":
                 us = bench(lambda i: ops.dense_gemm(x, ws[i % 3], out=out))
+            elif v.startswith("own:"):                               # own:<tile>, e.g. own:256x192, own:auto
+                us = bench(lambda i: ops.dense_gemm(x, ws[i % 3], out=out, tile=v[4:]))
+            elif v.startswith("swiglu:"):                            # gate_up with the SwiGLU epilogue (no interleave needed to time it)
+                if name != "gate_up":
+                    continue
+                o2 = torch.empty(M, N // 2, device=dev, dtype=torch.float16)
+                us = bench(lambda i: ops.dense_gemm(x, ws[i % 3], out=o2, tile=v[7:], swiglu=True))
+            elif v == "lib+silu":
+                if name != "gate_up":
+                    continue
+                o2 = torch.empty(M, N // 2, device=dev, dtype=torch.float16)
+                us = bench(lambda i: ops.silu_mul(torch.nn.functional.linear(x, ws[i % 3]), o2))
             elif v == "sk":
                 us = bench(lambda i: ops.streamk_gemm(x, ws[i % 3]))
             elif v == "sk32":
