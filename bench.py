@@ -513,7 +513,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL initialises lazily (no device_id): an eager communicator creates its HSA queues before the head's streams
+        # and the two decode streams of a rank then interfere (140 instead of 117 ms per two images, measured at world 1)
+        dist.init_process_group("nccl")
         world = dist.get_world_size()                                  # the ranks RCCL actually sees
         if world != a.gpus and rank == 0:
             print(f"bench.py: --gpus {a.gpus} but the job has {world} rank(s); reporting n_gpus = {world}",
@@ -526,6 +528,7 @@ def main():
     pairs_per_image = N * (N - 1)
 
     drain = lambda: None  # noqa: E731  (the pipelined step below replaces it)
+    per_rank, step_forms = 1, None
     if world == 1 and not force_dist:
         scene = make_scene((a.size, a.size), N, seed=0, device=str(dev), num_categories=a.categories)
         inputs = scene_inputs(scene)
@@ -552,6 +555,31 @@ def main():
             def drain():
                 while pending:
                     pending.popleft().result()
+
+            # images in flight only pay when the slots' streams sit on hardware queues that overlap (e.g.
+            # not with GPU_MAX_HW_QUEUES=2): time both step forms before the warm-up and keep the faster one
+            def timed(fn, n, after=lambda: None):
+                fn()
+                after()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                after()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n
+            for _ in range(2):
+                step()
+            drain()
+            t_pipe, t_one = timed(step, 4, drain), timed(lambda: head(inputs), 2)
+            step_forms = {"in_flight_tried": a.in_flight, "ms_per_image_in_flight": round(t_pipe * 1e3, 2),
+                          "ms_per_image_one_at_a_time": round(t_one * 1e3, 2), "in_flight_used": a.in_flight}
+            if t_pipe > 0.97 * t_one:
+                a.serial, step_forms["in_flight_used"] = True, 1
+                drain = lambda: None  # noqa: E731
+
+                def step():
+                    return head(inputs)
         elif a.workload == "full":
             def step():
                 return head(inputs)
@@ -569,12 +597,37 @@ def main():
     else:
         import torch.distributed as dist
         from openpsg_amd.dist import PairShardedPipeline
-        scenes = [make_scene((a.size, a.size), N, seed=m, device=str(dev)) for m in range(world)]
+        # a step is `per_rank` images per rank (2 by default, as on one GPU: a rank's two decodes run side by side on the
+        # head's slot streams, dist.step_gen); every image's pairs are sharded over all ranks
+        per_rank = 1 if (a.serial or a.workload != "full") else max(1, a.in_flight)
+        scenes = [make_scene((a.size, a.size), N, seed=m, device=str(dev)) for m in range(world * per_rank)]
         pipe = PairShardedPipeline(head, dist.group.WORLD, decode=a.workload == "full")
+        barrier = lambda: dist.barrier(device_ids=[local])  # noqa: E731
+        if per_rank > 1:
+            # Two decodes side by side on one GPU only pay when their streams land on hardware queues that overlap (a
+            # property of the process's queue creation order): time both step forms before the warm-up and
+            # keep the faster one - the same choice on every rank.
+            def timed(sc, n):
+                pipe.step(sc)
+                torch.cuda.synchronize()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    pipe.step(sc)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n
+            t_multi = timed(scenes, 2) / per_rank
+            t_one = timed(scenes[:world], 2)
+            worse = torch.tensor([1.0 if t_multi > 0.97 * t_one else 0.0], device=dev)
+            dist.all_reduce(worse, op=dist.ReduceOp.MAX)
+            step_forms = {"images_per_rank_tried": per_rank, "ms_per_image_side_by_side": round(t_multi * 1e3, 2),
+                          "ms_per_image_one_at_a_time": round(t_one * 1e3, 2)}
+            if worse.item() > 0:
+                per_rank, scenes = 1, scenes[:world]
+            step_forms["images_per_rank_used"] = per_rank
 
         def step():
             return pipe.step(scenes)
-        barrier = dist.barrier
 
     for _ in range(a.warmup):
         step()
@@ -611,12 +664,12 @@ def main():
         for _ in range(2):
             pipe1.step_one_image(scene4)
         torch.cuda.synchronize()
-        dist.barrier()
+        barrier()
         t1 = time.perf_counter()
         for _ in range(ks):
             pipe1.step_one_image(scene4)
         torch.cuda.synchronize()
-        dist.barrier()
+        barrier()
         t = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el1 = float(t.item()) / ks
@@ -626,7 +679,7 @@ def main():
         ref1 = time_steps(lambda: head(inputs4) if a.workload == "full" else head.run_relation_query(
             scene4["mask_features"], scene4["img_meta"], [int(i) for i in scene4["object_id_list"]],
             pipe1.be._names(scene4), scene4["pan_results"]), 1, 3) / 3
-        dist.barrier()
+        barrier()
         strong = {"workload": f"ONE {a.size}x{a.size} image, {n4} masks ({n4 * (n4 - 1)} pairs), pairs sharded over "
                               f"{world} rank(s), top-20 decodes dealt round-robin",
                   "ms_per_image": round(el1 * 1e3, 3), "value": round(n4 * (n4 - 1) / el1, 1), "unit": "pairs/s",
@@ -637,7 +690,7 @@ def main():
                            "relation query and the compute-bound prompt pass shrink with N"}
 
     if rank == 0:
-        ips = a.images_per_step if (world == 1 and not force_dist and a.workload == "full") else world
+        ips = a.images_per_step if (world == 1 and not force_dist and a.workload == "full") else world * per_rank
         images = ips * a.steps
         wl = ("C3: 1024x1024, 50 masks, full path incl. LMM autoregressive relation decode (Llama-2-7B shape, top-20 "
               "pairs, 16 new tokens each, EOS suppressed)") if a.workload == "full" else \
@@ -659,7 +712,11 @@ def main():
                                        "caches), so one image's latency-bound row kernels run under the other's weight "
                                        "streaming; every image processed in full inside the timed region, results "
                                        "identical to one image at a time") if pipelined else
-                                      ("single GPU" if world == 1 else f"pairs of every image sharded over {world} ranks")},
+                                      ("single GPU" if world == 1 and not force_dist else
+                                       f"{ips} images per step, pairs of every image sharded over {world} rank(s) (all-gather of "
+                                       f"patches / probabilities / token ids, reduce-scatter of the selected pair features); "
+                                       f"rank r decodes images r, r + {world}, ... of the step"
+                                       + (" side by side on two HIP streams" if per_rank > 1 else ""))},
         }
         if pipelined:
             line["one_image_at_a_time"] = {"ms_per_image": round(serial_ms, 3),
@@ -772,6 +829,8 @@ def main():
                 line["batched_decode"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         if strong is not None:
             line["strong_scaling"] = strong
+        if step_forms is not None:
+            line["step_forms"] = step_forms
         oracle_part = None
         if not a.no_cpu_baseline and world == 1 and not force_dist:
             scene_cpu = make_scene((a.size, a.size), N, seed=0)

@@ -160,6 +160,12 @@ class HipBackend:
                                         to_host=False)
         return out["tokens"]
 
+    def decode_multi(self, scenes, selected_list, features_list):
+        """The decodes of several images of this rank, side by side on the head's slot streams."""
+        items = [dict(rq=dict(num_objects=self.num_objects(s)), names=self._names(s), selected=sel, pair_features=f)
+                 for s, sel, f in zip(scenes, selected_list, features_list)]
+        return [o["tokens"] for o in self.head.decode_concurrent(items)]
+
 
 def deal_indices(k: int, world: int, rank: int):
     """Positions (into the selection) of the pairs rank `rank` decodes: round-robin."""
@@ -298,7 +304,8 @@ class PairShardedPipeline:
         return self._drive(self.step_one_image_gen(scene, deal_decodes))
 
     def step(self, scenes):
-        """scenes[m] = inputs of image m, resident on every rank (object counts and image sizes may differ).
+        """scenes[m] = inputs of image m, resident on every rank (object counts and image sizes may differ); P * world
+        of them, image m owned by rank m % world.
         Returns dict with per-image lists: existence probabilities, selections and (if decoding) token ids."""
         return self._drive(self.step_gen(scenes))
 
@@ -386,37 +393,46 @@ class PairShardedPipeline:
         return out
 
     def step_gen(self, scenes):
+        """P * R images per step, image m owned (patch-embedded and decoded) by rank m % R; P = 1 is SURVEY 8e's job of R
+        images for R ranks.  With P > 1 a rank's P decodes run side by side on the head's slot streams
+        (`decode_concurrent`: one image's row kernels under the other's weight streaming, as `head.submit` does on one
+        GPU) - the collectives stay four per step, on the caller's stream."""
         be, R, r = self.be, self.world, self.rank
-        assert len(scenes) == R, "one image per rank per step"
+        assert len(scenes) and len(scenes) % R == 0, "a step is P images per rank: P * world scenes"
+        n_img, P = len(scenes), len(scenes) // R
         Ns = [be.num_objects(s) for s in scenes]
         Bs = [n * n for n in Ns]
-        # 1. patches of my image -> everyone (images of different sizes: padded to the longest patch list)
-        mine_p = be.patch_embed(scenes[r])
+        # 1. patches of my images -> everyone (images of different sizes: padded to the longest patch list)
         ps = self._patch_size()
         Ls = [(s["mask_features"].shape[-2] // ps) * (s["mask_features"].shape[-1] // ps) for s in scenes]
-        assert mine_p.shape[0] == Ls[r]
         Lmax = max(Ls)
-        if mine_p.shape[0] < Lmax:
-            mine_p = torch.cat([mine_p, mine_p.new_zeros((Lmax - mine_p.shape[0], mine_p.shape[1]))])
-        allp = yield ("all_gather", mine_p)                                         # [R, Lmax, C]
-        patches = [allp[m, :Ls[m]].contiguous() for m in range(R)]
+        mine = []
+        for q in range(P):
+            mp = be.patch_embed(scenes[q * R + r])
+            assert mp.shape[0] == Ls[q * R + r]
+            if mp.shape[0] < Lmax:
+                mp = torch.cat([mp, mp.new_zeros((Lmax - mp.shape[0], mp.shape[1]))])
+            mine.append(mp)
+        allp = yield ("all_gather", torch.stack(mine))                              # [R, P, Lmax, C]
+        patches = [allp[m % R, m // R, :Ls[m]].contiguous() for m in range(n_img)]
         dev = allp.device
         # 2. my pair shard of every image (the shard length depends on the image's object count)
-        ranges = [shard_range(Bs[m], R, r) for m in range(R)]
+        ranges = [shard_range(Bs[m], R, r) for m in range(n_img)]
         smax = max(1, max(rg[2] for rg in ranges))
-        prob_pad = torch.full((R, smax), -1.0, device=dev, dtype=torch.float32)
+        prob_pad = torch.full((n_img, smax), -1.0, device=dev, dtype=torch.float32)
         hidden = []
         if hasattr(be, "query_shards"):
             shards = be.query_shards(scenes, patches, [(rg[0], rg[1]) for rg in ranges])
         else:
-            shards = [be.query_shard(scenes[m], patches[m], ranges[m][0], ranges[m][1]) for m in range(R)]
+            shards = [be.query_shard(scenes[m], patches[m], ranges[m][0], ranges[m][1]) for m in range(n_img)]
         for m, (h, prob) in enumerate(shards):
             hidden.append(h)
             prob_pad[m, :ranges[m][1] - ranges[m][0]] = prob
         gathered = yield ("all_gather", prob_pad)                                   # [rank, image, smax]
-        probs = [gathered[:, m, :ranges[m][2]].reshape(-1)[:Bs[m]].contiguous() for m in range(R)]
+        probs = [gathered[:, m, :ranges[m][2]].reshape(-1)[:Bs[m]].contiguous() for m in range(n_img)]
         # 3. identical deterministic selection everywhere (K_m may be data dependent: threshold selector, tiny images)
-        sel = [be.select(probs[m], Ns[m]) if Bs[m] else torch.zeros(0, dtype=torch.int32, device=dev) for m in range(R)]
+        sel = [be.select(probs[m], Ns[m]) if Bs[m] else torch.zeros(0, dtype=torch.int32, device=dev)
+               for m in range(n_img)]
         Ks = [int(s.numel()) for s in sel]
         out = dict(exist_prob=probs, selected=sel)
         if not self.decode:
@@ -426,27 +442,33 @@ class PairShardedPipeline:
         Kmax = max(1, max(Ks))
         ar = torch.arange(nv, device=dev, dtype=torch.int64)
         rows_list = []
-        for m in range(R):
+        for m in range(n_img):
             s = sel[m].to(torch.int64)
             p0, p1 = ranges[m][0], ranges[m][1]
-            mine = (s >= p0) & (s < p1)
+            own = (s >= p0) & (s < p1)
             rows = (s - p0)[:, None] * be.q_rows + 1 + ar[None, :]               # pair_feature = hidden[:, 1:]
-            rows_list.append(torch.where(mine[:, None], rows, torch.full_like(rows, -1)).reshape(-1).to(torch.int32))
-        live = [m for m in range(R) if Ks[m]]
+            rows_list.append(torch.where(own[:, None], rows, torch.full_like(rows, -1)).reshape(-1).to(torch.int32))
+        live = [m for m in range(n_img) if Ks[m]]
         if hasattr(be, "gather_features_multi"):
             got = be.gather_features_multi([hidden[m] for m in live], [rows_list[m] for m in live])
         else:
             got = [be.gather_features(hidden[m], rows_list[m]) for m in live]
-        send = torch.zeros((R, Kmax * nv, be.hidden), device=dev, dtype=got[0].dtype if got else torch.float32)
+        send = torch.zeros((R, P, Kmax * nv, be.hidden), device=dev, dtype=got[0].dtype if got else torch.float32)
         for m, f in zip(live, got):
-            send[m, :Ks[m] * nv] = f
-        recv = yield ("reduce_scatter", send)                                      # [Kmax*nv, hidden] of MY image
-        # 5. decode my image; 6. token ids to everyone
-        tok_pad = torch.full((Kmax, be.max_new), -1, device=dev, dtype=torch.int32)
-        if Ks[r]:
-            tok_pad[:Ks[r]] = be.decode(scenes[r], sel[r], recv[:Ks[r] * nv].contiguous())
-        allt = yield ("all_gather", tok_pad)                                        # [R, Kmax, max_new]
-        out["tokens"] = [allt[m, :Ks[m]].contiguous() for m in range(R)]
+            send[m % R, m // R, :Ks[m] * nv] = f
+        recv = yield ("reduce_scatter", send)                                      # [P, Kmax*nv, hidden] of MY images
+        # 5. decode my images (side by side when there are several); 6. token ids to everyone
+        tok_pad = torch.full((P, Kmax, be.max_new), -1, device=dev, dtype=torch.int32)
+        todo = [q for q in range(P) if Ks[q * R + r]]
+        if len(todo) > 1 and hasattr(be, "decode_multi"):
+            toks = be.decode_multi([scenes[q * R + r] for q in todo], [sel[q * R + r] for q in todo],
+                                   [recv[q, :Ks[q * R + r] * nv].contiguous() for q in todo])
+        else:
+            toks = [be.decode(scenes[q * R + r], sel[q * R + r], recv[q, :Ks[q * R + r] * nv].contiguous()) for q in todo]
+        for q, t in zip(todo, toks):
+            tok_pad[q, :Ks[q * R + r]] = t
+        allt = yield ("all_gather", tok_pad)                                        # [R, P, Kmax, max_new]
+        out["tokens"] = [allt[m % R, m // R, :Ks[m]].contiguous() for m in range(n_img)]
         return out
 
     def _patch_size(self):

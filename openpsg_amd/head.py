@@ -274,7 +274,17 @@ class RelationTransformerHeadV4(nn.Module):
         self.llm_tokenizer.pad_token = self.llm_tokenizer.unk_token        # V4:105
         self.last = {}
         self._gather_cache = {}
+        # The first two slot streams are created AND used here, one right after the other: HIP binds a stream to one of
+        # its GPU_MAX_HW_QUEUES (4) hardware queues at the stream's first launch, round-robin, and two slots that land on
+        # the same queue run one after the other.  Measured with the slots first used around the decode graphs' capture
+        # streams: 140 instead of 117 ms for two decodes side by side whenever the number of streams first used in
+        # between was a multiple of the queue count (RCCL initialised eagerly; GPU_MAX_HW_QUEUES = 3, 4, 6, 8).
         self._slot_streams = {}
+        if torch.cuda.is_available() and self.device.type == "cuda":
+            for slot in (0, 1):
+                st = self._slot_streams[slot] = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)
         self._decode_done = None
         self._front_done = None
         # submit(): image k+1's decode steps wait for image k's (its relation query and prompt pass do not).  Measured A/B
@@ -482,9 +492,7 @@ class RelationTransformerHeadV4(nn.Module):
         static buffers; `forward` has its own) and must not be re-submitted before its pending result was taken."""
         if self.training:
             raise PsgHipError("submit: inference only")
-        st = self._slot_streams.get(slot)
-        if st is None:
-            st = self._slot_streams[slot] = torch.cuda.Stream(device=self.device)
+        st = self._slot_stream(slot)
         st.wait_stream(torch.cuda.current_stream(self.device))          # the inputs were produced on the caller's stream
         with torch.cuda.stream(st):
             feat, meta, info, obj_ids, names = self._unpack(inputs)
@@ -497,27 +505,67 @@ class RelationTransformerHeadV4(nn.Module):
             # workspace (stream-K / split-K, picked at 40-80 rows) were seen to dead-lock the GPU that way
             # (tools/inflight_stress.py batch).  What overlaps is image k's decode steps - own kernels only - with
             # image k+1's front half and decode.
-            if self._front_done is not None:
-                st.wait_event(self._front_done)
-            if self._decode_done is not None and (self.cfg.num_selected > 32 or (
-                    self.pair_selector == "threshold" and self.max_selected > 32) or not self.llm_engine.use_skinny):
-                st.wait_event(self._decode_done)              # > 32 decode rows = library GEMMs in the decode: no overlap at all
+            self._wait_front(st)
             rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
-            prev, front_done, gated = self._decode_done, torch.cuda.Event(), [False]
-
-            def gate():                                         # between the prompt pass and the decode steps
-                front_done.record(st)
-                gated[0] = True
-                if prev is not None and self.serialize_decodes:     # A/B switch: decode steps of two images never overlap
-                    st.wait_event(prev)
-            # graph slot 0 belongs to `forward` (the caller's stream): a pending submit never shares its KV caches
-            out = self.decode_selected(rq, names, to_host=False, slot=slot + 1, gate=gate)
-            if not gated[0]:                                    # eager run, or every pair ended inside the first graph
-                front_done.record(st)
-            self._front_done = front_done
-            self._decode_done = torch.cuda.Event()
-            self._decode_done.record(st)
+            out = self._enqueue_decode(st, rq, names, slot)
         return _Pending(self, st, rq, out, N)
+
+    def _slot_stream(self, slot):
+        st = self._slot_streams.get(slot)
+        if st is None:
+            st = self._slot_streams[slot] = torch.cuda.Stream(device=self.device)
+        return st
+
+    def _wait_front(self, st):
+        """Orders the library-GEMM phases of consecutive images (see `submit`); with more than 32 decode rows the decode
+        steps hold library GEMMs too and nothing may overlap."""
+        if self._front_done is not None:
+            st.wait_event(self._front_done)
+        if self._decode_done is not None and (self.cfg.num_selected > 32 or (
+                self.pair_selector == "threshold" and self.max_selected > 32) or not self.llm_engine.use_skinny):
+            st.wait_event(self._decode_done)
+
+    def _enqueue_decode(self, st, rq, names, slot, selected=None, pair_features=None):
+        """The decode of one image on slot stream `st` (the caller is inside `torch.cuda.stream(st)` and has called
+        `_wait_front`): prompt pass, event, decode steps; no host wait."""
+        prev, front_done, gated = self._decode_done, torch.cuda.Event(), [False]
+
+        def gate():                                             # between the prompt pass and the decode steps
+            front_done.record(st)
+            gated[0] = True
+            if prev is not None and self.serialize_decodes:         # A/B switch: decode steps of two images never overlap
+                st.wait_event(prev)
+        # graph slot 0 belongs to `forward` (the caller's stream): a pending submit never shares its KV caches
+        out = self.decode_selected(rq, names, selected=selected, pair_features=pair_features, to_host=False,
+                                   slot=slot + 1, gate=gate)
+        if not gated[0]:                                        # eager run, or every pair ended inside the first graph
+            front_done.record(st)
+        self._front_done = front_done
+        self._decode_done = torch.cuda.Event()
+        self._decode_done.record(st)
+        return out
+
+    def decode_concurrent(self, items):
+        """The decodes of several images side by side: items[p] = dict(rq, names, selected, pair_features) runs on slot
+        stream p like a `submit` (its prompt pass ordered behind the previous item's, its decode steps beside the
+        others'), and the caller's stream waits for all of them.  Returns the `decode_selected` dicts (device tensors).
+        Used by the pair-sharded pipeline when a rank owns more than one image of a step (dist.step_gen)."""
+        cur = torch.cuda.current_stream(self.device)
+        outs = []
+        for p, it in enumerate(items):
+            st = self._slot_stream(p)
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self._wait_front(st)
+                out = self._enqueue_decode(st, it["rq"], it["names"], p, selected=it.get("selected"),
+                                           pair_features=it.get("pair_features"))
+            for t in out.values():
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)                        # allocated on the slot stream, consumed on the caller's
+            outs.append(out)
+        for p in range(len(items)):
+            cur.wait_stream(self._slot_stream(p))
+        return outs
 
     # ---- training branch: forward arithmetic of the losses (SURVEY 8f rank 3) -------------------------------------
     def qformer_sampler(self, relation_target):

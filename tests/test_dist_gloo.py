@@ -124,15 +124,17 @@ def _worker(rank, world, port, n_obj, ret, threshold=None):
     cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 1, 512, 512))
     w = make_weights_numpy(cfg, seed=3, with_llm=False)
     # n_obj: one count for every image, or one count per image (different object counts AND image sizes in one step)
+    # (more counts than ranks: several images per rank and step, image m owned by rank m % world)
     counts = [n_obj] * world if isinstance(n_obj, int) else list(n_obj)
-    sizes = [(256, 256)] * world if isinstance(n_obj, int) else [(256, 256), (256, 384)][:world]
-    scenes = [make_scene(sizes[m], counts[m], seed=40 + m, tiny_object=True) for m in range(world)]
+    n_img = len(counts)
+    sizes = [(256, 256)] * n_img if isinstance(n_obj, int) else [[(256, 256), (256, 384)][m % 2] for m in range(n_img)]
+    scenes = [make_scene(sizes[m], counts[m], seed=40 + m, tiny_object=True) for m in range(n_img)]
     be = OracleBackend(cfg, w, threshold=threshold)
     with torch.no_grad():
         out = PairShardedPipeline(be, dist.group.WORLD, decode=True).step(scenes)
         # single-process reference: the whole pair range of every image on one rank
         ok = True
-        for m in range(world):
+        for m in range(n_img):
             B = counts[m] * counts[m]
             be1 = OracleBackend(cfg, w, threshold=threshold)
             h, prob = be1.query_shard(scenes[m], be1.patch_embed(scenes[m]), 0, B)
@@ -142,11 +144,11 @@ def _worker(rank, world, port, n_obj, ret, threshold=None):
             ok &= out["selected"][m].tolist() == sel
             want_tok = be1.decode(scenes[m], torch.tensor(sel), h[:1])
             ok &= torch.equal(out["tokens"][m], want_tok)
-            if m == rank:
+            if m % world == rank and m + world >= n_img:          # the last image this rank decoded
                 # features routed through the reduce-scatter == rows of the single-rank hidden state
                 rows = (torch.tensor(sel)[:, None] * 33 + 1 + torch.arange(32)[None, :]).reshape(-1)
                 ok &= torch.allclose(be.received, h[rows], atol=1e-4)
-        want_calls = [shard_range(counts[m] ** 2, world, rank)[:2] for m in range(world)]
+        want_calls = [shard_range(counts[m] ** 2, world, rank)[:2] for m in range(n_img)]
         ok &= be.calls == want_calls
     ret[rank] = bool(ok)
     dist.destroy_process_group()
@@ -159,6 +161,17 @@ def test_pair_sharding_world2_gloo(n_obj):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, n_obj, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_pair_sharding_two_images_per_rank_world2_gloo():
+    """A step of P * world images (P = 2: bench.py's multi-GPU step, each rank decoding its two images side by side):
+    image m is embedded and decoded by rank m % world; patches, features and token ids travel as [P, ...] blocks."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, (4, 3, 2, 4), ret, 0.5), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
 
 

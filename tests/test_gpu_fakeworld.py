@@ -120,16 +120,20 @@ def test_one_c4_image_sharded_mixed_mode_is_within_rounding(c4):
         assert torch.equal(outs[r]["selected"], outs[0]["selected"]) and torch.equal(outs[r]["tokens"], outs[0]["tokens"])
 
 
-@pytest.mark.parametrize("world,selector", [(4, "topk"), (4, "threshold"), (2, "topk"), (8, "topk")])
-def test_step_with_unequal_images_over_fake_ranks(world, selector):
-    """`step`: R images per step, every image's pairs sharded over all R ranks.  The images differ in object count
-    (different shard lengths, different K under the threshold selector) and in size (different patch counts)."""
+@pytest.mark.parametrize("world,selector,per_rank", [(4, "topk", 1), (4, "threshold", 1), (2, "topk", 1), (8, "topk", 1),
+                                                     (2, "topk", 2), (4, "threshold", 2), (2, "topk", 3)])
+def test_step_with_unequal_images_over_fake_ranks(world, selector, per_rank):
+    """`step`: P * R images per step, every image's pairs sharded over all R ranks, image m decoded by rank m % R (with
+    P > 1 a rank's decodes run side by side on the head's slot streams: bench.py's multi-GPU step).  The images differ
+    in object count (different shard lengths, different K under the threshold selector) and in size (different patch
+    counts)."""
     from openpsg_amd.dist import HipBackend, LoopbackWorld
     from openpsg_amd.synthetic import make_scene
     kw = dict(pair_selector="threshold", exclude_diagonal=True, max_selected=24) if selector == "threshold" else {}
     head = _mk_head("fp32", 50, **kw)
     geo = ([((1024, 1024), 50), ((768, 1024), 23), ((512, 512), 9), ((1024, 1344), 31)] +
-           [((1024, 1024), 50)] * 4)[:world]                       # world 8: bench.py's weak-scaling step (N = 50 images) too
+           [((1024, 1024), 50)] * 4)[:world * per_rank]            # 8 images: bench.py's weak-scaling step (N = 50 images) too
+    geo = (geo * per_rank)[:world * per_rank]
     scenes = [make_scene(hw, n, seed=60 + m, device="cuda:0", tiny_object=True) for m, (hw, n) in enumerate(geo)]
     if selector == "threshold":
         # a threshold in the middle of each image's scores gives a data-dependent K; use one between the 7th and 8th
@@ -147,7 +151,7 @@ def test_step_with_unequal_images_over_fake_ranks(world, selector):
     outs = fw.run([p.step_gen(scenes) for p in fw.pipelines(HipBackend(head))])
     torch.cuda.synchronize()
     ks = []
-    for m in range(world):
+    for m in range(world * per_rank):
         d = (outs[0]["exist_prob"][m] - refs[m]["prob"]).abs().max().item()
         assert d < 2e-5, (m, d)
         ks.append(refs[m]["sel"].numel())
@@ -156,7 +160,7 @@ def test_step_with_unequal_images_over_fake_ranks(world, selector):
             assert _same_selection(outs[r]["selected"][m], refs[m]["sel"], refs[m]["prob"]), (r, m)
             same = (outs[r]["selected"][m] == refs[m]["sel"]).cpu().numpy()
             assert np.array_equal(outs[r]["tokens"][m].cpu().numpy()[same], refs[m]["tokens"][same]), (r, m)
-    print(f"world {world}, {selector}: K per image {ks}")
+    print(f"world {world} x {per_rank} images per rank, {selector}: K per image {ks}")
     if selector == "threshold":
         assert len(set(ks)) > 1, "the threshold case should exercise different K per image"
 
