@@ -571,7 +571,7 @@ def main():
             for _ in range(2):
                 step()
             drain()
-            t_pipe, t_one = timed(step, 4, drain), timed(lambda: head(inputs), 2)
+            t_pipe, t_one = timed(step, 8, drain), timed(lambda: head(inputs), 3)
             step_forms = {"in_flight_tried": a.in_flight, "ms_per_image_in_flight": round(t_pipe * 1e3, 2),
                           "ms_per_image_one_at_a_time": round(t_one * 1e3, 2), "in_flight_used": a.in_flight}
             if t_pipe > 0.97 * t_one:

@@ -274,17 +274,14 @@ class RelationTransformerHeadV4(nn.Module):
         self.llm_tokenizer.pad_token = self.llm_tokenizer.unk_token        # V4:105
         self.last = {}
         self._gather_cache = {}
-        # The first two slot streams are created AND used here, one right after the other: HIP binds a stream to one of
-        # its GPU_MAX_HW_QUEUES (4) hardware queues at the stream's first launch, round-robin, and two slots that land on
-        # the same queue run one after the other.  Measured with the slots first used around the decode graphs' capture
-        # streams: 140 instead of 117 ms for two decodes side by side whenever the number of streams first used in
-        # between was a multiple of the queue count (RCCL initialised eagerly; GPU_MAX_HW_QUEUES = 3, 4, 6, 8).
+        # Two slots whose streams share a hardware queue run one after the other (67.8 instead of 57 ms per image), and
+        # which of its GPU_MAX_HW_QUEUES queues HIP binds a stream to depends on the order in which every stream of the
+        # process is first used.  Streams of different PRIORITY never share a queue (HIP keeps one queue pool per
+        # priority), so odd slots are high-priority streams; the first two are created and first used here.
         self._slot_streams = {}
         if torch.cuda.is_available() and self.device.type == "cuda":
             for slot in (0, 1):
-                st = self._slot_streams[slot] = torch.cuda.Stream(device=self.device)
-                with torch.cuda.stream(st):
-                    torch.zeros(1, device=self.device)
+                self._slot_stream(slot)
         self._decode_done = None
         self._front_done = None
         # submit(): image k+1's decode steps wait for image k's (its relation query and prompt pass do not).  Measured A/B
@@ -513,7 +510,9 @@ class RelationTransformerHeadV4(nn.Module):
     def _slot_stream(self, slot):
         st = self._slot_streams.get(slot)
         if st is None:
-            st = self._slot_streams[slot] = torch.cuda.Stream(device=self.device)
+            st = self._slot_streams[slot] = torch.cuda.Stream(device=self.device, priority=-(slot & 1))
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=self.device)             # first use: binds the stream to its hardware queue now
         return st
 
     def _wait_front(self, st):
