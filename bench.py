@@ -63,6 +63,8 @@ def parse():
                     help="single-GPU throughput mode: images per step whose selected pairs are decoded together")
     ap.add_argument("--no-batched", action="store_true", help="skip the secondary 4-images-per-step measurement")
     ap.add_argument("--in-flight", type=int, default=2, help="images in flight of the pipelined step (head.submit slots)")
+    ap.add_argument("--slot-priorities", default="0,-1",
+                    help="HIP stream priorities of the in-flight slots (A/B: 0,0 = both slots in the normal queue pool)")
     ap.add_argument("--serialize-decodes", action="store_true",
                     help="pipelined step A/B: image k+1's decode steps wait for image k's (measured: no gain over --serial)")
     ap.add_argument("--serial", action="store_true",
@@ -115,7 +117,8 @@ def setup_head(a, dev):
     w = make_weights_device(cfg, 0, dev, llm_dtype=tdt, with_llm=a.workload == "full")
     head = RelationTransformerHeadV4(dtype=dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
                                      llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True,
-                                     cls_first=not a.one_phase)
+                                     cls_first=not a.one_phase,
+                                     slot_priorities=tuple(int(p) for p in getattr(a, "slot_priorities", "0,-1").split(",")))
     head.load_weights(w)
     if getattr(a, "pair_chunk", 0) > 0:
         head.pair_chunk = a.pair_chunk

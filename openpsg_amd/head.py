@@ -179,6 +179,8 @@ class RelationTransformerHeadV4(nn.Module):
                                                # of the selected pairs only (same results; qformer.forward_pairs_cls)
                  train_dropout=True,           # the gradient path applies the Q-Former dropouts the reference trains with
                                                # (HF defaults 0.1 / 0.1, V4:78-84); False = deterministic (oracle checks)
+                 slot_priorities=(0, -1),      # HIP stream priority of submit() slot k = slot_priorities[k % len]: streams
+                                               # of different priority never share a hardware queue (see _slot_stream)
                  train_losses_without_grad=False,   # forward() in training mode returns the two losses WITHOUT a graph
                                                # (forward_train); off: it raises, so that an mmdet-style loop cannot sum
                                                # them and silently train nothing in this head
@@ -279,6 +281,7 @@ class RelationTransformerHeadV4(nn.Module):
         # process is first used.  Streams of different PRIORITY never share a queue (HIP keeps one queue pool per
         # priority), so odd slots are high-priority streams; the first two are created and first used here.
         self._slot_streams = {}
+        self.slot_priorities = tuple(int(p) for p in slot_priorities)
         if torch.cuda.is_available() and self.device.type == "cuda":
             for slot in (0, 1):
                 self._slot_stream(slot)
@@ -510,7 +513,8 @@ class RelationTransformerHeadV4(nn.Module):
     def _slot_stream(self, slot):
         st = self._slot_streams.get(slot)
         if st is None:
-            st = self._slot_streams[slot] = torch.cuda.Stream(device=self.device, priority=-(slot & 1))
+            st = self._slot_streams[slot] = torch.cuda.Stream(
+                device=self.device, priority=self.slot_priorities[slot % len(self.slot_priorities)])
             with torch.cuda.stream(st):
                 torch.zeros(1, device=self.device)             # first use: binds the stream to its hardware queue now
         return st
