@@ -359,7 +359,8 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
   }
 }
 
-// Tile geometries: code = 100 BM/32... kept small on purpose (every entry is 2 element types x its epilogues)
+// The built tile geometries (enum psg_tile -> waves and 32 x 32 accumulator tiles per wave); a short list on purpose:
+// every entry is instantiated for two element types and two epilogues
 struct dg_geom {
   int id, wm, wn, ti, tj;
 };
