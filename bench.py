@@ -828,6 +828,11 @@ def main():
                 el = time_steps(lambda: head.forward_batch(batch), 1, k)
                 line["batched_decode"] = {"images_per_step": B3, "value": round(B3 * k * pairs_per_image / el, 1),
                                           "unit": "pairs/s", "ms_per_step": round(el / k * 1e3, 3), "steps": k}
+                B8 = 8                                                 # BASELINE C5's batch: 160 decode rows per step
+                batch += [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev))) for m in range(B3, B8)]
+                el8 = time_steps(lambda: head.forward_batch(batch), 1, 2)
+                line["batched_decode"]["eight_images"] = {"value": round(B8 * 2 * pairs_per_image / el8, 1),
+                                                          "ms_per_step": round(el8 / 2 * 1e3, 3), "steps": 2}
             except Exception as exc:                                   # never lose the headline line
                 line["batched_decode"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         if strong is not None:
