@@ -40,8 +40,11 @@ _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.flo
 class _Pending:
     """An image submitted with `head.submit`: its kernels are enqueued on `stream`; `result()` is the only host wait."""
 
-    def __init__(self, head, stream, rq, out, num_objects):
+    def __init__(self, head, stream, rq, out, num_objects, inputs=None):
         self.head, self.stream, self.rq, self.out, self.N = head, stream, rq, out, num_objects
+        # the caller's input tensors are read on `stream`, possibly long after `submit` returned: they stay referenced
+        # here until the result is taken (and carry a record_stream mark in case the handle is dropped first)
+        self.inputs = inputs
         self._result = None
 
     def result(self):
@@ -53,12 +56,14 @@ class _Pending:
         h, out = self.head, self.out
         with torch.cuda.stream(self.stream):
             sel = self.rq["selected"]
+            if "_finish" in out:                                           # natural EOS: the chunks behind the first
+                out.pop("_finish")()
             out["tokens_host"] = out["tokens"].cpu().numpy()               # waits for this stream's work only
             out["selected_host"] = sel.cpu().numpy()
         self.rq.update(out)
         h.last = self.rq
         rel_pred, rel_score = h.parse(out["tokens_host"], out["selected_host"], self.N)
-        self.rq = self.out = None
+        self.rq = self.out = self.inputs = None
         self._result = dict(rel_pred=rel_pred, rel_score=rel_score)
         return self._result
 
@@ -499,6 +504,11 @@ class RelationTransformerHeadV4(nn.Module):
             N = len(obj_ids)
             if N == 0:
                 return _Pending(self, st, None, None, 0)
+            # the caller may drop its tensors as soon as this returns (a detector's mask_features are a temporary): the
+            # caching allocator must not hand their blocks out again before the slot stream has read them
+            for t in (feat, info["pan_results"], *[x for x in info['object_id_list'] if torch.is_tensor(x)]):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(st)
             # The front halves (relation query + prompt pass: the only part with LIBRARY GEMMs) of consecutive images are
             # ordered by an event - free in the steady state, where image k's front half ended long before image k+1 is
             # submitted -, so that two library GEMMs never run side by side on two streams: hipBLASLt kernels with a
@@ -507,8 +517,8 @@ class RelationTransformerHeadV4(nn.Module):
             # image k+1's front half and decode.
             self._wait_front(st)
             rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
-            out = self._enqueue_decode(st, rq, names, slot)
-        return _Pending(self, st, rq, out, N)
+            out = self._enqueue_decode(st, rq, names, slot, defer=True)
+        return _Pending(self, st, rq, out, N, inputs=inputs)
 
     def _slot_stream(self, slot):
         st = self._slot_streams.get(slot)
@@ -528,9 +538,10 @@ class RelationTransformerHeadV4(nn.Module):
                 self.pair_selector == "threshold" and self.max_selected > 32) or not self.llm_engine.use_skinny):
             st.wait_event(self._decode_done)
 
-    def _enqueue_decode(self, st, rq, names, slot, selected=None, pair_features=None):
+    def _enqueue_decode(self, st, rq, names, slot, selected=None, pair_features=None, defer=False):
         """The decode of one image on slot stream `st` (the caller is inside `torch.cuda.stream(st)` and has called
-        `_wait_front`): prompt pass, event, decode steps; no host wait."""
+        `_wait_front`): prompt pass, event, decode steps; no host wait with `defer` (natural EOS: the chunks behind the
+        first are replayed by `out["_finish"]`)."""
         prev, front_done, gated = self._decode_done, torch.cuda.Event(), [False]
 
         def gate():                                             # between the prompt pass and the decode steps
@@ -540,7 +551,7 @@ class RelationTransformerHeadV4(nn.Module):
                 st.wait_event(prev)
         # graph slot 0 belongs to `forward` (the caller's stream): a pending submit never shares its KV caches
         out = self.decode_selected(rq, names, selected=selected, pair_features=pair_features, to_host=False,
-                                   slot=slot + 1, gate=gate)
+                                   slot=slot + 1, gate=gate, defer=defer)
         if not gated[0]:                                        # eager run, or every pair ended inside the first graph
             front_done.record(st)
         self._front_done = front_done
@@ -1104,8 +1115,10 @@ class RelationTransformerHeadV4(nn.Module):
         pids, plen = tbl_d[trow].contiguous(), lens_d[trow].contiguous()
         return self.llm_engine.build_inputs(pf, pids, plen), plen
 
-    def decode_selected(self, rq, names, selected=None, pair_features=None, to_host=True, slot=0, gate=None):
-        """A9: batched greedy decode of the selected pairs."""
+    def decode_selected(self, rq, names, selected=None, pair_features=None, to_host=True, slot=0, gate=None, defer=False):
+        """A9: batched greedy decode of the selected pairs.
+        defer (`submit`): nothing waits for the GPU here; with natural EOS the chunks behind the first are replayed by
+        `out["_finish"]()` (called by the pending result), which also fills `tokens` / `first_logits`."""
         sel = rq["selected"] if selected is None else selected
         K = sel.numel()
         sel_in = sel
@@ -1118,12 +1131,23 @@ class RelationTransformerHeadV4(nn.Module):
                 nv = self.cfg.qformer.num_query
                 pair_features = torch.cat([pair_features, pair_features[-nv:].repeat(4 - K % 4, 1)]).contiguous()
         X, plen = self.llm_inputs(rq, names, sel_in, pair_features)
-        tokens, first_logits = self.llm_engine.generate(X, plen, suppress_eos=self.suppress_eos,
-                                                        return_first_logits=True, slot=slot, gate=gate)
-        tokens, first_logits, X, plen = tokens[:K], first_logits[:K], X[:K], plen[:K]
-        out = dict(tokens=tokens, first_logits=first_logits, llm_inputs=X, prompt_len=plen)
+        eng = self.llm_engine
+        # deferring leaves later chunks un-enqueued when the next image's front half starts: only when the decode steps
+        # hold own kernels alone (library GEMMs of two streams side by side were seen to hang, `submit`)
+        defer = bool(defer) and eng.use_skinny and sel_in.numel() <= 32
+        res = eng.generate(X, plen, suppress_eos=self.suppress_eos, return_first_logits=True, slot=slot, gate=gate,
+                           defer=defer)
+        out = dict(llm_inputs=X[:K], prompt_len=plen[:K])
+
+        def finish():
+            tokens, first_logits = res() if defer else res
+            out["tokens"], out["first_logits"] = tokens[:K], first_logits[:K]
+        if defer:
+            out["_finish"] = finish
+            return out
+        finish()
         if to_host:
-            out["tokens_host"], out["selected_host"] = tokens.cpu().numpy(), sel.cpu().numpy()
+            out["tokens_host"], out["selected_host"] = out["tokens"].cpu().numpy(), sel.cpu().numpy()
         return out
 
     def parse(self, tokens_host, selected_host, object_num):

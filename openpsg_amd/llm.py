@@ -268,7 +268,7 @@ class LlamaDecodeEngine:
 
     @torch.no_grad()
     def generate(self, X, prompt_len, max_new_tokens=None, suppress_eos=False, return_first_logits=False, slot=0,
-                 gate=None):
+                 gate=None, defer=False):
         """Batched greedy decode.  X [K, 32+Tp, D]; prompt_len int32 [K] (# of prompt tokens).
         Returns tokens int32 [K, max_new] (device; -1 after a pair's EOS) and optionally the
         first-step logits [K, vocab].
@@ -281,21 +281,28 @@ class LlamaDecodeEngine:
             replay stops as soon as every pair has emitted EOS (one 4-byte read-back per chunk).
         slot: graphs (with their KV caches and static buffers) are kept per slot, so that two generations - of two
         images on two HIP streams, `head.submit` - can be in flight at once; a slot is used by one stream at a time.
-        gate: callable run between the prompt pass (+ first token) and the decode steps, which are then two graphs - the
-        caller makes the stream wait there for the previous image's decode (the prompt pass of image k+1 is matrix-core
-        work that fits beside image k's HBM-bound decode steps; two decodes side by side only share the HBM)."""
+        gate: callable run between the prompt pass (+ first token) and the decode steps, which are then separate graphs -
+        the caller makes the stream wait there for the previous image's decode (the prompt pass of image k+1 is
+        matrix-core work that fits beside image k's HBM-bound decode steps; two decodes side by side only share the HBM).
+        defer (natural EOS only): enqueue the prompt pass and the first chunk of steps WITHOUT a host wait and return a
+        callable instead of the results; calling it replays the remaining chunks (with their "all done?" read-backs) and
+        returns what the direct call returns.  `head.submit` hands it to the pending result, so that `result()` stays
+        the only host wait of an image in flight."""
         max_new = self.cfg.max_new_tokens if max_new_tokens is None else max_new_tokens
         if not self.use_graph:
-            return self._finish(self._generate_eager(X, prompt_len, max_new, suppress_eos, return_first_logits),
+            outs = self._finish(self._generate_eager(X, prompt_len, max_new, suppress_eos, return_first_logits),
                                 return_first_logits)
+            return (lambda: outs) if defer else outs
         chunk = 0 if suppress_eos else int(self.early_exit_chunk)
-        split = gate is not None and chunk <= 0 and max_new > 1
+        split = gate is not None and max_new > 1
         key = (tuple(X.shape), max_new, bool(suppress_eos), bool(return_first_logits), chunk, int(slot), split)
         ent = self._graphs.get(key)
         if ent is not None:
             self._graphs.move_to_end(key)
         if ent is None:
             while len(self._graphs) >= self.max_graphs:        # least recently used shape: frees its graph pool
+                # the evicted graph (or its KV pool) may still be replaying on another slot's stream
+                torch.cuda.synchronize(self.device)
                 self._graphs.popitem(last=False)
             Xs, ps = X.clone(), prompt_len.to(torch.int32).clone()
             side = torch.cuda.Stream(device=self.device)
@@ -304,8 +311,10 @@ class LlamaDecodeEngine:
                 self._generate_eager(Xs, ps, max_new, suppress_eos, return_first_logits)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
-            bounds = ([1, max_new] if split else [max_new]) if chunk <= 0 else sorted(
-                set(list(range(chunk, max_new, chunk)) + [max_new]))
+            bounds = [max_new] if chunk <= 0 else list(range(chunk, max_new, chunk)) + [max_new]
+            if split:                                          # the gate sits right behind the prompt pass + first token
+                bounds = [1] + bounds
+            bounds = sorted(set(bounds))
             graphs, st, lo = [], None, 0
             for hi in bounds:                                  # graph i runs steps [lo, hi); step 0 includes the prefill
                 g = torch.cuda.CUDAGraph()
@@ -313,10 +322,9 @@ class LlamaDecodeEngine:
                     if st is None:
                         st = self._prefill(Xs, ps, max_new, suppress_eos, return_first_logits)
                         self._steps(st, 1, hi)
-                        all_done = st["done"].min() if chunk > 0 else None
                     else:
                         self._steps(st, lo, hi)
-                        all_done = st["done"].min() if chunk > 0 else None
+                    all_done = st["done"].min() if (chunk > 0 and hi >= chunk) else None
                 graphs.append((g, hi, all_done))
                 lo = hi
             ent = self._graphs[key] = (graphs, Xs, ps, st)
@@ -324,16 +332,34 @@ class LlamaDecodeEngine:
         Xs.copy_(X)
         ps.copy_(prompt_len)
         self.last_replays = 0
-        for gi, (g, hi, all_done) in enumerate(graphs):
-            if gi == 1 and gate is not None:
-                gate()
-            g.replay()
-            self.last_replays += 1
-            if hi < max_new and all_done is not None and int(all_done.item()) != 0:     # every pair has emitted EOS: the rest would be -1
-                break
-        # the graph's static buffers are overwritten by the next replay: hand out copies
-        fl = st["first_logits"]
-        return self._finish((st["tokens"].clone(), None if fl is None else fl.clone()), return_first_logits)
+        cursor = [0]
+
+        def advance(budget):
+            """Replays graphs from the cursor on; budget = how many graphs may be enqueued without a read-back (None: run
+            to the end, reading the all-done flag after every chunk)."""
+            while cursor[0] < len(graphs):
+                g, hi, all_done = graphs[cursor[0]]
+                if budget is not None and cursor[0] >= budget:
+                    return
+                if cursor[0] == 1 and gate is not None:
+                    gate()
+                g.replay()
+                cursor[0] += 1
+                self.last_replays += 1
+                if budget is None and hi < max_new and all_done is not None and int(all_done.item()) != 0:
+                    break                                       # every pair has emitted EOS: the rest would be -1
+            cursor[0] = len(graphs)
+
+        def finish():
+            advance(None)
+            # the graph's static buffers are overwritten by the next replay: hand out copies
+            fl = st["first_logits"]
+            return self._finish((st["tokens"].clone(), None if fl is None else fl.clone()), return_first_logits)
+        if defer and chunk > 0:
+            advance(2 if split else 1)                          # prompt pass (+ gate) + the first chunk of steps: no host wait
+            return finish
+        outs = finish()
+        return (lambda: outs) if defer else outs
 
     @staticmethod
     def _finish(outs, want_first):

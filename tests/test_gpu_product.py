@@ -192,3 +192,77 @@ def test_two_images_in_flight_give_the_results_of_forward():
             assert np.array_equal(sel, ws) and np.array_equal(toks, wt) and r == wr, f"{dtype}: image {k} differs"
         empty = head.submit(dict(ins[0], object_info=[dict(object_id_list=[], pan_results=scenes[0]["pan_results"])]), slot=0)
         assert empty.result() == dict(rel_pred=[], rel_score=[])
+
+
+def test_submit_keeps_the_callers_temporaries_alive_until_they_are_read():
+    """The caller drops its input tensors right after `submit` (a detector's mask_features are a temporary) and then
+    allocates and overwrites same-sized blocks on ITS stream while the slot stream has not yet read the inputs: the head
+    must hold the blocks (record_stream + a reference in the pending handle).  Results equal `forward`'s."""
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_device
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=30522), llm=tiny_llm(512, 2, 1024, 512), max_object_num=30)
+    w = make_weights_device(cfg, 7, torch.device("cuda:0"), llm_dtype=torch.float32)
+    head = RelationTransformerHeadV4(dtype="mixed", device="cuda:0", llm_config=cfg.llm, llm_feature_size=512,
+                                     tokenizers="word", max_object_num=30, on_parse_error="skip", suppress_eos=True)
+    head.load_weights(w)
+    scenes = [make_scene((1024, 1024), 30, seed=90 + m, tiny_object=True) for m in range(4)]      # host copies
+
+    def fresh(s):                                                      # a new device copy per image, as a segmenter makes
+        return dict(mask_features=s["mask_features"].cuda(), img_metas=[s["img_meta"]],
+                    object_info=[dict(object_id_list=s["object_id_list"], pan_results=s["pan_results"].cuda())])
+    want = []
+    for s in scenes:
+        r = head(fresh(s))
+        want.append((r, head.last["tokens_host"].copy()))
+    torch.cuda.synchronize()
+    got, pending = [], []
+    for k in range(3 * len(scenes)):
+        i = fresh(scenes[k % len(scenes)])
+        pending.append(head.submit(i, slot=k % 2))
+        shape = i["mask_features"].shape
+        del i                                                          # the caller's references are gone
+        for _ in range(3):                                             # the allocator would hand the block out again
+            junk = torch.full(shape, float("nan"), device="cuda:0")
+            del junk
+        if len(pending) > 1:
+            r = pending.pop(0).result()
+            got.append((r, head.last["tokens_host"].copy()))
+    r = pending.pop(0).result()
+    got.append((r, head.last["tokens_host"].copy()))
+    for k, (r, toks) in enumerate(got):
+        wr, wt = want[k % len(scenes)]
+        assert np.array_equal(toks, wt) and r == wr, f"image {k} differs from forward"
+
+
+def test_submit_with_natural_eos_does_not_wait_for_the_decode():
+    """Natural EOS (the product default): `submit` enqueues the prompt pass and the first chunk of steps and returns; the
+    all-done read-backs happen in `result()`.  Checked with an event recorded on the slot stream after `submit`: it has
+    not completed when `submit` returns (a stream busy with a long kernel in front), and results equal `forward`'s."""
+    from openpsg_amd.synthetic import make_scene
+    head, tok, chain = _rigged_head("bf16")
+    scenes = [make_scene((512, 512), 10, seed=5 + m) for m in range(3)]
+    ins = [_inputs(s) for s in scenes]
+    want = [head(i) for i in ins]
+    assert all(len(wr["rel_pred"]) == 40 for wr in want)
+    torch.cuda.synchronize()
+    # occupy the GPU on the caller's stream: the slot streams wait for it, so nothing submitted below can have finished
+    # when submit returns - a submit that waits for its decode would take as long as this kernel chain
+    a = torch.randn(8192, 8192, device="cuda:0")
+    t0 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(40):
+        a = (a @ a).clamp_(-1, 1)
+    busy = torch.cuda.Event()
+    busy.record()
+    import time
+    h0 = time.perf_counter()
+    p0 = head.submit(ins[0], slot=0)
+    p1 = head.submit(ins[1], slot=1)
+    host = time.perf_counter() - h0
+    assert not busy.query(), "the GPU was idle already: the probe kernel chain is too short for this box"
+    r0, r1 = p0.result(), p1.result()
+    assert r0 == want[0] and r1 == want[1]
+    assert host < 0.5, f"two submits took {host:.2f} s of host time"
+    assert head.llm_engine.last_replays <= 3                        # prompt pass, first chunk (+ at most one more)
