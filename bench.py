@@ -4,8 +4,17 @@
 
 One "step" = one pass of the hot path over one synthetic image per rank: BASELINE.json config C3
 (1024x1024, 50 masks = 2450 ordered pairs, relation Q-Former + existence head + top-20 selection +
-batched greedy Llama-2-7B-shaped decode of 16 tokens), bf16, random-init weights, inputs already
-resident in HBM.  `--workload rq` times config C2 (relation-query only).
+batched greedy Llama-2-7B-shaped decode of 16 tokens), random-init weights, inputs already resident in HBM;
+one `head(inputs)` call per step, its result awaited (wall time of ONE head call).
+
+PRECISION OF THE HEADLINE: the reference runs this path in fp32 (V4:99-100 loads the LLM without a dtype) and the
+north star's tolerance (logits 1e-3, argmax-exact) is an fp32 statement, so `value` is measured in the `fp32s` mode:
+fp32 weights, activations, KV cache, norms, softmaxes and decode-step projections (26.4 GB of fp32 weights streamed
+per decode step); the prompt pass's and the Q-Former's projections are split-fp16 products (x.w = xh.wh + xh.wl +
+xl.wh on the 16-bit matrix cores, fp32 accumulation: 3e-7 relative, the library SGEMM's own error class).  The line's
+`parity` block re-checks that mode against the CPU oracle in the same run.  The 16-bit figures of earlier rounds
+(`mixed`: fp16 operands, outside the tolerance) and the exact-fp32 figures are sub-objects, as is BASELINE config C2
+(`c2`).  `--workload rq` times config C2 alone.
 
 N > 1 (one rank per GPU, RCCL; launched by torch.distributed.run - by the driver, or by this script itself
 when `--gpus N` is given without a rendezvous in the environment): WEAK scaling.  The job is N images per step;
@@ -18,10 +27,12 @@ dealt round-robin - its latency is bounded below by the 16 weight passes of the 
 scope), which is stated next to the number.
 
 The JSON line also carries
-  roofline     - the dominant kernel (skinny_gemm_kernel: HBM stream of the LLM weights in the decode
+  roofline     - the dominant kernel (skinny_gemm_f32_kernel: HBM stream of the fp32 LLM weights in the decode
                  steps), timed with HIP events on the launch stream right after the timed region with the
                  same weights and shapes (inside the region the decode is ONE graph replay, which has no
-                 per-kernel events); profiles/ holds the rocprofv3 summary of the same command;
+                 per-kernel events); profiles/ holds the rocprofv3 summary of the same command; `roofline.image` =
+                 the whole image against its combined floor (15 weight passes at the HBM peak + the prompt pass's and
+                 the relation query's FLOPs at the matrix peak of the dtype they run in);
   cpu_baseline - the CPU oracle (oracle/psg_oracle.py, a restatement of the reference's PyTorch path)
                  timed on this box's host cores on a bounded sample, rank 0, N = 1 only;
   parity       - the same scene through the fp32 verification mode (ms/step, pairs/s: the mode the 1e-3 claim is
@@ -62,21 +73,24 @@ def parse():
     ap.add_argument("--images-per-step", type=int, default=1,
                     help="single-GPU throughput mode: images per step whose selected pairs are decoded together")
     ap.add_argument("--no-batched", action="store_true", help="skip the secondary 4-images-per-step measurement")
-    ap.add_argument("--in-flight", type=int, default=2, help="images in flight of the pipelined step (head.submit slots)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="images in flight of the timed step (head.submit slots).  Default 1: one head call per step, its "
+                         "result awaited (SURVEY 8d).  The two-in-flight figure is always reported as `two_in_flight`")
     ap.add_argument("--slot-priorities", default="0,-1",
                     help="HIP stream priorities of the in-flight slots (A/B: 0,0 = both slots in the normal queue pool)")
     ap.add_argument("--serialize-decodes", action="store_true",
                     help="pipelined step A/B: image k+1's decode steps wait for image k's (measured: no gain over --serial)")
-    ap.add_argument("--serial", action="store_true",
-                    help="one image at a time (every step waits for its result before the next image is submitted), as in "
-                         "rounds 1-3; default: two images in flight on two HIP streams (head.submit)")
+    ap.add_argument("--serial", action="store_true", help="same as --in-flight 1 (kept for the profile scripts)")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the 16-bit (mixed) sub-object")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 sub-object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--dtype", choices=["bf16", "fp16", "mixed"], default=None,
-                    help="precision mode of the measured path.  mixed (default of the full path) = fp16 GEMM operands "
-                         "and KV cache, fp32 accumulation, fp32 Llama residual stream: 8x closer to the fp32 engine "
-                         "than bf16 at 32 layers for +0.2 %% time (tests/test_gpu_llm7b.py); bf16 (default of "
-                         "--workload rq, BASELINE config 2 names it); fp16 (BASELINE config 5)")
+    ap.add_argument("--dtype", choices=["fp32s", "fp32", "bf16", "fp16", "mixed"], default=None,
+                    help="precision mode of the measured path.  fp32s (default of the full path): the reference's fp32 "
+                         "arithmetic with split-fp16 products in the prompt pass and the Q-Former - inside the north "
+                         "star's tolerance; fp32: exact everywhere; mixed = fp16 GEMM operands and KV cache, fp32 "
+                         "accumulation, fp32 Llama residual stream (rounds 3-4's headline, outside the tolerance); bf16 "
+                         "(default of --workload rq, BASELINE config 2 names it); fp16 (BASELINE config 5)")
     ap.add_argument("--no-untruncated", action="store_true",
                     help="cpu_baseline: skip the un-truncated 32-layer fp32 decode of one pair (27 GB of host memory)")
     ap.add_argument("--no-parity", action="store_true")
@@ -86,7 +100,10 @@ def parse():
     ap.add_argument("--pair-chunk", type=int, default=0, help="pairs per Q-Former pass (0: the head's default)")
     a = ap.parse_args()
     if a.dtype is None:
-        a.dtype = "mixed" if a.workload == "full" else "bf16"
+        a.dtype = "fp32s" if a.workload == "full" else "bf16"
+    if a.serial:
+        a.in_flight = 1
+    a.serial = a.in_flight <= 1
     return a
 
 
@@ -346,109 +363,120 @@ def decode_parity(h, oracle_part, scene, names, eos):
                 tokens_before_first_divergence=f"{matched}/{total}")
 
 
-def parity_block(a, dev, scene, oracle_part, headline_ms):
-    """fp32 verification mode on the bench scene (full path timed) + per-dtype deviation from the CPU oracle (relation
-    query on all pairs; decode leg at 7B width with 2 layers) + ms/step of the full path in every 16-bit mode."""
-    import copy
+def parity_block(a, dev, scene, oracle_part):
+    """Per precision mode: deviation from the CPU oracle on the bench scene - the relation query on ALL pairs (existence
+    logits, top-20) and the decode leg at Llama-2-7B width with 2 layers (the oracle's pair features injected).  The
+    headline mode's numbers are copied to the top of the block."""
     from openpsg_amd.categories import INSTANCE_OFFSET, object_categories
-    from openpsg_amd.config import LlamaConfig, PSGConfig, QFormerConfig
     from openpsg_amd.head import RelationTransformerHeadV4
-    from openpsg_amd.weights import make_weights_device
     N = a.objects
     out = {}
     ids_ = [int(i) for i in scene["object_id_list"]]
     names_ = [object_categories[i % INSTANCE_OFFSET] for i in ids_]
     modes = {}
-    if oracle_part is not None:
-        w, n = oracle_part["w"], oracle_part["n"]
-        full = a.workload == "full" and oracle_part["decodes"] is not None
-        ocfg = oracle_part["cfg"]
-        k = min(20, n)
-        for dt in ("fp32", "fp32s", "bf16", "fp16", "mixed"):
-            kw = dict(llm_config=ocfg.llm, llm_truncate_num=oracle_part["n_layers"], suppress_eos=True) if full else {}
-            h = RelationTransformerHeadV4(dtype=dt, device=str(dev), tokenizers="word", max_object_num=N,
-                                          on_parse_error="skip", **kw)
-            h.load_weights(w if full else {k_: v for k_, v in w.items() if not k_.startswith("language_model.")})
-            # the whole image through the benchmarked path (cls-first last layer) against the oracle's logits of ALL pairs
-            rq = h.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_, scene["pan_results"])
-            m = dict(max_logit_err_vs_oracle=float(f"{(rq['exist_logit'][:n].cpu() - oracle_part['logit']).abs().max().item():.3e}"),
-                     top20_overlap=f"{len(set(rq['selected'].cpu().tolist()) & set(oracle_part['selected']))}/{k}")
-            if full:
-                m["decode_7b_width_2_layers"] = decode_parity(h, oracle_part, scene, names_, ocfg.llm.eos)
-            modes[dt] = m
-            del h, rq
-            torch.cuda.empty_cache()
-        out["pairs_checked"] = n
-        out["tolerance_fp32"] = 1e-3
-        out["fp32_max_logit_err_vs_oracle"] = modes["fp32"]["max_logit_err_vs_oracle"]
-    if a.workload == "full":
-        cfg = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=a.llm_layers), max_object_num=N)
-        w32 = make_weights_device(cfg, 0, dev, llm_dtype=torch.float32)
-        h = RelationTransformerHeadV4(dtype="fp32", device=str(dev), tokenizers="word", max_object_num=N,
-                                      llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True)
-        h.load_weights(w32)
-        inputs = scene_inputs(scene)
-        el = median_step(lambda: h(inputs), 2, 3)
-        out.update(fp32_mode_ms_per_step=round(el * 1e3, 2), fp32_mode_pairs_per_s=round(N * (N - 1) / el, 1),
-                   headline_over_fp32_speed=round(el * 1e3 / headline_ms, 2))
-        # the reference-precision path as a first-class measurement: its own dominant kernel against the HBM roofline
-        # (the fp32 weight-streaming decode GEMM, psg_gemm_f32.hip: 26.4 GB of fp32 weights per decode step)
-        el_p = time_in_flight(h, inputs, 2, 6) / 6
-        grade = dict(mode="fp32 weights / activations / KV cache (the reference's own arithmetic, V4:99-100): the only mode "
-                          "inside the north star's 1e-3 / argmax-exact tolerance",
-                     ms_per_step=round(el * 1e3, 2), pairs_per_s=round(N * (N - 1) / el, 1), steps=3,
-                     two_in_flight=dict(ms_per_step=round(el_p * 1e3, 2), pairs_per_s=round(N * (N - 1) / el_p, 1), steps=6),
-                     max_logit_err_vs_oracle=modes.get("fp32", {}).get("max_logit_err_vs_oracle"),
-                     decode_7b_width_2_layers=modes.get("fp32", {}).get("decode_7b_width_2_layers"))
-        if not a.no_roofline:
-            bpl, spl, nl = measure_decode_gemm(h, min(20, N * N))
-            ach = bpl / spl / 1e9
-            grade["roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_f32_kernel (psg_skinny_gemm with PSG_F32: "
-                                 "v_mfma_f32_16x16x1_4b + v_mfma_f32_4x4x1_16b on LDS-DMA rings)",
-                                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(bpl),
-                                 "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": nl,
-                                 "bytes_per_decode_step": int(bpl * nl), "traffic": None}
-            pmc32 = os.path.join(REPO, "profiles", "pmc_skinny_gemm_f32.json")
-            if os.path.exists(pmc32):
-                grade["roofline"]["traffic"] = json.load(open(pmc32)).get("hbm_bytes_per_launch")
-                grade["roofline"]["traffic_source"] = ("profiles/pmc_skinny_gemm_f32.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                       "passes of this kernel; not re-measured in this run)")
-        del h
+    w, n = oracle_part["w"], oracle_part["n"]
+    full = a.workload == "full" and oracle_part["decodes"] is not None
+    ocfg = oracle_part["cfg"]
+    k = min(20, n)
+    for dt in ("fp32s", "fp32", "bf16", "fp16", "mixed"):
+        kw = dict(llm_config=ocfg.llm, llm_truncate_num=oracle_part["n_layers"], suppress_eos=True) if full else {}
+        h = RelationTransformerHeadV4(dtype=dt, device=str(dev), tokenizers="word", max_object_num=N,
+                                      on_parse_error="skip", **kw)
+        h.load_weights(w if full else {k_: v for k_, v in w.items() if not k_.startswith("language_model.")})
+        # the whole image through the benchmarked path (cls-first last layer) against the oracle's logits of ALL pairs
+        rq = h.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_, scene["pan_results"])
+        m = dict(max_logit_err_vs_oracle=float(f"{(rq['exist_logit'][:n].cpu() - oracle_part['logit']).abs().max().item():.3e}"),
+                 top20_overlap=f"{len(set(rq['selected'].cpu().tolist()) & set(oracle_part['selected']))}/{k}")
+        if full:
+            m["decode_7b_width_2_layers"] = decode_parity(h, oracle_part, scene, names_, ocfg.llm.eos)
+        modes[dt] = m
+        del h, rq
         torch.cuda.empty_cache()
-        # the same path with the prompt pass's and the Q-Former's projections as split-fp16 products ('fp32s': fp32-grade,
-        # ~7e-7 per product; decode steps, attention, KV cache and every row operation stay exact fp32)
-        h = RelationTransformerHeadV4(dtype="fp32s", device=str(dev), tokenizers="word", max_object_num=N,
-                                      llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True)
-        h.load_weights(w32)
-        del w32
-        els = median_step(lambda: h(inputs), 2, 3)
-        els_p = time_in_flight(h, inputs, 2, 6) / 6
-        grade["fp32s"] = dict(two_in_flight=dict(ms_per_step=round(els_p * 1e3, 2), pairs_per_s=round(N * (N - 1) / els_p, 1),
-                                                 steps=6),
-                              mode="fp32 with split-fp16 products (x.w = xh.wh + xh.wl + xl.wh on the 16-bit matrix cores, "
-                                   "fp32 accumulation) in the prompt pass and the Q-Former; decode steps exact fp32",
-                              ms_per_step=round(els * 1e3, 2), pairs_per_s=round(N * (N - 1) / els, 1), steps=3,
-                              max_logit_err_vs_oracle=modes.get("fp32s", {}).get("max_logit_err_vs_oracle"),
-                              top20_overlap=modes.get("fp32s", {}).get("top20_overlap"),
-                              decode_7b_width_2_layers=modes.get("fp32s", {}).get("decode_7b_width_2_layers"))
-        out["_parity_grade"] = grade
-        torch.cuda.empty_cache()
-        # the full path in the other 16-bit modes (same scene, same step, their own 32-layer engine)
-        for dt in ("bf16", "fp16", "mixed"):
-            m = modes.setdefault(dt, {})
-            if dt == a.dtype:
-                m["ms_per_step"] = round(headline_ms, 3)
-                continue
-            b = copy.copy(a)
-            b.dtype_override = dt
-            h = setup_head(b, dev)
-            el = time_steps(lambda: h(inputs), 2, 5) / 5
-            m["ms_per_step"] = round(el * 1e3, 3)
-            del h
-            torch.cuda.empty_cache()
+    out["pairs_checked"] = n
+    out["tolerance"] = "existence logits within 1e-3 of the fp32 oracle, greedy tokens identical (BASELINE.json north_star)"
+    hm = modes.get(a.dtype, {})
+    out["headline_mode"] = a.dtype
+    out["headline_max_logit_err_vs_oracle"] = hm.get("max_logit_err_vs_oracle")
+    out["headline_within_tolerance"] = bool(
+        hm.get("max_logit_err_vs_oracle", 1.0) < 1e-3 and hm.get("top20_overlap") == f"{k}/{k}" and (
+            not full or hm["decode_7b_width_2_layers"]["exact_sequences"].split("/")[0]
+            == hm["decode_7b_width_2_layers"]["exact_sequences"].split("/")[1]))
+    out["fp32_max_logit_err_vs_oracle"] = modes["fp32"]["max_logit_err_vs_oracle"]
+    out["fp32s_max_logit_err_vs_oracle"] = modes["fp32s"]["max_logit_err_vs_oracle"]
     out["modes"] = modes
     return out
+
+
+PRECISION = {
+    "fp32s": "fp32 (the reference's arithmetic, V4:99-100): fp32 weights, activations, KV cache, norms, softmaxes and "
+             "decode-step projections; the prompt pass's and the Q-Former's projections are split-fp16 products "
+             "(x.w = xh.wh + xh.wl + xl.wh on the 16-bit matrix cores, fp32 accumulation; ~3e-7 relative per product, "
+             "the error class of an fp32 GEMM) - head dtype 'fp32s'",
+    "fp32": "fp32 everywhere, exact (fp32-input matrix instructions / library SGEMM) - head dtype 'fp32'",
+    "mixed": "mixed: fp16 GEMM operands / KV cache, fp32 accumulation, fp32 Llama residual stream (outside the north "
+             "star's 1e-3 tolerance: existence logits ~0.025 off the fp32 oracle)",
+    "fp16": "fp16 operands and residual stream, fp32 accumulation",
+    "bf16": "bf16 operands and residual stream, fp32 accumulation"}
+DTYPE_LABEL = {"fp32s": "fp32", "fp32": "fp32", "mixed": "fp16", "fp16": "fp16", "bf16": "bf16"}
+# matrix peak the mode's dense projections run against, and how many matrix products one algorithmic product costs
+MATRIX_PEAK = {"fp32s": (2.5e15, 3), "fp32": (157.3e12, 1), "mixed": (2.5e15, 1), "fp16": (2.5e15, 1), "bf16": (2.5e15, 1)}
+
+
+def decode_roofline(head, N, pmc_file, kernel):
+    bpl, spl, n = measure_decode_gemm(head, min(20, N * N))
+    ach = bpl / spl / 1e9
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(bpl),
+         "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n, "bytes_per_decode_step": int(bpl * n)}
+    pmc = os.path.join(REPO, "profiles", pmc_file)
+    if os.path.exists(pmc):
+        r["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        r["traffic_source"] = (f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel; "
+                               "not re-measured in this run)")
+    return r
+
+
+def image_floor(head, a, dtype, bytes_per_step, ms_measured):
+    """The whole image against its combined floor: (max_new - 1) weight passes at the HBM peak + the prompt pass's and the
+    relation query's algorithmic FLOPs at the dense matrix peak of the dtype they run in (fp32s: three fp16 products per
+    algorithmic product)."""
+    m = head.cfg.llm
+    peak, mult = MATRIX_PEAK[dtype]
+    steps = head.cfg.max_new_tokens - 1
+    X = head.last.get("llm_inputs") if head.last is not None else None
+    rows = int(X.shape[0] * X.shape[1]) if X is not None else head.cfg.num_selected * 49
+    per_layer = 4 * m.hidden * m.hidden + 3 * m.hidden * m.inter
+    fl_prompt = 2.0 * rows * per_layer * a.llm_layers
+    T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
+    fl_rq = relation_query_flops(a.objects, (a.size // 64) ** 2, T, head.cls_first, head.cfg.num_selected)
+    t_dec = steps * bytes_per_step / (HBM_PEAK_GBS * 1e9)
+    t_pp = fl_prompt * mult / peak
+    t_rq = fl_rq * mult / peak
+    floor = (t_dec + t_pp + t_rq) * 1e3
+    return {"floor_ms": round(floor, 2), "measured_ms": round(ms_measured, 2), "frac": round(floor / ms_measured, 4),
+            "terms_ms": {"decode_weight_passes": round(t_dec * 1e3, 2), "prompt_pass": round(t_pp * 1e3, 2),
+                         "relation_query": round(t_rq * 1e3, 2)},
+            "assumptions": f"{steps} decode steps x {bytes_per_step / 1e9:.2f} GB at {HBM_PEAK_GBS / 1e3:.0f} TB/s; prompt pass "
+                           f"{fl_prompt / 1e12:.1f} TFLOP over {rows} rows and relation query {fl_rq / 1e12:.2f} TFLOP, x{mult} "
+                           f"matrix products each, at {peak / 1e12:.0f} TFLOP/s"}
+
+
+def rq_stage(head, a, scene, pairs_per_image, steps=10):
+    from openpsg_amd.categories import INSTANCE_OFFSET, object_categories
+    N = a.objects
+    ids_ = [int(i) for i in scene["object_id_list"]]
+    names_ = [object_categories[i % INSTANCE_OFFSET] for i in ids_]
+
+    def rq_step():
+        rq = head.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_, scene["pan_results"])
+        head.selected_pair_features(rq)
+        return rq["selected"].cpu()
+    el = time_steps(rq_step, 2, steps) / steps
+    T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
+    fl = relation_query_flops(N, (a.size // 64) ** 2, T, head.cls_first, head.cfg.num_selected)
+    U = max([v[3][0].shape[0] for v in head._gather_cache.values() if len(v) > 3] or [N * N])
+    fx = relation_query_flops_executed(N, (a.size // 64) ** 2, T, U, head.cfg.num_selected) if head.cls_first else fl
+    return el, fl, fx, U, T
 
 
 def scene_inputs(scene):
@@ -529,10 +557,11 @@ def main():
     head = setup_head(a, dev)
     N = a.objects
     pairs_per_image = N * (N - 1)
+    single = world == 1 and not force_dist
 
-    drain = lambda: None  # noqa: E731  (the pipelined step below replaces it)
-    per_rank, step_forms = 1, None
-    if world == 1 and not force_dist:
+    drain = lambda: None  # noqa: E731  (a pipelined step replaces it)
+    per_rank = 1
+    if single:
         scene = make_scene((a.size, a.size), N, seed=0, device=str(dev), num_categories=a.categories)
         inputs = scene_inputs(scene)
         if a.workload == "full" and a.images_per_step > 1:
@@ -541,11 +570,8 @@ def main():
 
             def step():
                 return head.forward_batch(batch)
-        elif a.workload == "full" and not a.serial:
-            # two images in flight (head.submit): image k+1 is enqueued on a second HIP stream before image k's result is
-            # awaited, so the two images' kernels interleave - one image's latency-bound row kernels and launch ramps run
-            # under the other's weight streaming.  Every image is processed in full and its result taken before the
-            # timed region ends (`drain`)
+        elif a.workload == "full" and a.in_flight > 1:
+            # --in-flight k (not the default): image j+1 is enqueued on another HIP stream before image j's result is awaited
             import collections
             pending, issued = collections.deque(), [0]
             head.serialize_decodes = a.serialize_decodes
@@ -558,33 +584,8 @@ def main():
             def drain():
                 while pending:
                     pending.popleft().result()
-
-            # images in flight only pay when the slots' streams sit on hardware queues that overlap (e.g.
-            # not with GPU_MAX_HW_QUEUES=2): time both step forms before the warm-up and keep the faster one
-            def timed(fn, n, after=lambda: None):
-                fn()
-                after()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                after()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t0) / n
-            for _ in range(2):
-                step()
-            drain()
-            t_pipe, t_one = timed(step, 8, drain), timed(lambda: head(inputs), 3)
-            step_forms = {"in_flight_tried": a.in_flight, "ms_per_image_in_flight": round(t_pipe * 1e3, 2),
-                          "ms_per_image_one_at_a_time": round(t_one * 1e3, 2), "in_flight_used": a.in_flight}
-            if t_pipe > 0.97 * t_one:
-                a.serial, step_forms["in_flight_used"] = True, 1
-                drain = lambda: None  # noqa: E731
-
-                def step():
-                    return head(inputs)
         elif a.workload == "full":
-            def step():
+            def step():                                                # ONE head call, its result awaited
                 return head(inputs)
         else:
             from openpsg_amd.categories import INSTANCE_OFFSET, object_categories
@@ -600,34 +601,12 @@ def main():
     else:
         import torch.distributed as dist
         from openpsg_amd.dist import PairShardedPipeline
-        # a step is `per_rank` images per rank (2 by default, as on one GPU: a rank's two decodes run side by side on the
-        # head's slot streams, dist.step_gen); every image's pairs are sharded over all ranks
-        per_rank = 1 if (a.serial or a.workload != "full") else max(1, a.in_flight)
+        # a step is `per_rank` images per rank (--in-flight; default 1: a rank decodes one image of the step); every
+        # image's pairs are sharded over all ranks
+        per_rank = 1 if a.workload != "full" else max(1, a.in_flight)
         scenes = [make_scene((a.size, a.size), N, seed=m, device=str(dev)) for m in range(world * per_rank)]
         pipe = PairShardedPipeline(head, dist.group.WORLD, decode=a.workload == "full")
         barrier = lambda: dist.barrier(device_ids=[local])  # noqa: E731
-        if per_rank > 1:
-            # Two decodes side by side on one GPU only pay when their streams land on hardware queues that overlap (a
-            # property of the process's queue creation order): time both step forms before the warm-up and
-            # keep the faster one - the same choice on every rank.
-            def timed(sc, n):
-                pipe.step(sc)
-                torch.cuda.synchronize()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    pipe.step(sc)
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t0) / n
-            t_multi = timed(scenes, 2) / per_rank
-            t_one = timed(scenes[:world], 2)
-            worse = torch.tensor([1.0 if t_multi > 0.97 * t_one else 0.0], device=dev)
-            dist.all_reduce(worse, op=dist.ReduceOp.MAX)
-            step_forms = {"images_per_rank_tried": per_rank, "ms_per_image_side_by_side": round(t_multi * 1e3, 2),
-                          "ms_per_image_one_at_a_time": round(t_one * 1e3, 2)}
-            if worse.item() > 0:
-                per_rank, scenes = 1, scenes[:world]
-            step_forms["images_per_rank_used"] = per_rank
 
         def step():
             return pipe.step(scenes)
@@ -644,18 +623,15 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    pipelined = world == 1 and not force_dist and a.workload == "full" and a.images_per_step == 1 and not a.serial
-    serial_ms = None
-    if pipelined:                                                      # the same images one at a time (rounds 1-3's step)
-        serial_ms = time_steps(lambda: head(inputs), 2, max(5, a.steps // 2)) / max(5, a.steps // 2) * 1e3
-    if world > 1 or force_dist:
+    if not single:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    plain = single and a.workload == "full" and a.images_per_step == 1
 
     strong = None
-    if (world > 1 or force_dist) and not a.no_strong:
+    if not single and not a.no_strong:
         # STRONG scaling: one BASELINE-C4 image (100 masks) for all ranks; max over ranks like the headline
         import torch.distributed as dist
         from openpsg_amd.dist import PairShardedPipeline
@@ -683,180 +659,197 @@ def main():
             scene4["mask_features"], scene4["img_meta"], [int(i) for i in scene4["object_id_list"]],
             pipe1.be._names(scene4), scene4["pan_results"]), 1, 3) / 3
         barrier()
+        wbytes = 26.4 if a.dtype in ("fp32", "fp32s") else 13.2
         strong = {"workload": f"ONE {a.size}x{a.size} image, {n4} masks ({n4 * (n4 - 1)} pairs), pairs sharded over "
                               f"{world} rank(s), top-20 decodes dealt round-robin",
                   "ms_per_image": round(el1 * 1e3, 3), "value": round(n4 * (n4 - 1) / el1, 1), "unit": "pairs/s",
                   "steps": ks, "single_gpu_reference_ms": round(ref1 * 1e3, 3),
-                  "speedup_vs_single_gpu": round(ref1 / el1, 3),
-                  "bound": "16 passes over the 13.5 GB of Llama weights per image on every decoding rank (a decode "
+                  "speedup_vs_single_gpu": round(ref1 / el1, 3), "dtype": DTYPE_LABEL[a.dtype], "mode": a.dtype,
+                  "bound": f"16 passes over the {wbytes} GB of Llama weights per image on every decoding rank (a decode "
                            "step streams all weights for 1 row as for 20; no tensor parallelism, SURVEY 8e): only the "
                            "relation query and the compute-bound prompt pass shrink with N"}
 
     if rank == 0:
-        ips = a.images_per_step if (world == 1 and not force_dist and a.workload == "full") else world * per_rank
+        ips = a.images_per_step if (single and a.workload == "full") else world * per_rank
         images = ips * a.steps
         wl = ("C3: 1024x1024, 50 masks, full path incl. LMM autoregressive relation decode (Llama-2-7B shape, top-20 "
               "pairs, 16 new tokens each, EOS suppressed)") if a.workload == "full" else \
              "C2: 1024x1024, 50 masks, relation-query transformer only"
         if (a.size, a.objects, a.categories) != (1024, 50, 133):
             wl = f"custom: {a.size}x{a.size}, {a.objects} masks from {a.categories} classes, {a.workload}"
+        if not single:
+            par = (f"{ips} images per step, pairs of every image sharded over {world} rank(s) (all-gather of patches / "
+                   f"probabilities / token ids, reduce-scatter of the selected pair features); rank r decodes images r, "
+                   f"r + {world}, ... of the step" + (" side by side on two HIP streams" if per_rank > 1 else ""))
+        elif plain and a.in_flight > 1:
+            par = (f"single GPU, {a.in_flight} images in flight (head.submit: image j+1 enqueued on another HIP stream before "
+                   "image j's result is awaited; every image processed in full inside the timed region)")
+        else:
+            par = "single GPU, one head call per step, its result awaited before the next image is submitted"
+        ms_step = elapsed / a.steps * 1e3
         line = {
             "metric": METRIC, "value": round(images * pairs_per_image / elapsed, 1), "unit": "pairs/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp16" if a.dtype == "mixed" else a.dtype, "data": "synthetic",
+            "dtype": DTYPE_LABEL[a.dtype], "data": "synthetic",
             "config": {"workload": wl, "objects": N, "pairs_per_image": pairs_per_image, "images_per_step": ips,
                        "patches": (a.size // 64) ** 2, "llm_layers": a.llm_layers if a.workload == "full" else 0,
-                       "precision": {"mixed": "mixed: fp16 GEMM operands / KV cache, fp32 accumulation, fp32 Llama residual "
-                                              "stream", "fp16": "fp16 operands and residual stream, fp32 accumulation",
-                                     "bf16": "bf16 operands and residual stream, fp32 accumulation"}[a.dtype],
-                       "parallelism": (f"single GPU, {a.in_flight} images in flight: image k+1 is submitted on a second HIP stream "
-                                       "before image k's result is awaited (head.submit; per-slot decode graphs and KV "
-                                       "caches), so one image's latency-bound row kernels run under the other's weight "
-                                       "streaming; every image processed in full inside the timed region, results "
-                                       "identical to one image at a time") if pipelined else
-                                      ("single GPU" if world == 1 and not force_dist else
-                                       f"{ips} images per step, pairs of every image sharded over {world} rank(s) (all-gather of "
-                                       f"patches / probabilities / token ids, reduce-scatter of the selected pair features); "
-                                       f"rank r decodes images r, r + {world}, ... of the step"
-                                       + (" side by side on two HIP streams" if per_rank > 1 else ""))},
+                       "mode": a.dtype, "precision": PRECISION[a.dtype], "parallelism": par},
         }
-        if pipelined:
-            line["one_image_at_a_time"] = {"ms_per_image": round(serial_ms, 3),
-                                           "value": round(pairs_per_image / serial_ms * 1e3, 1), "unit": "pairs/s",
-                                           "note": "head(inputs) per step, each result awaited before the next image is "
-                                                   "submitted (the step of rounds 1-3; the latency of one image)"}
+        f32 = a.dtype in ("fp32", "fp32s")
+        k_name = ("skinny_gemm_f32_kernel (psg_skinny_gemm with PSG_F32: v_mfma_f32_16x16x1_4b + v_mfma_f32_4x4x1_16b on "
+                  "LDS-DMA rings; fp32 weights)") if f32 else \
+                 "skinny_gemm_dma_kernel (psg_skinny_gemm; 8-wave slabs, 11-wave for gate/up, 12-wave for q/k/v)"
+        pmc_file = "pmc_skinny_gemm_f32.json" if f32 else "pmc_skinny_gemm.json"
         if not a.no_roofline and a.workload == "full":
-            bpl, spl, n = measure_decode_gemm(head, min(20, N * N))
-            ach = bpl / spl / 1e9
-            traffic = None
-            pmc = os.path.join(REPO, "profiles", "pmc_skinny_gemm.json")
-            if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            line["roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_dma_kernel (psg_skinny_gemm; 8-wave slabs, 11-wave for gate/up, 12-wave for q/k/v)", "achieved": round(ach, 1),
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                "traffic": traffic,
-                                "traffic_source": "profiles/pmc_skinny_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                  "passes of this kernel; not re-measured in this run)",
-                                "bytes_per_launch": int(bpl),
-                                "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n}
-        if a.workload == "rq" and not a.no_roofline and world == 1 and not force_dist:
+            line["roofline"] = decode_roofline(head, N, pmc_file, k_name)
+            if plain and a.in_flight <= 1:
+                line["roofline"]["image"] = image_floor(head, a, a.dtype, line["roofline"]["bytes_per_decode_step"], ms_step)
+        if a.workload == "rq" and not a.no_roofline and single:
             T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
             fl = relation_query_flops(N, (a.size // 64) ** 2, T, head.cls_first, head.cfg.num_selected)
+            peak, mult = MATRIX_PEAK[a.dtype]
             ach = fl / (elapsed / a.steps) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "relation-query stage (bf16 GEMMs + cross_attn_dma_kernel + "
-                                "self_attn_mfma_kernel + qformer_cls_attn_input_kernel)", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                                "frac": round(ach / 2500.0, 4), "traffic": None, "flops_per_step": int(fl)}
-        if world == 1 and not force_dist and a.images_per_step == 1 and a.workload == "full":
-            # stage split (not part of the contract): relation-query stage alone, against the dense bf16 MFMA peak
-            from openpsg_amd.categories import INSTANCE_OFFSET, object_categories
-            ids_ = [int(i) for i in scene["object_id_list"]]
-            names_ = [object_categories[i % INSTANCE_OFFSET] for i in ids_]
-
-            def rq_step():
-                rq = head.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_,
-                                             scene["pan_results"])
-                head.selected_pair_features(rq)
-                return rq["selected"].cpu()
-            el = time_steps(rq_step, 2, 10) / 10
-            T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
-            fl = relation_query_flops(N, (a.size // 64) ** 2, T, head.cls_first, head.cfg.num_selected)
-            # algorithmic FLOPs per pair (SURVEY 8d's formula minus work nobody reads) next to what the kernels execute
-            # (the prompt-only share once per distinct prompt)
-            U = max([v[3][0].shape[0] for v in head._gather_cache.values() if len(v) > 3] or [N * N])
-            fx = relation_query_flops_executed(N, (a.size // 64) ** 2, T, U, head.cfg.num_selected) if head.cls_first else fl
+            line["roofline"] = {"bound": "mfma", "kernel": "relation-query stage (GEMMs + cross-attention + self-attention + "
+                                "qformer_cls_attn_input_kernel)", "achieved": round(ach, 1), "peak": peak / mult / 1e12,
+                                "unit": "TFLOP/s", "frac": round(ach * 1e12 * mult / peak, 4), "traffic": None,
+                                "flops_per_step": int(fl)}
+        if plain:
+            # the same mode with two images in flight (fixed form, no best-of selection): head.submit on two slot streams
+            try:
+                k2 = max(6, a.steps // 2)
+                el_p = time_in_flight(head, inputs, 2, k2) / k2
+                line["two_in_flight"] = {"ms_per_image": round(el_p * 1e3, 3), "value": round(pairs_per_image / el_p, 1),
+                                         "unit": "pairs/s", "steps": k2, "mode": a.dtype,
+                                         "note": "head.submit, image j+1 enqueued on a second HIP stream before image j's "
+                                                 "result is awaited; whether the slots overlap depends on the HIP runtime's "
+                                                 "stream -> hardware-queue binding (DESIGN 4.5)"}
+            except Exception as exc:                                   # never lose the headline line
+                line["two_in_flight"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            # stage split (not part of the contract): relation-query stage alone in the headline mode
+            el, fl, fx, U, T = rq_stage(head, a, scene, pairs_per_image)
+            peak, mult = MATRIX_PEAK[a.dtype]
             line["stages"] = {"relation_query_ms": round(el * 1e3, 3),
                               "relation_query_pairs_per_s": round(pairs_per_image / el, 1),
                               "relation_query_tflops": round(fl / el / 1e12, 1),
-                              "relation_query_mfma_frac": round(fl / el / 2.5e15, 4),
+                              "relation_query_matrix_frac": round(fl * mult / el / peak, 4),
                               "relation_query_executed_tflops": round(fx / el / 1e12, 1),
-                              "relation_query_executed_mfma_frac": round(fx / el / 2.5e15, 4),
                               "distinct_prompts": int(U), "prompt_tokens": T}
-            if world == 1 and not force_dist and a.images_per_step == 1:
-                # the timed region repeats ONE scene (hot per-names caches); what an image with a class list never seen
-                # before costs: six other scenes, each run once (head.warm_prompts() as a deployment does at start-up)
+            # the timed region repeats ONE scene (hot per-names caches); what an image with a class list never seen
+            # before costs: six other scenes, each run once (head.warm_prompts() as a deployment does at start-up)
+            try:
+                head.warm_prompts()
+                fresh = [make_scene((a.size, a.size), N, seed=100 + m, device=str(dev), num_categories=a.categories)
+                         for m in range(6)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for sc in fresh:
+                    head(scene_inputs(sc))
+                torch.cuda.synchronize()
+                line["stages"]["new_scene_ms_per_image"] = round((time.perf_counter() - t0) / len(fresh) * 1e3, 3)
+                del fresh
+            except Exception as e:  # noqa: BLE001
+                line["stages"]["new_scene_ms_per_image"] = f"failed: {e}"
+        # ---- sub-objects measured with their own heads: the headline head is released first -------------------------
+        if plain:
+            import copy
+            del head
+            torch.cuda.empty_cache()
+            if a.dtype != "fp32" and not a.no_exact:
+                try:                                                   # exact fp32 everywhere
+                    b = copy.copy(a)
+                    b.dtype_override = "fp32"
+                    h = setup_head(b, dev)
+                    ke = max(5, a.steps // 4)
+                    el = time_steps(lambda: h(inputs), 2, ke) / ke
+                    line["exact_fp32"] = {"mode": "fp32", "precision": PRECISION["fp32"], "ms_per_step": round(el * 1e3, 3),
+                                          "value": round(pairs_per_image / el, 1), "unit": "pairs/s", "steps": ke}
+                    if not a.no_roofline:
+                        r = decode_roofline(h, N, "pmc_skinny_gemm_f32.json", "skinny_gemm_f32_kernel")
+                        r["image"] = image_floor(h, a, "fp32", r["bytes_per_decode_step"], el * 1e3)
+                        line["exact_fp32"]["roofline"] = r
+                    del h
+                    torch.cuda.empty_cache()
+                except Exception as exc:
+                    line["exact_fp32"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            if a.dtype != "mixed" and not a.no_mixed:
+                try:                                                   # rounds 3-4's headline mode, outside the tolerance
+                    b = copy.copy(a)
+                    b.dtype_override = "mixed"
+                    h = setup_head(b, dev)
+                    km = max(10, a.steps // 2)
+                    el = time_steps(lambda: h(inputs), 3, km) / km
+                    el_p = time_in_flight(h, inputs, 2, km) / km
+                    mx = {"mode": "mixed", "dtype": "fp16", "precision": PRECISION["mixed"],
+                          "one_image_at_a_time": {"ms_per_image": round(el * 1e3, 3), "value": round(pairs_per_image / el, 1),
+                                                  "unit": "pairs/s", "steps": km},
+                          "two_in_flight": {"ms_per_image": round(el_p * 1e3, 3), "value": round(pairs_per_image / el_p, 1),
+                                            "unit": "pairs/s", "steps": km}}
+                    if not a.no_roofline:
+                        r = decode_roofline(h, N, "pmc_skinny_gemm.json", "skinny_gemm_dma_kernel")
+                        r["image"] = image_floor(h, a, "mixed", r["bytes_per_decode_step"], el * 1e3)
+                        mx["roofline"] = r
+                    if not a.no_batched:
+                        # four / eight such images per step, their 80 / 160 selected pairs decoded together so that the
+                        # Llama weights stream once per decode step for all of them (head.forward_batch)
+                        try:
+                            B3 = 4
+                            batch = [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev))) for m in range(B3)]
+                            k = max(2, min(a.steps, 5))
+                            elb = time_steps(lambda: h.forward_batch(batch), 1, k)
+                            mx["batched_decode"] = {"images_per_step": B3, "value": round(B3 * k * pairs_per_image / elb, 1),
+                                                    "unit": "pairs/s", "ms_per_step": round(elb / k * 1e3, 3), "steps": k}
+                            B8 = 8                                     # BASELINE C5's batch: 160 decode rows per step
+                            batch += [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev)))
+                                      for m in range(B3, B8)]
+                            el8 = time_steps(lambda: h.forward_batch(batch), 1, 2)
+                            mx["batched_decode"]["eight_images"] = {"value": round(B8 * 2 * pairs_per_image / el8, 1),
+                                                                    "ms_per_step": round(el8 / 2 * 1e3, 3), "steps": 2}
+                            del batch
+                        except Exception as exc:
+                            mx["batched_decode"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+                    line["mixed"] = mx
+                    del h
+                    torch.cuda.empty_cache()
+                except Exception as exc:
+                    line["mixed"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            if not a.no_roofline:
+                # BASELINE config C2 (relation-query transformer only, bf16) as an object of the SAME line, so that the
+                # driver's default run records it: its own bf16 head (no LLM), the stage timed as `--workload rq` times it
                 try:
-                    head.warm_prompts()
-                    fresh = [make_scene((a.size, a.size), N, seed=100 + m, device=str(dev), num_categories=a.categories)
-                             for m in range(6)]
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for sc in fresh:
-                        head(scene_inputs(sc))
-                    torch.cuda.synchronize()
-                    line["stages"]["new_scene_ms_per_image"] = round((time.perf_counter() - t0) / len(fresh) * 1e3, 3)
-                except Exception as e:  # noqa: BLE001
-                    line["stages"]["new_scene_ms_per_image"] = f"failed: {e}"
-        if world == 1 and not force_dist and a.images_per_step == 1 and a.workload == "full" and not a.no_roofline:
-            # BASELINE config C2 (relation-query transformer only, bf16) as an object of the SAME line, so that the driver's
-            # default run records it: its own bf16 head (no LLM), the stage timed as `--workload rq` times it
-            try:
-                import copy
-                b = copy.copy(a)
-                b.workload, b.dtype_override = "rq", "bf16"
-                h2 = setup_head(b, dev)
-
-                def rq2():
-                    rq = h2.run_relation_query(scene["mask_features"], scene["img_meta"], ids_, names_, scene["pan_results"])
-                    h2.selected_pair_features(rq)
-                    return rq["selected"].cpu()
-                k2 = max(10, a.steps)
-                el2 = time_steps(rq2, 3, k2) / k2
-                T2 = max(v[2].shape[1] for k_, v in h2._table_cache.items() if k_[0] == "q")
-                fl2 = relation_query_flops(N, (a.size // 64) ** 2, T2, h2.cls_first, h2.cfg.num_selected)
-                U2 = max([v[3][0].shape[0] for v in h2._gather_cache.values() if len(v) > 3] or [N * N])
-                fx2 = relation_query_flops_executed(N, (a.size // 64) ** 2, T2, U2, h2.cfg.num_selected) if h2.cls_first else fl2
-                line["c2"] = {"workload": "C2: 1024x1024, 50 masks, relation-query transformer only, 1xMI355X bf16",
-                              "value": round(pairs_per_image / el2, 1), "unit": "pairs/s", "ms_per_step": round(el2 * 1e3, 3),
-                              "steps": k2, "dtype": "bf16",
-                              "roofline": {"bound": "mfma", "achieved": round(fl2 / el2 / 1e12, 1), "peak": 2500.0,
-                                           "unit": "TFLOP/s", "frac": round(fl2 / el2 / 2.5e15, 4),
-                                           "executed_tflops": round(fx2 / el2 / 1e12, 1),
-                                           "executed_frac": round(fx2 / el2 / 2.5e15, 4), "flops_per_step": int(fl2)}}
-                del h2
-                torch.cuda.empty_cache()
-            except Exception as exc:                                   # never lose the headline line
-                line["c2"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
-        if (not a.no_batched and a.workload == "full" and world == 1 and not force_dist
-                and a.images_per_step == 1):
-            # secondary figure, not `value`: four such images per step, their 80 selected pairs decoded together
-            # so the Llama weights stream once per decode step for all of them (head.forward_batch)
-            try:
-                B3 = 4
-                batch = [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev))) for m in range(B3)]
-                k = max(2, min(a.steps, 5))
-                el = time_steps(lambda: head.forward_batch(batch), 1, k)
-                line["batched_decode"] = {"images_per_step": B3, "value": round(B3 * k * pairs_per_image / el, 1),
-                                          "unit": "pairs/s", "ms_per_step": round(el / k * 1e3, 3), "steps": k}
-                B8 = 8                                                 # BASELINE C5's batch: 160 decode rows per step
-                batch += [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev))) for m in range(B3, B8)]
-                el8 = time_steps(lambda: head.forward_batch(batch), 1, 2)
-                line["batched_decode"]["eight_images"] = {"value": round(B8 * 2 * pairs_per_image / el8, 1),
-                                                          "ms_per_step": round(el8 / 2 * 1e3, 3), "steps": 2}
-            except Exception as exc:                                   # never lose the headline line
-                line["batched_decode"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+                    b = copy.copy(a)
+                    b.workload, b.dtype_override = "rq", "bf16"
+                    h2 = setup_head(b, dev)
+                    k2 = max(10, a.steps)
+                    el2, fl2, fx2, U2, T2 = rq_stage(h2, b, scene, pairs_per_image, steps=k2)
+                    line["c2"] = {"workload": "C2: 1024x1024, 50 masks, relation-query transformer only, 1xMI355X bf16",
+                                  "value": round(pairs_per_image / el2, 1), "unit": "pairs/s", "ms_per_step": round(el2 * 1e3, 3),
+                                  "steps": k2, "dtype": "bf16",
+                                  "roofline": {"bound": "mfma", "achieved": round(fl2 / el2 / 1e12, 1), "peak": 2500.0,
+                                               "unit": "TFLOP/s", "frac": round(fl2 / el2 / 2.5e15, 4),
+                                               "executed_tflops": round(fx2 / el2 / 1e12, 1),
+                                               "executed_frac": round(fx2 / el2 / 2.5e15, 4), "flops_per_step": int(fl2)}}
+                    del h2
+                    torch.cuda.empty_cache()
+                except Exception as exc:                               # never lose the headline line
+                    line["c2"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         if strong is not None:
             line["strong_scaling"] = strong
-        if step_forms is not None:
-            line["step_forms"] = step_forms
         oracle_part = None
-        if not a.no_cpu_baseline and world == 1 and not force_dist:
+        if not a.no_cpu_baseline and single:
             scene_cpu = make_scene((a.size, a.size), N, seed=0)
             line["cpu_baseline"], oracle_part = cpu_baseline(a, scene_cpu)
-        if not a.no_parity and world == 1 and not force_dist and a.images_per_step == 1:
+        if not a.no_parity and single and a.images_per_step == 1 and oracle_part is not None:
             try:
                 # the GPU scene is generated on the device (another generator than the CPU scene's): the parity
                 # legs run the CPU scene, uploaded, so that oracle and kernels see identical inputs
                 sc = make_scene((a.size, a.size), N, seed=0)
                 sc_dev = dict(sc, mask_features=sc["mask_features"].to(dev), pan_results=sc["pan_results"].to(dev))
-                line["parity"] = parity_block(a, dev, sc_dev, oracle_part,
-                                              serial_ms if serial_ms is not None else elapsed / a.steps * 1e3)
-                if "_parity_grade" in line["parity"]:
-                    line["parity_grade"] = line["parity"].pop("_parity_grade")
+                line["parity"] = parity_block(a, dev, sc_dev, oracle_part)
             except Exception as exc:                                   # never lose the headline line
                 line["parity"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         print(json.dumps(line), flush=True)
-    if world > 1 or force_dist:
+    if not single:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -111,8 +111,8 @@ class LlamaDecodeEngine:
         """Bias-free projection.  Decode-step shapes (<= 32 rows) use the hand-written weight-streaming kernel - in
         the 16-bit modes and in the fp32 mode (the reference's own precision, V4:99-100) alike; the prompt pass goes
         through hipBLASLt."""
-        if (self.use_skinny and x.shape[0] <= 32 and w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0
-                and w.shape[1] >= 256):
+        if (self.use_skinny and x.shape[0] <= 32 and x.dtype == w.dtype and w.shape[0] % 16 == 0
+                and w.shape[1] % 64 == 0 and w.shape[1] >= 256):
             return ops.skinny_gemm(x, w)          # fp32 split-K partials, reduced by the consumer kernel
         if ws is not None and x.dtype == torch.float32:
             return self.linear_split(x, ws)

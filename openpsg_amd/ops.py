@@ -438,14 +438,14 @@ def skinny_gemm(x, w, splits=None) -> Partials:
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K
+    if x.dtype not in _DT or w.dtype != x.dtype:
+        raise PsgHipError(f"skinny_gemm: x / w must both be bf16, fp16 or fp32, got {x.dtype} / {w.dtype}")
     if splits is None:
         import ctypes
         s = ctypes.c_int(0)
         check(lib.psg_skinny_gemm_plan(ctx, M, N, K, _dt(x), ctypes.byref(s)), "psg_skinny_gemm_plan")
         splits = s.value
     part = torch.empty((splits, M, N), device=x.device, dtype=torch.float32)
-    if x.dtype not in _DT or w.dtype != x.dtype:
-        raise PsgHipError(f"skinny_gemm: x / w must both be bf16, fp16 or fp32, got {x.dtype} / {w.dtype}")
     check(lib.psg_skinny_gemm(ctx, _p(x, name="x"), _p(w, name="w"), _p(part), M, N, K, splits, _dt(x), st),
           "psg_skinny_gemm")
     return Partials(part)
