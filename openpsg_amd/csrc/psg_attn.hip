@@ -8,6 +8,8 @@
 
 int psg_self_attn_mfma_launch(const void* qkv, const void* q_shared, const uint8_t* text_mask, int B, int T_, int nq, int heads,
                               int query_rows_only, void* out, int dtype, hipStream_t st);
+int psg_self_attn_f32_launch(const void* qkv, const void* q_shared, const uint8_t* text_mask, int B, int T_, int nq,
+                             int heads, int query_rows_only, void* out, hipStream_t st);
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -94,6 +96,8 @@ extern "C" int psg_qformer_self_attn(psg_ctx* ctx, const void* qkv, const uint8_
   const int force_scalar = ctx->opt.selfattn_scalar;
   if ((dtype == PSG_BF16 || dtype == PSG_F16) && nq >= 32 && nq + T_ <= 64 && !force_scalar)
     return psg_self_attn_mfma_launch(qkv, nullptr, text_mask, B, T_, nq, heads, query_rows_only, out, dtype, (hipStream_t)stream);
+  if (dtype == PSG_F32 && !force_scalar)                    // exact f32 matrix instructions (psg_attn_f32.hip)
+    return psg_self_attn_f32_launch(qkv, nullptr, text_mask, B, T_, nq, heads, query_rows_only, out, (hipStream_t)stream);
   int64_t units = (int64_t)B * heads;
   PSG_DISPATCH_DTYPE(dtype, "psg_qformer_self_attn",
                      (qformer_self_attn_kernel<T><<<(unsigned)((units + 3) / 4), 256, 0, (hipStream_t)stream>>>(
@@ -492,7 +496,10 @@ extern "C" int psg_qformer_self_attn_shared(psg_ctx* ctx, const void* qkv_query,
               "psg_qformer_self_attn_shared: NULL argument");
   PSG_REQUIRE(B > 0 && T_ >= 0 && nq > 0 && heads > 0 && nq + T_ <= 64, PSG_ERR_INVALID,
               "psg_qformer_self_attn_shared: B=%d T=%d nq=%d", B, T_, nq);
-  PSG_REQUIRE(dtype == PSG_BF16 || dtype == PSG_F16, PSG_ERR_UNSUPPORTED, "psg_qformer_self_attn_shared: 16-bit only");
+  if (dtype == PSG_F32)
+    return psg_self_attn_f32_launch(qkv_text ? qkv_text : qkv_query, qkv_query, text_mask, B, T_, nq, heads, 0, out,
+                                    (hipStream_t)stream);
+  PSG_REQUIRE(dtype == PSG_BF16 || dtype == PSG_F16, PSG_ERR_UNSUPPORTED, "psg_qformer_self_attn_shared: dtype %d", dtype);
   return psg_self_attn_mfma_launch(qkv_text ? qkv_text : qkv_query, qkv_query, text_mask, B, T_, nq, heads, 0, out,
                                    dtype, (hipStream_t)stream);
 }

@@ -387,17 +387,23 @@ extern "C" int psg_prefill_attn_rope(psg_ctx* ctx_, const void* qkv, const int32
   return PSG_OK;
 }
 
+int psg_prefill_attn_f32_launch(const void* q, const void* kc, const void* vc, const int32_t* tok_pos, int pairs, int rpp,
+                                int heads, int ctx, void* out, hipStream_t st);
+
 extern "C" int psg_prefill_attn(psg_ctx* ctx_, const void* q, const void* k_cache, const void* v_cache,
                                 const int32_t* tok_pos, int pairs, int rows_per_pair, int heads, int head_dim, int ctx,
                                 void* out, int dtype, void* stream) {
   PSG_REQUIRE(ctx_ && q && k_cache && v_cache && tok_pos && out, PSG_ERR_INVALID, "psg_prefill_attn: NULL argument");
-  PSG_REQUIRE(dtype == PSG_BF16 || dtype == PSG_F16, PSG_ERR_UNSUPPORTED,
-              "psg_prefill_attn: 16-bit activations only (fp32: psg_llm_attn)");
+  PSG_REQUIRE(dtype == PSG_BF16 || dtype == PSG_F16 || dtype == PSG_F32, PSG_ERR_UNSUPPORTED,
+              "psg_prefill_attn: dtype %d", dtype);
   PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_prefill_attn: head_dim=%d (kernel is built for 128)", head_dim);
   PSG_REQUIRE(rows_per_pair >= 1 && rows_per_pair <= 64 && rows_per_pair <= ctx, PSG_ERR_UNSUPPORTED,
               "psg_prefill_attn: rows_per_pair=%d (1..64, <= ctx=%d); longer prompts: psg_llm_attn", rows_per_pair, ctx);
   PSG_REQUIRE(pairs >= 0 && heads > 0, PSG_ERR_INVALID, "psg_prefill_attn: pairs=%d heads=%d", pairs, heads);
   if (pairs == 0) return PSG_OK;
+  if (dtype == PSG_F32)                                      // exact f32 matrix instructions (psg_attn_f32.hip)
+    return psg_prefill_attn_f32_launch(q, k_cache, v_cache, tok_pos, pairs, rows_per_pair, heads, ctx, out,
+                                       (hipStream_t)stream);
   PSG_DISPATCH_E16(dtype, "psg_prefill_attn",
                    (prefill_attn_mfma_kernel<E><<<(unsigned)(pairs * heads), 64, 0, (hipStream_t)stream>>>(
                        (const uint16_t*)q, (const uint16_t*)k_cache, (const uint16_t*)v_cache, tok_pos, pairs,

@@ -513,6 +513,10 @@ static int xa_v1_launch(psg_ctx* ctx, const void* q, const void* k, const void* 
   return PSG_OK;
 }
 
+int psg_cross_attn_f32_launch(const void* q, const void* k, const void* v, const uint64_t* bits, int words,
+                              const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy, void* out,
+                              hipStream_t st);
+
 extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
                                       int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads,
                                       int empty_policy, int variant, void* out, int dtype, void* stream) {
@@ -528,8 +532,11 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
                                         st);
   PSG_REQUIRE(variant == PSG_XATTN_MFMA || variant == PSG_XATTN_MFMA_V1, PSG_ERR_INVALID,
               "psg_qformer_cross_attn: variant=%d", variant);
+  // fp32 activations: exact f32 matrix instructions over the compacted key list (psg_attn_f32.hip)
+  if (dtype == PSG_F32 && variant == PSG_XATTN_MFMA)
+    return psg_cross_attn_f32_launch(q, k, v, bits, words, pair_index, N, P, L, nq, heads, empty_policy, out, st);
   PSG_REQUIRE(dtype == PSG_BF16 || dtype == PSG_F16, PSG_ERR_UNSUPPORTED,
-              "psg_qformer_cross_attn: the MFMA variants compute in bf16 / fp16; use PSG_XATTN_SIMPLE for fp32");
+              "psg_qformer_cross_attn: PSG_XATTN_MFMA_V1 computes in bf16 / fp16");
   // second-generation kernel (full-line Q / context traffic through LDS-DMA) whenever its LDS image fits
   if (variant == PSG_XATTN_MFMA && ctx->opt.xattn_dma && psg_cross_attn_dma_lds_bytes(N, words, L) <= 160 * 1024 &&
       L <= 384)

@@ -153,13 +153,14 @@ class LlamaDecodeEngine:
         q = torch.empty_like(n)
         att = torch.empty_like(n)
         act = torch.empty((rows, m.inter), device=self.device, dtype=self.dtype)
-        mfma_prefill = (prefill_shape is not None and self.dtype in (torch.bfloat16, torch.float16) and m.head_dim == 128
-                        and prefill_shape[1] <= 64 and not self.prefill_attn_scalar)
+        mfma_prefill = (prefill_shape is not None and m.head_dim == 128 and prefill_shape[1] <= 64
+                        and not self.prefill_attn_scalar)
+        fused_rope = mfma_prefill and self.dtype in (torch.bfloat16, torch.float16)       # rotary + cache write in the launch
         for l, L in enumerate(self.layers):
             qkv = self.linear(n, L["wqkv"], L.get("wqkv_s"))
             if decode:
                 ops.decode_attn(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, kc[l], vc[l], att)
-            elif mfma_prefill and isinstance(qkv, torch.Tensor) and rope_pos is None:
+            elif fused_rope and isinstance(qkv, torch.Tensor) and rope_pos is None:
                 ops.prefill_attn_rope(qkv, tok_pos, self.rope, prefill_shape[0], prefill_shape[1], m.heads, m.head_dim,
                                       ctx_len, kc[l], vc[l], att)
             else:

@@ -219,7 +219,7 @@ def qformer_cls_attn_input(x, g, text_mask, B, T, nq, heads, x_text=None, text_i
 
 
 def qformer_self_attn_shared(qkv_query, qkv_text, text_mask, B, T, nq, heads, out):
-    """Layer-0 self-attention with ONE shared [nq, 3*hidden] projection of the query rows (bf16 / fp16)."""
+    """Layer-0 self-attention with ONE shared [nq, 3*hidden] projection of the query rows."""
     lib, ctx, st = _env(qkv_query)
     hidden = qkv_query.shape[1] // 3
     assert qkv_query.shape == (nq, 3 * hidden) and qkv_text.shape == (B * T, 3 * hidden)
@@ -239,7 +239,7 @@ def qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, out=None, empty_
     if variant is None:
         # the matrix-core kernel keeps all keys of one head in LDS (L <= 512 patches = images up to ~1450 px);
         # larger inputs take the row kernel (the reference runs them too)
-        variant = PSG_XATTN_MFMA if (q.dtype in (torch.bfloat16, torch.float16) and L <= 512) else PSG_XATTN_SIMPLE
+        variant = PSG_XATTN_MFMA if L <= 512 else PSG_XATTN_SIMPLE
     out = torch.empty_like(q) if out is None else out
     check(lib.psg_qformer_cross_attn(ctx, _p(q), _p(k), _p(v), _p(bits, torch.int64, "bits"), bits.shape[1],
                                      _p(pair_index, torch.int32, "pair_index"), int(N), P, L, nq, heads,
@@ -371,7 +371,7 @@ def llm_attn(q, k_cache, v_cache, tok_pair, tok_pos, heads, head_dim, ctx_len, o
 
 
 def prefill_attn(q, k_cache, v_cache, tok_pos, pairs, rows_per_pair, heads, head_dim, ctx_len, out):
-    """Causal attention of a pair-major prompt batch on the matrix cores (bf16 / fp16, rows_per_pair <= 64)."""
+    """Causal attention of a pair-major prompt batch on the matrix cores (bf16 / fp16 / exact fp32, rows_per_pair <= 64)."""
     lib, ctx, st = _env(q)
     assert q.shape[0] == pairs * rows_per_pair
     check(lib.psg_prefill_attn(ctx, _p(q, name="q"), _p(k_cache, q.dtype), _p(v_cache, q.dtype),

@@ -128,7 +128,7 @@ class RelationQueryEngine:
         X = torch.empty((R, H), device=self.device, dtype=self.dtype)
         X32 = torch.empty((R, H), device=self.device, dtype=torch.float32) if self.res32 else None
         first = X32 if self.res32 else X
-        shared0 = (len(self.layers) > 1 and T > 0 and self.dtype != torch.float32 and self.share_query_qkv)
+        shared0 = len(self.layers) > 1 and T > 0 and self.share_query_qkv
         if shared0:
             ops.qformer_embed_split(ids, self.word_emb, self.pos_emb, self.query_rows, self.emb_ln[0], self.emb_ln[1],
                                     q.ln_eps, first[:nq], first[RQ:])
