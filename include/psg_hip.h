@@ -59,8 +59,11 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *        psg_train_* gradient kernels, psg_add_layernorm_res32, psg_gather_pair_rows,
  *        psg_masked_split_mean_pool added)
  *   400  round 4 (psg_skinny_gemm_plan: dtype; psg_skinny_gemm accepts PSG_F32 = the reference's own precision;
- *        psg_train_attn_fwd / _bwd: attention-probability dropout mask; psg_split_f16x3, psg_scale_rows_cols added) */
-#define PSG_ABI_VERSION 401
+ *        psg_train_attn_fwd / _bwd: attention-probability dropout mask; psg_split_f16x3, psg_scale_rows_cols added)
+ *   401  round 4 (psg_dense_gemm_tiled, psg_interleave_gate_up added)
+ *   500  round 5 (psg_decode_layer*: one persistent launch per decoder layer of the decode step; psg_qformer_cross_attn /
+ *        psg_qformer_self_attn(_shared) / psg_prefill_attn accept PSG_F32 on the matrix cores) */
+#define PSG_ABI_VERSION 500
 int psg_version(void);
 const char* psg_last_error(void);
 int psg_create(int device, psg_ctx** out);
@@ -311,6 +314,26 @@ typedef struct psg_prologue {
 } psg_prologue;
 int psg_skinny_gemm_fused(psg_ctx*, const psg_prologue* pro, void* x, const void* w, float* part, int M, int N, int K,
                           int splits, int dtype, void* stream);
+
+/* ---- one Llama decoder layer of the decode step as ONE persistent launch (V4:293-312 -> HF-LL:53-67, 130-214, 243-281):
+ * resid += attention block; resid += MLP block, for M <= 32 rows that each hold the newest token of their pair -
+ * bit-identical to the chain psg_rmsnorm -> psg_skinny_gemm(q|k|v) -> psg_decode_attn -> psg_skinny_gemm(o) -> psg_rmsnorm
+ * -> psg_skinny_gemm(gate|up) -> psg_silu_mul -> psg_skinny_gemm(down), whose first RMSNorm consumes `delta` (the previous
+ * layer's down-projection partials, delta_splits slices, or NULL) and whose last projection leaves its 16 split-K slices
+ * in down_part [16][M][hidden] for the next layer (or for the final psg_rmsnorm).  256 workgroups stay resident and keep
+ * their weight rings filled across the row operations (csrc/psg_decode_layer.hip).  fp32 weights / activations / caches,
+ * hidden = 4096 = 32 heads x 128, inter % 128 == 0, 13..32 rows, a 256-CU device: psg_decode_layer_supported() says
+ * whether a shape qualifies (else keep the chain).  workspace: psg_decode_layer_workspace() floats, contents
+ * irrelevant; counters: that many uint32 words ZEROED by the caller before every launch (one block per launch inside a
+ * captured graph); word [255] != 0 afterwards = a bounded poll gave up.  At most ONE of these launches may run on a
+ * device at a time (every workgroup must be resident). */
+int psg_decode_layer_workspace(psg_ctx*, int M, int hidden, int inter, int64_t* floats, int64_t* counters);
+int psg_decode_layer_supported(psg_ctx*, int M, int hidden, int inter, int heads, int dtype);
+int psg_decode_layer(psg_ctx*, void* resid, const void* delta, int delta_splits, const float* ln1, const float* ln2,
+                     const void* wqkv, const void* wo, const void* wgu, const void* wdown, const int32_t* tok_pair,
+                     const int32_t* tok_pos, const float* rope_cos, const float* rope_sin, int M, int hidden, int inter,
+                     int heads, int ctx_len, float eps, void* k_cache, void* v_cache, float* workspace, uint32_t* counters,
+                     float* down_part, int dtype, void* stream);
 
 /* ---- fp32-grade products on the 16-bit matrix cores (prompt pass of the reference-precision mode, V4:99-100 with
  * HF-LL:163-177): an fp32 row, scaled by a power of two so that its largest magnitude lies in [2^13, 2^14), is written as

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpsg_hip.so")
 
-PSG_ABI_VERSION = 401            # include/psg_hip.h; checked against psg_version() of the loaded library
+PSG_ABI_VERSION = 500            # include/psg_hip.h; checked against psg_version() of the loaded library
 PSG_F32, PSG_BF16, PSG_F16 = 0, 1, 2
 PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED = 0, 1
 PSG_XATTN_MFMA, PSG_XATTN_SIMPLE, PSG_XATTN_MFMA_V1 = 0, 1, 2
@@ -75,6 +75,10 @@ SIGNATURES = {
     "psg_skinny_gemm_plan": [_vp, _i, _i, _i, _i, C.POINTER(_i)],
     "psg_skinny_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "psg_skinny_gemm_fused": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "psg_decode_layer_workspace": [_vp, _i, _i, _i, C.POINTER(_i64), C.POINTER(_i64)],
+    "psg_decode_layer_supported": [_vp, _i, _i, _i, _i, _i],
+    "psg_decode_layer": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,
+                         _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "psg_reduce_partials": [_vp, _vp, _i, _i64, _vp, _i, _vp],
     "psg_masked_mean_pool_workspace": [_vp, _i, _i, _i, _i, C.POINTER(_i64)],
     "psg_masked_mean_pool": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i64, _vp],

@@ -271,6 +271,10 @@ __global__ void __launch_bounds__(256) cross_attn_f32_kernel(const float* __rest
   mk.keys = keys;
   mk.empty = !pair_any;
   mk.uniform = policy == PSG_EMPTY_UNIFORM;
+  // Key list of a cls unit: ALIGNED tiles of 16 keys in natural order, those in which any pair of the group has a key.
+  // A tile without a key of pair n leaves that column's state untouched bit for bit (max, sum and accumulators are
+  // multiplied by exp(0) and get + 0), so a pair's result does not depend on which pairs share its group - a pair shard
+  // reproduces the full pass exactly.
   int cnt = 0;
   if (some_empty) {
     for (int b = 0; b < L; b += 64)
@@ -282,7 +286,17 @@ __global__ void __launch_bounds__(256) cross_attn_f32_kernel(const float* __rest
       uint64_t u = 0ull;                                              // union over the 16 pairs of the group
 #pragma unroll
       for (int i = 0; i < 16; ++i) u |= gw[i * AFX_MAXW + wd];
-      cnt = af_append_bits(keys, cnt, u, wd * 64, L);
+      // spread every 16-bit field that has a bit over the whole field
+      uint64_t t = u | (u >> 1);
+      t |= t >> 2;
+      t |= t >> 4;
+      t |= t >> 8;                                                    // bit 16 f = OR of field f
+      t &= 0x0001000100010001ull;
+      t = (t << 16) - t;                                              // 0xffff per flagged field
+      const bool on = ((t >> lane) & 1ull) && wd * 64 + lane < L;     // keys past L only shorten the very last tile
+      const uint64_t bal = __ballot(on);
+      if (on) keys[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = wd * 64 + lane;
+      cnt += __popcll(bal);
     }
   }
   af_pad_list(keys, cnt);

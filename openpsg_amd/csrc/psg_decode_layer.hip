@@ -1,0 +1,747 @@
+// One Llama decoder layer of the decode step (M <= 32 rows, fp32 weights = the reference's precision, V4:99-100) as ONE
+// persistent launch: RMSNorm -> q|k|v projection -> rotary + KV append + attention -> o projection -> RMSNorm ->
+// gate|up projection -> SwiGLU -> down projection (HF-LL:53-67, 130-214, 243-281 via V4:293-312), bit-identical to the
+// chain of eight launches it replaces (psg_rmsnorm / psg_skinny_gemm / psg_decode_attn / psg_silu_mul).
+//
+// Why: the chain's four weight-streaming launches each spend ~6 us filling and draining their DMA rings around the
+// 5-57 us their bytes need, and the four row kernels between them are ~5-15 us of dependent round trips during which
+// HBM idles - 192 us per layer for 809 MB = 4.2 TB/s, against 6.3 TB/s achievable.  Here 256 workgroups (one per CU)
+// stay resident for the whole layer; a wave's weight ring is refilled across every phase boundary (the next
+// projection's weights depend on nothing), so the row operations and hand-offs run under the stream.
+//
+// Structure (MI355X_MICROARCH.md "Persistent kernels"; cdna_hip_programming.md Guideline 16):
+//   * workgroup b = (gx, by): K slice `by` of S, column group `gx` of 256 / S, exactly the (slab, slice) arithmetic of
+//     skinny_gemm_f32_kernel (psg_gemm_f32.hip): per-wave LDS-DMA rings of non-temporal 128-byte lines, the x slice in
+//     LDS, v_mfma_f32_16x16x1_4b + v_mfma_f32_4x4x1_16b, fp32 split-K partials summed in slice order by their reader;
+//   * every value another workgroup reads is stored WRITE-THROUGH (8-byte relaxed agent-scope atomic stores =
+//     global_store_dwordx2 sc1) and read with sc1 loads / sc1 LDS-DMA; a producer drains its stores (vmcnt(0)), the
+//     workgroup meets at a barrier, ONE lane adds to an arrival counter; a consumer's wave 0 polls the counters it needs
+//     (relaxed, bounded, s_sleep) and releases the workgroup through a barrier.  No fences, no grid-wide barrier: each
+//     edge waits for exactly the workgroups that produce its bytes:
+//       RMSNorm  : column owner b (16 columns) sums the split-K slices + residual, publishes the residual and the
+//                  quad-level partial sums of squares; EVERY workgroup then rebuilds the row statistics in the reduction
+//                  tree of rmsnorm_kernel<float, 1, float> (1024 threads) and normalises its own x slice into LDS;
+//       attention: head h = column group gx of the q|k|v projection (slabs h, 32 + h, 64 + h), so a head's 8 producers
+//                  count into one word; the units (row, head) are dealt to all workgroups, four waves each, in the
+//                  arithmetic of decode_attn4_kernel<float>;
+//       o proj   : K slice by = heads 4 by .. 4 by + 3: waits for the units of those heads;
+//       SwiGLU   : (row, 128-column block) items dealt to waves, each waits for the two column groups that produced its
+//                  gate and up blocks; the down projection waits for the blocks of its K slice.
+//   * all counters live in a caller-provided, zeroed int32 array (one per launch: a memset node replayed first);
+//     every poll is bounded and reports through cnt[PSG_DL_TIMEOUT].
+// Shapes: hidden = 4096 = 32 heads x 128, inter % 128 == 0, 256 compute units (Llama-2-7B on MI355X); anything else
+// keeps the launch chain (the host wrapper checks).  One persistent launch at a time per device: two of them could each
+// hold CUs the other's missing workgroups need (the engine uses it for `forward`, not for the in-flight slots).
+#include <stdlib.h>
+
+#include "psg_common.h"
+
+#define PSG_DL_WG 256
+#define PSG_DL_WAVES 8
+#define PSG_DL_CNT_X1 0        // 8 words (one per b % 8): owners of layer-input columns, 32 arrivals each
+#define PSG_DL_CNT_HEAD 8      // 32: q|k|v column group gx done for K slice by, 8 arrivals each
+#define PSG_DL_CNT_ATT 40      // 8: attention units of heads 4 g .. 4 g + 3 stored, 4 * M arrivals each
+#define PSG_DL_CNT_OSLAB 48    // 32: o-projection slab done for K slice by, 8 arrivals each
+#define PSG_DL_CNT_X2 80       // 8: owners of post-attention columns, 32 arrivals each
+#define PSG_DL_CNT_GU 88       // 32: gate|up column group gx done for K slice by, 8 arrivals each
+#define PSG_DL_CNT_H 120       // inter / 128 words: SwiGLU block j stored, M arrivals each
+#define PSG_DL_TIMEOUT 255
+#define PSG_DL_NCNT 256
+
+typedef float df32x4_t __attribute__((ext_vector_type(4)));
+typedef float df32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned long long du64;
+
+struct psg_dl_args {
+  float* resid;               // [M][D] residual stream, updated in place
+  const float* delta;         // previous layer's down partials [dsplits][M][D] (NULL: none)
+  int dsplits;
+  const float* ln1;
+  const float* ln2;
+  const float* wqkv;          // [3 D][D]
+  const float* wo;            // [D][D]
+  const float* wgu;           // [2 I][D]
+  const float* wdown;         // [D][I]
+  const int32_t* tok_pair;
+  const int32_t* tok_pos;
+  const float* cos_tab;
+  const float* sin_tab;
+  float* kc;
+  float* vc;
+  float* qkv_part;            // [8][M][3 D]
+  float* att;                 // [M][D]
+  float* o_part;              // [8][M][D]
+  float* ssq;                 // [2][256][32] quad sums of squares of the two RMSNorms
+  float* gu_part;             // [8][M][2 I]
+  float* h;                   // [M][I]
+  float* down_part;           // [16][M][D]   (output: the next layer's delta)
+  unsigned* cnt;              // [PSG_DL_NCNT], zeroed
+  int M, D, I, heads, ctx;
+  float eps;
+};
+
+// ---- write-through stores / sc1 loads --------------------------------------------------------------------------------
+__device__ __forceinline__ void dl_st2(float* p, float a, float b) {              // 8-byte aligned
+  const du64 w = (du64)__float_as_uint(a) | ((du64)__float_as_uint(b) << 32);
+  __hip_atomic_store(reinterpret_cast<du64*>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void dl_st1(float* p, float a) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 dl_ld2(const float* p) {
+  const du64 w = __hip_atomic_load(reinterpret_cast<const du64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+}
+__device__ __forceinline__ float dl_ld1(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void dl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void dl_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// publish: every wave has drained its stores (dl_drain) BEFORE it comes here; ONE lane counts the workgroup in
+__device__ __forceinline__ void dl_publish(unsigned* word, unsigned n = 1u) {
+  dl_barrier();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(word, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void dl_arrive(unsigned* word, unsigned n = 1u) {
+  dl_drain();
+  dl_publish(word, n);
+}
+// wave 0 polls `nw` consecutive words (nw <= 64) until each is >= want; the workgroup is released through a barrier
+__device__ __forceinline__ void dl_wait(unsigned* cnt, int first, int nw, unsigned want) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+      if (lane < nw) ok = __hip_atomic_load(cnt + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 21)) {                                    // a producer died: report, do not hang the GPU
+        if (lane == 0) __hip_atomic_store(cnt + PSG_DL_TIMEOUT, 0x5047u + (unsigned)first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  dl_barrier();
+}
+
+// sum over the four 16-lane rows (psg_gemm_f32.hip: sgf_sum_kq)
+__device__ __forceinline__ float dl_sum_kq(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 7\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  const float s = a + b;
+  float c = s, d = s;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(d));
+  return c + d;
+}
+__device__ __forceinline__ void dl_ds_write128(uint32_t lds_addr, df32x4_t v) {
+  asm volatile("s_nop 15\n\tds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ df32x4_t dl_ds_read128(uint32_t lds_addr) {
+  df32x4_t v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr) : "memory");
+  return v;
+}
+template <int N_>
+__device__ __forceinline__ void dl_vmwait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+template <int MAXN>
+struct DlWait {
+  static __device__ __forceinline__ void go(int newer) {
+    if (newer >= MAXN) dl_vmwait<(MAXN * 2 < 63 ? MAXN * 2 : 63)>();
+    else DlWait<MAXN - 1>::go(newer);
+  }
+};
+template <>
+struct DlWait<0> {
+  static __device__ __forceinline__ void go(int) { dl_vmwait<0>(); }
+};
+
+#define DL_XPAD 16
+#define DL_BLOCK 2048                                                   // 16 rows x 128 B of one wave's ring slot
+
+// One weight-streaming projection of this workgroup: the (slab, K slice) walk of skinny_gemm_f32_kernel.
+template <int SLOTS, int G16, int G4>
+struct DlGemm {
+  static constexpr int ROWS = PSG_DL_WAVES * 16;
+  static constexpr int OT_PITCH = ROWS + 4;
+  static constexpr int MP = G16 * 16 + G4 * 4;
+  static constexpr int NG4 = G4 > 0 ? G4 : 1, NG16 = G16 > 0 ? G16 : 1;
+  const unsigned char* wb;
+  int64_t row_bytes;
+  int N, M, G, gx, by, kbA, nkb, nslab, total, xstride;
+  unsigned char* ring;
+  int lt, lb, ls;
+  const unsigned char* src;
+
+  __device__ __forceinline__ const unsigned char* dma_src(int t) const {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int dr = lane >> 3, dp = (lane & 7) ^ (lane >> 3);
+    int r = (gx + t * G) * ROWS + wid * 16 + dr;
+    r = r + 8 < N ? r : (N - 9 > 0 ? N - 9 : 0);
+    return wb + (int64_t)r * row_bytes + (int64_t)kbA * 128 + dp * 16;
+  }
+  __device__ __forceinline__ void setup(const float* w, int N_, int K, int S, int by_, int gx_, int M_, unsigned char* smem) {
+    const int wid = threadIdx.x >> 6;
+    wb = reinterpret_cast<const unsigned char*>(w);
+    row_bytes = (int64_t)K * 4;
+    N = N_; M = M_; G = PSG_DL_WG / S; gx = gx_; by = by_;
+    const int KB = K >> 5;
+    kbA = (int)((unsigned)(KB * by) / (unsigned)S);
+    const int kbB = (int)((unsigned)(KB * (by + 1)) / (unsigned)S);
+    nkb = kbB - kbA;
+    const int nslab_all = (N + ROWS - 1) / ROWS;
+    nslab = gx < nslab_all ? (nslab_all - gx + G - 1) / G : 0;
+    total = nslab * nkb;
+    xstride = ((KB + S - 1) / S) * 128 + DL_XPAD;
+    ring = smem + wid * (SLOTS * DL_BLOCK);
+    lt = lb = ls = 0;
+    src = dma_src(0);
+  }
+  __device__ __forceinline__ void issue() {
+    unsigned char* dst = ring + ls * DL_BLOCK;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * row_bytes),
+                                     (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 2);
+    src += 128;
+    if (++ls == SLOTS) ls = 0;
+    if (++lb == nkb) { lb = 0; ++lt; src = dma_src(lt); }
+  }
+  // the first blocks of the stream: issued as soon as the rings are free, long before x exists
+  __device__ __forceinline__ void prefetch() {
+    for (int i = 0; i < SLOTS - 1; ++i)
+      if (i < total) issue();
+  }
+  // x slice [M][K slice] from global (written through by other workgroups) by sc1 LDS-DMA; caller waits + barriers
+  __device__ __forceinline__ void stage_x_dma(const float* x, int64_t x_row_floats, unsigned char* xs) const {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
+    const int pieces = nkb * 8;
+    const int cpr = (pieces + 63) >> 6;
+    const int items = M * cpr;
+    for (int it = wid; it < items; it += PSG_DL_WAVES) {
+      const int r = it / cpr, j = it - r * cpr;
+      const int c = j * 64 + lane;
+      if (c < pieces)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(xb + (int64_t)r * x_row_floats * 4 + (int64_t)kbA * 128 + c * 16),
+            (__attribute__((address_space(3))) void*)(xs + r * xstride + j * 1024), 16, 0, 16);
+    }
+  }
+  // the stream; x is in LDS (all waves past a barrier).  part[by][M][N] written through.
+  __device__ __forceinline__ void run(float* __restrict__ part, unsigned char* smem, const unsigned char* xs) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const uint32_t otile_lds =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(smem + PSG_DL_WAVES * SLOTS * DL_BLOCK);
+    const unsigned char* x16[NG16];
+    const unsigned char* x4[NG4];
+#pragma unroll
+    for (int g = 0; g < G16; ++g) x16[g] = xs + min(16 * g + n, M - 1) * xstride + kq * 32;
+#pragma unroll
+    for (int q = 0; q < G4; ++q) x4[q] = xs + min(16 * G16 + 4 * q + (lane & 3), M - 1) * xstride + kq * 32;
+    const int arow = (n >> 3) * 1024 + (n & 7) * 128;
+    const int a0off = arow + (((2 * kq) ^ (n & 7)) * 16), a1off = arow + (((2 * kq + 1) ^ (n & 7)) * 16);
+    const df32x4_t zero4 = {0, 0, 0, 0};
+    const df32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    df32x16_t acc16[NG16];
+    df32x4_t acc4[NG4];
+#pragma unroll
+    for (int g = 0; g < G16; ++g) acc16[g] = zero16;
+#pragma unroll
+    for (int q = 0; q < G4; ++q) acc4[q] = zero4;
+    int ct = 0, cb = 0, cs = 0;
+    auto finish_slab = [&]() {
+#pragma unroll
+      for (int q = 0; q < G4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc4[q][r] = dl_sum_kq(acc4[q][r]);
+      dl_barrier();                                                   // previous slab's tile fully read
+      {
+        const uint32_t tp16 = otile_lds + (uint32_t)(n * OT_PITCH + wid * 16 + 4 * kq) * 4u;
+#pragma unroll
+        for (int g = 0; g < G16; ++g) {
+          df32x4_t v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (acc16[g][r] + acc16[g][4 + r]) + (acc16[g][8 + r] + acc16[g][12 + r]);
+          dl_ds_write128(tp16 + (uint32_t)(16 * g * OT_PITCH) * 4u, v);
+        }
+        const int g4 = (lane >> 2) & 3, j = lane & 3;
+        const uint32_t tp4 = otile_lds + (uint32_t)((16 * G16 + j) * OT_PITCH + wid * 16 + 4 * g4) * 4u;
+#pragma unroll
+        for (int q = 0; q < G4; ++q)
+          if (kq == (q & 3)) dl_ds_write128(tp4 + (uint32_t)(4 * q * OT_PITCH) * 4u, acc4[q]);
+      }
+      dl_barrier();
+      {
+        const int nblk = (gx + ct * G) * ROWS;
+        constexpr int C4 = ROWS / 4;
+        for (int e = tid; e < M * C4; e += PSG_DL_WAVES * 64) {
+          const int m = e / C4, c4 = e - m * C4;
+          if (nblk + c4 * 4 + 4 <= N) {
+            const df32x4_t v = dl_ds_read128(otile_lds + (uint32_t)(m * OT_PITCH + c4 * 4) * 4u);
+            float* dst = part + ((int64_t)by * M + m) * N + nblk + c4 * 4;
+            dl_st2(dst, v[0], v[1]);
+            dl_st2(dst + 2, v[2], v[3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G16; ++g) acc16[g] = zero16;
+#pragma unroll
+      for (int q = 0; q < G4; ++q) acc4[q] = zero4;
+      cb = 0;
+      ++ct;
+    };
+    if (nkb == 0) {
+      for (int t = 0; t < nslab; ++t) finish_slab();
+      return;
+    }
+    for (int j = 0; j < total; ++j) {
+      if (j + SLOTS - 1 < total) issue();
+      DlWait<SLOTS - 1>::go(total - 1 - j);
+      const unsigned char* slot = ring + cs * DL_BLOCK;
+      if (++cs == SLOTS) cs = 0;
+      const int o = cb * 128;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const df32x4_t a = *reinterpret_cast<const df32x4_t*>(slot + (h ? a1off : a0off));
+        df32x4_t b16[NG16], b4[NG4];
+#pragma unroll
+        for (int g = 0; g < G16; ++g) b16[g] = *reinterpret_cast<const df32x4_t*>(x16[g] + o + 16 * h);
+#pragma unroll
+        for (int q = 0; q < G4; ++q) b4[q] = *reinterpret_cast<const df32x4_t*>(x4[q] + o + 16 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int g = 0; g < G16; ++g) acc16[g] = __builtin_amdgcn_mfma_f32_16x16x1f32(a[i], b16[g][i], acc16[g], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < G4; ++q) acc4[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[i], b4[q][i], acc4[q], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (++cb == nkb) finish_slab();
+    }
+  }
+};
+
+// ---- RMSNorm, producer side: workgroup b owns columns [16 b, 16 b + 16) -----------------------------------------------
+// thread (m, q) = chain thread 4 b + q of row m (rmsnorm_kernel<float, 1, float> with 1024 threads: 4 columns each)
+__device__ __forceinline__ void dl_norm_owner(const psg_dl_args& a, const float* delta, int dsplits, float* ssq_out, int b) {
+  const int tid = threadIdx.x;
+  const int m = tid >> 2, q = tid & 3;
+  const int D = a.D;
+  float ss = 0.f;
+  if (m < a.M) {
+    const int col = 16 * b + 4 * q;
+    const int64_t i = (int64_t)m * D + col;
+    const float2 r0 = dl_ld2(a.resid + i), r1 = dl_ld2(a.resid + i + 2);
+    float v[4] = {r0.x, r0.y, r1.x, r1.y};
+    if (delta) {
+      float d[4];
+      const int64_t slice = (int64_t)a.M * D;
+      float2 t0[PSG_MAX_SPLITS], t1[PSG_MAX_SPLITS];
+#pragma unroll
+      for (int s = 0; s < PSG_MAX_SPLITS; ++s)
+        if (s < dsplits) {
+          t0[s] = dl_ld2(delta + (int64_t)s * slice + i);
+          t1[s] = dl_ld2(delta + (int64_t)s * slice + i + 2);
+        }
+      d[0] = t0[0].x; d[1] = t0[0].y; d[2] = t1[0].x; d[3] = t1[0].y;
+#pragma unroll
+      for (int s = 1; s < PSG_MAX_SPLITS; ++s)
+        if (s < dsplits) { d[0] += t0[s].x; d[1] += t0[s].y; d[2] += t1[s].x; d[3] += t1[s].y; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += d[e];
+      dl_st2(a.resid + i, v[0], v[1]);
+      dl_st2(a.resid + i + 2, v[2], v[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ss += v[e] * v[e];
+  }
+  // the first two levels of wave_sum's tree (row_shr:1, row_shr:2): lane 4 k + 3 = (t3 + t2) + (t1 + t0)
+  ss += psg_dpp<0x111, 0xf>(0.f, ss);
+  ss += psg_dpp<0x112, 0xf>(0.f, ss);
+  if (m < a.M && q == 3) dl_st1(ssq_out + (int64_t)b * 32 + m, ss);
+}
+
+// ---- RMSNorm, consumer side: row statistics from the 256 quad sums, then this workgroup's x slice into LDS -----------
+__device__ __forceinline__ void dl_norm_stage(const psg_dl_args& a, const float* ssq, const float* gamma, int kbA, int nkb,
+                                              int xstride, unsigned char* xs, float* s_inv) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int m = wid; m < a.M; m += PSG_DL_WAVES) {
+    // lane L: quads 4 L .. 4 L + 3 = one 16-lane row of the chain's wave L / 4
+    const float q0 = dl_ld1(ssq + (int64_t)(4 * lane) * 32 + m), q1 = dl_ld1(ssq + (int64_t)(4 * lane + 1) * 32 + m);
+    const float q2 = dl_ld1(ssq + (int64_t)(4 * lane + 2) * 32 + m), q3 = dl_ld1(ssq + (int64_t)(4 * lane + 3) * 32 + m);
+    float r = (q3 + q2) + (q1 + q0);                                  // row_shr:4, row_shr:8
+    r += psg_dpp<0x111, 0xf>(0.f, r);                                 // row_bcast:15 / row_bcast:31 have the quad shape too:
+    r += psg_dpp<0x112, 0xf>(0.f, r);                                 // lane 4 w + 3 = (R3 + R2) + (R1 + R0) = chain wave w
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 4 * w + 3));
+    if (lane == 0) s_inv[m] = 1.0f / sqrtf(tot / (float)a.D + a.eps);
+  }
+  dl_barrier();
+  const int cols = nkb * 32;                                          // floats of the slice
+  const int c0 = kbA * 32;
+  const int pairs = cols >> 1;
+  for (int e = tid; e < a.M * pairs; e += PSG_DL_WAVES * 64) {
+    const int m = e / pairs, c = (e - m * pairs) * 2;
+    const float2 v = dl_ld2(a.resid + (int64_t)m * a.D + c0 + c);
+    const float2 g = *reinterpret_cast<const float2*>(gamma + c0 + c);
+    const float inv = s_inv[m];
+    *reinterpret_cast<float2*>(xs + m * xstride + c * 4) = make_float2(g.x * (v.x * inv), g.y * (v.y * inv));
+  }
+}
+
+// ---- attention unit (row, head) by four waves: decode_attn4_kernel<float> -----------------------------------------------
+struct DlAttnScratch {
+  float q[128];
+  float p[4][16];
+  float o[4][128];
+  float ml[4][2];
+  float snew[4];
+};
+
+__device__ __forceinline__ void dl_attn_round(const psg_dl_args& a, int unit, DlAttnScratch* sc) {
+  // unit < 0: this group of four waves has nothing to do in this round (it still meets the barriers)
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
+  const int heads = a.heads, hidden = a.D, ctx = a.ctx, rows = a.M;
+  const bool live0 = unit >= 0;
+  const int row = live0 ? unit / heads : 0, h = live0 ? unit % heads : 0;
+  const int pos = live0 ? a.tok_pos[row] : -1;
+  const bool live = pos >= 0;
+  const int64_t cbase = ((int64_t)(live ? a.tok_pair[row] : 0) * heads + h) * ctx * 128;
+  const float scale = 0.08838834764831845f;
+  const int kl = lane >> 2, part = lane & 3;
+  float4 t[8];
+  float av[16], cv[16];
+  auto load_kv = [&](int b0) {
+    const int j = b0 + 16 * wid + kl;
+    const float* kp = a.kc + cbase + (int64_t)(j < pos ? j : 0) * 128 + part * 32;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) t[d] = *reinterpret_cast<const float4*>(kp + d * 4);
+    const int kbase = b0 + 16 * wid;
+    const int nk = min(16, pos - kbase);
+    const float* vp = a.vc + cbase + (int64_t)(nk > 0 ? kbase : 0) * 128;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int uu = u < nk ? u : 0;
+      av[u] = vp[(int64_t)uu * 128 + lane];
+      cv[u] = vp[(int64_t)uu * 128 + lane + 64];
+    }
+  };
+  if (live) load_kv(0);
+  float vn1 = 0.f, vn2 = 0.f;
+  if (live && wid == 0) {
+    const int64_t base = (int64_t)row * 3 * hidden + h * 128;
+    const int64_t sl = (int64_t)rows * 3 * hidden;
+    const float cs = a.cos_tab[pos * 64 + lane], sn = a.sin_tab[pos * 64 + lane];
+    const int64_t idx[6] = {base + lane, base + lane + 64, base + hidden + lane, base + hidden + lane + 64,
+                            base + 2 * hidden + lane, base + 2 * hidden + lane + 64};
+    float x[6], tt[8][6];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int e = 0; e < 6; ++e) tt[s][e] = dl_ld1(a.qkv_part + (int64_t)s * sl + idx[e]);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) x[e] = tt[0][e];
+#pragma unroll
+    for (int s = 1; s < 8; ++s)
+#pragma unroll
+      for (int e = 0; e < 6; ++e) x[e] += tt[s][e];
+    const float q1 = x[0], q2 = x[1], k1 = x[2], k2 = x[3], v1 = x[4], v2 = x[5];
+    const float qa = q1 * cs - q2 * sn, qb = q2 * cs + q1 * sn;
+    const float ka = k1 * cs - k2 * sn, kb = k2 * cs + k1 * sn;
+    a.kc[cbase + (int64_t)pos * 128 + lane] = ka;
+    a.kc[cbase + (int64_t)pos * 128 + lane + 64] = kb;
+    a.vc[cbase + (int64_t)pos * 128 + lane] = v1;
+    a.vc[cbase + (int64_t)pos * 128 + lane + 64] = v2;
+    sc->q[lane] = qa;
+    sc->q[lane + 64] = qb;
+    const float sn_ = wave_sum(qa * ka + qb * kb) * scale;
+    if (lane == 0) sc->snew[0] = sn_;
+    vn1 = v1;
+    vn2 = v2;
+  }
+  __syncthreads();
+  float m_run = -INFINITY, l_run = 0.f, o1 = 0.f, o2 = 0.f;
+  if (live) {
+    for (int b0 = 0; b0 < pos; b0 += 64) {
+      if (b0 > 0) load_kv(b0);
+      const int j = b0 + 16 * wid + kl;
+      float s = -INFINITY;
+      {
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const float* qq = sc->q + part * 32 + d * 4;
+          acc = fmaf(qq[0], t[d].x, acc);
+          acc = fmaf(qq[1], t[d].y, acc);
+          acc = fmaf(qq[2], t[d].z, acc);
+          acc = fmaf(qq[3], t[d].w, acc);
+        }
+        acc = quad_sum(acc);
+        if (j < pos) s = acc * scale;
+      }
+      const float m_new = fmaxf(m_run, wave_max(s));
+      if (m_new == -INFINITY) continue;
+      const float alpha = expf(m_run - m_new);
+      const float pj = expf(s - m_new);
+      l_run = l_run * alpha + wave_sum(pj) * 0.25f;
+      o1 *= alpha;
+      o2 *= alpha;
+      if (part == 0) sc->p[wid][kl] = pj;
+      __builtin_amdgcn_wave_barrier();
+      const int nk = min(16, pos - (b0 + 16 * wid));
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float pv = u < nk ? sc->p[wid][u] : 0.f;
+        o1 = fmaf(pv, av[u], o1);
+        o2 = fmaf(pv, cv[u], o2);
+      }
+      __builtin_amdgcn_wave_barrier();
+      m_run = m_new;
+    }
+  }
+  sc->o[wid][lane] = o1;
+  sc->o[wid][lane + 64] = o2;
+  if (lane == 0) {
+    sc->ml[wid][0] = m_run;
+    sc->ml[wid][1] = l_run;
+  }
+  __syncthreads();
+  if (live && wid == 0) {
+    const float sn_ = sc->snew[0];
+    float m = sn_;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) m = fmaxf(m, sc->ml[w][0]);
+    float e_new = expf(sn_ - m);
+    float l = e_new, r1 = e_new * vn1, r2 = e_new * vn2;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = expf(sc->ml[w][0] - m);
+      l += f * sc->ml[w][1];
+      r1 = fmaf(f, sc->o[w][lane], r1);
+      r2 = fmaf(f, sc->o[w][lane + 64], r2);
+    }
+    const float inv = 1.0f / l;
+    dl_st1(a.att + (int64_t)row * hidden + h * 128 + lane, r1 * inv);
+    dl_st1(a.att + (int64_t)row * hidden + h * 128 + lane + 64, r2 * inv);
+  }
+  __syncthreads();                                                  // scratch free for the next round
+}
+
+template <int SLOTS, int G16, int G4>
+__global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(const psg_dl_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Gemm = DlGemm<SLOTS, G16, G4>;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int M = a.M, D = a.D, I = a.I;
+  unsigned char* const xs = smem + PSG_DL_WAVES * SLOTS * DL_BLOCK + Gemm::MP * Gemm::OT_PITCH * 4;
+  float* const s_inv = reinterpret_cast<float*>(smem + PSG_DL_WAVES * SLOTS * DL_BLOCK);   // the tile area, free between phases
+  unsigned* const cnt = a.cnt;
+
+  // ---- q|k|v: S = 8, G = 32: column group gx = head h (slabs h, 32 + h, 64 + h) -------------------------------------
+  Gemm g;
+  g.setup(a.wqkv, 3 * D, D, 8, b & 7, b >> 3, M, smem);
+  g.prefetch();
+  dl_norm_owner(a, a.delta, a.dsplits, a.ssq, b);
+  dl_arrive(cnt + PSG_DL_CNT_X1 + (b & 7));
+  dl_wait(cnt, PSG_DL_CNT_X1, 8, 32u);
+  dl_norm_stage(a, a.ssq, a.ln1, g.kbA, g.nkb, g.xstride, xs, s_inv);
+  dl_barrier();
+  g.run(a.qkv_part, smem, xs);
+  // the o projection's first blocks (slab b >> 3, K slice b & 7) while the attention runs
+  Gemm go;
+  go.setup(a.wo, D, D, 8, b & 7, b >> 3, M, smem);
+  dl_drain();                                                       // this wave's partial-tile stores are out
+  go.prefetch();                                                    // its own ring is free: the next stream starts now
+  dl_publish(cnt + PSG_DL_CNT_HEAD + (b >> 3));
+
+  // ---- attention: units (row, head) dealt to workgroups, two at a time (four waves each) ------------------------------
+  {
+    DlAttnScratch* sc = reinterpret_cast<DlAttnScratch*>(xs) + (wid >> 2);
+    const int nunit = M * a.heads;                                    // even: unit u = row * heads + head
+    for (int u0 = 2 * b; u0 < nunit; u0 += 2 * PSG_DL_WG) {
+      const int h0 = u0 % a.heads;                                    // even; the round's units are heads h0, h0 + 1 of one row
+      dl_wait(cnt, PSG_DL_CNT_HEAD + h0, 2, 8u);                      // each head's 8 producers (K slices)
+      dl_attn_round(a, u0 + (wid >> 2), sc);
+      dl_drain();
+      dl_barrier();
+      if (tid == 0) __hip_atomic_fetch_add(cnt + PSG_DL_CNT_ATT + (h0 >> 2), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  // ---- o projection: K slice by = heads 4 by .. 4 by + 3 -----------------------------------------------------------------
+  dl_wait(cnt, PSG_DL_CNT_ATT + (b & 7), 1, (unsigned)(4 * M));
+  go.stage_x_dma(a.att, D, xs);
+  dl_drain();
+  dl_barrier();
+  go.run(a.o_part, smem, xs);
+  Gemm gg;
+  gg.setup(a.wgu, 2 * I, D, 8, b & 7, b >> 3, M, smem);
+  dl_drain();
+  gg.prefetch();
+  dl_publish(cnt + PSG_DL_CNT_OSLAB + (b >> 3));
+
+  // ---- post-attention RMSNorm: owner b's 16 columns lie in o slab b >> 3 ---------------------------------------------------
+  dl_wait(cnt, PSG_DL_CNT_OSLAB + (b >> 3), 1, 8u);
+  dl_norm_owner(a, a.o_part, 8, a.ssq + 256 * 32, b);
+  dl_arrive(cnt + PSG_DL_CNT_X2 + (b & 7));
+  dl_wait(cnt, PSG_DL_CNT_X2, 8, 32u);
+  dl_norm_stage(a, a.ssq + 256 * 32, a.ln2, gg.kbA, gg.nkb, gg.xstride, xs, s_inv);
+  dl_barrier();
+  gg.run(a.gu_part, smem, xs);
+  Gemm gd;
+  gd.setup(a.wdown, D, I, 16, b & 15, b >> 4, M, smem);
+  dl_drain();
+  gd.prefetch();
+  dl_publish(cnt + PSG_DL_CNT_GU + (b >> 3));
+
+  // ---- SwiGLU: items (row, 128-column block) dealt to waves; silu_mul_kernel<float>'s arithmetic ---------------------------
+  {
+    const int nblk = I >> 7;                                          // gate block j: slab j, up block j: slab nblk + j
+    const int nitem = M * nblk;
+    const int64_t sl = (int64_t)M * 2 * I;
+    for (int it0 = b * PSG_DL_WAVES; it0 < nitem; it0 += PSG_DL_WG * PSG_DL_WAVES) {
+      const int it = it0 + wid;
+      const bool liv = it < nitem;
+      const int m = liv ? it / nblk : 0, j = liv ? it - m * nblk : 0;
+      // the producers of the round's blocks: column groups (slab % 32) of gate and up
+      if (tid < 64) {
+        const int itl = it0 + (lane & 7);
+        const int jl = itl < nitem ? itl % nblk : 0;
+        const int grp = (lane & 8) ? (nblk + jl) & 31 : jl & 31;
+        unsigned spins = 0;
+        for (;;) {
+          const bool ok = lane >= 16 || __hip_atomic_load(cnt + PSG_DL_CNT_GU + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 8u;
+          if (__all(ok)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 21)) {
+            if (lane == 0) __hip_atomic_store(cnt + PSG_DL_TIMEOUT, 0x5147u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      dl_barrier();
+      if (liv) {
+        const int c = j * 128 + 2 * lane;
+        const int64_t ig = (int64_t)m * 2 * I + c, iu = ig + I;
+        float2 tg[8], tu[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          tg[s] = dl_ld2(a.gu_part + (int64_t)s * sl + ig);
+          tu[s] = dl_ld2(a.gu_part + (int64_t)s * sl + iu);
+        }
+        float2 gsum = tg[0], usum = tu[0];
+#pragma unroll
+        for (int s = 1; s < 8; ++s) { gsum.x += tg[s].x; gsum.y += tg[s].y; usum.x += tu[s].x; usum.y += tu[s].y; }
+        const float s0 = gsum.x / (1.0f + expf(-gsum.x)), s1 = gsum.y / (1.0f + expf(-gsum.y));
+        dl_st2(a.h + (int64_t)m * I + c, s0 * usum.x, s1 * usum.y);
+        dl_drain();
+        if (lane == 0) __hip_atomic_fetch_add(cnt + PSG_DL_CNT_H + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+
+  // ---- down projection: S = 16, G = 16; K slice by: blocks of 128 columns [kbA / 4, (kbB + 3) / 4) --------------------------
+  {
+    const int j0 = gd.kbA >> 2, j1 = (gd.kbA + gd.nkb + 3) >> 2;
+    dl_wait(cnt, PSG_DL_CNT_H + j0, j1 - j0, (unsigned)M);
+  }
+  gd.stage_x_dma(a.h, I, xs);
+  dl_drain();
+  dl_barrier();
+  gd.run(a.down_part, smem, xs);
+}
+
+static size_t dl_lds(int M, int slots, int mp) {
+  const size_t xmax = (size_t)M * (22 * 128 + DL_XPAD);               // the down projection's slice (K = 11008, S = 16)
+  const size_t attn = 2 * sizeof(DlAttnScratch);
+  return (size_t)PSG_DL_WAVES * slots * DL_BLOCK + (size_t)mp * (PSG_DL_WAVES * 16 + 4) * 4 + (xmax > attn ? xmax : attn);
+}
+
+extern "C" int psg_decode_layer_workspace(psg_ctx* ctx, int M, int hidden, int inter, int64_t* floats, int64_t* counters) {
+  PSG_REQUIRE(ctx && floats && counters, PSG_ERR_INVALID, "psg_decode_layer_workspace: NULL argument");
+  PSG_REQUIRE(M >= 1 && M <= 32, PSG_ERR_UNSUPPORTED, "psg_decode_layer: M=%d (1..32 rows)", M);
+  // qkv_part 8 M 3D | att M D | o_part 8 M D | ssq 2*256*32 | gu_part 8 M 2I | h M I   (down_part is the caller's output)
+  *floats = (int64_t)8 * M * 3 * hidden + (int64_t)M * hidden + (int64_t)8 * M * hidden + 2 * 256 * 32 +
+            (int64_t)8 * M * 2 * inter + (int64_t)M * inter;
+  *counters = PSG_DL_NCNT;
+  return PSG_OK;
+}
+
+extern "C" int psg_decode_layer_supported(psg_ctx* ctx, int M, int hidden, int inter, int heads, int dtype) {
+  if (!ctx) return 0;
+  const int KBd = inter >> 5;
+  return dtype == PSG_F32 && ctx->num_cu == PSG_DL_WG && M >= 13 && M <= 32 && hidden == 4096 && heads == 32 &&
+         inter % 128 == 0 && inter / 128 <= PSG_DL_TIMEOUT - PSG_DL_CNT_H && (KBd + 15) / 16 <= 22 && inter >= 2048;
+}
+
+// resid [M][hidden] fp32 in/out; delta = the previous layer's down partials (delta_splits slices, or NULL);
+// down_part [16][M][hidden] out; workspace / counters as psg_decode_layer_workspace (counters zeroed by the caller).
+extern "C" int psg_decode_layer(psg_ctx* ctx, void* resid, const void* delta, int delta_splits, const float* ln1,
+                                const float* ln2, const void* wqkv, const void* wo, const void* wgu, const void* wdown,
+                                const int32_t* tok_pair, const int32_t* tok_pos, const float* rope_cos,
+                                const float* rope_sin, int M, int hidden, int inter, int heads, int ctx_len, float eps,
+                                void* k_cache, void* v_cache, float* workspace, uint32_t* counters, float* down_part,
+                                int dtype, void* stream) {
+  PSG_REQUIRE(ctx && resid && ln1 && ln2 && wqkv && wo && wgu && wdown && tok_pair && tok_pos && rope_cos && rope_sin &&
+                  k_cache && v_cache && workspace && counters && down_part,
+              PSG_ERR_INVALID, "psg_decode_layer: NULL argument");
+  PSG_REQUIRE(psg_decode_layer_supported(ctx, M, hidden, inter, heads, dtype), PSG_ERR_UNSUPPORTED,
+              "psg_decode_layer: M=%d hidden=%d inter=%d heads=%d dtype=%d on %d CUs (fp32, 13..32 rows, 4096 = 32 x 128, "
+              "256 CUs)", M, hidden, inter, heads, dtype, ctx->num_cu);
+  PSG_REQUIRE(delta_splits >= 0 && delta_splits <= PSG_MAX_SPLITS && (delta || delta_splits == 0), PSG_ERR_INVALID,
+              "psg_decode_layer: delta_splits=%d", delta_splits);
+  psg_dl_args a;
+  a.resid = (float*)resid;
+  a.delta = delta_splits > 0 ? (const float*)delta : nullptr;
+  a.dsplits = delta_splits;
+  a.ln1 = ln1; a.ln2 = ln2;
+  a.wqkv = (const float*)wqkv; a.wo = (const float*)wo; a.wgu = (const float*)wgu; a.wdown = (const float*)wdown;
+  a.tok_pair = tok_pair; a.tok_pos = tok_pos; a.cos_tab = rope_cos; a.sin_tab = rope_sin;
+  a.kc = (float*)k_cache; a.vc = (float*)v_cache;
+  float* w = workspace;
+  a.qkv_part = w; w += (size_t)8 * M * 3 * hidden;
+  a.att = w; w += (size_t)M * hidden;
+  a.o_part = w; w += (size_t)8 * M * hidden;
+  a.ssq = w; w += 2 * 256 * 32;
+  a.gu_part = w; w += (size_t)8 * M * 2 * inter;
+  a.h = w;
+  a.down_part = down_part;
+  a.cnt = counters;
+  a.M = M; a.D = hidden; a.I = inter; a.heads = heads; a.ctx = ctx_len; a.eps = eps;
+  hipStream_t st = (hipStream_t)stream;
+  const int g16 = M <= 28 ? 1 : 2, g4 = (M <= 16 || M > 28) ? 0 : (M - 16 + 3) / 4;
+  const int mp = g16 * 16 + g4 * 4;
+  const int slots = dl_lds(M, 5, mp) <= 160 * 1024 ? 5 : 3;
+  const size_t lds = dl_lds(M, slots, mp);
+  PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_decode_layer: %zu B of LDS", lds);
+#define DL_K(SL, A, B)                                                                                      \
+  do {                                                                                                      \
+    (void)hipFuncSetAttribute((const void*)decode_layer_f32_kernel<SL, A, B>,                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
+    decode_layer_f32_kernel<SL, A, B><<<PSG_DL_WG, PSG_DL_WAVES * 64, lds, st>>>(a);                        \
+  } while (0)
+#define DL_L(A, B)              \
+  do {                          \
+    if (slots == 5) DL_K(5, A, B); \
+    else DL_K(3, A, B);         \
+  } while (0)
+  switch (g16 * 4 + g4) {
+    case 4: DL_L(1, 0); break;
+    case 5: DL_L(1, 1); break;
+    case 6: DL_L(1, 2); break;
+    case 7: DL_L(1, 3); break;
+    default: DL_L(2, 0); break;
+  }
+#undef DL_L
+#undef DL_K
+  PSG_CHECK_LAUNCH("psg_decode_layer");
+  return PSG_OK;
+}

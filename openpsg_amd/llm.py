@@ -86,6 +86,11 @@ class LlamaDecodeEngine:
         dev_i = self.device.index or 0
         self.fuse_rowops = frozenset({"rmsnorm"}) if _lib.get_option(dev_i, "llm_fuse_rmsnorm") else frozenset()
         self.prefill_attn_scalar = bool(_lib.get_option(dev_i, "prefill_attn_scalar"))
+        # decode steps as ONE persistent launch per layer (psg_decode_layer; fp32 engines at Llama-2-7B width on a 256-CU
+        # device, 13..32 rows): bit-identical to the launch chain, so every other shape - and the in-flight slots, since
+        # only one persistent launch may run on a device at a time - simply keeps the chain
+        self.persistent_layer = bool(_lib.get_option(dev_i, "decode_persistent"))
+        self._dl_ws = {}
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
         self.early_exit_chunk = 4        # natural-EOS decode: steps per graph between "all pairs done?" checks
         self.last_replays = 0
@@ -189,6 +194,32 @@ class LlamaDecodeEngine:
             ops.rmsnorm(resid, d, nxt, m.rms_eps, n)                           # resid += d ; n = norm(resid)
         return n
 
+    def _can_persist(self, rows, slot):
+        m = self.cfg.llm
+        return (self.persistent_layer and self.use_skinny and slot == 0 and self.dtype == torch.float32
+                and ops.decode_layer_supported(rows, m.hidden, m.inter, m.heads, self.dtype, self.device))
+
+    def _decode_step_persistent(self, st, counters):
+        """One decode step on psg_decode_layer: a launch per layer, the final RMSNorm and the lm_head as in the chain.
+        counters: int32 [layers * 256], zeroed."""
+        m = self.cfg.llm
+        x = st["x"]
+        K = x.shape[0]
+        ent = self._dl_ws.get(K)
+        if ent is None:
+            ws, ncnt = ops.decode_layer_workspace(K, m.hidden, m.inter, self.device)
+            ent = self._dl_ws[K] = (ws, ncnt, [torch.empty((16, K, m.hidden), device=self.device, dtype=torch.float32)
+                                               for _ in range(2)])
+        ws, ncnt, dparts = ent
+        delta = None
+        for l, L in enumerate(self.layers):
+            delta = ops.decode_layer(x, delta, L["ln1"], L["ln2"], L["wqkv"], L["wo"], L["wgu"], L["wdown"], st["dec_pair"],
+                                     st["dec_pos"], self.rope, m.heads, st["ctx_len"], m.rms_eps, st["kc"][l], st["vc"][l],
+                                     ws, counters[l * ncnt:(l + 1) * ncnt], dparts[l & 1])
+        n = torch.empty_like(x)
+        ops.rmsnorm(x, delta, self.final_norm, m.rms_eps, n)
+        return self.logits(n)
+
     def _can_fuse(self, rows):
         m = self.cfg.llm
         D = m.hidden
@@ -291,7 +322,7 @@ class LlamaDecodeEngine:
         the only host wait of an image in flight."""
         max_new = self.cfg.max_new_tokens if max_new_tokens is None else max_new_tokens
         if not self.use_graph:
-            outs = self._finish(self._generate_eager(X, prompt_len, max_new, suppress_eos, return_first_logits),
+            outs = self._finish(self._generate_eager(X, prompt_len, max_new, suppress_eos, return_first_logits, slot=slot),
                                 return_first_logits)
             return (lambda: outs) if defer else outs
         chunk = 0 if suppress_eos else int(self.early_exit_chunk)
@@ -309,7 +340,7 @@ class LlamaDecodeEngine:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                      # warm-up: lazy library init must not be captured
-                self._generate_eager(Xs, ps, max_new, suppress_eos, return_first_logits)
+                self._generate_eager(Xs, ps, max_new, suppress_eos, return_first_logits, slot=slot)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             bounds = [max_new] if chunk <= 0 else list(range(chunk, max_new, chunk)) + [max_new]
@@ -321,7 +352,7 @@ class LlamaDecodeEngine:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=graphs[0][0].pool() if graphs else None):
                     if st is None:
-                        st = self._prefill(Xs, ps, max_new, suppress_eos, return_first_logits)
+                        st = self._prefill(Xs, ps, max_new, suppress_eos, return_first_logits, slot=slot)
                         self._steps(st, 1, hi)
                     else:
                         self._steps(st, lo, hi)
@@ -366,12 +397,12 @@ class LlamaDecodeEngine:
     def _finish(outs, want_first):
         return outs if want_first else outs[0]
 
-    def _generate_eager(self, X, prompt_len, max_new, suppress_eos, return_first_logits):
-        st = self._prefill(X, prompt_len, max_new, suppress_eos, return_first_logits)
+    def _generate_eager(self, X, prompt_len, max_new, suppress_eos, return_first_logits, slot=0):
+        st = self._prefill(X, prompt_len, max_new, suppress_eos, return_first_logits, slot=slot)
         self._steps(st, 1, max_new)
         return st["tokens"], st["first_logits"]
 
-    def _prefill(self, X, prompt_len, max_new, suppress_eos, return_first_logits):
+    def _prefill(self, X, prompt_len, max_new, suppress_eos, return_first_logits, slot=0):
         """Prompt pass + first greedy token.  Returns the decode state (KV caches, token / flag buffers)."""
         m = self.cfg.llm
         K, maxlen, D = X.shape
@@ -403,17 +434,23 @@ class LlamaDecodeEngine:
         ops.greedy_step(logits, 0, max_new, m.eos, sup, tokens, done, next_ids, dec_pos,
                         dtype=torch.float32 if self.exact_argmax else self.dtype, embed=self.embed, x_out=x)
         return dict(kc=kc, vc=vc, ctx_len=ctx_len, tokens=tokens, done=done, next_ids=next_ids, dec_pos=dec_pos,
-                    dec_pair=dec_pair, sup=sup, x=x, max_new=max_new, first_logits=first_logits)
+                    dec_pair=dec_pair, sup=sup, x=x, max_new=max_new, first_logits=first_logits, slot=int(slot))
 
     def _steps(self, st, lo, hi):
         """Decode steps lo .. hi-1 (step s writes tokens[:, s])."""
         m = self.cfg.llm
-        fused = self._can_fuse(st["x"].shape[0]) and hi > lo
+        persist = hi > lo and self._can_persist(st["x"].shape[0], st.get("slot", 0))
+        fused = not persist and self._can_fuse(st["x"].shape[0]) and hi > lo
+        if persist:                                            # 256 counter words per layer launch, zeroed once per call
+            per_step = 256 * len(self.layers)
+            sync = torch.zeros((hi - lo) * per_step, device=self.device, dtype=torch.int32)
         if fused:                                              # two counter words per fused launch, zeroed once per call
             per_step = 2 * (4 * len(self.layers) + 1)
             sync = torch.zeros((hi - lo) * per_step, device=self.device, dtype=torch.int32)
         for step in range(lo, hi):
-            if fused:
+            if persist:
+                logits = self._decode_step_persistent(st, sync[(step - lo) * per_step:(step - lo + 1) * per_step])
+            elif fused:
                 logits = self._decode_step_fused(st, sync[(step - lo) * per_step:(step - lo + 1) * per_step])
             else:
                 h = self._forward(st["x"], st["dec_pair"], st["dec_pos"], st["kc"], st["vc"], st["ctx_len"], decode=True)

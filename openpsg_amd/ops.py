@@ -403,6 +403,47 @@ def decode_attn(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, k_cache,
     return out
 
 
+def decode_layer_supported(rows, hidden, inter, heads, dtype, device) -> bool:
+    """Does psg_decode_layer (one persistent launch per decoder layer of the decode step) take this shape?"""
+    if dtype not in _DT or not torch.device(device).type == "cuda":
+        return False
+    dev = torch.device(device)
+    lib, ctx = _lib.load(), _lib.ctx(dev.index or 0)
+    return bool(lib.psg_decode_layer_supported(ctx, int(rows), int(hidden), int(inter), int(heads), _DT[dtype]))
+
+
+def decode_layer_workspace(rows, hidden, inter, device):
+    """(workspace fp32 tensor, counter words per launch) of psg_decode_layer for `rows` decode rows."""
+    import ctypes
+    dev = torch.device(device)
+    lib, ctx = _lib.load(), _lib.ctx(dev.index or 0)
+    nf, nc = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib.psg_decode_layer_workspace(ctx, int(rows), int(hidden), int(inter), ctypes.byref(nf), ctypes.byref(nc)),
+          "psg_decode_layer_workspace")
+    return torch.empty(nf.value, device=dev, dtype=torch.float32), int(nc.value)
+
+
+def decode_layer(resid, delta, ln1, ln2, wqkv, wo, wgu, wdown, tok_pair, tok_pos, rope, heads, ctx_len, eps, k_cache,
+                 v_cache, workspace, counters, down_part) -> Partials:
+    """One decoder layer of the decode step in ONE persistent launch (psg_decode_layer), bit-identical to
+    rmsnorm -> skinny_gemm -> decode_attn -> skinny_gemm -> rmsnorm -> skinny_gemm -> silu_mul -> skinny_gemm.
+    resid [M, hidden] fp32 (updated in place); delta: the previous layer's down-projection Partials or None;
+    counters: int32 [>= 256], ZERO; down_part fp32 [16, M, hidden] receives this layer's down partials (returned)."""
+    lib, ctx, st = _env(resid)
+    M, hidden = resid.shape
+    inter = wdown.shape[1]
+    assert wqkv.shape == (3 * hidden, hidden) and wo.shape == (hidden, hidden) and wgu.shape == (2 * inter, hidden)
+    assert down_part.shape == (16, M, hidden) and counters.dtype == torch.int32 and counters.numel() >= 256
+    dp, ds = (None, 0) if delta is None else _in(delta, resid.dtype)
+    check(lib.psg_decode_layer(ctx, _p(resid, torch.float32, "resid"), dp, ds, _p(ln1, torch.float32), _p(ln2, torch.float32),
+                               _p(wqkv, resid.dtype, "wqkv"), _p(wo, resid.dtype), _p(wgu, resid.dtype), _p(wdown, resid.dtype),
+                               _p(tok_pair, torch.int32), _p(tok_pos, torch.int32), _p(rope[0], torch.float32),
+                               _p(rope[1], torch.float32), M, hidden, inter, int(heads), int(ctx_len), float(eps),
+                               _p(k_cache, resid.dtype), _p(v_cache, resid.dtype), _p(workspace, torch.float32),
+                               _p(counters), _p(down_part, torch.float32), _dt(resid), st), "psg_decode_layer")
+    return Partials(down_part)
+
+
 def silu_mul(gate_up, out):
     lib, ctx, st = _env(out)
     rows, inter = out.shape

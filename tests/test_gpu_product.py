@@ -246,8 +246,8 @@ def test_submit_with_natural_eos_does_not_wait_for_the_decode():
     ins = [_inputs(s) for s in scenes]
     want = [head(i) for i in ins]
     assert all(len(wr["rel_pred"]) == 40 for wr in want)
-    for sl in (0, 1):                                                  # first use of a slot captures its graphs (synchronises)
-        assert head.submit(ins[2], slot=sl).result() == want[2]
+    for sl in (0, 1):                                                  # first use of a (slot, shape) captures its graphs (synchronises)
+        assert head.submit(ins[sl], slot=sl).result() == want[sl]
     torch.cuda.synchronize()
     # occupy the GPU on the caller's stream: the slot streams wait for it, so nothing submitted below can have finished
     # when submit returns - a submit that waits for its decode would take as long as this kernel chain
