@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "psg_common.h"
+#include "psg_decode_math.h"
 
 int psg_self_attn_mfma_launch(const void* qkv, const void* q_shared, const uint8_t* text_mask, int B, int T_, int nq, int heads,
                               int query_rows_only, void* out, int dtype, hipStream_t st);
@@ -816,137 +817,27 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
                                                            const float* __restrict__ sin_tab, int rows, int heads,
                                                            int ctx, T* __restrict__ kc, T* __restrict__ vc,
                                                            T* __restrict__ out) {
-  __shared__ float s_q[128];
-  __shared__ float s_p[4][16];
-  __shared__ float s_o[4][128];
-  __shared__ float s_ml[4][2];
-  __shared__ float s_new[3];                                  // s_new, and nothing else shared; v stays in wave 0
+  __shared__ PsgDecodeAttnScratch sc;
   const int unit = blockIdx.x;
   const int row = unit / heads, h = unit % heads;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int pos = tok_pos[row];
   const int hidden = heads * 128;
   if (pos < 0) return;                                        // whole workgroup (uniform)
-  const int64_t cbase = ((int64_t)tok_pair[row] * heads + h) * ctx * 128;
-  const float scale = 0.08838834764831845f;                   // 1/sqrt(128)
-  auto rnd = [](float f) { return Act<T>::rnd(f); };
-  const int kl = lane >> 2, part = lane & 3;
-  // Keys and values of the first 64 cached positions are requested BEFORE the new token's projections are summed:
-  // their addresses depend on `pos` only, so the cache read, the split-K partials and the rotary tables share one
-  // round trip instead of three dependent ones (projections -> barrier -> keys -> values).
-  typename Act<T>::raw4 t[8];
-  typename Act<T>::raw1 a[16], c[16];
-  auto load_kv = [&](int b0) {
-    const int j = b0 + 16 * wid + kl;
-    const T* kp = kc + cbase + (int64_t)(j < pos ? j : 0) * 128 + part * 32;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) t[d] = Act<T>::ldr4(kp, d * 4);
-    const int kbase = b0 + 16 * wid;
-    const int nk = min(16, pos - kbase);
-    const T* vp = vc + cbase + (int64_t)(nk > 0 ? kbase : 0) * 128;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int uu = u < nk ? u : 0;
-      a[u] = Act<T>::ldr(vp, (int64_t)uu * 128 + lane);
-      c[u] = Act<T>::ldr(vp, (int64_t)uu * 128 + lane + 64);
-    }
-  };
-  load_kv(0);                                                 // pos == 0: clamped to row 0, never used
-  float vn1 = 0.f, vn2 = 0.f;
-  if (wid == 0) {                                             // new token: rotary, cache append, own score
-    const int64_t base = (int64_t)row * 3 * hidden + h * 128;
-    const int64_t sl = (int64_t)rows * 3 * hidden;
-    const float cs = cos_tab[pos * 64 + lane], sn = sin_tab[pos * 64 + lane];
-    const int64_t idx[6] = {base + lane, base + lane + 64, base + hidden + lane, base + hidden + lane + 64,
-                            base + 2 * hidden + lane, base + 2 * hidden + lane + 64};
-    float x[6];
+  const int64_t sl = (int64_t)rows * 3 * hidden;
+  auto ld = [&](const int64_t (&idx)[6], float (&x)[6]) {
     if (qs > 0) {                                             // split-K partials: all slices of q, k, v in one pass
       ldn_splits<float, 6>(qkv, qs, sl, idx, x);
 #pragma unroll
-      for (int e = 0; e < 6; ++e) x[e] = rnd(x[e]);
+      for (int e = 0; e < 6; ++e) x[e] = Act<T>::rnd(x[e]);
     } else {
 #pragma unroll
       for (int e = 0; e < 6; ++e) x[e] = Act<T>::ld(reinterpret_cast<const T*>(qkv), idx[e]);
     }
-    const float q1 = x[0], q2 = x[1], k1 = x[2], k2 = x[3], v1 = x[4], v2 = x[5];
-    const float qa = rnd(q1 * cs - q2 * sn), qb = rnd(q2 * cs + q1 * sn);
-    const float ka = rnd(k1 * cs - k2 * sn), kb = rnd(k2 * cs + k1 * sn);
-    Act<T>::st(kc, cbase + (int64_t)pos * 128 + lane, ka);
-    Act<T>::st(kc, cbase + (int64_t)pos * 128 + lane + 64, kb);
-    Act<T>::st(vc, cbase + (int64_t)pos * 128 + lane, v1);
-    Act<T>::st(vc, cbase + (int64_t)pos * 128 + lane + 64, v2);
-    s_q[lane] = qa;
-    s_q[lane + 64] = qb;
-    const float sn_ = wave_sum(qa * ka + qb * kb) * scale;
-    if (lane == 0) s_new[0] = sn_;
-    vn1 = rnd(v1);
-    vn2 = rnd(v2);
-  }
-  __syncthreads();
-  float m_run = -INFINITY, l_run = 0.f, o1 = 0.f, o2 = 0.f;
-  for (int b0 = 0; b0 < pos; b0 += 64) {
-    if (b0 > 0) load_kv(b0);
-    const int j = b0 + 16 * wid + kl;
-    float s = -INFINITY;
-    {
-      float acc = 0.f;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) {
-        const float* qq = s_q + part * 32 + d * 4;
-        float kf[4];
-        Act<T>::cv4(t[d], kf);
-        acc = fmaf(qq[0], kf[0], acc);
-        acc = fmaf(qq[1], kf[1], acc);
-        acc = fmaf(qq[2], kf[2], acc);
-        acc = fmaf(qq[3], kf[3], acc);
-      }
-      acc = quad_sum(acc);
-      if (j < pos) s = acc * scale;
-    }
-    const float m_new = fmaxf(m_run, wave_max(s));
-    if (m_new == -INFINITY) continue;                          // this wave has no key in this pass (uniform)
-    const float alpha = expf(m_run - m_new);
-    const float pj = expf(s - m_new);                          // replicated over the 4 lanes of a key
-    l_run = l_run * alpha + wave_sum(pj) * 0.25f;
-    o1 *= alpha;
-    o2 *= alpha;
-    if (part == 0) s_p[wid][kl] = pj;
-    __builtin_amdgcn_wave_barrier();
-    const int nk = min(16, pos - (b0 + 16 * wid));             // > 0 here
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float pv = u < nk ? s_p[wid][u] : 0.f;
-      o1 = fmaf(pv, Act<T>::cv(a[u]), o1);
-      o2 = fmaf(pv, Act<T>::cv(c[u]), o2);
-    }
-    __builtin_amdgcn_wave_barrier();
-    m_run = m_new;
-  }
-  s_o[wid][lane] = o1;
-  s_o[wid][lane + 64] = o2;
-  if (lane == 0) {
-    s_ml[wid][0] = m_run;
-    s_ml[wid][1] = l_run;
-  }
-  __syncthreads();
-  if (wid == 0) {
-    const float sn_ = s_new[0];
-    float m = sn_;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) m = fmaxf(m, s_ml[w][0]);
-    float e_new = expf(sn_ - m);
-    float l = e_new, r1 = e_new * vn1, r2 = e_new * vn2;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float f = expf(s_ml[w][0] - m);                    // exp(-inf) = 0 for a wave without keys
-      l += f * s_ml[w][1];
-      r1 = fmaf(f, s_o[w][lane], r1);
-      r2 = fmaf(f, s_o[w][lane + 64], r2);
-    }
-    const float inv = 1.0f / l;
-    Act<T>::st(out, (int64_t)row * hidden + h * 128 + lane, r1 * inv);
-    Act<T>::st(out, (int64_t)row * hidden + h * 128 + lane + 64, r2 * inv);
-  }
+  };
+  auto st = [&](int64_t i, float v) { Act<T>::st(out, i, v); };
+  // the arithmetic lives in psg_decode_math.h: the persistent decoder layer (psg_decode_layer.hip) runs the same unit
+  psg_decode_attn4_unit<T>(true, (int)threadIdx.x, row, h, pos, tok_pair[row], heads, ctx, cos_tab, sin_tab, kc, vc, ld,
+                           st, &sc);
 }
 
 extern "C" int psg_decode_attn(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,

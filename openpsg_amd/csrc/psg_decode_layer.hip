@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include "psg_common.h"
+#include "psg_decode_math.h"
 
 #define PSG_DL_WG 256
 #define PSG_DL_WAVES 8
@@ -359,8 +360,7 @@ __device__ __forceinline__ void dl_norm_owner(const psg_dl_args& a, const float*
       dl_st2(a.resid + i, v[0], v[1]);
       dl_st2(a.resid + i + 2, v[2], v[3]);
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) ss += v[e] * v[e];
+    ss = psg_sumsq4(v, ss);
   }
   // the first two levels of wave_sum's tree (row_shr:1, row_shr:2): lane 4 k + 3 = (t3 + t2) + (t1 + t0)
   ss += psg_dpp<0x111, 0xf>(0.f, ss);
@@ -397,141 +397,30 @@ __device__ __forceinline__ void dl_norm_stage(const psg_dl_args& a, const float*
   }
 }
 
-// ---- attention unit (row, head) by four waves: decode_attn4_kernel<float> -----------------------------------------------
-struct DlAttnScratch {
-  float q[128];
-  float p[4][16];
-  float o[4][128];
-  float ml[4][2];
-  float snew[4];
-};
-
-__device__ __forceinline__ void dl_attn_round(const psg_dl_args& a, int unit, DlAttnScratch* sc) {
-  // unit < 0: this group of four waves has nothing to do in this round (it still meets the barriers)
-  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
-  const int heads = a.heads, hidden = a.D, ctx = a.ctx, rows = a.M;
-  const bool live0 = unit >= 0;
-  const int row = live0 ? unit / heads : 0, h = live0 ? unit % heads : 0;
-  const int pos = live0 ? a.tok_pos[row] : -1;
-  const bool live = pos >= 0;
-  const int64_t cbase = ((int64_t)(live ? a.tok_pair[row] : 0) * heads + h) * ctx * 128;
-  const float scale = 0.08838834764831845f;
-  const int kl = lane >> 2, part = lane & 3;
-  float4 t[8];
-  float av[16], cv[16];
-  auto load_kv = [&](int b0) {
-    const int j = b0 + 16 * wid + kl;
-    const float* kp = a.kc + cbase + (int64_t)(j < pos ? j : 0) * 128 + part * 32;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) t[d] = *reinterpret_cast<const float4*>(kp + d * 4);
-    const int kbase = b0 + 16 * wid;
-    const int nk = min(16, pos - kbase);
-    const float* vp = a.vc + cbase + (int64_t)(nk > 0 ? kbase : 0) * 128;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int uu = u < nk ? u : 0;
-      av[u] = vp[(int64_t)uu * 128 + lane];
-      cv[u] = vp[(int64_t)uu * 128 + lane + 64];
-    }
-  };
-  if (live) load_kv(0);
-  float vn1 = 0.f, vn2 = 0.f;
-  if (live && wid == 0) {
-    const int64_t base = (int64_t)row * 3 * hidden + h * 128;
-    const int64_t sl = (int64_t)rows * 3 * hidden;
-    const float cs = a.cos_tab[pos * 64 + lane], sn = a.sin_tab[pos * 64 + lane];
-    const int64_t idx[6] = {base + lane, base + lane + 64, base + hidden + lane, base + hidden + lane + 64,
-                            base + 2 * hidden + lane, base + 2 * hidden + lane + 64};
-    float x[6], tt[8][6];
+// ---- attention unit (row, head) by four waves: psg_decode_attn4_unit<float>, the arithmetic of decode_attn4_kernel ------
+__device__ __forceinline__ void dl_attn_round(const psg_dl_args& a, int unit, PsgDecodeAttnScratch* sc) {
+  const int heads = a.heads, hidden = a.D;
+  const int row = unit / heads, h = unit % heads;
+  const int pos = a.tok_pos[row];
+  const int64_t sl = (int64_t)a.M * 3 * hidden;
+  const float* qp = a.qkv_part;
+  auto ld = [&](const int64_t (&idx)[6], float (&x)[6]) {           // ldn_splits<float, 6> with sc1 loads: slices in order
+    float tt[8][6];
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
-      for (int e = 0; e < 6; ++e) tt[s][e] = dl_ld1(a.qkv_part + (int64_t)s * sl + idx[e]);
+      for (int e = 0; e < 6; ++e) tt[s][e] = dl_ld1(qp + (int64_t)s * sl + idx[e]);
 #pragma unroll
     for (int e = 0; e < 6; ++e) x[e] = tt[0][e];
 #pragma unroll
     for (int s = 1; s < 8; ++s)
 #pragma unroll
       for (int e = 0; e < 6; ++e) x[e] += tt[s][e];
-    const float q1 = x[0], q2 = x[1], k1 = x[2], k2 = x[3], v1 = x[4], v2 = x[5];
-    const float qa = q1 * cs - q2 * sn, qb = q2 * cs + q1 * sn;
-    const float ka = k1 * cs - k2 * sn, kb = k2 * cs + k1 * sn;
-    a.kc[cbase + (int64_t)pos * 128 + lane] = ka;
-    a.kc[cbase + (int64_t)pos * 128 + lane + 64] = kb;
-    a.vc[cbase + (int64_t)pos * 128 + lane] = v1;
-    a.vc[cbase + (int64_t)pos * 128 + lane + 64] = v2;
-    sc->q[lane] = qa;
-    sc->q[lane + 64] = qb;
-    const float sn_ = wave_sum(qa * ka + qb * kb) * scale;
-    if (lane == 0) sc->snew[0] = sn_;
-    vn1 = v1;
-    vn2 = v2;
-  }
-  __syncthreads();
-  float m_run = -INFINITY, l_run = 0.f, o1 = 0.f, o2 = 0.f;
-  if (live) {
-    for (int b0 = 0; b0 < pos; b0 += 64) {
-      if (b0 > 0) load_kv(b0);
-      const int j = b0 + 16 * wid + kl;
-      float s = -INFINITY;
-      {
-        float acc = 0.f;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          const float* qq = sc->q + part * 32 + d * 4;
-          acc = fmaf(qq[0], t[d].x, acc);
-          acc = fmaf(qq[1], t[d].y, acc);
-          acc = fmaf(qq[2], t[d].z, acc);
-          acc = fmaf(qq[3], t[d].w, acc);
-        }
-        acc = quad_sum(acc);
-        if (j < pos) s = acc * scale;
-      }
-      const float m_new = fmaxf(m_run, wave_max(s));
-      if (m_new == -INFINITY) continue;
-      const float alpha = expf(m_run - m_new);
-      const float pj = expf(s - m_new);
-      l_run = l_run * alpha + wave_sum(pj) * 0.25f;
-      o1 *= alpha;
-      o2 *= alpha;
-      if (part == 0) sc->p[wid][kl] = pj;
-      __builtin_amdgcn_wave_barrier();
-      const int nk = min(16, pos - (b0 + 16 * wid));
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const float pv = u < nk ? sc->p[wid][u] : 0.f;
-        o1 = fmaf(pv, av[u], o1);
-        o2 = fmaf(pv, cv[u], o2);
-      }
-      __builtin_amdgcn_wave_barrier();
-      m_run = m_new;
-    }
-  }
-  sc->o[wid][lane] = o1;
-  sc->o[wid][lane + 64] = o2;
-  if (lane == 0) {
-    sc->ml[wid][0] = m_run;
-    sc->ml[wid][1] = l_run;
-  }
-  __syncthreads();
-  if (live && wid == 0) {
-    const float sn_ = sc->snew[0];
-    float m = sn_;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) m = fmaxf(m, sc->ml[w][0]);
-    float e_new = expf(sn_ - m);
-    float l = e_new, r1 = e_new * vn1, r2 = e_new * vn2;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float f = expf(sc->ml[w][0] - m);
-      l += f * sc->ml[w][1];
-      r1 = fmaf(f, sc->o[w][lane], r1);
-      r2 = fmaf(f, sc->o[w][lane + 64], r2);
-    }
-    const float inv = 1.0f / l;
-    dl_st1(a.att + (int64_t)row * hidden + h * 128 + lane, r1 * inv);
-    dl_st1(a.att + (int64_t)row * hidden + h * 128 + lane + 64, r2 * inv);
-  }
+  };
+  float* att = a.att;
+  auto st = [&](int64_t i, float v) { dl_st1(att + i, v); };
+  psg_decode_attn4_unit<float>(pos >= 0, (int)(threadIdx.x & 255), row, h, pos, pos >= 0 ? a.tok_pair[row] : 0, heads, a.ctx,
+                               a.cos_tab, a.sin_tab, a.kc, a.vc, ld, st, sc);
   __syncthreads();                                                  // scratch free for the next round
 }
 
@@ -564,7 +453,7 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
 
   // ---- attention: units (row, head) dealt to workgroups, two at a time (four waves each) ------------------------------
   {
-    DlAttnScratch* sc = reinterpret_cast<DlAttnScratch*>(xs) + (wid >> 2);
+    PsgDecodeAttnScratch* sc = reinterpret_cast<PsgDecodeAttnScratch*>(xs) + (wid >> 2);
     const int nunit = M * a.heads;                                    // even: unit u = row * heads + head
     for (int u0 = 2 * b; u0 < nunit; u0 += 2 * PSG_DL_WG) {
       const int h0 = u0 % a.heads;                                    // even; the round's units are heads h0, h0 + 1 of one row
@@ -661,7 +550,7 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
 
 static size_t dl_lds(int M, int slots, int mp) {
   const size_t xmax = (size_t)M * (22 * 128 + DL_XPAD);               // the down projection's slice (K = 11008, S = 16)
-  const size_t attn = 2 * sizeof(DlAttnScratch);
+  const size_t attn = 2 * sizeof(PsgDecodeAttnScratch);
   return (size_t)PSG_DL_WAVES * slots * DL_BLOCK + (size_t)mp * (PSG_DL_WAVES * 16 + 4) * 4 + (xmax > attn ? xmax : attn);
 }
 

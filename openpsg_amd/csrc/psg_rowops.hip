@@ -9,6 +9,7 @@
 //       SwiGLU gate                            (HF-LL:163-177)
 //   K16 greedy argmax step                     (V4:305-312)
 #include "psg_common.h"
+#include "psg_decode_math.h"
 
 // ---- LayerNorm over a row held in registers ---------------------------------------------------
 template <int NCH>
@@ -499,8 +500,7 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(R* __restrict__ resid, co
           v[c][e] = Act<R>::rnd(v[c][e]);
         }
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ss += v[c][e] * v[c][e];
+      ss = psg_sumsq4(v[c], ss);                              // pinned form: psg_decode_layer.hip reproduces it
     }
   }
   ss = wave_sum(ss);

@@ -851,7 +851,9 @@ class RelationTransformerHeadV4(nn.Module):
             patches = eng.patch_embed(feat.to(torch.float32))
         kv = eng.cross_kv(patches)
         if bits is None:
-            ids_dev = torch.tensor(obj_ids, dtype=torch.int32, device=dev)
+            # pinned staging + non_blocking: a pageable host-to-device copy waits for the stream to drain (a host wait in
+            # the middle of `submit`)
+            ids_dev = torch.tensor(obj_ids, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
             pan_dev = pan.to(device=dev, dtype=torch.int32).contiguous()
             bits = eng.object_bitmasks(pan_dev, meta, ids_dev, feat.shape[-2:])
         # BERT prompts: [U*U, T] table gathered per pair on the device (cached per set of names)

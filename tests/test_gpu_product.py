@@ -237,34 +237,36 @@ def test_submit_keeps_the_callers_temporaries_alive_until_they_are_read():
 
 
 def test_submit_with_natural_eos_does_not_wait_for_the_decode():
-    """Natural EOS (the product default): `submit` enqueues the prompt pass and the first chunk of steps and returns; the
-    all-done read-backs happen in `result()`.  Checked with an event recorded on the slot stream after `submit`: it has
-    not completed when `submit` returns (a stream busy with a long kernel in front), and results equal `forward`'s."""
+    """Natural EOS (the product default): `submit` enqueues the prompt pass and the first chunk of decode steps and
+    returns without reading the all-done flag back; the remaining chunks and their read-backs run in `result()`.
+    Results equal `forward`'s, image by image, with two images in flight."""
     from openpsg_amd.synthetic import make_scene
     head, tok, chain = _rigged_head("bf16")
     scenes = [make_scene((512, 512), 10, seed=5 + m) for m in range(3)]
     ins = [_inputs(s) for s in scenes]
     want = [head(i) for i in ins]
     assert all(len(wr["rel_pred"]) == 40 for wr in want)
-    for sl in (0, 1):                                                  # first use of a (slot, shape) captures its graphs (synchronises)
-        assert head.submit(ins[sl], slot=sl).result() == want[sl]
-    torch.cuda.synchronize()
-    # occupy the GPU on the caller's stream: the slot streams wait for it, so nothing submitted below can have finished
-    # when submit returns - a submit that waits for its decode would take as long as this kernel chain
-    a = torch.randn(8192, 8192, device="cuda:0")
-    t0 = torch.cuda.Event(enable_timing=True)
-    t0.record()
-    for _ in range(40):
-        a = (a @ a).clamp_(-1, 1)
-    busy = torch.cuda.Event()
-    busy.record()
-    import time
-    h0 = time.perf_counter()
-    p0 = head.submit(ins[0], slot=0)
-    p1 = head.submit(ins[1], slot=1)
-    host = time.perf_counter() - h0
-    assert not busy.query(), "the GPU was idle already: the probe kernel chain is too short for this box"
-    r0, r1 = p0.result(), p1.result()
-    assert r0 == want[0] and r1 == want[1]
-    assert host < 0.5, f"two submits took {host:.2f} s of host time"
-    assert head.llm_engine.last_replays <= 3                        # prompt pass, first chunk (+ at most one more)
+    eng = head.llm_engine
+    calls = []
+    orig = torch.Tensor.item
+
+    def spy(self_):
+        calls.append(1)
+        return orig(self_)
+    pending = []
+    for k in range(6):
+        torch.Tensor.item = spy
+        try:
+            n0 = len(calls)
+            p = head.submit(ins[k % 3], slot=k % 2)
+            assert len(calls) == n0, "submit read a device scalar back (a host wait)"
+        finally:
+            torch.Tensor.item = orig
+        assert "_finish" in p.out and eng.last_replays == 2          # prompt pass + first token | first chunk of steps
+        pending.append((k % 3, p))
+        if len(pending) > 1:
+            j, q = pending.pop(0)
+            assert q.result() == want[j]
+    j, q = pending.pop(0)
+    assert q.result() == want[j]
+    assert eng.last_replays <= 3                                    # the chain ends at the first all-EOS check
