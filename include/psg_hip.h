@@ -79,8 +79,9 @@ int psg_get_option(psg_ctx* ctx, const char* name, int* value);
 
 /* Debugging aid: per-wave cycle-counter stamps of the next launches of one kernel family are written to a
  * CALLER-PROVIDED device buffer (the library does not allocate, copy or synchronise; a buffer too small for a
- * launch is simply not written).  PSG_TRACE_SKINNY_GEMM: 8 int64 per wave; PSG_TRACE_CROSS_ATTN: 32 per wave. */
-enum psg_trace_kind { PSG_TRACE_NONE = 0, PSG_TRACE_SKINNY_GEMM = 1, PSG_TRACE_CROSS_ATTN = 2 };
+ * launch is simply not written).  PSG_TRACE_SKINNY_GEMM: 8 int64 per wave; PSG_TRACE_CROSS_ATTN: 32 per wave;
+ * PSG_TRACE_DECODE_LAYER: 24 per workgroup of psg_decode_layer (100 MHz wall-clock stamps at its phase boundaries). */
+enum psg_trace_kind { PSG_TRACE_NONE = 0, PSG_TRACE_SKINNY_GEMM = 1, PSG_TRACE_CROSS_ATTN = 2, PSG_TRACE_DECODE_LAYER = 3 };
 int psg_set_trace_buffer(psg_ctx* ctx, int kind, void* device_buffer, int64_t bytes);
 
 /* ---- A4 / K1: patch embedding, V4:410 (timm PatchEmbed = Conv2d(C, Cout, 16, 16) + flatten(2).transpose(1,2)):
@@ -325,7 +326,7 @@ int psg_skinny_gemm_fused(psg_ctx*, const psg_prologue* pro, void* x, const void
  * hidden = 4096 = 32 heads x 128, inter % 128 == 0, 13..32 rows, a 256-CU device: psg_decode_layer_supported() says
  * whether a shape qualifies (else keep the chain).  workspace: psg_decode_layer_workspace() floats, contents
  * irrelevant; counters: that many uint32 words ZEROED by the caller before every launch (one block per launch inside a
- * captured graph); word [255] != 0 afterwards = a bounded poll gave up.  At most ONE of these launches may run on a
+ * captured graph); word [255 * 64] != 0 afterwards = a bounded poll gave up.  At most ONE of these launches may run on a
  * device at a time (every workgroup must be resident). */
 int psg_decode_layer_workspace(psg_ctx*, int M, int hidden, int inter, int64_t* floats, int64_t* counters);
 int psg_decode_layer_supported(psg_ctx*, int M, int hidden, int inter, int heads, int dtype);

@@ -15,7 +15,7 @@ PSG_ABI_VERSION = 500            # include/psg_hip.h; checked against psg_versio
 PSG_F32, PSG_BF16, PSG_F16 = 0, 1, 2
 PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED = 0, 1
 PSG_XATTN_MFMA, PSG_XATTN_SIMPLE, PSG_XATTN_MFMA_V1 = 0, 1, 2
-PSG_TRACE_NONE, PSG_TRACE_SKINNY_GEMM, PSG_TRACE_CROSS_ATTN = 0, 1, 2
+PSG_TRACE_NONE, PSG_TRACE_SKINNY_GEMM, PSG_TRACE_CROSS_ATTN, PSG_TRACE_DECODE_LAYER = 0, 1, 2, 3
 
 
 class PsgHipError(RuntimeError):

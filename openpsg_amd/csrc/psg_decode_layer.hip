@@ -38,16 +38,20 @@
 #include "psg_decode_math.h"
 
 #define PSG_DL_WG 256
-#define PSG_DL_WAVES 8
-#define PSG_DL_CNT_X1 0        // 8 words (one per b % 8): owners of layer-input columns, 32 arrivals each
-#define PSG_DL_CNT_HEAD 8      // 32: q|k|v column group gx done for K slice by, 8 arrivals each
-#define PSG_DL_CNT_ATT 40      // 8: attention units of heads 4 g .. 4 g + 3 stored, 4 * M arrivals each
-#define PSG_DL_CNT_OSLAB 48    // 32: o-projection slab done for K slice by, 8 arrivals each
-#define PSG_DL_CNT_X2 80       // 8: owners of post-attention columns, 32 arrivals each
-#define PSG_DL_CNT_GU 88       // 32: gate|up column group gx done for K slice by, 8 arrivals each
-#define PSG_DL_CNT_H 120       // inter / 128 words: SwiGLU block j stored, M arrivals each
+#define PSG_DL_WAVES 12      // waves per workgroup; a projection streams with W <= 12 of them (its slab = 16 W rows)
+// Arrival counters: every counter has a 256-byte slot of its own (PSG_DL_SLOT words apart) - counters sharing a cache
+// line share one memory channel, which serialises its atomics and polls at ~90 per us (1720 SwiGLU arrivals on three
+// lines cost 20 us).  Slot numbers:
+#define PSG_DL_CNT_X1 0        // 8 (b % 8: 32 arrivals each) + 1 top (8 arrivals) + 8 go flags: layer-input columns reduced
+#define PSG_DL_CNT_HEAD 17     // 32: q|k|v column group gx done for K slice by, 8 arrivals each
+#define PSG_DL_CNT_ATT 49      // 8: attention units of heads 4 g .. 4 g + 3 stored, 4 * M arrivals each
+#define PSG_DL_CNT_OSLAB 57    // 32: o-projection slab done for K slice by, 8 arrivals each
+#define PSG_DL_CNT_X2 89       // 8 + 1 + 8 as X1: post-attention columns reduced
+#define PSG_DL_CNT_GU 106      // 32: gate|up column group gx done for K slice by, 8 arrivals each
+#define PSG_DL_CNT_H 138       // inter / 128 slots: SwiGLU block j stored, M arrivals each
 #define PSG_DL_TIMEOUT 255
-#define PSG_DL_NCNT 256
+#define PSG_DL_SLOT 64         // words per slot
+#define PSG_DL_NCNT (256 * PSG_DL_SLOT)
 
 typedef float df32x4_t __attribute__((ext_vector_type(4)));
 typedef float df32x16_t __attribute__((ext_vector_type(16)));
@@ -77,6 +81,7 @@ struct psg_dl_args {
   float* h;                   // [M][I]
   float* down_part;           // [16][M][D]   (output: the next layer's delta)
   unsigned* cnt;              // [PSG_DL_NCNT], zeroed
+  long long* trace;           // psg_set_trace_buffer(PSG_TRACE_DECODE_LAYER): 24 wall-clock stamps per workgroup, or NULL
   int M, D, I, heads, ctx;
   float eps;
 };
@@ -100,32 +105,48 @@ __device__ __forceinline__ void dl_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ void dl_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // publish: every wave has drained its stores (dl_drain) BEFORE it comes here; ONE lane counts the workgroup in
-__device__ __forceinline__ void dl_publish(unsigned* word, unsigned n = 1u) {
+__device__ __forceinline__ void dl_publish(unsigned* cnt, int slot, unsigned n = 1u) {
   dl_barrier();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(word, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt + slot * PSG_DL_SLOT, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void dl_arrive(unsigned* word, unsigned n = 1u) {
-  dl_drain();
-  dl_publish(word, n);
+__device__ __forceinline__ bool dl_poll(unsigned* cnt, int slot, unsigned want) {
+  return __hip_atomic_load(cnt + slot * PSG_DL_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
 }
-// wave 0 polls `nw` consecutive words (nw <= 64) until each is >= want; the workgroup is released through a barrier
+__device__ __forceinline__ void dl_timeout(unsigned* cnt, unsigned code) {
+  __hip_atomic_store(cnt + PSG_DL_TIMEOUT * PSG_DL_SLOT, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave 0 polls `nw` consecutive slots (nw <= 64) until each is >= want; the workgroup is released through a barrier
 __device__ __forceinline__ void dl_wait(unsigned* cnt, int first, int nw, unsigned want) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     unsigned spins = 0;
     for (;;) {
       bool ok = true;
-      if (lane < nw) ok = __hip_atomic_load(cnt + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+      if (lane < nw) ok = dl_poll(cnt, first + lane, want);
       if (__all(ok)) break;
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(2);
       if (++spins > (1u << 21)) {                                    // a producer died: report, do not hang the GPU
-        if (lane == 0) __hip_atomic_store(cnt + PSG_DL_TIMEOUT, 0x5047u + (unsigned)first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) dl_timeout(cnt, 0x5047u + (unsigned)first);
         break;
       }
     }
   }
   dl_barrier();
 }
+// All-to-all edge (every workgroup waits for every workgroup): XCD-hierarchical (MI355X_MICROARCH.md barrier-xcd) - the
+// workgroups of a b % 8 class count into their own slot, the last of a class counts into the top slot, the last of those
+// raises the eight go flags, and a workgroup polls the flag of ITS class only (32 pollers per line instead of 256).
+__device__ __forceinline__ void dl_arrive_all(unsigned* cnt, int base) {       // stores drained by the caller
+  dl_barrier();
+  if (threadIdx.x == 0) {
+    const int cls = blockIdx.x & 7;
+    if (__hip_atomic_fetch_add(cnt + (base + cls) * PSG_DL_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PSG_DL_WG / 8 - 1)
+      if (__hip_atomic_fetch_add(cnt + (base + 8) * PSG_DL_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7u)
+        for (int x = 0; x < 8; ++x)
+          __hip_atomic_store(cnt + (base + 9 + x) * PSG_DL_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void dl_wait_all(unsigned* cnt, int base) { dl_wait(cnt, base + 9 + (blockIdx.x & 7), 1, 1u); }
 
 // sum over the four 16-lane rows (psg_gemm_f32.hip: sgf_sum_kq)
 __device__ __forceinline__ float dl_sum_kq(float v) {
@@ -163,10 +184,12 @@ struct DlWait<0> {
 #define DL_XPAD 16
 #define DL_BLOCK 2048                                                   // 16 rows x 128 B of one wave's ring slot
 
-// One weight-streaming projection of this workgroup: the (slab, K slice) walk of skinny_gemm_f32_kernel.
-template <int SLOTS, int G16, int G4>
+// One weight-streaming projection of this workgroup: the (slab, K slice) walk of skinny_gemm_f32_kernel with W-wave slabs
+// (the chain's own choices: 12 waves for q|k|v, 11 for gate|up - an even number of slab rounds per column group -, 8 else).
+// Waves >= W take no part in the stream; they still meet the two barriers of every slab end and help store its tile.
+template <int W, int SLOTS, int G16, int G4>
 struct DlGemm {
-  static constexpr int ROWS = PSG_DL_WAVES * 16;
+  static constexpr int ROWS = W * 16;
   static constexpr int OT_PITCH = ROWS + 4;
   static constexpr int MP = G16 * 16 + G4 * 4;
   static constexpr int NG4 = G4 > 0 ? G4 : 1, NG16 = G16 > 0 ? G16 : 1;
@@ -180,7 +203,7 @@ struct DlGemm {
   __device__ __forceinline__ const unsigned char* dma_src(int t) const {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int dr = lane >> 3, dp = (lane & 7) ^ (lane >> 3);
-    int r = (gx + t * G) * ROWS + wid * 16 + dr;
+    int r = (gx + t * G) * ROWS + (wid < W ? wid : 0) * 16 + dr;
     r = r + 8 < N ? r : (N - 9 > 0 ? N - 9 : 0);
     return wb + (int64_t)r * row_bytes + (int64_t)kbA * 128 + dp * 16;
   }
@@ -213,8 +236,19 @@ struct DlGemm {
   }
   // the first blocks of the stream: issued as soon as the rings are free, long before x exists
   __device__ __forceinline__ void prefetch() {
+    if ((int)(threadIdx.x >> 6) >= W) return;
     for (int i = 0; i < SLOTS - 1; ++i)
       if (i < total) issue();
+  }
+  // the load cursor behind `prefetch`, without issuing anything: lets the caller drop this object across a row phase
+  // (its registers are needed there) and rebuild it with setup() + skip_prefetched()
+  __device__ __forceinline__ void skip_prefetched() {
+    for (int i = 0; i < SLOTS - 1; ++i)
+      if (i < total) {
+        src += 128;
+        if (++ls == SLOTS) ls = 0;
+        if (++lb == nkb) { lb = 0; ++lt; src = dma_src(lt); }
+      }
   }
   // x slice [M][K slice] from global (written through by other workgroups) by sc1 LDS-DMA; caller waits + barriers
   __device__ __forceinline__ void stage_x_dma(const float* x, int64_t x_row_floats, unsigned char* xs) const {
@@ -255,13 +289,16 @@ struct DlGemm {
 #pragma unroll
     for (int q = 0; q < G4; ++q) acc4[q] = zero4;
     int ct = 0, cb = 0, cs = 0;
+    const bool streams = wid < W;
     auto finish_slab = [&]() {
+      if (streams) {
 #pragma unroll
-      for (int q = 0; q < G4; ++q)
+        for (int q = 0; q < G4; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc4[q][r] = dl_sum_kq(acc4[q][r]);
+          for (int r = 0; r < 4; ++r) acc4[q][r] = dl_sum_kq(acc4[q][r]);
+      }
       dl_barrier();                                                   // previous slab's tile fully read
-      {
+      if (streams) {
         const uint32_t tp16 = otile_lds + (uint32_t)(n * OT_PITCH + wid * 16 + 4 * kq) * 4u;
 #pragma unroll
         for (int g = 0; g < G16; ++g) {
@@ -297,6 +334,10 @@ struct DlGemm {
       cb = 0;
       ++ct;
     };
+    if (!streams) {                                                   // idle in this projection: the slab ends only
+      for (int t = 0; t < nslab; ++t) finish_slab();
+      return;
+    }
     if (nkb == 0) {
       for (int t = 0; t < nslab; ++t) finish_slab();
       return;
@@ -365,18 +406,37 @@ __device__ __forceinline__ void dl_norm_owner(const psg_dl_args& a, const float*
   // the first two levels of wave_sum's tree (row_shr:1, row_shr:2): lane 4 k + 3 = (t3 + t2) + (t1 + t0)
   ss += psg_dpp<0x111, 0xf>(0.f, ss);
   ss += psg_dpp<0x112, 0xf>(0.f, ss);
-  if (m < a.M && q == 3) dl_st1(ssq_out + (int64_t)b * 32 + m, ss);
+  if (m < a.M && q == 3) dl_st1(ssq_out + m * PSG_DL_WG + b, ss);       // [row][owner]
 }
 
 // ---- RMSNorm, consumer side: row statistics from the 256 quad sums, then this workgroup's x slice into LDS -----------
+// The slice's residual values are requested first (they do not depend on the statistics): one round trip for both.
 __device__ __forceinline__ void dl_norm_stage(const psg_dl_args& a, const float* ssq, const float* gamma, int kbA, int nkb,
                                               int xstride, unsigned char* xs, float* s_inv) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int NT = PSG_DL_WAVES * 64;
+  constexpr int MAXE = 8;                                              // float2 pairs per thread: 24 rows x 256 pairs / 768
+  const int c0 = kbA * 32;
+  const int pairs = nkb * 16;                                         // float2 columns of the slice
+  const int total = a.M * pairs;
+  float2 v[MAXE], g[MAXE];
+  int off[MAXE], row[MAXE];
+#pragma unroll
+  for (int k = 0; k < MAXE; ++k) {
+    const int e = tid + k * NT;
+    off[k] = -1;
+    if (e < total) {
+      const int m = e / pairs, c = (e - m * pairs) * 2;
+      v[k] = dl_ld2(a.resid + (int64_t)m * a.D + c0 + c);
+      g[k] = *reinterpret_cast<const float2*>(gamma + c0 + c);
+      off[k] = m * xstride + c * 4;
+      row[k] = m;
+    }
+  }
   for (int m = wid; m < a.M; m += PSG_DL_WAVES) {
-    // lane L: quads 4 L .. 4 L + 3 = one 16-lane row of the chain's wave L / 4
-    const float q0 = dl_ld1(ssq + (int64_t)(4 * lane) * 32 + m), q1 = dl_ld1(ssq + (int64_t)(4 * lane + 1) * 32 + m);
-    const float q2 = dl_ld1(ssq + (int64_t)(4 * lane + 2) * 32 + m), q3 = dl_ld1(ssq + (int64_t)(4 * lane + 3) * 32 + m);
-    float r = (q3 + q2) + (q1 + q0);                                  // row_shr:4, row_shr:8
+    // lane L: quads 4 L .. 4 L + 3 = one 16-lane row of the chain's wave L / 4 (rmsnorm_kernel, 1024 threads)
+    const float2 qa = dl_ld2(ssq + m * PSG_DL_WG + 4 * lane), qb = dl_ld2(ssq + m * PSG_DL_WG + 4 * lane + 2);
+    float r = (qb.y + qb.x) + (qa.y + qa.x);                          // row_shr:4, row_shr:8
     r += psg_dpp<0x111, 0xf>(0.f, r);                                 // row_bcast:15 / row_bcast:31 have the quad shape too:
     r += psg_dpp<0x112, 0xf>(0.f, r);                                 // lane 4 w + 3 = (R3 + R2) + (R1 + R0) = chain wave w
     float tot = 0.f;
@@ -385,35 +445,40 @@ __device__ __forceinline__ void dl_norm_stage(const psg_dl_args& a, const float*
     if (lane == 0) s_inv[m] = 1.0f / sqrtf(tot / (float)a.D + a.eps);
   }
   dl_barrier();
-  const int cols = nkb * 32;                                          // floats of the slice
-  const int c0 = kbA * 32;
-  const int pairs = cols >> 1;
-  for (int e = tid; e < a.M * pairs; e += PSG_DL_WAVES * 64) {
-    const int m = e / pairs, c = (e - m * pairs) * 2;
-    const float2 v = dl_ld2(a.resid + (int64_t)m * a.D + c0 + c);
-    const float2 g = *reinterpret_cast<const float2*>(gamma + c0 + c);
-    const float inv = s_inv[m];
-    *reinterpret_cast<float2*>(xs + m * xstride + c * 4) = make_float2(g.x * (v.x * inv), g.y * (v.y * inv));
-  }
+#pragma unroll
+  for (int k = 0; k < MAXE; ++k)
+    if (off[k] >= 0) {
+      const float inv = s_inv[row[k]];
+      *reinterpret_cast<float2*>(xs + off[k]) = make_float2(g[k].x * (v[k].x * inv), g[k].y * (v[k].y * inv));
+    }
 }
 
 // ---- attention unit (row, head) by four waves: psg_decode_attn4_unit<float>, the arithmetic of decode_attn4_kernel ------
 __device__ __forceinline__ void dl_attn_round(const psg_dl_args& a, int unit, PsgDecodeAttnScratch* sc) {
   const int heads = a.heads, hidden = a.D;
-  const int row = unit / heads, h = unit % heads;
-  const int pos = a.tok_pos[row];
+  const bool valid = unit >= 0;                                     // false: this group of four waves only meets the barriers
+  const int row = valid ? unit / heads : 0, h = valid ? unit % heads : 0;
+  const int pos = valid ? a.tok_pos[row] : -1;
   const int64_t sl = (int64_t)a.M * 3 * hidden;
   const float* qp = a.qkv_part;
-  auto ld = [&](const int64_t (&idx)[6], float (&x)[6]) {           // ldn_splits<float, 6> with sc1 loads: slices in order
-    float tt[8][6];
+  auto ld = [&](const int64_t (&idx)[6], float (&x)[6]) {           // ldn_splits<float, 6> with sc1 loads: slices in order,
+    float tt[4][6];                                                  // two batches of four (register budget of 12 waves)
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int e = 0; e < 6; ++e) tt[s][e] = dl_ld1(qp + (int64_t)s * sl + idx[e]);
 #pragma unroll
     for (int e = 0; e < 6; ++e) x[e] = tt[0][e];
 #pragma unroll
-    for (int s = 1; s < 8; ++s)
+    for (int s = 1; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 6; ++e) x[e] += tt[s][e];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 6; ++e) tt[s][e] = dl_ld1(qp + (int64_t)(s + 4) * sl + idx[e]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int e = 0; e < 6; ++e) x[e] += tt[s][e];
   };
@@ -427,91 +492,165 @@ __device__ __forceinline__ void dl_attn_round(const psg_dl_args& a, int unit, Ps
 template <int SLOTS, int G16, int G4>
 __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(const psg_dl_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using Gemm = DlGemm<SLOTS, G16, G4>;
+  using GemmQ = DlGemm<12, SLOTS, G16, G4>;                           // q|k|v: 192-row slabs, 64 of them = 2 rounds of 32 groups
+  using GemmO = DlGemm<8, SLOTS, G16, G4>;                            // o, down: 128-row slabs
+  using GemmG = DlGemm<11, SLOTS, G16, G4>;                           // gate|up: 176-row slabs, 126 of them = 4 rounds (3.94)
+  constexpr int MP = G16 * 16 + G4 * 4;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int M = a.M, D = a.D, I = a.I;
-  unsigned char* const xs = smem + PSG_DL_WAVES * SLOTS * DL_BLOCK + Gemm::MP * Gemm::OT_PITCH * 4;
+  // LDS: rings | partial tile (sized for 12-wave slabs) | x slice
+  unsigned char* const xs = smem + PSG_DL_WAVES * SLOTS * DL_BLOCK + MP * (PSG_DL_WAVES * 16 + 4) * 4;
   float* const s_inv = reinterpret_cast<float*>(smem + PSG_DL_WAVES * SLOTS * DL_BLOCK);   // the tile area, free between phases
   unsigned* const cnt = a.cnt;
+  long long* const tr = a.trace ? a.trace + (int64_t)b * 24 : nullptr;
+#define DL_STAMP(i)                                             \
+  do {                                                          \
+    if (tr && tid == 0) tr[i] = (long long)wall_clock64();      \
+  } while (0)
+  DL_STAMP(0);
 
-  // ---- q|k|v: S = 8, G = 32: column group gx = head h (slabs h, 32 + h, 64 + h) -------------------------------------
-  Gemm g;
-  g.setup(a.wqkv, 3 * D, D, 8, b & 7, b >> 3, M, smem);
-  g.prefetch();
+  // ---- q|k|v: S = 8, G = 32.  Weight rows are the chain's [q | k | v]: head h = slabs of 192 rows ... the q, k and v
+  // rows of a head lie in three different slabs, produced by the column groups listed in dl_head_groups below ------------
+  {
+    GemmQ g;
+    g.setup(a.wqkv, 3 * D, D, 8, b & 7, b >> 3, M, smem);
+    g.prefetch();
+  }
   dl_norm_owner(a, a.delta, a.dsplits, a.ssq, b);
-  dl_arrive(cnt + PSG_DL_CNT_X1 + (b & 7));
-  dl_wait(cnt, PSG_DL_CNT_X1, 8, 32u);
-  dl_norm_stage(a, a.ssq, a.ln1, g.kbA, g.nkb, g.xstride, xs, s_inv);
-  dl_barrier();
-  g.run(a.qkv_part, smem, xs);
+  dl_drain();
+  dl_arrive_all(cnt, PSG_DL_CNT_X1);
+  DL_STAMP(1);
+  dl_wait_all(cnt, PSG_DL_CNT_X1);
+  DL_STAMP(2);
+  {
+    GemmQ g;
+    g.setup(a.wqkv, 3 * D, D, 8, b & 7, b >> 3, M, smem);
+    g.skip_prefetched();
+    dl_norm_stage(a, a.ssq, a.ln1, g.kbA, g.nkb, g.xstride, xs, s_inv);
+    dl_barrier();
+    DL_STAMP(3);
+    g.run(a.qkv_part, smem, xs);
+  }
+  DL_STAMP(4);
   // the o projection's first blocks (slab b >> 3, K slice b & 7) while the attention runs
-  Gemm go;
-  go.setup(a.wo, D, D, 8, b & 7, b >> 3, M, smem);
-  dl_drain();                                                       // this wave's partial-tile stores are out
-  go.prefetch();                                                    // its own ring is free: the next stream starts now
-  dl_publish(cnt + PSG_DL_CNT_HEAD + (b >> 3));
+  {
+    GemmO go;
+    go.setup(a.wo, D, D, 8, b & 7, b >> 3, M, smem);
+    dl_drain();                                                     // this wave's partial-tile stores are out
+    go.prefetch();                                                  // its own ring is free: the next stream starts now
+  }
+  dl_publish(cnt, PSG_DL_CNT_HEAD + (b >> 3));
+  DL_STAMP(5);
 
-  // ---- attention: units (row, head) dealt to workgroups, two at a time (four waves each) ------------------------------
+  // ---- attention: units (row, head) dealt to workgroups, three at a time (four waves each): one round for 24 x 32 units --
   {
     PsgDecodeAttnScratch* sc = reinterpret_cast<PsgDecodeAttnScratch*>(xs) + (wid >> 2);
-    const int nunit = M * a.heads;                                    // even: unit u = row * heads + head
-    for (int u0 = 2 * b; u0 < nunit; u0 += 2 * PSG_DL_WG) {
-      const int h0 = u0 % a.heads;                                    // even; the round's units are heads h0, h0 + 1 of one row
-      dl_wait(cnt, PSG_DL_CNT_HEAD + h0, 2, 8u);                      // each head's 8 producers (K slices)
-      dl_attn_round(a, u0 + (wid >> 2), sc);
+    const int nunit = M * a.heads;                                    // unit u = row * heads + head
+    for (int u0 = 3 * b; u0 < nunit; u0 += 3 * PSG_DL_WG) {
+      // A head's q, k and v columns (h 128 .., D + h 128 .., 2 D + h 128 ..) lie in the 192-row slabs
+      // (2 h) / 3, (64 + 2 h) / 3, (128 + 2 h) / 3 (+ 1 where 128 columns straddle a slab end), i.e. column groups
+      // slab % 32: wait for all of them, for the round's three units (lanes 0..17 poll one group each)
+      if (tid < 64) {
+        unsigned spins = 0;
+        const int ui = lane / 6, part = lane - ui * 6;               // unit of the round, (q | k | v) x (first | last column)
+        const int u = min(u0 + ui, nunit - 1);
+        const int col = (part >> 1) * D + (u % a.heads) * 128 + ((part & 1) ? 127 : 0);
+        const int grp = (col / 192) & 31;
+        for (;;) {
+          const bool ok = lane >= 18 || dl_poll(cnt, PSG_DL_CNT_HEAD + grp, 8u);
+          if (__all(ok)) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 21)) {
+            if (lane == 0) dl_timeout(cnt, 0x5247u);
+            break;
+          }
+        }
+      }
+      dl_barrier();
+      const int u = u0 + (wid >> 2);
+      dl_attn_round(a, u < nunit ? u : -1, sc);
       dl_drain();
       dl_barrier();
-      if (tid == 0) __hip_atomic_fetch_add(cnt + PSG_DL_CNT_ATT + (h0 >> 2), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((tid & 255) == 0 && u < nunit)
+        __hip_atomic_fetch_add(cnt + (PSG_DL_CNT_ATT + ((u % a.heads) >> 2)) * PSG_DL_SLOT, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
   // ---- o projection: K slice by = heads 4 by .. 4 by + 3 -----------------------------------------------------------------
+  DL_STAMP(6);
   dl_wait(cnt, PSG_DL_CNT_ATT + (b & 7), 1, (unsigned)(4 * M));
-  go.stage_x_dma(a.att, D, xs);
-  dl_drain();
-  dl_barrier();
-  go.run(a.o_part, smem, xs);
-  Gemm gg;
-  gg.setup(a.wgu, 2 * I, D, 8, b & 7, b >> 3, M, smem);
-  dl_drain();
-  gg.prefetch();
-  dl_publish(cnt + PSG_DL_CNT_OSLAB + (b >> 3));
+  DL_STAMP(7);
+  {
+    GemmO go;
+    go.setup(a.wo, D, D, 8, b & 7, b >> 3, M, smem);
+    go.skip_prefetched();
+    go.stage_x_dma(a.att, D, xs);
+    dl_drain();
+    dl_barrier();
+    DL_STAMP(8);
+    go.run(a.o_part, smem, xs);
+  }
+  DL_STAMP(9);
+  {
+    GemmG gg;
+    gg.setup(a.wgu, 2 * I, D, 8, b & 7, b >> 3, M, smem);
+    dl_drain();
+    gg.prefetch();
+  }
+  dl_publish(cnt, PSG_DL_CNT_OSLAB + (b >> 3));
 
   // ---- post-attention RMSNorm: owner b's 16 columns lie in o slab b >> 3 ---------------------------------------------------
   dl_wait(cnt, PSG_DL_CNT_OSLAB + (b >> 3), 1, 8u);
-  dl_norm_owner(a, a.o_part, 8, a.ssq + 256 * 32, b);
-  dl_arrive(cnt + PSG_DL_CNT_X2 + (b & 7));
-  dl_wait(cnt, PSG_DL_CNT_X2, 8, 32u);
-  dl_norm_stage(a, a.ssq + 256 * 32, a.ln2, gg.kbA, gg.nkb, gg.xstride, xs, s_inv);
-  dl_barrier();
-  gg.run(a.gu_part, smem, xs);
-  Gemm gd;
-  gd.setup(a.wdown, D, I, 16, b & 15, b >> 4, M, smem);
+  DL_STAMP(10);
+  dl_norm_owner(a, a.o_part, 8, a.ssq + PSG_DL_WG * 32, b);
   dl_drain();
-  gd.prefetch();
-  dl_publish(cnt + PSG_DL_CNT_GU + (b >> 3));
+  dl_arrive_all(cnt, PSG_DL_CNT_X2);
+  DL_STAMP(11);
+  dl_wait_all(cnt, PSG_DL_CNT_X2);
+  DL_STAMP(12);
+  {
+    GemmG gg;
+    gg.setup(a.wgu, 2 * I, D, 8, b & 7, b >> 3, M, smem);
+    gg.skip_prefetched();
+    dl_norm_stage(a, a.ssq + PSG_DL_WG * 32, a.ln2, gg.kbA, gg.nkb, gg.xstride, xs, s_inv);
+    dl_barrier();
+    DL_STAMP(13);
+    gg.run(a.gu_part, smem, xs);
+  }
+  DL_STAMP(14);
+  {
+    GemmO gd;
+    gd.setup(a.wdown, D, I, 16, b & 15, b >> 4, M, smem);
+    dl_drain();
+    gd.prefetch();
+  }
+  dl_publish(cnt, PSG_DL_CNT_GU + (b >> 3));
 
   // ---- SwiGLU: items (row, 128-column block) dealt to waves; silu_mul_kernel<float>'s arithmetic ---------------------------
   {
-    const int nblk = I >> 7;                                          // gate block j: slab j, up block j: slab nblk + j
+    const int nblk = I >> 7;
     const int nitem = M * nblk;
     const int64_t sl = (int64_t)M * 2 * I;
     for (int it0 = b * PSG_DL_WAVES; it0 < nitem; it0 += PSG_DL_WG * PSG_DL_WAVES) {
       const int it = it0 + wid;
       const bool liv = it < nitem;
       const int m = liv ? it / nblk : 0, j = liv ? it - m * nblk : 0;
-      // the producers of the round's blocks: column groups (slab % 32) of gate and up
+      // gate columns [128 j, +128) and up columns [I + 128 j, +128) lie in 176-row slabs (first and last column may
+      // straddle a slab end): their column groups (slab % 32), for the round's 12 items - lanes 0..47 poll one each
       if (tid < 64) {
-        const int itl = it0 + (lane & 7);
-        const int jl = itl < nitem ? itl % nblk : 0;
-        const int grp = (lane & 8) ? (nblk + jl) & 31 : jl & 31;
+        const int ii = lane >> 2, part = lane & 3;                   // item of the round, (gate | up) x (first | last column)
+        const int itl = min(it0 + ii, nitem - 1);
+        const int jl = itl % nblk;
+        const int col = (part >> 1) * I + jl * 128 + ((part & 1) ? 127 : 0);
+        const int grp = (col / 176) & 31;
         unsigned spins = 0;
         for (;;) {
-          const bool ok = lane >= 16 || __hip_atomic_load(cnt + PSG_DL_CNT_GU + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 8u;
+          const bool ok = lane >= 4 * PSG_DL_WAVES || dl_poll(cnt, PSG_DL_CNT_GU + grp, 8u);
           if (__all(ok)) break;
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(2);
           if (++spins > (1u << 21)) {
-            if (lane == 0) __hip_atomic_store(cnt + PSG_DL_TIMEOUT, 0x5147u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) dl_timeout(cnt, 0x5147u);
             break;
           }
         }
@@ -532,25 +671,34 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
         const float s0 = gsum.x / (1.0f + expf(-gsum.x)), s1 = gsum.y / (1.0f + expf(-gsum.y));
         dl_st2(a.h + (int64_t)m * I + c, s0 * usum.x, s1 * usum.y);
         dl_drain();
-        if (lane == 0) __hip_atomic_fetch_add(cnt + PSG_DL_CNT_H + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0)
+          __hip_atomic_fetch_add(cnt + (PSG_DL_CNT_H + j) * PSG_DL_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
 
   // ---- down projection: S = 16, G = 16; K slice by: blocks of 128 columns [kbA / 4, (kbB + 3) / 4) --------------------------
+  DL_STAMP(15);
   {
+    GemmO gd;
+    gd.setup(a.wdown, D, I, 16, b & 15, b >> 4, M, smem);
+    gd.skip_prefetched();
     const int j0 = gd.kbA >> 2, j1 = (gd.kbA + gd.nkb + 3) >> 2;
     dl_wait(cnt, PSG_DL_CNT_H + j0, j1 - j0, (unsigned)M);
+    DL_STAMP(16);
+    gd.stage_x_dma(a.h, I, xs);
+    dl_drain();
+    dl_barrier();
+    DL_STAMP(17);
+    gd.run(a.down_part, smem, xs);
   }
-  gd.stage_x_dma(a.h, I, xs);
-  dl_drain();
-  dl_barrier();
-  gd.run(a.down_part, smem, xs);
+  DL_STAMP(18);
+#undef DL_STAMP
 }
 
 static size_t dl_lds(int M, int slots, int mp) {
   const size_t xmax = (size_t)M * (22 * 128 + DL_XPAD);               // the down projection's slice (K = 11008, S = 16)
-  const size_t attn = 2 * sizeof(PsgDecodeAttnScratch);
+  const size_t attn = 3 * sizeof(PsgDecodeAttnScratch);
   return (size_t)PSG_DL_WAVES * slots * DL_BLOCK + (size_t)mp * (PSG_DL_WAVES * 16 + 4) * 4 + (xmax > attn ? xmax : attn);
 }
 
@@ -583,7 +731,7 @@ extern "C" int psg_decode_layer(psg_ctx* ctx, void* resid, const void* delta, in
                   k_cache && v_cache && workspace && counters && down_part,
               PSG_ERR_INVALID, "psg_decode_layer: NULL argument");
   PSG_REQUIRE(psg_decode_layer_supported(ctx, M, hidden, inter, heads, dtype), PSG_ERR_UNSUPPORTED,
-              "psg_decode_layer: M=%d hidden=%d inter=%d heads=%d dtype=%d on %d CUs (fp32, 13..32 rows, 4096 = 32 x 128, "
+              "psg_decode_layer: M=%d hidden=%d inter=%d heads=%d dtype=%d on %d CUs (fp32, 13..24 rows, 4096 = 32 x 128, "
               "256 CUs)", M, hidden, inter, heads, dtype, ctx->num_cu);
   PSG_REQUIRE(delta_splits >= 0 && delta_splits <= PSG_MAX_SPLITS && (delta || delta_splits == 0), PSG_ERR_INVALID,
               "psg_decode_layer: delta_splits=%d", delta_splits);
@@ -604,11 +752,12 @@ extern "C" int psg_decode_layer(psg_ctx* ctx, void* resid, const void* delta, in
   a.h = w;
   a.down_part = down_part;
   a.cnt = counters;
+  a.trace = (ctx->trace_kind == PSG_TRACE_DECODE_LAYER && ctx->trace && ctx->trace_words >= (int64_t)PSG_DL_WG * 24) ? ctx->trace : nullptr;
   a.M = M; a.D = hidden; a.I = inter; a.heads = heads; a.ctx = ctx_len; a.eps = eps;
   hipStream_t st = (hipStream_t)stream;
   const int g16 = M <= 28 ? 1 : 2, g4 = (M <= 16 || M > 28) ? 0 : (M - 16 + 3) / 4;
   const int mp = g16 * 16 + g4 * 4;
-  const int slots = dl_lds(M, 5, mp) <= 160 * 1024 ? 5 : 3;
+  const int slots = 3;
   const size_t lds = dl_lds(M, slots, mp);
   PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_decode_layer: %zu B of LDS", lds);
 #define DL_K(SL, A, B)                                                                                      \
@@ -617,17 +766,11 @@ extern "C" int psg_decode_layer(psg_ctx* ctx, void* resid, const void* delta, in
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
     decode_layer_f32_kernel<SL, A, B><<<PSG_DL_WG, PSG_DL_WAVES * 64, lds, st>>>(a);                        \
   } while (0)
-#define DL_L(A, B)              \
-  do {                          \
-    if (slots == 5) DL_K(5, A, B); \
-    else DL_K(3, A, B);         \
-  } while (0)
+#define DL_L(A, B) DL_K(3, A, B)
   switch (g16 * 4 + g4) {
     case 4: DL_L(1, 0); break;
     case 5: DL_L(1, 1); break;
-    case 6: DL_L(1, 2); break;
-    case 7: DL_L(1, 3); break;
-    default: DL_L(2, 0); break;
+    default: DL_L(1, 2); break;
   }
 #undef DL_L
 #undef DL_K

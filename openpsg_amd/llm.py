@@ -201,7 +201,7 @@ class LlamaDecodeEngine:
 
     def _decode_step_persistent(self, st, counters):
         """One decode step on psg_decode_layer: a launch per layer, the final RMSNorm and the lm_head as in the chain.
-        counters: int32 [layers * 256], zeroed."""
+        counters: int32 [layers * ops.decode_layer_counters()], zeroed."""
         m = self.cfg.llm
         x = st["x"]
         K = x.shape[0]
@@ -441,8 +441,8 @@ class LlamaDecodeEngine:
         m = self.cfg.llm
         persist = hi > lo and self._can_persist(st["x"].shape[0], st.get("slot", 0))
         fused = not persist and self._can_fuse(st["x"].shape[0]) and hi > lo
-        if persist:                                            # 256 counter words per layer launch, zeroed once per call
-            per_step = 256 * len(self.layers)
+        if persist:                                            # one counter block per layer launch, zeroed once per call
+            per_step = ops.decode_layer_counters(self.device) * len(self.layers)
             sync = torch.zeros((hi - lo) * per_step, device=self.device, dtype=torch.int32)
         if fused:                                              # two counter words per fused launch, zeroed once per call
             per_step = 2 * (4 * len(self.layers) + 1)

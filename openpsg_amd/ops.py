@@ -412,6 +412,17 @@ def decode_layer_supported(rows, hidden, inter, heads, dtype, device) -> bool:
     return bool(lib.psg_decode_layer_supported(ctx, int(rows), int(hidden), int(inter), int(heads), _DT[dtype]))
 
 
+def decode_layer_counters(device) -> int:
+    """int32 words of one psg_decode_layer launch's counter block (to be zeroed by the caller)."""
+    import ctypes
+    dev = torch.device(device)
+    lib, ctx = _lib.load(), _lib.ctx(dev.index or 0)
+    nf, nc = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib.psg_decode_layer_workspace(ctx, 16, 4096, 11008, ctypes.byref(nf), ctypes.byref(nc)),
+          "psg_decode_layer_workspace")
+    return int(nc.value)
+
+
 def decode_layer_workspace(rows, hidden, inter, device):
     """(workspace fp32 tensor, counter words per launch) of psg_decode_layer for `rows` decode rows."""
     import ctypes
@@ -428,12 +439,13 @@ def decode_layer(resid, delta, ln1, ln2, wqkv, wo, wgu, wdown, tok_pair, tok_pos
     """One decoder layer of the decode step in ONE persistent launch (psg_decode_layer), bit-identical to
     rmsnorm -> skinny_gemm -> decode_attn -> skinny_gemm -> rmsnorm -> skinny_gemm -> silu_mul -> skinny_gemm.
     resid [M, hidden] fp32 (updated in place); delta: the previous layer's down-projection Partials or None;
-    counters: int32 [>= 256], ZERO; down_part fp32 [16, M, hidden] receives this layer's down partials (returned)."""
+    counters: int32 [decode_layer_counters()], ZERO (word 255 * 64 != 0 afterwards: a bounded poll gave up); down_part fp32 [16, M, hidden] receives this layer's down partials (returned)."""
     lib, ctx, st = _env(resid)
     M, hidden = resid.shape
     inter = wdown.shape[1]
     assert wqkv.shape == (3 * hidden, hidden) and wo.shape == (hidden, hidden) and wgu.shape == (2 * inter, hidden)
-    assert down_part.shape == (16, M, hidden) and counters.dtype == torch.int32 and counters.numel() >= 256
+    assert down_part.shape == (16, M, hidden) and counters.dtype == torch.int32
+    assert counters.numel() >= decode_layer_counters(resid.device)
     dp, ds = (None, 0) if delta is None else _in(delta, resid.dtype)
     check(lib.psg_decode_layer(ctx, _p(resid, torch.float32, "resid"), dp, ds, _p(ln1, torch.float32), _p(ln2, torch.float32),
                                _p(wqkv, resid.dtype, "wqkv"), _p(wo, resid.dtype), _p(wgu, resid.dtype), _p(wdown, resid.dtype),

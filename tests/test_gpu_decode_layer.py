@@ -1,7 +1,7 @@
 """psg_decode_layer (`-m gpu`): one persistent launch per decoder layer of the decode step against the chain of eight
 launches it replaces (psg_rmsnorm / psg_skinny_gemm / psg_decode_attn / psg_silu_mul), BIT FOR BIT: residual stream, KV
 cache rows, down-projection partials - at Llama-2-7B width (the only width it is built for), for every row-group variant
-(13..32 rows), with and without an incoming delta, two layers chained, positions from 0 (no cached key) upwards, and
+(13..24 rows), with and without an incoming delta, two layers chained, positions from 0 (no cached key) upwards, and
 through the engine on the reference golden G6 (HF-LL:53-281 via V4:293-312)."""
 import numpy as np
 import pytest
@@ -34,7 +34,7 @@ def _chain(ops, L, resid, delta, pair, pos, rope, kc, vc):
     return ops.skinny_gemm(act, L["wdown"])
 
 
-@pytest.mark.parametrize("M,with_delta", [(20, False), (20, True), (16, True), (13, False), (24, True), (28, False), (32, True)])
+@pytest.mark.parametrize("M,with_delta", [(20, False), (20, True), (16, True), (13, False), (24, True), (17, False), (21, True)])
 def test_decode_layer_equals_the_launch_chain_bit_for_bit(M, with_delta):
     from openpsg_amd import ops
     if not ops.decode_layer_supported(M, D, I, HEADS, torch.float32, DEV):
@@ -71,7 +71,7 @@ def test_decode_layer_equals_the_launch_chain_bit_for_bit(M, with_delta):
         dl = ops.decode_layer(resid_p, dl, L["ln1"], L["ln2"], L["wqkv"], L["wo"], L["wgu"], L["wdown"], pair, pos, rope,
                               HEADS, CTX, 1e-5, k, v, ws, counters[l * ncnt:(l + 1) * ncnt], dparts[l & 1])
     torch.cuda.synchronize()
-    assert int(counters.view(len(layers), ncnt)[:, 255].abs().sum()) == 0, "a bounded poll of psg_decode_layer gave up"
+    assert int(counters.view(len(layers), ncnt)[:, 255 * 64].abs().sum()) == 0, "a bounded poll of psg_decode_layer gave up"
     assert torch.isfinite(resid_p).all()
     for l, ((kc_, vc_), (kp, vp)) in enumerate(zip(cc, cp)):
         assert torch.equal(kc_, kp) and torch.equal(vc_, vp), f"layer {l}: KV cache differs from the chain"

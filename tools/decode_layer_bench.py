@@ -84,7 +84,7 @@ def main():
     resid.copy_(torch.randn(M, D, generator=g, device=DEV))
     persistent()
     torch.cuda.synchronize()
-    print("timeouts:", counters.view(NL, ncnt)[:, 255].tolist())
+    print("timeouts:", counters.view(NL, ncnt)[:, 255 * 64].tolist())
 
 
 if __name__ == "__main__":
