@@ -454,15 +454,47 @@ __device__ __forceinline__ void dl_norm_stage(const psg_dl_args& a, const float*
 }
 
 // ---- attention unit (row, head) by four waves: psg_decode_attn4_unit<float>, the arithmetic of decode_attn4_kernel ------
-__device__ __forceinline__ void dl_attn_round(const psg_dl_args& a, int unit, PsgDecodeAttnScratch* sc) {
+// The unit's first wave waits for the column groups that produced its q, k and v columns INSIDE the loader, i.e. after
+// the cached keys and values were requested (their addresses need `pos` only): the cache round trip runs under the wait.
+struct DlAttnArgs {
+  const float* qkv_part;
+  float* att;
+  float* kc;
+  float* vc;
+  const int32_t* tok_pair;
+  const int32_t* tok_pos;
+  const float* cos_tab;
+  const float* sin_tab;
+  unsigned* cnt;
+  int M, D, heads, ctx;
+};
+__device__ __forceinline__ void dl_attn_round(const DlAttnArgs a, int unit, PsgDecodeAttnScratch* sc) {
   const int heads = a.heads, hidden = a.D;
   const bool valid = unit >= 0;                                     // false: this group of four waves only meets the barriers
   const int row = valid ? unit / heads : 0, h = valid ? unit % heads : 0;
   const int pos = valid ? a.tok_pos[row] : -1;
   const int64_t sl = (int64_t)a.M * 3 * hidden;
   const float* qp = a.qkv_part;
-  auto ld = [&](const int64_t (&idx)[6], float (&x)[6]) {           // ldn_splits<float, 6> with sc1 loads: slices in order,
-    float tt[4][6];                                                  // two batches of four (register budget of 12 waves)
+  unsigned* cnt = a.cnt;
+  auto ld = [&](const int64_t (&idx)[6], float (&x)[6]) {           // ldn_splits<float, 6> with sc1 loads: slices in order
+    {
+      // q, k, v columns (h 128 .., D + h 128 .., 2 D + h 128 ..) lie in the 192-row slabs col / 192 (two where 128 columns
+      // straddle a slab end), produced by the column groups slab % 32: lanes 0..5 poll one group each
+      const int lane = threadIdx.x & 63;
+      const int col = (lane >> 1) * hidden + h * 128 + ((lane & 1) ? 127 : 0);
+      const int grp = lane < 6 ? (col / 192) & 31 : 0;
+      unsigned spins = 0;
+      for (;;) {
+        const bool ok = lane >= 6 || dl_poll(cnt, PSG_DL_CNT_HEAD + grp, 8u);
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 21)) {
+          if (lane == 0) dl_timeout(cnt, 0x5247u);
+          break;
+        }
+      }
+    }
+    float tt[4][6];                                                  // two batches of four slices (register budget)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -547,28 +579,9 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
     PsgDecodeAttnScratch* sc = reinterpret_cast<PsgDecodeAttnScratch*>(xs) + (wid >> 2);
     const int nunit = M * a.heads;                                    // unit u = row * heads + head
     for (int u0 = 3 * b; u0 < nunit; u0 += 3 * PSG_DL_WG) {
-      // A head's q, k and v columns (h 128 .., D + h 128 .., 2 D + h 128 ..) lie in the 192-row slabs
-      // (2 h) / 3, (64 + 2 h) / 3, (128 + 2 h) / 3 (+ 1 where 128 columns straddle a slab end), i.e. column groups
-      // slab % 32: wait for all of them, for the round's three units (lanes 0..17 poll one group each)
-      if (tid < 64) {
-        unsigned spins = 0;
-        const int ui = lane / 6, part = lane - ui * 6;               // unit of the round, (q | k | v) x (first | last column)
-        const int u = min(u0 + ui, nunit - 1);
-        const int col = (part >> 1) * D + (u % a.heads) * 128 + ((part & 1) ? 127 : 0);
-        const int grp = (col / 192) & 31;
-        for (;;) {
-          const bool ok = lane >= 18 || dl_poll(cnt, PSG_DL_CNT_HEAD + grp, 8u);
-          if (__all(ok)) break;
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 21)) {
-            if (lane == 0) dl_timeout(cnt, 0x5247u);
-            break;
-          }
-        }
-      }
-      dl_barrier();
       const int u = u0 + (wid >> 2);
-      dl_attn_round(a, u < nunit ? u : -1, sc);
+      const DlAttnArgs aa = {a.qkv_part, a.att, a.kc, a.vc, a.tok_pair, a.tok_pos, a.cos_tab, a.sin_tab, a.cnt, a.M, a.D, a.heads, a.ctx};
+      dl_attn_round(aa, u < nunit ? u : -1, sc);
       dl_drain();
       dl_barrier();
       if ((tid & 255) == 0 && u < nunit)
