@@ -347,6 +347,22 @@ int psg_split_f16x3(psg_ctx*, const float* x, int64_t rows, int K, int64_t row_s
 int psg_scale_rows_cols(psg_ctx*, float* y, int64_t rows, int N, const float* row_scale, const float* col_scale,
                         void* stream);
 
+/* Round 5: the same split / un-scaling inside the row kernels around the prompt pass's projections (fp32; bit-identical to
+ * the separate kernels).  A raw fp16-GEMM result y travels with its scale vectors and its reader applies
+ * y * (row_scale[m] * col_scale[n]) while loading:
+ *   psg_rmsnorm_split       resid += delta * scales (delta may be NULL); RMSNorm(resid) * w -> out3 [rows][3 hidden] fp16
+ *                           ([hi | hi | lo]) + inv_scale [rows]                              (HF-LL:53-67)
+ *   psg_rope_kvwrite_scaled psg_rope_kvwrite on a raw q|k|v result                            (HF-LL:130-160)
+ *   psg_silu_mul_split      silu(gate) * up of a raw gate|up result -> out3 [rows][3 inter] + inv_scale   (HF-LL:163-177) */
+int psg_rmsnorm_split(psg_ctx*, float* resid, const float* delta, const float* delta_row_scale, const float* delta_col_scale,
+                      const float* w, float eps, int64_t rows, int hidden, void* out3, float* inv_scale, void* stream);
+int psg_rope_kvwrite_scaled(psg_ctx*, const float* qkv, const float* row_scale, const float* col_scale,
+                            const int32_t* tok_pair, const int32_t* tok_pos, const float* rope_cos, const float* rope_sin,
+                            int64_t rows, int heads, int head_dim, int ctx, float* q_out, float* k_cache, float* v_cache,
+                            void* stream);
+int psg_silu_mul_split(psg_ctx*, const float* gate_up, const float* row_scale, const float* col_scale, int64_t rows,
+                       int inter, void* out3, float* inv_scale, void* stream);
+
 /* ---- Q-Former dense projections with fused epilogue (HF-IB:563-596 intermediate(_query): Linear + exact-erf GELU):
  * out[M][N] = epilogue(x[M][K] . w[N][K]^T + bias[N]); x / w / out bf16 or fp16 row-major, bias fp32 (may be NULL),
  * fp32 accumulate.  N % 16 == 0, K % 64 == 0.  One pass instead of a library GEMM + psg_bias_gelu. */

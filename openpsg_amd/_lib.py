@@ -75,6 +75,9 @@ SIGNATURES = {
     "psg_skinny_gemm_plan": [_vp, _i, _i, _i, _i, C.POINTER(_i)],
     "psg_skinny_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "psg_skinny_gemm_fused": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "psg_rmsnorm_split": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp],
+    "psg_rope_kvwrite_scaled": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "psg_silu_mul_split": [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp],
     "psg_decode_layer_workspace": [_vp, _i, _i, _i, C.POINTER(_i64), C.POINTER(_i64)],
     "psg_decode_layer_supported": [_vp, _i, _i, _i, _i, _i],
     "psg_decode_layer": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,

@@ -36,6 +36,7 @@ struct psg_opts {
   int qformer_dedup_prompts = 1;    // prompt-only work of the two-layer Q-Former once per distinct prompt
   int llm_fuse_rmsnorm = 0;     // decode step: RMSNorm as the prologue of the projection it feeds (psg_skinny_gemm_fused)
   int prefill_attn_scalar = 0;  // prompt pass: scalar cache-attention kernel instead of the matrix-core one
+  int llm_fuse_split = 1;       // fp32s prompt pass: operand splits / result scalings inside the row kernels (psg_split.hip)
   int decode_persistent = 0;    // fp32 decode steps: one persistent launch per decoder layer (psg_decode_layer) instead of the
                                 // chain of eight launches (bit-identical; Llama-2-7B width, 13..32 rows, 256 CUs)
   int xattn_dynamic = 1;        // LDS-DMA cross-attention: a workgroup's waves draw their tiles from an LDS counter

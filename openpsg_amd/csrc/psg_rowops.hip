@@ -688,11 +688,14 @@ __global__ void rope_kvwrite_kernel(const void* __restrict__ qkv, int qs, const 
   const float v1 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane);
   const float v2 = ld1_in<T>(qkv, qs, sl, base + 2 * hidden + lane + 64);
   // q*cos + rotate_half(q)*sin, rotate_half(x) = cat(-x2, x1)   (HF-LL:130-160)
-  Act<T>::st(q_out, row * hidden + h * 128 + lane, q1 * cs - q2 * sn);
-  Act<T>::st(q_out, row * hidden + h * 128 + lane + 64, q2 * cs + q1 * sn);
+  float qa, qb, ka, kb;
+  psg_rope_pair(q1, q2, cs, sn, qa, qb);                    // pinned form (psg_decode_math.h), shared with the decode step
+  psg_rope_pair(k1, k2, cs, sn, ka, kb);
+  Act<T>::st(q_out, row * hidden + h * 128 + lane, qa);
+  Act<T>::st(q_out, row * hidden + h * 128 + lane + 64, qb);
   const int64_t cbase = (((int64_t)tok_pair[row] * heads + h) * ctx + pos) * 128;
-  Act<T>::st(kc, cbase + lane, k1 * cs - k2 * sn);
-  Act<T>::st(kc, cbase + lane + 64, k2 * cs + k1 * sn);
+  Act<T>::st(kc, cbase + lane, ka);
+  Act<T>::st(kc, cbase + lane + 64, kb);
   Act<T>::st(vc, cbase + lane, v1);
   Act<T>::st(vc, cbase + lane + 64, v2);
 }

@@ -105,3 +105,228 @@ extern "C" int psg_scale_rows_cols(psg_ctx* ctx, float* y, int64_t rows, int N, 
   PSG_CHECK_LAUNCH("psg_scale_rows_cols");
   return PSG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the split and the un-scaling live in the row kernels that produce / consume the operands (prompt pass of the
+// fp32s mode, HF-LL:53-67, 130-177, 243-281).  A projection's raw fp16-GEMM result y is handed on WITH its two scale
+// vectors; its reader applies y * (row_scale * col_scale) while loading (exactly what psg_scale_rows_cols stores), and the
+// RMSNorm / SwiGLU kernels write their result straight as [hi | hi | lo] fp16 segments + the row's inverse scale (exactly
+// what psg_split_f16x3 computes from their fp32 output): bit-identical to the separate kernels, 7 launches per layer less.
+// ---------------------------------------------------------------------------------------------------------------------
+#include "psg_decode_math.h"
+
+__device__ __forceinline__ float sp_row_scale(float mx, float* inv_scale_out) {   // psg_split_f16x3's scale of a row maximum
+  int e = (int)((__float_as_uint(mx) >> 23) & 255u) - 127;
+  if (!(mx > 0.f) || e == 128) e = 13;
+  int se = 127 + 13 - e;
+  se = se < 1 ? 1 : (se > 253 ? 253 : se);
+  if (inv_scale_out) *inv_scale_out = __uint_as_float((uint32_t)(254 - se) << 23);
+  return __uint_as_float((uint32_t)se << 23);
+}
+__device__ __forceinline__ void sp_store3(uint16_t* o0, int K, int c, const float (&x)[4], float scale) {   // [hi | hi | lo]
+  ushort4 h, l;
+  uint16_t* hp = &h.x;
+  uint16_t* lp = &l.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float s = x[i] * scale;
+    const uint16_t hb = f32_to_f16(s);
+    hp[i] = hb;
+    lp[i] = f32_to_f16(s - f16_to_f32(hb));
+  }
+  *reinterpret_cast<ushort4*>(o0 + c) = h;
+  *reinterpret_cast<ushort4*>(o0 + K + c) = h;
+  *reinterpret_cast<ushort4*>(o0 + 2 * (int64_t)K + c) = l;
+}
+
+// resid += delta * (d_rs[row] * d_cs[col]);  x = RMSNorm(resid) * w  ->  out3 [rows][3 hidden] fp16, inv_scale [rows].
+// One 256-thread workgroup per row in the arithmetic order of rmsnorm_kernel<float, NCH, float> launched with 256 threads.
+template <int NCH>
+__global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ resid, const float* __restrict__ delta,
+                                                            const float* __restrict__ d_rs, const float* __restrict__ d_cs,
+                                                            const float* __restrict__ w, float eps, int hidden,
+                                                            uint16_t* __restrict__ out3, float* __restrict__ inv_scale) {
+  __shared__ float s_part[4], s_max[4];
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float v[NCH][4];
+  float4 g[NCH];
+  const float rs = delta ? d_rs[row] : 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 256 + tid) * 4;
+    if (col < hidden) {
+      const float4 r = *reinterpret_cast<const float4*>(resid + row * hidden + col);
+      g[c] = *reinterpret_cast<const float4*>(w + col);
+      v[c][0] = r.x; v[c][1] = r.y; v[c][2] = r.z; v[c][3] = r.w;
+      if (delta) {
+        const float4 d = *reinterpret_cast<const float4*>(delta + row * hidden + col);
+        const float4 cs = *reinterpret_cast<const float4*>(d_cs + col);
+        v[c][0] += d.x * (rs * cs.x); v[c][1] += d.y * (rs * cs.y); v[c][2] += d.z * (rs * cs.z); v[c][3] += d.w * (rs * cs.w);
+      }
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if ((c * 256 + tid) * 4 < hidden) ss = psg_sumsq4(v[c], ss);
+  ss = wave_sum(ss);
+  if (lane == 0) s_part[wid] = ss;
+  __syncthreads();
+  ss = 0.f;
+  for (int i = 0; i < 4; ++i) ss += s_part[i];
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  float x[NCH][4];
+  float mx = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 256 + tid) * 4;
+    if (col < hidden) {
+      if (delta) *reinterpret_cast<float4*>(resid + row * hidden + col) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+      x[c][0] = g[c].x * (v[c][0] * inv); x[c][1] = g[c].y * (v[c][1] * inv);
+      x[c][2] = g[c].z * (v[c][2] * inv); x[c][3] = g[c].w * (v[c][3] * inv);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x[c][0]), fabsf(x[c][1]))), fmaxf(fabsf(x[c][2]), fabsf(x[c][3])));
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) s_max[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  const float scale = sp_row_scale(mx, tid == 0 ? inv_scale + row : nullptr);
+  uint16_t* o0 = out3 + row * 3 * (int64_t)hidden;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 256 + tid) * 4;
+    if (col < hidden) sp_store3(o0, hidden, col, x[c], scale);
+  }
+}
+
+extern "C" int psg_rmsnorm_split(psg_ctx* ctx, float* resid, const float* delta, const float* delta_row_scale,
+                                 const float* delta_col_scale, const float* w, float eps, int64_t rows, int hidden,
+                                 void* out3, float* inv_scale, void* stream) {
+  PSG_REQUIRE(ctx && resid && w && out3 && inv_scale && (!delta || (delta_row_scale && delta_col_scale)), PSG_ERR_INVALID,
+              "psg_rmsnorm_split: NULL argument");
+  PSG_REQUIRE(hidden % 4 == 0 && hidden > 0 && hidden <= 8192 && rows >= 0 && rows < (1ll << 31), PSG_ERR_UNSUPPORTED,
+              "psg_rmsnorm_split: hidden=%d rows=%lld", hidden, (long long)rows);
+  if (rows == 0) return PSG_OK;
+  const int nch = (hidden + 1023) / 1024;
+  hipStream_t st = (hipStream_t)stream;
+#define RNS(N)                                                                                                      \
+  rmsnorm_split_kernel<N><<<(unsigned)rows, 256, 0, st>>>(resid, delta, delta_row_scale, delta_col_scale, w, eps, hidden, \
+                                                          (uint16_t*)out3, inv_scale)
+  switch (nch) {
+    case 1: RNS(1); break;
+    case 2: RNS(2); break;
+    case 3: RNS(3); break;
+    case 4: RNS(4); break;
+    case 5: RNS(5); break;
+    case 6: RNS(6); break;
+    case 7: RNS(7); break;
+    default: RNS(8); break;
+  }
+#undef RNS
+  PSG_CHECK_LAUNCH("psg_rmsnorm_split");
+  return PSG_OK;
+}
+
+// act = silu(g) * u of gate_up * (row_scale x col_scale)  ->  out3 [rows][3 inter] fp16, inv_scale [rows]; a workgroup per row
+#define SP_MAXCH 16
+__global__ void __launch_bounds__(256) silu_mul_split_kernel(const float* __restrict__ gu, const float* __restrict__ rsv,
+                                                             const float* __restrict__ csv, int inter,
+                                                             uint16_t* __restrict__ out3, float* __restrict__ inv_scale) {
+  __shared__ float s_max[4];
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float rs = rsv[row];
+  const float* gr = gu + row * 2 * (int64_t)inter;
+  float o[SP_MAXCH][4];
+  float mx = 0.f;
+#pragma unroll
+  for (int c = 0; c < SP_MAXCH; ++c) {
+    const int col = (c * 256 + tid) * 4;
+    if (col < inter) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gr + col), u4 = *reinterpret_cast<const float4*>(gr + inter + col);
+      const float4 cg = *reinterpret_cast<const float4*>(csv + col), cu = *reinterpret_cast<const float4*>(csv + inter + col);
+      const float g[4] = {g4.x * (rs * cg.x), g4.y * (rs * cg.y), g4.z * (rs * cg.z), g4.w * (rs * cg.w)};
+      const float u[4] = {u4.x * (rs * cu.x), u4.y * (rs * cu.y), u4.z * (rs * cu.z), u4.w * (rs * cu.w)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = g[e] / (1.0f + expf(-g[e]));                  // silu_mul_kernel<float>
+        o[c][e] = s * u[e];
+        mx = fmaxf(mx, fabsf(o[c][e]));
+      }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) s_max[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  const float scale = sp_row_scale(mx, tid == 0 ? inv_scale + row : nullptr);
+  uint16_t* o0 = out3 + row * 3 * (int64_t)inter;
+#pragma unroll
+  for (int c = 0; c < SP_MAXCH; ++c) {
+    const int col = (c * 256 + tid) * 4;
+    if (col < inter) sp_store3(o0, inter, col, o[c], scale);
+  }
+}
+
+extern "C" int psg_silu_mul_split(psg_ctx* ctx, const float* gate_up, const float* row_scale, const float* col_scale,
+                                  int64_t rows, int inter, void* out3, float* inv_scale, void* stream) {
+  PSG_REQUIRE(ctx && gate_up && row_scale && col_scale && out3 && inv_scale, PSG_ERR_INVALID,
+              "psg_silu_mul_split: NULL argument");
+  PSG_REQUIRE(inter > 0 && inter % 4 == 0 && inter <= SP_MAXCH * 1024 && rows >= 0 && rows < (1ll << 31),
+              PSG_ERR_UNSUPPORTED, "psg_silu_mul_split: inter=%d (multiple of 4, <= %d)", inter, SP_MAXCH * 1024);
+  if (rows == 0) return PSG_OK;
+  silu_mul_split_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(gate_up, row_scale, col_scale, inter,
+                                                                         (uint16_t*)out3, inv_scale);
+  PSG_CHECK_LAUNCH("psg_silu_mul_split");
+  return PSG_OK;
+}
+
+// psg_rope_kvwrite on a raw q|k|v projection result with its scale vectors (fp32; rotary position = cache slot)
+__global__ void rope_kvwrite_scaled_kernel(const float* __restrict__ qkv, const float* __restrict__ rsv,
+                                           const float* __restrict__ csv, const int32_t* __restrict__ tok_pair,
+                                           const int32_t* __restrict__ tok_pos, const float* __restrict__ cos_tab,
+                                           const float* __restrict__ sin_tab, int64_t rows, int heads, int ctx,
+                                           float* __restrict__ q_out, float* __restrict__ kc, float* __restrict__ vc) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= rows * heads) return;
+  const int64_t row = wave / heads;
+  const int h = (int)(wave % heads);
+  const int pos = tok_pos[row];
+  if (pos < 0) return;
+  const int hidden = heads * 128;
+  const int c0 = h * 128 + lane;
+  const int64_t base = row * 3 * hidden;
+  const float rs = rsv[row];
+  const float cs = cos_tab[pos * 64 + lane], sn = sin_tab[pos * 64 + lane];
+  auto ld = [&](int col) { return qkv[base + col] * (rs * csv[col]); };
+  const float q1 = ld(c0), q2 = ld(c0 + 64), k1 = ld(hidden + c0), k2 = ld(hidden + c0 + 64);
+  const float v1 = ld(2 * hidden + c0), v2 = ld(2 * hidden + c0 + 64);
+  float qa, qb, ka, kb;
+  psg_rope_pair(q1, q2, cs, sn, qa, qb);
+  psg_rope_pair(k1, k2, cs, sn, ka, kb);
+  q_out[row * hidden + c0] = qa;
+  q_out[row * hidden + c0 + 64] = qb;
+  const int64_t cbase = (((int64_t)tok_pair[row] * heads + h) * ctx + pos) * 128;
+  kc[cbase + lane] = ka;
+  kc[cbase + lane + 64] = kb;
+  vc[cbase + lane] = v1;
+  vc[cbase + lane + 64] = v2;
+}
+
+extern "C" int psg_rope_kvwrite_scaled(psg_ctx* ctx_, const float* qkv, const float* row_scale, const float* col_scale,
+                                       const int32_t* tok_pair, const int32_t* tok_pos, const float* rope_cos,
+                                       const float* rope_sin, int64_t rows, int heads, int head_dim, int ctx, float* q_out,
+                                       float* k_cache, float* v_cache, void* stream) {
+  PSG_REQUIRE(ctx_ && qkv && row_scale && col_scale && tok_pair && tok_pos && rope_cos && rope_sin && q_out && k_cache &&
+                  v_cache, PSG_ERR_INVALID, "psg_rope_kvwrite_scaled: NULL argument");
+  PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_rope_kvwrite_scaled: head_dim=%d (kernel is built for 128)", head_dim);
+  if (rows == 0) return PSG_OK;
+  const int64_t waves = rows * heads;
+  rope_kvwrite_scaled_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      qkv, row_scale, col_scale, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, q_out, k_cache, v_cache);
+  PSG_CHECK_LAUNCH("psg_rope_kvwrite_scaled");
+  return PSG_OK;
+}

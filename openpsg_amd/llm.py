@@ -90,6 +90,9 @@ class LlamaDecodeEngine:
         # device, 13..32 rows): bit-identical to the launch chain, so every other shape - and the in-flight slots, since
         # only one persistent launch may run on a device at a time - simply keeps the chain
         self.persistent_layer = bool(_lib.get_option(dev_i, "decode_persistent"))
+        # fp32s prompt pass: the split of a projection's operand and the un-scaling of its result inside the row kernels
+        # next to it (psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split; bit-identical, 7 launches per layer less)
+        self.fuse_split = bool(_lib.get_option(dev_i, "llm_fuse_split"))
         self._dl_ws = {}
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
         self.early_exit_chunk = 4        # natural-EOS decode: steps per graph between "all pairs done?" checks
@@ -153,6 +156,10 @@ class LlamaDecodeEngine:
         attention - output projection, norms, MLP - on those k rows only; returns [k, D]."""
         m = self.cfg.llm
         rows, D = resid.shape
+        if (self.prefill_split and self.fuse_split and not decode and prefill_shape is not None and rope_pos is None
+                and rows > 32 and m.head_dim == 128 and prefill_shape[1] <= 64 and not self.prefill_attn_scalar
+                and m.inter <= 16384 and D <= 8192):
+            return self._forward_split(resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape, keep_rows)
         n = torch.empty((rows, D), device=self.device, dtype=self.dtype)
         ops.rmsnorm(resid, None, self.layers[0]["ln1"], m.rms_eps, n)
         q = torch.empty_like(n)
@@ -192,6 +199,42 @@ class LlamaDecodeEngine:
             d = self.linear(act, L["wdown"], L.get("wdown_s"))
             nxt = self.layers[l + 1]["ln1"] if l + 1 < len(self.layers) else self.final_norm
             ops.rmsnorm(resid, d, nxt, m.rms_eps, n)                           # resid += d ; n = norm(resid)
+        return n
+
+    def _forward_split(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape, keep_rows):
+        """`_forward` for the prompt pass of the fp32s mode with the operand splits and result scalings fused into the row
+        kernels: RMSNorm and SwiGLU write [hi | hi | lo] fp16 segments, every projection result stays raw (`ops.Scaled`)
+        until its reader applies the scales while loading.  Same arithmetic as `_forward` + linear_split, bit for bit."""
+        m = self.cfg.llm
+        rows, D = resid.shape
+        mm = lambda a3, ws: torch.mm(a3, ws[0].t(), out_dtype=torch.float32)       # noqa: E731
+        a3, inv_r = ops.rmsnorm_split(resid, None, self.layers[0]["ln1"], m.rms_eps)
+        q = torch.empty((rows, D), device=self.device, dtype=torch.float32)
+        att = torch.empty_like(q)
+        n = None
+        for l, L in enumerate(self.layers):
+            qkv = ops.Scaled(mm(a3, L["wqkv_s"]), inv_r, L["wqkv_s"][1])
+            ops.rope_kvwrite_scaled(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, q, kc[l], vc[l])
+            ops.prefill_attn(q, kc[l], vc[l], tok_pos, prefill_shape[0], prefill_shape[1], m.heads, m.head_dim, ctx_len, att)
+            last = l == len(self.layers) - 1
+            if keep_rows is not None and last:
+                k = keep_rows.numel()
+                att_k = torch.empty((k, D), device=self.device, dtype=torch.float32)
+                resid_k = torch.empty((k, D), device=self.device, dtype=torch.float32)
+                ops.gather_rows(att, keep_rows, att_k)
+                ops.gather_rows(resid, keep_rows, resid_k)
+                att, resid = att_k, resid_k
+            a3o, inv_o = ops.split_f16x3(att)                   # a row's maximum spans all heads: stays a kernel of its own
+            o = ops.Scaled(mm(a3o, L["wo_s"]), inv_o, L["wo_s"][1])
+            a3, inv_r = ops.rmsnorm_split(resid, o, L["ln2"], m.rms_eps)
+            gu = ops.Scaled(mm(a3, L["wgu_s"]), inv_r, L["wgu_s"][1])
+            a3a, inv_a = ops.silu_mul_split(gu, m.inter)
+            d = ops.Scaled(mm(a3a, L["wdown_s"]), inv_a, L["wdown_s"][1])
+            if last:                                            # the lm_head reads fp32 rows
+                n = torch.empty_like(resid)
+                ops.rmsnorm(resid, d.dense(), self.final_norm, m.rms_eps, n)
+            else:
+                a3, inv_r = ops.rmsnorm_split(resid, d, self.layers[l + 1]["ln1"], m.rms_eps)
         return n
 
     def _can_persist(self, rows, slot):

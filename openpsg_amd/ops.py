@@ -682,3 +682,51 @@ def scale_rows_cols(y, row_scale, col_scale):
     check(lib.psg_scale_rows_cols(ctx, _p(y, torch.float32, "y"), rows, N, _p(row_scale, torch.float32),
                                   _p(col_scale, torch.float32), st), "psg_scale_rows_cols")
     return y
+
+
+class Scaled:
+    """A raw split-fp16 GEMM result y [rows, N] fp32 with the power-of-two scales that turn it into the product:
+    value = y * (row_scale[m] * col_scale[n]).  Consumed by rmsnorm_split / rope_kvwrite_scaled / silu_mul_split."""
+    __slots__ = ("y", "row_scale", "col_scale")
+
+    def __init__(self, y, row_scale, col_scale):
+        assert y.dtype == torch.float32 and y.dim() == 2 and row_scale.numel() == y.shape[0] and col_scale.numel() == y.shape[1]
+        self.y, self.row_scale, self.col_scale = y, row_scale, col_scale
+
+    def dense(self):
+        return scale_rows_cols(self.y, self.row_scale, self.col_scale)
+
+
+def rmsnorm_split(resid, delta, w, eps):
+    """resid += delta (a `Scaled` or None); RMSNorm(resid) * w as split-fp16 segments: (fp16 [rows, 3 hidden], inv_scale)."""
+    lib, ctx, st = _env(resid)
+    rows, hidden = resid.shape
+    out = torch.empty((rows, 3 * hidden), device=resid.device, dtype=torch.float16)
+    inv = torch.empty(rows, device=resid.device, dtype=torch.float32)
+    dp, rp, cp = (None, None, None) if delta is None else (_p(delta.y), _p(delta.row_scale, torch.float32),
+                                                           _p(delta.col_scale, torch.float32))
+    check(lib.psg_rmsnorm_split(ctx, _p(resid, torch.float32, "resid"), dp, rp, cp, _p(w, torch.float32), float(eps), rows,
+                                hidden, _p(out), _p(inv), st), "psg_rmsnorm_split")
+    return out, inv
+
+
+def rope_kvwrite_scaled(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, q_out, k_cache, v_cache):
+    lib, ctx, st = _env(q_out)
+    rows = q_out.shape[0]
+    assert isinstance(qkv, Scaled) and qkv.y.shape == (rows, 3 * heads * head_dim)
+    check(lib.psg_rope_kvwrite_scaled(ctx, _p(qkv.y), _p(qkv.row_scale, torch.float32), _p(qkv.col_scale, torch.float32),
+                                      _p(tok_pair, torch.int32), _p(tok_pos, torch.int32), _p(rope[0], torch.float32),
+                                      _p(rope[1], torch.float32), rows, heads, head_dim, ctx_len, _p(q_out, torch.float32),
+                                      _p(k_cache, torch.float32), _p(v_cache, torch.float32), st), "psg_rope_kvwrite_scaled")
+
+
+def silu_mul_split(gate_up, inter):
+    """silu(gate) * up of a `Scaled` gate|up result as split-fp16 segments: (fp16 [rows, 3 inter], inv_scale)."""
+    lib, ctx, st = _env(gate_up.y)
+    rows = gate_up.y.shape[0]
+    assert gate_up.y.shape[1] == 2 * inter
+    out = torch.empty((rows, 3 * inter), device=gate_up.y.device, dtype=torch.float16)
+    inv = torch.empty(rows, device=gate_up.y.device, dtype=torch.float32)
+    check(lib.psg_silu_mul_split(ctx, _p(gate_up.y), _p(gate_up.row_scale, torch.float32), _p(gate_up.col_scale, torch.float32),
+                                 rows, inter, _p(out), _p(inv), st), "psg_silu_mul_split")
+    return out, inv

@@ -181,8 +181,8 @@ def test_prompt_dedup_equals_per_pair_path(dtype, chunk, monkeypatch):
         # (two fp32 paths whose library GEMMs see other row counts - per pair / per prompt, 33 shared query rows - and
         # whose LayerNorm chains amplify one rounding: both are ~1e-5 from the fp64 truth)
         assert err < 5e-5 and np.abs(la - lb).max() < 5e-5 and len(common) >= len(a["sel"]) - 4
-        np.testing.assert_allclose(pa, pb, atol=2e-5)
-        np.testing.assert_allclose(a["hidden"], b["hidden"], atol=2e-5)       # last layer of EVERY pair, both ways
+        np.testing.assert_allclose(pa, pb, atol=5e-5)
+        np.testing.assert_allclose(a["hidden"], b["hidden"], atol=5e-5)       # last layer of EVERY pair, both ways
         assert np.array_equal(a["tokens"][ia], b["tokens"][ib])
     else:
         assert err < 0.06 and len(common) >= len(a["sel"]) - 6

@@ -185,3 +185,91 @@ def test_dense_gemm_fp32_output_with_split_scales(M, N, K, gelu):
         a2, r2 = ops.split_f16x3(x[:m2].contiguous())
         y2 = ops.dense_gemm(a2, b3, b, gelu=gelu, out_dtype=torch.float32, row_scale=r2, col_scale=inv_c)
         assert torch.equal(y2, y[:m2])
+
+
+def test_fused_split_kernels_equal_the_separate_kernels_bit_for_bit():
+    """psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split against psg_scale_rows_cols + psg_rmsnorm /
+    psg_rope_kvwrite / psg_silu_mul + psg_split_f16x3 on the prompt pass's shapes: identical bits (no GEMM involved)."""
+    from openpsg_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(11)
+    rows, D, I, heads, ctx = 200, 4096, 11008, 32, 64
+    pw2 = lambda n: torch.exp2(torch.randint(-20, 4, (n,), generator=g, device=dev).float())   # noqa: E731
+    # RMSNorm
+    resid0 = torch.randn(rows, D, generator=g, device=dev)
+    w = 1.0 + 0.1 * torch.randn(D, generator=g, device=dev)
+    for with_delta in (False, True):
+        y, rs, cs = torch.randn(rows, D, generator=g, device=dev) * 1e3, pw2(rows), pw2(D)
+        ra, rb = resid0.clone(), resid0.clone()
+        n = torch.empty_like(ra)
+        ops.rmsnorm(ra, ops.scale_rows_cols(y.clone(), rs, cs) if with_delta else None, w, 1e-5, n)
+        a3, inv = ops.split_f16x3(n)
+        b3, binv = ops.rmsnorm_split(rb, ops.Scaled(y.clone(), rs, cs) if with_delta else None, w, 1e-5)
+        assert torch.equal(ra, rb) and torch.equal(a3, b3) and torch.equal(inv, binv)
+    # SwiGLU
+    y, rs, cs = torch.randn(rows, 2 * I, generator=g, device=dev) * 1e3, pw2(rows), pw2(2 * I)
+    act = torch.empty(rows, I, device=dev)
+    ops.silu_mul(ops.scale_rows_cols(y.clone(), rs, cs), act)
+    a3, inv = ops.split_f16x3(act)
+    b3, binv = ops.silu_mul_split(ops.Scaled(y.clone(), rs, cs), I)
+    assert torch.equal(a3, b3) and torch.equal(inv, binv)
+    # rotary + cache write
+    K, S = 5, 40
+    rows = K * S
+    y, rs, cs = torch.randn(rows, 3 * D, generator=g, device=dev) * 1e3, pw2(rows), pw2(3 * D)
+    inv_f = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128))
+    ang = torch.arange(ctx, dtype=torch.float32)[:, None] * inv_f[None, :]
+    rope = (ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev))
+    pos = torch.arange(S, dtype=torch.int32).repeat(K)
+    pos[S - 3:S] = -1
+    pos = pos.to(dev)
+    pair = torch.arange(K, dtype=torch.int32)[:, None].expand(-1, S).reshape(-1).contiguous().to(dev)
+    outs = []
+    for fused in (False, True):
+        q = torch.zeros(rows, D, device=dev)
+        kc, vc = torch.zeros(K, heads, ctx, 128, device=dev), torch.zeros(K, heads, ctx, 128, device=dev)
+        if fused:
+            ops.rope_kvwrite_scaled(ops.Scaled(y.clone(), rs, cs), pair, pos, rope, heads, 128, ctx, q, kc, vc)
+        else:
+            ops.rope_kvwrite(ops.scale_rows_cols(y.clone(), rs, cs), pair, pos, rope, heads, 128, ctx, q, kc, vc)
+        outs.append((q, kc, vc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_fp32s_prompt_pass_with_fused_splits_matches_the_separate_kernels():
+    """fp32s mode, G6 (Llama-2-7B width, 2 layers): the prompt pass with the operand splits / result scalings inside
+    RMSNorm, rotary and SwiGLU against the separate launches: the same greedy tokens (the reference's) and first-step
+    logits to 1e-4 (the kernels are bit-identical, previous test; the library GEMM between them is not run-to-run)."""
+    import numpy as np
+    from openpsg_amd import _lib
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from tests import helpers as H
+    g, cfg, w, scene = H.load_case("G6_llm_7b_width_n6")
+    dev = torch.device("cuda:0")
+    ids = [int(i) for i in scene["object_id_list"]]
+    names = H.object_names(scene)
+    sel = torch.from_numpy(g["selected"].astype(np.int32)).to(dev)
+    outs = {}
+    for flag in (0, 1):
+        _lib.set_option(0, "llm_fuse_split", flag)
+        try:
+            head = RelationTransformerHeadV4(dtype="fp32s", device="cuda:0", qformer_vocab_size=cfg.qformer.vocab,
+                                             llm_config=cfg.llm, llm_feature_size=cfg.llm.hidden, tokenizers="word",
+                                             max_object_num=cfg.max_object_num, on_parse_error="skip",
+                                             suppress_eos=bool(g["suppress_eos"]))
+            head.load_weights(w)
+            assert head.llm_engine.fuse_split == bool(flag)
+            rq = head.run_relation_query(scene["mask_features"].to(dev), scene["img_meta"], ids, names,
+                                         scene["pan_results"].to(dev))
+            dec = head.decode_selected(rq, names, selected=sel)
+            outs[flag] = (dec["tokens_host"].copy(), dec["first_logits"].float().cpu())
+        finally:
+            _lib.set_option(0, "llm_fuse_split", 1)
+        del head
+        torch.cuda.empty_cache()
+    assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-4
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for i in range(outs[1][0].shape[0]):
+        want = g["gen_tokens"][i]
+        assert [int(t) for t in outs[1][0][i] if t >= 0] == want[want >= 0].tolist()
