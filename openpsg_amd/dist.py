@@ -160,6 +160,19 @@ class HipBackend:
                                         to_host=False)
         return out["tokens"]
 
+    def decode_dealt(self, scene, selected, features):
+        """`decode` for a DEALT subset of an image's selected pairs (strong scaling): an fp32s head
+        switches its prompt pass to the row-count-invariant projections, so that a pair decodes to the same bits in a
+        batch of 3 on this rank as in the batch of 20 on one GPU (the single-GPU head gives those bits with
+        `head.llm_engine.row_invariant = True`; with the library GEMM it is fp32-grade noise apart)."""
+        eng = self.head.llm_engine
+        prev = eng.row_invariant
+        eng.row_invariant = prev or bool(eng.prefill_split)
+        try:
+            return self.decode(scene, selected, features)
+        finally:
+            eng.row_invariant = prev
+
     def decode_multi(self, scenes, selected_list, features_list):
         """The decodes of several images of this rank, side by side on the head's slot streams."""
         items = [dict(rq=dict(num_objects=self.num_objects(s)), names=self._names(s), selected=sel, pair_features=f)
@@ -380,7 +393,8 @@ class PairShardedPipeline:
             if idx:
                 it = torch.tensor(idx, device=patches.device, dtype=torch.int64)
                 frow = (it[:, None] * nv + torch.arange(nv, device=patches.device)[None, :]).reshape(-1)
-                tok_pad[:len(idx)] = be.decode(scene, sel[it].contiguous(), feats[frow].contiguous())
+                tok_pad[:len(idx)] = getattr(be, "decode_dealt", be.decode)(scene, sel[it].contiguous(),
+                                                                             feats[frow].contiguous())
             allt = yield ("all_gather", tok_pad)                                     # [R, per, max_new]
             tokens = torch.empty((K, be.max_new), device=patches.device, dtype=torch.int32)
             for rr in range(R):

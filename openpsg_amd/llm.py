@@ -72,6 +72,13 @@ class LlamaDecodeEngine:
             for L in self.layers:
                 for k in ("wqkv", "wo", "wgu", "wdown"):
                     L[k + "_s"] = ops.split_f16x3(L[k], weights=True)
+        # row_invariant (fp32s engines): the prompt pass's projections and the language projection on psg_dense_gemm - one
+        # k-ordered accumulation per output element whatever the row count of the call - instead of the library GEMM, whose
+        # kernel choice follows the row count: a pair decoded in a batch of 3 (decodes DEALT over the ranks of a pair-sharded
+        # job) then gives the bits it gives in the batch of 20.  ~1.3x the prompt pass's GEMM time: the sharded
+        # pipeline switches it on, a single GPU does not need it
+        self.row_invariant = False
+        self.proj_s = ops.split_f16x3(self.proj_w, weights=True) if self.prefill_split else None
         # greedy argmax over the fp32 split-K sums of the lm_head, NOT over their 16-bit rounding: HF computes the logits of
         # a model cast to 16 bits in 16 bits, but the reference runs the LLM in fp32 (V4:99-100), and a 16-bit logit has
         # an ulp of 0.008-0.016 (fp16) / 0.06 (bf16) at |x| ~ 8-16 - wider than many top-2 margins of a 32000-way
@@ -112,6 +119,8 @@ class LlamaDecodeEngine:
         are exact in fp32, so what is lost against an fp32 GEMM is the xl.wl term and the split residuals: ~7e-7
         relative per product (fp32 rounds each product to 6e-8), at 3/16 of the fp32 matrix time."""
         a3, inv_r = ops.split_f16x3(x)
+        if self.row_invariant and ws[0].shape[0] % 256 == 0 and ws[0].shape[1] % 64 == 0:
+            return ops.dense_gemm(a3, ws[0], None, out_dtype=torch.float32, row_scale=inv_r, col_scale=ws[1])
         y = torch.mm(a3, ws[0].t(), out_dtype=torch.float32)
         return ops.scale_rows_cols(y, inv_r, ws[1])
 
@@ -156,7 +165,8 @@ class LlamaDecodeEngine:
         attention - output projection, norms, MLP - on those k rows only; returns [k, D]."""
         m = self.cfg.llm
         rows, D = resid.shape
-        if (self.prefill_split and self.fuse_split and not decode and prefill_shape is not None and rope_pos is None
+        if (self.prefill_split and self.fuse_split and not self.row_invariant and not decode and prefill_shape is not None
+                and rope_pos is None
                 and rows > 32 and m.head_dim == 128 and prefill_shape[1] <= 64 and not self.prefill_attn_scalar
                 and m.inter <= 16384 and D <= 8192):
             return self._forward_split(resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape, keep_rows)
@@ -314,7 +324,12 @@ class LlamaDecodeEngine:
         K, Tp = prompt_ids.shape
         nv = self.cfg.qformer.num_query
         X = torch.empty((K, nv + Tp, m.hidden), device=self.device, dtype=self.dtype)
-        vis = F.linear(pair_feature_rows, self.proj_w, self.proj_b).view(K, nv, m.hidden)
+        if self.row_invariant and self.proj_s is not None and m.hidden % 256 == 0 and pair_feature_rows.shape[1] % 64 == 0:
+            a3, inv_r = ops.split_f16x3(pair_feature_rows.contiguous())
+            vis = ops.dense_gemm(a3, self.proj_s[0], self.proj_b, out_dtype=torch.float32, row_scale=inv_r,
+                                 col_scale=self.proj_s[1]).view(K, nv, m.hidden)
+        else:
+            vis = F.linear(pair_feature_rows, self.proj_w, self.proj_b).view(K, nv, m.hidden)
         X[:, :nv] = vis
         tok = torch.empty((K * Tp, m.hidden), device=self.device, dtype=self.dtype)
         ops.gather_rows(self.embed, prompt_ids.reshape(-1).contiguous(), tok)
@@ -370,7 +385,8 @@ class LlamaDecodeEngine:
             return (lambda: outs) if defer else outs
         chunk = 0 if suppress_eos else int(self.early_exit_chunk)
         split = gate is not None and max_new > 1
-        key = (tuple(X.shape), max_new, bool(suppress_eos), bool(return_first_logits), chunk, int(slot), split)
+        key = (tuple(X.shape), max_new, bool(suppress_eos), bool(return_first_logits), chunk, int(slot), split,
+               bool(self.row_invariant))
         ent = self._graphs.get(key)
         if ent is not None:
             self._graphs.move_to_end(key)

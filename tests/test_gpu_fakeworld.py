@@ -50,6 +50,8 @@ def c4():
     heads = {}
     for dt in ("fp32", "mixed", "fp32s"):
         h = _mk_head(dt, 100)
+        if dt == "fp32s":                       # the single-GPU reference of the bit-exact test: row-count-invariant
+            h.llm_engine.row_invariant = True   # projections in the prompt pass too, as the dealt decodes use them
         h(_inputs(scene))
         torch.cuda.synchronize()
         heads[dt] = (h, dict(prob=h.last["exist_prob"].clone(), sel=h.last["selected"].clone(),
@@ -87,7 +89,7 @@ def test_one_c4_image_sharded_is_bit_exact_with_row_invariant_projections(c4, wo
     """SURVEY 8e "bit-exactness across R": in the fp32s mode every Q-Former projection runs on psg_dense_gemm (one
     k-ordered accumulation per output element, whatever the row count of the call), every other kernel computes a pair
     independently of its neighbours - so the all-gathered probabilities of a sharded pass EQUAL the single-GPU head's,
-    bit for bit, and the top-20 is the same list."""
+    bit for bit, the top-20 is the same list, and - with the prompt pass on the same kernel - so is every decoded token."""
     from openpsg_amd.dist import HipBackend, LoopbackWorld
     scene, heads = c4
     head, ref = heads["fp32s"]
@@ -100,7 +102,11 @@ def test_one_c4_image_sharded_is_bit_exact_with_row_invariant_projections(c4, wo
         assert torch.equal(outs[r]["selected"], ref["sel"])
     same = int((outs[0]["tokens"].cpu().numpy() == ref["tokens"]).all(axis=1).sum())
     print(f"fp32s, world {world}: probabilities bit-exact, selection 20/20, identical token sequences {same}/20")
-    assert same >= 19              # the dealt prompt passes see other row counts in the LIBRARY GEMM (fp32-grade noise)
+    # the dealt prompt passes (10 / 3-or-2 pairs per rank) run on the row-count-invariant projections (psg_dense_gemm,
+    # HipBackend.decode_dealt), the decode steps on kernels that are batch-invariant by construction: EVERY token
+    assert same == 20
+    for r in range(world):
+        assert np.array_equal(outs[r]["tokens"].cpu().numpy(), ref["tokens"])
 
 
 def test_one_c4_image_sharded_mixed_mode_is_within_rounding(c4):

@@ -234,7 +234,7 @@ def test_fp32_head_vs_oracle_at_full_size(N):
         orq = O.relation_query(w, cfg, scene["mask_features"], scene["img_meta"], ids, scene["pan_results"], qids, qmask)
     want_sel = O.select_topk(orq["exist_prob"], 20)
     errs = {}
-    for dtype in ("fp32", "bf16"):
+    for dtype in ("fp32", "fp32s", "bf16"):
         head = RelationTransformerHeadV4(dtype=dtype, device="cuda:0", qformer_vocab_size=512, llm_config=cfg.llm,
                                          llm_feature_size=256, tokenizers="word", max_object_num=N)
         head.load_weights(w)
@@ -245,10 +245,15 @@ def test_fp32_head_vs_oracle_at_full_size(N):
             assert rq["exist_logit"].numel() == N * N
             herr = (rq["hidden"].float().cpu().view(N * N, 33, 768) - orq["qformer_out"]).abs().max().item()
             assert rq["selected"].cpu().tolist() == want_sel
+        elif dtype == "fp32s":                                    # the benchmarked mode: the fp32 bar on ALL pairs
+            herr_s = (rq["hidden"].float().cpu().view(N * N, 33, 768) - orq["qformer_out"]).abs().max().item()
+            assert rq["selected"].cpu().tolist() == want_sel
         else:
             overlap = len(set(rq["selected"].cpu().tolist()) & set(want_sel))
         del head
     print(f"N={N} ({N * N} pairs): fp32 max |logit - oracle| = {errs['fp32']:.3e}, hidden {herr:.3e}; "
           f"bf16 {errs['bf16']:.3e}, top-20 overlap {overlap}/20")
+    print(f"N={N}: fp32s (split-fp16 products, the headline mode) max |logit - oracle| = {errs['fp32s']:.3e}, hidden {herr_s:.3e}")
     assert errs["fp32"] < 1e-3 and herr < 1e-3
+    assert errs["fp32s"] < 1e-3 and herr_s < 1e-3
     assert errs["bf16"] < 0.35 and overlap >= 14
