@@ -72,7 +72,7 @@ def test_collective_wrappers_with_c4_shapes_and_dtypes(rccl):
     assert back[0]["rel_pred"] == [[1, 2, 3]] and np.array_equal(back[0]["pan"], res[0][1]["pan"]) and back[1]["rel_pred"] == []
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "mixed"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp32s", "mixed"])
 def test_pipelines_over_rccl_world1_match_the_head(rccl, dtype):
     """`step_one_image` and `step` driven by the real process group (every collective a RCCL call) == head.forward."""
     from openpsg_amd.dist import PairShardedPipeline
@@ -89,3 +89,13 @@ def test_pipelines_over_rccl_world1_match_the_head(rccl, dtype):
     many = pipe.step([scene])
     assert torch.equal(many["exist_prob"][0], ref["prob"]) and torch.equal(many["selected"][0], ref["sel"])
     assert np.array_equal(many["tokens"][0].cpu().numpy(), ref["tokens"])
+
+    # two images per rank and step (the side-by-side decodes of `bench.py --gpus N --in-flight 2`): the collectives carry
+    # [P, ...] blocks, a rank's P decodes run on the head's slot streams
+    scene2 = make_scene((512, 512), 9, seed=9, device="cuda:0", tiny_object=True)
+    head(_inputs(scene2))
+    ref2 = dict(prob=head.last["exist_prob"].clone(), sel=head.last["selected"].clone(), tokens=head.last["tokens_host"].copy())
+    both = pipe.step([scene, scene2])
+    for m, rf in enumerate((ref, ref2)):
+        assert torch.equal(both["exist_prob"][m], rf["prob"]) and torch.equal(both["selected"][m], rf["sel"])
+        assert np.array_equal(both["tokens"][m].cpu().numpy(), rf["tokens"])
