@@ -335,6 +335,14 @@ int psg_decode_layer(psg_ctx*, void* resid, const void* delta, int delta_splits,
                      const int32_t* tok_pos, const float* rope_cos, const float* rope_sin, int M, int hidden, int inter,
                      int heads, int ctx_len, float eps, void* k_cache, void* v_cache, float* workspace, uint32_t* counters,
                      float* down_part, int dtype, void* stream);
+/* The same for n_layers decoder layers chained inside ONE launch (the whole stack of a decode step).  layer_table: device
+ * array of n_layers x 8 pointers {ln1, ln2, wqkv, wo, wgu, wdown, k_cache, v_cache}; layer l leaves its down partials in
+ * down_parts + (l & 1) * 16 * M * hidden floats (the caller's final psg_rmsnorm reads buffer (n_layers - 1) & 1);
+ * counters: n_layers blocks of psg_decode_layer_workspace()'s size, zeroed. */
+int psg_decode_layers(psg_ctx*, void* resid, const void* delta, int delta_splits, const void* layer_table, int n_layers,
+                      const int32_t* tok_pair, const int32_t* tok_pos, const float* rope_cos, const float* rope_sin, int M,
+                      int hidden, int inter, int heads, int ctx_len, float eps, float* workspace, uint32_t* counters,
+                      float* down_parts, int dtype, void* stream);
 
 /* ---- fp32-grade products on the 16-bit matrix cores (prompt pass of the reference-precision mode, V4:99-100 with
  * HF-LL:163-177): an fp32 row, scaled by a power of two so that its largest magnitude lies in [2^13, 2^14), is written as

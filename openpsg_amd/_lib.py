@@ -80,6 +80,7 @@ SIGNATURES = {
     "psg_silu_mul_split": [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp],
     "psg_decode_layer_workspace": [_vp, _i, _i, _i, C.POINTER(_i64), C.POINTER(_i64)],
     "psg_decode_layer_supported": [_vp, _i, _i, _i, _i, _i],
+    "psg_decode_layers": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],
     "psg_decode_layer": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,
                          _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "psg_reduce_partials": [_vp, _vp, _i, _i64, _vp, _i, _vp],

@@ -49,6 +49,7 @@
 #define PSG_DL_CNT_X2 89       // 8 + 1 + 8 as X1: post-attention columns reduced
 #define PSG_DL_CNT_GU 106      // 32: gate|up column group gx done for K slice by, 8 arrivals each
 #define PSG_DL_CNT_H 138       // inter / 128 slots: SwiGLU block j stored, M arrivals each
+#define PSG_DL_CNT_DGRP 236    // 16: down-projection column group gx done for K slice by, 16 arrivals each (layer chaining)
 #define PSG_DL_TIMEOUT 255
 #define PSG_DL_SLOT 64         // words per slot
 #define PSG_DL_NCNT (256 * PSG_DL_SLOT)
@@ -57,22 +58,28 @@ typedef float df32x4_t __attribute__((ext_vector_type(4)));
 typedef float df32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned long long du64;
 
+struct psg_dl_layer {          // one decoder layer's tensors (psg_decode_layers: an array of these in device memory)
+  const float* ln1;
+  const float* ln2;
+  const float* wqkv;
+  const float* wo;
+  const float* wgu;
+  const float* wdown;
+  float* kc;
+  float* vc;
+};
+
 struct psg_dl_args {
+  const psg_dl_layer* table;  // n_layers entries, device memory
+  int n_layers;
+  float* down_part2;          // the other half of the double-buffered down partials (layer l writes buffer l & 1)
   float* resid;               // [M][D] residual stream, updated in place
   const float* delta;         // previous layer's down partials [dsplits][M][D] (NULL: none)
   int dsplits;
-  const float* ln1;
-  const float* ln2;
-  const float* wqkv;          // [3 D][D]
-  const float* wo;            // [D][D]
-  const float* wgu;           // [2 I][D]
-  const float* wdown;         // [D][I]
   const int32_t* tok_pair;
   const int32_t* tok_pos;
   const float* cos_tab;
   const float* sin_tab;
-  float* kc;
-  float* vc;
   float* qkv_part;            // [8][M][3 D]
   float* att;                 // [M][D]
   float* o_part;              // [8][M][D]
@@ -85,6 +92,20 @@ struct psg_dl_args {
   int M, D, I, heads, ctx;
   float eps;
 };
+
+// Thread / workgroup index through an opaque (empty) asm statement: everything derived from them is recomputed where it is
+// used instead of being hoisted out of the layer loop - hoisted, the per-phase address arithmetic of four projections and
+// five row phases stays live across the whole loop body and spills INSIDE the weight streams (measured: 188 -> 294 us).
+__device__ __forceinline__ int dl_tid() {
+  int t = (int)threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+__device__ __forceinline__ int dl_bid() {
+  int t = (int)blockIdx.x;
+  asm volatile("" : "+s"(t));
+  return t;
+}
 
 // ---- write-through stores / sc1 loads --------------------------------------------------------------------------------
 __device__ __forceinline__ void dl_st2(float* p, float a, float b) {              // 8-byte aligned
@@ -107,7 +128,7 @@ __device__ __forceinline__ void dl_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 // publish: every wave has drained its stores (dl_drain) BEFORE it comes here; ONE lane counts the workgroup in
 __device__ __forceinline__ void dl_publish(unsigned* cnt, int slot, unsigned n = 1u) {
   dl_barrier();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt + slot * PSG_DL_SLOT, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (dl_tid() == 0) __hip_atomic_fetch_add(cnt + slot * PSG_DL_SLOT, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool dl_poll(unsigned* cnt, int slot, unsigned want) {
   return __hip_atomic_load(cnt + slot * PSG_DL_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
@@ -117,8 +138,8 @@ __device__ __forceinline__ void dl_timeout(unsigned* cnt, unsigned code) {
 }
 // wave 0 polls `nw` consecutive slots (nw <= 64) until each is >= want; the workgroup is released through a barrier
 __device__ __forceinline__ void dl_wait(unsigned* cnt, int first, int nw, unsigned want) {
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
+  if (dl_tid() < 64) {
+    const int lane = dl_tid();
     unsigned spins = 0;
     for (;;) {
       bool ok = true;
@@ -138,15 +159,15 @@ __device__ __forceinline__ void dl_wait(unsigned* cnt, int first, int nw, unsign
 // raises the eight go flags, and a workgroup polls the flag of ITS class only (32 pollers per line instead of 256).
 __device__ __forceinline__ void dl_arrive_all(unsigned* cnt, int base) {       // stores drained by the caller
   dl_barrier();
-  if (threadIdx.x == 0) {
-    const int cls = blockIdx.x & 7;
+  if (dl_tid() == 0) {
+    const int cls = dl_bid() & 7;
     if (__hip_atomic_fetch_add(cnt + (base + cls) * PSG_DL_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PSG_DL_WG / 8 - 1)
       if (__hip_atomic_fetch_add(cnt + (base + 8) * PSG_DL_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7u)
         for (int x = 0; x < 8; ++x)
           __hip_atomic_store(cnt + (base + 9 + x) * PSG_DL_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__device__ __forceinline__ void dl_wait_all(unsigned* cnt, int base) { dl_wait(cnt, base + 9 + (blockIdx.x & 7), 1, 1u); }
+__device__ __forceinline__ void dl_wait_all(unsigned* cnt, int base) { dl_wait(cnt, base + 9 + (dl_bid() & 7), 1, 1u); }
 
 // sum over the four 16-lane rows (psg_gemm_f32.hip: sgf_sum_kq)
 __device__ __forceinline__ float dl_sum_kq(float v) {
@@ -201,14 +222,14 @@ struct DlGemm {
   const unsigned char* src;
 
   __device__ __forceinline__ const unsigned char* dma_src(int t) const {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = dl_tid() & 63, wid = dl_tid() >> 6;
     const int dr = lane >> 3, dp = (lane & 7) ^ (lane >> 3);
     int r = (gx + t * G) * ROWS + (wid < W ? wid : 0) * 16 + dr;
     r = r + 8 < N ? r : (N - 9 > 0 ? N - 9 : 0);
     return wb + (int64_t)r * row_bytes + (int64_t)kbA * 128 + dp * 16;
   }
   __device__ __forceinline__ void setup(const float* w, int N_, int K, int S, int by_, int gx_, int M_, unsigned char* smem) {
-    const int wid = threadIdx.x >> 6;
+    const int wid = dl_tid() >> 6;
     wb = reinterpret_cast<const unsigned char*>(w);
     row_bytes = (int64_t)K * 4;
     N = N_; M = M_; G = PSG_DL_WG / S; gx = gx_; by = by_;
@@ -236,7 +257,7 @@ struct DlGemm {
   }
   // the first blocks of the stream: issued as soon as the rings are free, long before x exists
   __device__ __forceinline__ void prefetch() {
-    if ((int)(threadIdx.x >> 6) >= W) return;
+    if ((int)(dl_tid() >> 6) >= W) return;
     for (int i = 0; i < SLOTS - 1; ++i)
       if (i < total) issue();
   }
@@ -252,7 +273,7 @@ struct DlGemm {
   }
   // x slice [M][K slice] from global (written through by other workgroups) by sc1 LDS-DMA; caller waits + barriers
   __device__ __forceinline__ void stage_x_dma(const float* x, int64_t x_row_floats, unsigned char* xs) const {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = dl_tid() & 63, wid = dl_tid() >> 6;
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
     const int pieces = nkb * 8;
     const int cpr = (pieces + 63) >> 6;
@@ -268,7 +289,7 @@ struct DlGemm {
   }
   // the stream; x is in LDS (all waves past a barrier).  part[by][M][N] written through.
   __device__ __forceinline__ void run(float* __restrict__ part, unsigned char* smem, const unsigned char* xs) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = dl_tid(), lane = tid & 63, wid = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
     const uint32_t otile_lds =
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(smem + PSG_DL_WAVES * SLOTS * DL_BLOCK);
@@ -373,7 +394,7 @@ struct DlGemm {
 // ---- RMSNorm, producer side: workgroup b owns columns [16 b, 16 b + 16) -----------------------------------------------
 // thread (m, q) = chain thread 4 b + q of row m (rmsnorm_kernel<float, 1, float> with 1024 threads: 4 columns each)
 __device__ __forceinline__ void dl_norm_owner(const psg_dl_args& a, const float* delta, int dsplits, float* ssq_out, int b) {
-  const int tid = threadIdx.x;
+  const int tid = dl_tid();
   const int m = tid >> 2, q = tid & 3;
   const int D = a.D;
   float ss = 0.f;
@@ -413,7 +434,7 @@ __device__ __forceinline__ void dl_norm_owner(const psg_dl_args& a, const float*
 // The slice's residual values are requested first (they do not depend on the statistics): one round trip for both.
 __device__ __forceinline__ void dl_norm_stage(const psg_dl_args& a, const float* ssq, const float* gamma, int kbA, int nkb,
                                               int xstride, unsigned char* xs, float* s_inv) {
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = dl_tid(), lane = tid & 63, wid = tid >> 6;
   constexpr int NT = PSG_DL_WAVES * 64;
   constexpr int MAXE = 8;                                              // float2 pairs per thread: 24 rows x 256 pairs / 768
   const int c0 = kbA * 32;
@@ -480,7 +501,7 @@ __device__ __forceinline__ void dl_attn_round(const DlAttnArgs a, int unit, PsgD
     {
       // q, k, v columns (h 128 .., D + h 128 .., 2 D + h 128 ..) lie in the 192-row slabs col / 192 (two where 128 columns
       // straddle a slab end), produced by the column groups slab % 32: lanes 0..5 poll one group each
-      const int lane = threadIdx.x & 63;
+      const int lane = dl_tid() & 63;
       const int col = (lane >> 1) * hidden + h * 128 + ((lane & 1) ? 127 : 0);
       const int grp = lane < 6 ? (col / 192) & 31 : 0;
       unsigned spins = 0;
@@ -516,39 +537,55 @@ __device__ __forceinline__ void dl_attn_round(const DlAttnArgs a, int unit, PsgD
   };
   float* att = a.att;
   auto st = [&](int64_t i, float v) { dl_st1(att + i, v); };
-  psg_decode_attn4_unit<float>(pos >= 0, (int)(threadIdx.x & 255), row, h, pos, pos >= 0 ? a.tok_pair[row] : 0, heads, a.ctx,
+  psg_decode_attn4_unit<float>(pos >= 0, (int)(dl_tid() & 255), row, h, pos, pos >= 0 ? a.tok_pair[row] : 0, heads, a.ctx,
                                a.cos_tab, a.sin_tab, a.kc, a.vc, ld, st, sc);
   __syncthreads();                                                  // scratch free for the next round
 }
 
 template <int SLOTS, int G16, int G4>
-__global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(const psg_dl_args a) {
+__global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(const psg_dl_args a0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using GemmQ = DlGemm<12, SLOTS, G16, G4>;                           // q|k|v: 192-row slabs, 64 of them = 2 rounds of 32 groups
   using GemmO = DlGemm<8, SLOTS, G16, G4>;                            // o, down: 128-row slabs
   using GemmG = DlGemm<11, SLOTS, G16, G4>;                           // gate|up: 176-row slabs, 126 of them = 4 rounds (3.94)
   constexpr int MP = G16 * 16 + G4 * 4;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int M = a.M, D = a.D, I = a.I;
+  const int b = dl_bid(), tid = dl_tid(), lane = tid & 63, wid = tid >> 6;
+  const int M = a0.M, D = a0.D, I = a0.I;
   // LDS: rings | partial tile (sized for 12-wave slabs) | x slice
   unsigned char* const xs = smem + PSG_DL_WAVES * SLOTS * DL_BLOCK + MP * (PSG_DL_WAVES * 16 + 4) * 4;
   float* const s_inv = reinterpret_cast<float*>(smem + PSG_DL_WAVES * SLOTS * DL_BLOCK);   // the tile area, free between phases
-  unsigned* const cnt = a.cnt;
-  long long* const tr = a.trace ? a.trace + (int64_t)b * 24 : nullptr;
+  const int nl = a0.n_layers;
+  // Layers are chained inside the launch (psg_decode_layers): layer l's down projection leaves its partials in buffer
+  // l & 1; the owners of layer l + 1 wait for the column group that produced their slab (16 K slices), and every
+  // workgroup requests the next layer's first q|k|v blocks as soon as its own down stream has ended.  The workspace
+  // buffers are reused layer after layer: each is rewritten only behind an all-to-all edge of the NEXT layer, which
+  // every reader of the previous layer has passed.
+  for (int l = 0; l < nl; ++l) {
+  // per-layer tensors are read from the table where they are used (a modified copy of the argument block would keep
+  // ~40 scalar registers alive across every phase: spills inside the streams)
+  const psg_dl_args& a = a0;
+  const psg_dl_layer* const T = a0.table + l;
+  float* const down_part = (l & 1) ? a0.down_part2 : a0.down_part;
+  const float* const delta = l > 0 ? ((l & 1) ? a0.down_part : a0.down_part2) : a0.delta;   // the previous layer's buffer
+  const int dsplits = l > 0 ? 16 : a0.dsplits;
+  unsigned* const cnt = a0.cnt + (int64_t)l * PSG_DL_NCNT;
+  long long* const tr = (a0.trace && l == nl - 1) ? a0.trace + (int64_t)b * 24 : nullptr;
 #define DL_STAMP(i)                                             \
   do {                                                          \
     if (tr && tid == 0) tr[i] = (long long)wall_clock64();      \
   } while (0)
   DL_STAMP(0);
 
-  // ---- q|k|v: S = 8, G = 32.  Weight rows are the chain's [q | k | v]: head h = slabs of 192 rows ... the q, k and v
-  // rows of a head lie in three different slabs, produced by the column groups listed in dl_head_groups below ------------
-  {
+  // ---- q|k|v: S = 8, G = 32: 192-row slabs; a head's q, k and v rows lie in up to six slabs (dl_attn_round) ------------
+  if (l == 0) {
     GemmQ g;
-    g.setup(a.wqkv, 3 * D, D, 8, b & 7, b >> 3, M, smem);
+    g.setup(T->wqkv, 3 * D, D, 8, b & 7, b >> 3, M, smem);
     g.prefetch();
+  } else {
+    // owner b's 16 columns lie in down slab b >> 3, produced (for its 16 K slices) by column group (b >> 3) & 15
+    dl_wait(cnt - PSG_DL_NCNT, PSG_DL_CNT_DGRP + ((b >> 3) & 15), 1, 16u);
   }
-  dl_norm_owner(a, a.delta, a.dsplits, a.ssq, b);
+  dl_norm_owner(a, delta, dsplits, a.ssq, b);
   dl_drain();
   dl_arrive_all(cnt, PSG_DL_CNT_X1);
   DL_STAMP(1);
@@ -556,9 +593,9 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
   DL_STAMP(2);
   {
     GemmQ g;
-    g.setup(a.wqkv, 3 * D, D, 8, b & 7, b >> 3, M, smem);
+    g.setup(T->wqkv, 3 * D, D, 8, b & 7, b >> 3, M, smem);
     g.skip_prefetched();
-    dl_norm_stage(a, a.ssq, a.ln1, g.kbA, g.nkb, g.xstride, xs, s_inv);
+    dl_norm_stage(a, a.ssq, T->ln1, g.kbA, g.nkb, g.xstride, xs, s_inv);
     dl_barrier();
     DL_STAMP(3);
     g.run(a.qkv_part, smem, xs);
@@ -567,7 +604,7 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
   // the o projection's first blocks (slab b >> 3, K slice b & 7) while the attention runs
   {
     GemmO go;
-    go.setup(a.wo, D, D, 8, b & 7, b >> 3, M, smem);
+    go.setup(T->wo, D, D, 8, b & 7, b >> 3, M, smem);
     dl_drain();                                                     // this wave's partial-tile stores are out
     go.prefetch();                                                  // its own ring is free: the next stream starts now
   }
@@ -580,7 +617,7 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
     const int nunit = M * a.heads;                                    // unit u = row * heads + head
     for (int u0 = 3 * b; u0 < nunit; u0 += 3 * PSG_DL_WG) {
       const int u = u0 + (wid >> 2);
-      const DlAttnArgs aa = {a.qkv_part, a.att, a.kc, a.vc, a.tok_pair, a.tok_pos, a.cos_tab, a.sin_tab, a.cnt, a.M, a.D, a.heads, a.ctx};
+      const DlAttnArgs aa = {a.qkv_part, a.att, T->kc, T->vc, a.tok_pair, a.tok_pos, a.cos_tab, a.sin_tab, cnt, a.M, a.D, a.heads, a.ctx};
       dl_attn_round(aa, u < nunit ? u : -1, sc);
       dl_drain();
       dl_barrier();
@@ -596,7 +633,7 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
   DL_STAMP(7);
   {
     GemmO go;
-    go.setup(a.wo, D, D, 8, b & 7, b >> 3, M, smem);
+    go.setup(T->wo, D, D, 8, b & 7, b >> 3, M, smem);
     go.skip_prefetched();
     go.stage_x_dma(a.att, D, xs);
     dl_drain();
@@ -607,7 +644,7 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
   DL_STAMP(9);
   {
     GemmG gg;
-    gg.setup(a.wgu, 2 * I, D, 8, b & 7, b >> 3, M, smem);
+    gg.setup(T->wgu, 2 * I, D, 8, b & 7, b >> 3, M, smem);
     dl_drain();
     gg.prefetch();
   }
@@ -624,9 +661,9 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
   DL_STAMP(12);
   {
     GemmG gg;
-    gg.setup(a.wgu, 2 * I, D, 8, b & 7, b >> 3, M, smem);
+    gg.setup(T->wgu, 2 * I, D, 8, b & 7, b >> 3, M, smem);
     gg.skip_prefetched();
-    dl_norm_stage(a, a.ssq + PSG_DL_WG * 32, a.ln2, gg.kbA, gg.nkb, gg.xstride, xs, s_inv);
+    dl_norm_stage(a, a.ssq + PSG_DL_WG * 32, T->ln2, gg.kbA, gg.nkb, gg.xstride, xs, s_inv);
     dl_barrier();
     DL_STAMP(13);
     gg.run(a.gu_part, smem, xs);
@@ -634,7 +671,7 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
   DL_STAMP(14);
   {
     GemmO gd;
-    gd.setup(a.wdown, D, I, 16, b & 15, b >> 4, M, smem);
+    gd.setup(T->wdown, D, I, 16, b & 15, b >> 4, M, smem);
     dl_drain();
     gd.prefetch();
   }
@@ -694,7 +731,7 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
   DL_STAMP(15);
   {
     GemmO gd;
-    gd.setup(a.wdown, D, I, 16, b & 15, b >> 4, M, smem);
+    gd.setup(T->wdown, D, I, 16, b & 15, b >> 4, M, smem);
     gd.skip_prefetched();
     const int j0 = gd.kbA >> 2, j1 = (gd.kbA + gd.nkb + 3) >> 2;
     dl_wait(cnt, PSG_DL_CNT_H + j0, j1 - j0, (unsigned)M);
@@ -703,12 +740,25 @@ __global__ void __launch_bounds__(PSG_DL_WAVES * 64) decode_layer_f32_kernel(con
     dl_drain();
     dl_barrier();
     DL_STAMP(17);
-    gd.run(a.down_part, smem, xs);
+    gd.run(down_part, smem, xs);
   }
   DL_STAMP(18);
+  if (l + 1 < nl) {                                                 // chain: next layer's first q|k|v blocks, then count in
+    GemmQ g;
+    g.setup(T[1].wqkv, 3 * D, D, 8, b & 7, b >> 3, M, smem);
+    dl_drain();
+    g.prefetch();
+    dl_publish(cnt, PSG_DL_CNT_DGRP + (b >> 4));
+  }
 #undef DL_STAMP
+  }
 }
 
+__global__ void dl_write_table_kernel(psg_dl_layer* tab, const psg_dl_layer one) { *tab = one; }
+static int64_t dl_ws_floats(int M, int hidden, int inter) {
+  return (int64_t)8 * M * 3 * hidden + (int64_t)M * hidden + (int64_t)8 * M * hidden + 2 * 256 * 32 + (int64_t)8 * M * 2 * inter +
+         (int64_t)M * inter;
+}
 static size_t dl_lds(int M, int slots, int mp) {
   const size_t xmax = (size_t)M * (22 * 128 + DL_XPAD);               // the down projection's slice (K = 11008, S = 16)
   const size_t attn = 3 * sizeof(PsgDecodeAttnScratch);
@@ -719,8 +769,7 @@ extern "C" int psg_decode_layer_workspace(psg_ctx* ctx, int M, int hidden, int i
   PSG_REQUIRE(ctx && floats && counters, PSG_ERR_INVALID, "psg_decode_layer_workspace: NULL argument");
   PSG_REQUIRE(M >= 1 && M <= 32, PSG_ERR_UNSUPPORTED, "psg_decode_layer: M=%d (1..32 rows)", M);
   // qkv_part 8 M 3D | att M D | o_part 8 M D | ssq 2*256*32 | gu_part 8 M 2I | h M I   (down_part is the caller's output)
-  *floats = (int64_t)8 * M * 3 * hidden + (int64_t)M * hidden + (int64_t)8 * M * hidden + 2 * 256 * 32 +
-            (int64_t)8 * M * 2 * inter + (int64_t)M * inter;
+  *floats = dl_ws_floats(M, hidden, inter) + 16;                   // + a one-entry layer table (psg_decode_layer)
   *counters = PSG_DL_NCNT;
   return PSG_OK;
 }
@@ -728,8 +777,43 @@ extern "C" int psg_decode_layer_workspace(psg_ctx* ctx, int M, int hidden, int i
 extern "C" int psg_decode_layer_supported(psg_ctx* ctx, int M, int hidden, int inter, int heads, int dtype) {
   if (!ctx) return 0;
   const int KBd = inter >> 5;
-  return dtype == PSG_F32 && ctx->num_cu == PSG_DL_WG && M >= 13 && M <= 32 && hidden == 4096 && heads == 32 &&
-         inter % 128 == 0 && inter / 128 <= PSG_DL_TIMEOUT - PSG_DL_CNT_H && (KBd + 15) / 16 <= 22 && inter >= 2048;
+  return dtype == PSG_F32 && ctx->num_cu == PSG_DL_WG && M >= 13 && M <= 24 && hidden == 4096 && heads == 32 &&
+         inter % 128 == 0 && inter / 128 <= PSG_DL_CNT_DGRP - PSG_DL_CNT_H && (KBd + 15) / 16 <= 22 && inter >= 2048;
+}
+
+static int dl_launch(psg_ctx* ctx, psg_dl_args& a, float* workspace, uint32_t* counters, hipStream_t st, const char* who) {
+  const int M = a.M, hidden = a.D, inter = a.I;
+  float* w = workspace;
+  a.qkv_part = w; w += (size_t)8 * M * 3 * hidden;
+  a.att = w; w += (size_t)M * hidden;
+  a.o_part = w; w += (size_t)8 * M * hidden;
+  a.ssq = w; w += 2 * 256 * 32;
+  a.gu_part = w; w += (size_t)8 * M * 2 * inter;
+  a.h = w;
+  a.cnt = counters;
+  a.trace = (ctx->trace_kind == PSG_TRACE_DECODE_LAYER && ctx->trace && ctx->trace_words >= (int64_t)PSG_DL_WG * 24) ? ctx->trace : nullptr;
+  const int g16 = 1, g4 = M <= 16 ? 0 : (M - 16 + 3) / 4;
+  const int mp = g16 * 16 + g4 * 4;
+  const size_t lds = dl_lds(M, 3, mp);
+  PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "%s: %zu B of LDS", who, lds);
+#define DL_K(A, B)                                                                                          \
+  do {                                                                                                      \
+    (void)hipFuncSetAttribute((const void*)decode_layer_f32_kernel<3, A, B>,                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
+    decode_layer_f32_kernel<3, A, B><<<PSG_DL_WG, PSG_DL_WAVES * 64, lds, st>>>(a);                         \
+  } while (0)
+  switch (g4) {
+    case 0: DL_K(1, 0); break;
+    case 1: DL_K(1, 1); break;
+    default: DL_K(1, 2); break;
+  }
+#undef DL_K
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    psg_set_error("%s: launch failed: %s", who, hipGetErrorString(e));
+    return PSG_ERR_HIP;
+  }
+  return PSG_OK;
 }
 
 // resid [M][hidden] fp32 in/out; delta = the previous layer's down partials (delta_splits slices, or NULL);
@@ -749,44 +833,45 @@ extern "C" int psg_decode_layer(psg_ctx* ctx, void* resid, const void* delta, in
   PSG_REQUIRE(delta_splits >= 0 && delta_splits <= PSG_MAX_SPLITS && (delta || delta_splits == 0), PSG_ERR_INVALID,
               "psg_decode_layer: delta_splits=%d", delta_splits);
   psg_dl_args a;
+  // the kernel reads its layers from a device table: a one-entry table behind the workspace's last buffer (psg_decode_layer_workspace counts it)
+  psg_dl_layer* tab = reinterpret_cast<psg_dl_layer*>(workspace + dl_ws_floats(M, hidden, inter));
+  const psg_dl_layer one = {ln1, ln2, (const float*)wqkv, (const float*)wo, (const float*)wgu, (const float*)wdown,
+                            (float*)k_cache, (float*)v_cache};
+  dl_write_table_kernel<<<1, 1, 0, (hipStream_t)stream>>>(tab, one);
+  a.table = tab; a.n_layers = 1; a.down_part2 = nullptr;
   a.resid = (float*)resid;
   a.delta = delta_splits > 0 ? (const float*)delta : nullptr;
   a.dsplits = delta_splits;
-  a.ln1 = ln1; a.ln2 = ln2;
-  a.wqkv = (const float*)wqkv; a.wo = (const float*)wo; a.wgu = (const float*)wgu; a.wdown = (const float*)wdown;
   a.tok_pair = tok_pair; a.tok_pos = tok_pos; a.cos_tab = rope_cos; a.sin_tab = rope_sin;
-  a.kc = (float*)k_cache; a.vc = (float*)v_cache;
-  float* w = workspace;
-  a.qkv_part = w; w += (size_t)8 * M * 3 * hidden;
-  a.att = w; w += (size_t)M * hidden;
-  a.o_part = w; w += (size_t)8 * M * hidden;
-  a.ssq = w; w += 2 * 256 * 32;
-  a.gu_part = w; w += (size_t)8 * M * 2 * inter;
-  a.h = w;
   a.down_part = down_part;
-  a.cnt = counters;
-  a.trace = (ctx->trace_kind == PSG_TRACE_DECODE_LAYER && ctx->trace && ctx->trace_words >= (int64_t)PSG_DL_WG * 24) ? ctx->trace : nullptr;
   a.M = M; a.D = hidden; a.I = inter; a.heads = heads; a.ctx = ctx_len; a.eps = eps;
-  hipStream_t st = (hipStream_t)stream;
-  const int g16 = M <= 28 ? 1 : 2, g4 = (M <= 16 || M > 28) ? 0 : (M - 16 + 3) / 4;
-  const int mp = g16 * 16 + g4 * 4;
-  const int slots = 3;
-  const size_t lds = dl_lds(M, slots, mp);
-  PSG_REQUIRE(lds <= 160 * 1024, PSG_ERR_UNSUPPORTED, "psg_decode_layer: %zu B of LDS", lds);
-#define DL_K(SL, A, B)                                                                                      \
-  do {                                                                                                      \
-    (void)hipFuncSetAttribute((const void*)decode_layer_f32_kernel<SL, A, B>,                               \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
-    decode_layer_f32_kernel<SL, A, B><<<PSG_DL_WG, PSG_DL_WAVES * 64, lds, st>>>(a);                        \
-  } while (0)
-#define DL_L(A, B) DL_K(3, A, B)
-  switch (g16 * 4 + g4) {
-    case 4: DL_L(1, 0); break;
-    case 5: DL_L(1, 1); break;
-    default: DL_L(1, 2); break;
-  }
-#undef DL_L
-#undef DL_K
-  PSG_CHECK_LAUNCH("psg_decode_layer");
-  return PSG_OK;
+  return dl_launch(ctx, a, workspace, counters, (hipStream_t)stream, "psg_decode_layer");
+}
+
+// n_layers decoder layers chained inside ONE launch.  layer_table: device array of n_layers x 8 pointers
+// {ln1, ln2, wqkv, wo, wgu, wdown, k_cache, v_cache}; delta feeds layer 0 (NULL: none); layer l leaves its down partials in
+// down_parts + (l & 1) * 16 M hidden - the caller's final RMSNorm reads buffer (n_layers - 1) & 1; counters: n_layers blocks
+// of psg_decode_layer_workspace's size, zeroed.
+extern "C" int psg_decode_layers(psg_ctx* ctx, void* resid, const void* delta, int delta_splits, const void* layer_table,
+                                 int n_layers, const int32_t* tok_pair, const int32_t* tok_pos, const float* rope_cos,
+                                 const float* rope_sin, int M, int hidden, int inter, int heads, int ctx_len, float eps,
+                                 float* workspace, uint32_t* counters, float* down_parts, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && resid && layer_table && tok_pair && tok_pos && rope_cos && rope_sin && workspace && counters && down_parts,
+              PSG_ERR_INVALID, "psg_decode_layers: NULL argument");
+  PSG_REQUIRE(n_layers >= 1 && n_layers <= 1024, PSG_ERR_INVALID, "psg_decode_layers: n_layers=%d", n_layers);
+  PSG_REQUIRE(psg_decode_layer_supported(ctx, M, hidden, inter, heads, dtype), PSG_ERR_UNSUPPORTED,
+              "psg_decode_layers: M=%d hidden=%d inter=%d heads=%d dtype=%d on %d CUs (fp32, 13..24 rows, 4096 = 32 x 128, "
+              "256 CUs)", M, hidden, inter, heads, dtype, ctx->num_cu);
+  PSG_REQUIRE(delta_splits >= 0 && delta_splits <= PSG_MAX_SPLITS && (delta || delta_splits == 0), PSG_ERR_INVALID,
+              "psg_decode_layers: delta_splits=%d", delta_splits);
+  psg_dl_args a;
+  a.table = (const psg_dl_layer*)layer_table; a.n_layers = n_layers;
+  a.resid = (float*)resid;
+  a.delta = delta_splits > 0 ? (const float*)delta : nullptr;
+  a.dsplits = delta_splits;
+  a.tok_pair = tok_pair; a.tok_pos = tok_pos; a.cos_tab = rope_cos; a.sin_tab = rope_sin;
+  a.down_part = down_parts;
+  a.down_part2 = down_parts + (size_t)16 * M * hidden;
+  a.M = M; a.D = hidden; a.I = inter; a.heads = heads; a.ctx = ctx_len; a.eps = eps;
+  return dl_launch(ctx, a, workspace, counters, (hipStream_t)stream, "psg_decode_layers");
 }

@@ -101,6 +101,7 @@ class LlamaDecodeEngine:
         # next to it (psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split; bit-identical, 7 launches per layer less)
         self.fuse_split = bool(_lib.get_option(dev_i, "llm_fuse_split"))
         self._dl_ws = {}
+        self._dl_host_buf = None
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
         self.early_exit_chunk = 4        # natural-EOS decode: steps per graph between "all pairs done?" checks
         self.last_replays = 0
@@ -253,22 +254,28 @@ class LlamaDecodeEngine:
                 and ops.decode_layer_supported(rows, m.hidden, m.inter, m.heads, self.dtype, self.device))
 
     def _decode_step_persistent(self, st, counters):
-        """One decode step on psg_decode_layer: a launch per layer, the final RMSNorm and the lm_head as in the chain.
+        """One decode step on psg_decode_layers: ONE launch for the whole stack of decoder layers (chained inside the
+        launch), then the final RMSNorm and the lm_head as in the chain.
         counters: int32 [layers * ops.decode_layer_counters()], zeroed."""
         m = self.cfg.llm
         x = st["x"]
         K = x.shape[0]
         ent = self._dl_ws.get(K)
         if ent is None:
-            ws, ncnt = ops.decode_layer_workspace(K, m.hidden, m.inter, self.device)
-            ent = self._dl_ws[K] = (ws, ncnt, [torch.empty((16, K, m.hidden), device=self.device, dtype=torch.float32)
-                                               for _ in range(2)])
-        ws, ncnt, dparts = ent
-        delta = None
-        for l, L in enumerate(self.layers):
-            delta = ops.decode_layer(x, delta, L["ln1"], L["ln2"], L["wqkv"], L["wo"], L["wgu"], L["wdown"], st["dec_pair"],
-                                     st["dec_pos"], self.rope, m.heads, st["ctx_len"], m.rms_eps, st["kc"][l], st["vc"][l],
-                                     ws, counters[l * ncnt:(l + 1) * ncnt], dparts[l & 1])
+            ws, _ = ops.decode_layer_workspace(K, m.hidden, m.inter, self.device)
+            ent = self._dl_ws[K] = (ws, torch.empty((2, 16, K, m.hidden), device=self.device, dtype=torch.float32))
+        ws, dparts = ent
+        if "dl_table" not in st:                               # per decode state: the table holds its KV-cache pointers
+            # (pinned staging + an async copy: capturable as a memcpy node, replayed with the graph)
+            rows = ops.decode_layer_table(self.layers, st["kc"], st["vc"], device="cpu")
+            host = self._dl_host_buf if self._dl_host_buf is not None else torch.empty_like(rows).pin_memory()
+            self._dl_host_buf = None                           # (allocated by generate() BEFORE the capture began)
+            host.copy_(rows)
+            st["dl_table_host"] = host
+            st["dl_table"] = torch.empty(host.shape, dtype=torch.int64, device=self.device)
+            st["dl_table"].copy_(host, non_blocking=True)
+        delta = ops.decode_layers(x, None, st["dl_table"], len(self.layers), st["dec_pair"], st["dec_pos"], self.rope, m.heads,
+                                  st["ctx_len"], m.rms_eps, m.inter, ws, counters, dparts)
         n = torch.empty_like(x)
         ops.rmsnorm(x, delta, self.final_norm, m.rms_eps, n)
         return self.logits(n)
@@ -396,12 +403,17 @@ class LlamaDecodeEngine:
                 torch.cuda.synchronize(self.device)
                 self._graphs.popitem(last=False)
             Xs, ps = X.clone(), prompt_len.to(torch.int32).clone()
+            if self.persistent_layer:                          # pinned staging of the layer table: not allocatable while capturing
+                self._dl_host_buf = None
+                pinned = torch.empty((len(self.layers), 8), dtype=torch.int64).pin_memory()
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                      # warm-up: lazy library init must not be captured
                 self._generate_eager(Xs, ps, max_new, suppress_eos, return_first_logits, slot=slot)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
+            if self.persistent_layer:
+                self._dl_host_buf = pinned
             bounds = [max_new] if chunk <= 0 else list(range(chunk, max_new, chunk)) + [max_new]
             if split:                                          # the gate sits right behind the prompt pass + first token
                 bounds = [1] + bounds

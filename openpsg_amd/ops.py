@@ -456,6 +456,32 @@ def decode_layer(resid, delta, ln1, ln2, wqkv, wo, wgu, wdown, tok_pair, tok_pos
     return Partials(down_part)
 
 
+def decode_layer_table(layers, k_caches, v_caches, device=None):
+    """Table for `decode_layers`: one row of 8 pointers per decoder layer (the tensors must outlive it); on the layers'
+    device unless `device` says otherwise (a caller inside a graph capture stages it through pinned memory)."""
+    rows = [[L["ln1"].data_ptr(), L["ln2"].data_ptr(), L["wqkv"].data_ptr(), L["wo"].data_ptr(), L["wgu"].data_ptr(),
+             L["wdown"].data_ptr(), k.data_ptr(), v.data_ptr()] for L, k, v in zip(layers, k_caches, v_caches)]
+    return torch.tensor(rows, dtype=torch.int64, device=layers[0]["wqkv"].device if device is None else device)
+
+
+def decode_layers(resid, delta, table, n_layers, tok_pair, tok_pos, rope, heads, ctx_len, eps, inter, workspace, counters,
+                  down_parts) -> Partials:
+    """All decoder layers of a decode step chained inside ONE persistent launch (psg_decode_layers).
+    table: `decode_layer_table`; counters int32 [n_layers * decode_layer_counters()], ZERO; down_parts fp32 [2, 16, M, hidden].
+    Returns the last layer's down-projection Partials (for the final rmsnorm)."""
+    lib, ctx, st = _env(resid)
+    M, hidden = resid.shape
+    assert down_parts.shape == (2, 16, M, hidden) and counters.dtype == torch.int32
+    assert counters.numel() >= n_layers * decode_layer_counters(resid.device) and table.shape == (n_layers, 8)
+    dp, ds = (None, 0) if delta is None else _in(delta, resid.dtype)
+    check(lib.psg_decode_layers(ctx, _p(resid, torch.float32, "resid"), dp, ds, _p(table), int(n_layers),
+                                _p(tok_pair, torch.int32), _p(tok_pos, torch.int32), _p(rope[0], torch.float32),
+                                _p(rope[1], torch.float32), M, hidden, int(inter), int(heads), int(ctx_len), float(eps),
+                                _p(workspace, torch.float32), _p(counters), _p(down_parts, torch.float32), _dt(resid), st),
+          "psg_decode_layers")
+    return Partials(down_parts[(n_layers - 1) & 1])
+
+
 def silu_mul(gate_up, out):
     lib, ctx, st = _env(out)
     rows, inter = out.shape

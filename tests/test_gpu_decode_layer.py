@@ -80,6 +80,49 @@ def test_decode_layer_equals_the_launch_chain_bit_for_bit(M, with_delta):
         f"down partials differ: max {(delta.t - dl.t).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("M,NL", [(20, 3), (16, 2), (23, 4)])
+def test_decode_layers_chained_in_one_launch_equal_the_launch_chain_bit_for_bit(M, NL):
+    """psg_decode_layers: NL decoder layers chained INSIDE one launch (the owners of layer l + 1 wait for the column groups
+    of layer l's down projection; workspace buffers reused layer after layer) against the chain of 8 NL launches."""
+    from openpsg_amd import ops
+    if not ops.decode_layer_supported(M, D, I, HEADS, torch.float32, DEV):
+        pytest.skip("psg_decode_layer needs a 256-CU device")
+    g = torch.Generator(device=DEV).manual_seed(7 * M + NL)
+    layers = [_layer(g) for _ in range(NL)]
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128))
+    ang = torch.arange(CTX, dtype=torch.float32)[:, None] * inv[None, :]
+    rope = (ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV))
+    pos = torch.randint(0, CTX - 1, (M,), generator=torch.Generator().manual_seed(M)).to(torch.int32).to(DEV)
+    pair = torch.randperm(M, generator=torch.Generator().manual_seed(M + 1)).to(torch.int32).to(DEV)
+    resid0 = torch.randn(M, D, generator=g, device=DEV)
+    caches = [(torch.randn(M, HEADS, CTX, 128, generator=g, device=DEV), torch.randn(M, HEADS, CTX, 128, generator=g, device=DEV))
+              for _ in layers]
+    resid_c = resid0.clone()
+    cc = [(k.clone(), v.clone()) for k, v in caches]
+    delta = None
+    for L, (k, v) in zip(layers, cc):
+        delta = _chain(ops, L, resid_c, delta, pair, pos, rope, k, v)
+    torch.cuda.synchronize()
+    resid_p = resid0.clone()
+    cp = [(k.clone(), v.clone()) for k, v in caches]
+    ws, ncnt = ops.decode_layer_workspace(M, D, I, DEV)
+    ws.fill_(float("nan"))
+    dparts = torch.full((2, 16, M, D), float("nan"), device=DEV)
+    table = ops.decode_layer_table(layers, [k for k, _ in cp], [v for _, v in cp])
+    for rep in range(2):                                            # the second run reuses workspace and (re-zeroed) counters
+        resid_p.copy_(resid0)
+        for (k, v), (k0, v0) in zip(cp, caches):
+            k.copy_(k0)
+            v.copy_(v0)
+        counters = torch.zeros(NL * ncnt, device=DEV, dtype=torch.int32)
+        dl = ops.decode_layers(resid_p, None, table, NL, pair, pos, rope, HEADS, CTX, 1e-5, I, ws, counters, dparts)
+        torch.cuda.synchronize()
+        assert int(counters.view(NL, ncnt)[:, 255 * 64].abs().sum()) == 0, "a bounded poll of psg_decode_layers gave up"
+        for l, ((kc_, vc_), (kp, vp)) in enumerate(zip(cc, cp)):
+            assert torch.equal(kc_, kp) and torch.equal(vc_, vp), f"layer {l}: KV cache differs from the chain"
+        assert torch.equal(resid_c, resid_p) and torch.equal(delta.t, dl.t)
+
+
 def test_engine_with_persistent_layers_decodes_the_reference_golden_and_equals_the_chain():
     """G6 (the LLM at the width the reference instantiates, 2 layers, 20 selected pairs) through the fp32 head with and
     without psg_decode_layer: identical tokens and first-step logits, both equal to the real reference's greedy tokens;

@@ -52,6 +52,13 @@ def main():
             delta = ops.decode_layer(resid, delta, L["ln1"], L["ln2"], L["wqkv"], L["wo"], L["wgu"], L["wdown"], pair, pos,
                                      rope, HEADS, CTX, 1e-5, kc[l], vc[l], ws, counters[l * ncnt:(l + 1) * ncnt], dparts[l & 1])
 
+    dparts2 = torch.empty((2, 16, M, D), device=DEV)
+    table = ops.decode_layer_table(layers, kc, vc)
+
+    def stack():
+        counters.zero_()
+        ops.decode_layers(resid, None, table, NL, pair, pos, rope, HEADS, CTX, 1e-5, I, ws, counters, dparts2)
+
     def timed(fn, graph):
         fn()
         torch.cuda.synchronize()
@@ -77,7 +84,7 @@ def main():
         return ts[len(ts) // 2]
 
     nbytes = sum(w.numel() * 4 for k, w in layers[0].items() if k.startswith("w"))
-    for name, fn in (("launch chain", chain), ("persistent layer", persistent)):
+    for name, fn in (("launch chain", chain), ("persistent layer", persistent), ("persistent stack", stack)):
         for graph in (False, True):
             us = timed(fn, graph)
             print(f"M={M} {name:17s} {'graph' if graph else 'eager'}: {us:7.1f} us per layer = {nbytes / us / 1e6:5.2f} TB/s of weights")

@@ -1,5 +1,5 @@
 """Phase timeline of psg_decode_layer (100 MHz wall-clock stamps per workgroup at its phase boundaries).
-   python tools/decode_layer_trace.py [M]"""
+   python tools/decode_layer_trace.py [M] [stack]"""
 import os
 import sys
 
@@ -44,6 +44,17 @@ def main():
             delta = ops.decode_layer(resid, delta, L["ln1"], L["ln2"], L["wqkv"], L["wo"], L["wgu"], L["wdown"], pair, pos,
                                      rope, HEADS, CTX, 1e-5, kc[l], vc[l], ws, counters[l * ncnt:(l + 1) * ncnt], dparts[l & 1])
         _lib.set_trace_buffer(0, _lib.PSG_TRACE_NONE)
+    stack = len(sys.argv) > 2 and sys.argv[2] == "stack"
+    if stack:                                                         # the layers chained inside one launch: the LAST one is stamped
+        table = ops.decode_layer_table(layers, kc, vc)
+        dp2 = torch.empty((2, 16, M, D), device=DEV)
+
+        def run(traced):                                              # noqa: F811
+            counters.zero_()
+            if traced:
+                _lib.set_trace_buffer(0, _lib.PSG_TRACE_DECODE_LAYER, trace)
+            ops.decode_layers(resid, None, table, NL, pair, pos, rope, HEADS, CTX, 1e-5, I, ws, counters, dp2)
+            _lib.set_trace_buffer(0, _lib.PSG_TRACE_NONE)
     run(False)
     run(False)
     torch.cuda.synchronize()
