@@ -55,17 +55,19 @@ def skinny(M, dtype=torch.bfloat16):
                 it[0] += 1
                 torch.nn.functional.linear(x, ws[it[0] % ncopy])
         ts, _ = timeit(run_s, iters=12, warm=2)
-        tl, _ = (ts, 0) if nolib else timeit(run_l, iters=12, warm=2)
-        ts, tl = ts / REP, tl / REP
+        tl = None if nolib else timeit(run_l, iters=12, warm=2)[0] / REP   # PSG_BENCH_NOLIB=1: no library column at all
+        ts = ts / REP
         gb = N * K * esz / 1e9
-        print(f"skinny {str(dtype)[6:]} M={M} {name:8s} N={N:6d} K={K:6d}: {ts:8.1f} us = {gb / ts * 1e6:7.0f} GB/s | "
-              f"hipBLASLt {tl:8.1f} us = {gb / tl * 1e6:7.0f} GB/s", flush=True)
+        lib = "" if tl is None else f" | library (F.linear) {tl:8.1f} us = {gb / tl * 1e6:7.0f} GB/s"
+        print(f"skinny {str(dtype)[6:]} M={M} {name:8s} N={N:6d} K={K:6d}: {ts:8.1f} us = {gb / ts * 1e6:7.0f} GB/s{lib}",
+              flush=True)
         mult = 1 if name == "lm_head" else 32
         tot_b += gb * mult
         tot_s += ts * mult
-        tot_l += tl * mult
+        tot_l += (tl or 0.0) * mult
+    lib = "" if nolib else f", library {tot_l / 1e3:.2f} ms ({tot_b / tot_l * 1e6:.0f} GB/s)"
     print(f"  one decode step (32 layers + lm_head): {tot_b:.2f} GB, skinny {tot_s / 1e3:.2f} ms "
-          f"({tot_b / tot_s * 1e6:.0f} GB/s), hipBLASLt {tot_l / 1e3:.2f} ms ({tot_b / tot_l * 1e6:.0f} GB/s)")
+          f"({tot_b / tot_s * 1e6:.0f} GB/s){lib}")
 
 
 def xattn(N=50, L=256):
