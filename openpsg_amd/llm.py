@@ -21,6 +21,8 @@ gate and the greedy step are HIP kernels.
 from __future__ import annotations
 
 import collections
+import os
+import sys
 
 import torch
 import torch.nn.functional as F
@@ -28,6 +30,68 @@ import torch.nn.functional as F
 from . import ops
 from ._lib import PsgHipError
 from .config import PSGConfig
+
+
+# How the library runs one split-fp16 product [rows, K'] x [N, K']^T -> fp32 best, per (rows, N, K', device): whole, or cut
+# into column / row parts written in place.  hipBLASLt's pick for a shape is a heuristic, and at K' = 3K it is erratic
+# (Llama-2-7B gate|up at 960 rows: 694 us whole, 480 us as two column halves; q|k|v at 1440 rows: 635 whole, 397 as halves;
+# tools/split_gemm_bench.py), so the cut is MEASURED once per shape and process, outside any graph capture.
+_SPLIT_PLANS: dict = {}
+
+
+def _split_mm(a3, w3, plan=None):
+    """a3 [rows, K'] . w3 [N, K']^T -> fp32 [rows, N] through the library, whole or in the parts `plan` names."""
+    if plan is None or plan[0] == "whole":
+        return torch.mm(a3, w3.t(), out_dtype=torch.float32)
+    rows, N = a3.shape[0], w3.shape[0]
+    y = torch.empty((rows, N), device=a3.device, dtype=torch.float32)
+    kind, parts = plan
+    if kind == "cols":                                         # ldc = N: the parts land where the whole product puts them
+        h = N // parts
+        for p_ in range(parts):
+            torch.mm(a3, w3[p_ * h:(p_ + 1) * h].t(), out_dtype=torch.float32, out=y[:, p_ * h:(p_ + 1) * h])
+    else:
+        h = -(-rows // (16 * parts)) * 16
+        for r0 in range(0, rows, h):
+            torch.mm(a3[r0:r0 + h], w3.t(), out_dtype=torch.float32, out=y[r0:r0 + h])
+    return y
+
+
+def _plan_split_mm(rows, w3):
+    """The fastest of {whole, 2 / 3 column parts, 2 / 3 / 4 row parts} for this shape, timed on the device (7 runs each,
+    minimum); a cut must win by 5 % to be taken.  Cached per process so that every engine uses the same cut."""
+    N, K3 = w3.shape
+    key = (int(rows), int(N), int(K3), w3.device.index or 0)
+    plan = _SPLIT_PLANS.get(key)
+    if plan is not None:
+        return plan
+    if rows < 128 or torch.cuda.is_current_stream_capturing():
+        return ("whole",)                                      # (not cached while capturing: planned at the next eager use)
+    cands = [("whole",)]
+    cands += [("cols", p_) for p_ in (2, 3) if N % (256 * p_) == 0 and N // p_ >= 2048]
+    cands += [("rows", p_) for p_ in (2, 3, 4) if rows >= 128 * p_]
+    a3 = torch.randn((rows, K3), device=w3.device, generator=torch.Generator(device=w3.device).manual_seed(0)).to(w3.dtype)
+    best, best_t, whole_t = cands[0], None, None
+    for c in cands:
+        ts = []
+        for i in range(9):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            _split_mm(a3, w3, c)
+            e_.record()
+            e_.synchronize()
+            if i >= 2:
+                ts.append(s_.elapsed_time(e_))
+        t = min(ts)
+        if c[0] == "whole":
+            whole_t = best_t = t
+        elif t < best_t and t < 0.95 * whole_t:
+            best, best_t = c, t
+    _SPLIT_PLANS[key] = best
+    if os.environ.get("PSG_DEBUG_PLANS"):
+        print(f"[psg] split product rows={rows} N={N} K'={K3}: {best} {best_t * 1e3:.0f} us (whole {whole_t * 1e3:.0f} us)",
+              file=sys.stderr, flush=True)
+    return best
 
 
 class LlamaDecodeEngine:
@@ -100,6 +164,8 @@ class LlamaDecodeEngine:
         # fp32s prompt pass: the split of a projection's operand and the un-scaling of its result inside the row kernels
         # next to it (psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split; bit-identical, 7 launches per layer less)
         self.fuse_split = bool(_lib.get_option(dev_i, "llm_fuse_split"))
+        # fp32s prompt pass: run each library product whole or in the column / row parts measured fastest (_plan_split_mm)
+        self.plan_split = True
         self._dl_ws = {}
         self._dl_host_buf = None
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
@@ -122,7 +188,7 @@ class LlamaDecodeEngine:
         a3, inv_r = ops.split_f16x3(x)
         if self.row_invariant and ws[0].shape[0] % 256 == 0 and ws[0].shape[1] % 64 == 0:
             return ops.dense_gemm(a3, ws[0], None, out_dtype=torch.float32, row_scale=inv_r, col_scale=ws[1])
-        y = torch.mm(a3, ws[0].t(), out_dtype=torch.float32)
+        y = _split_mm(a3, ws[0], _plan_split_mm(a3.shape[0], ws[0]) if self.plan_split else None)
         return ops.scale_rows_cols(y, inv_r, ws[1])
 
     def linear(self, x, w, ws=None):
@@ -218,7 +284,8 @@ class LlamaDecodeEngine:
         until its reader applies the scales while loading.  Same arithmetic as `_forward` + linear_split, bit for bit."""
         m = self.cfg.llm
         rows, D = resid.shape
-        mm = lambda a3, ws: torch.mm(a3, ws[0].t(), out_dtype=torch.float32)       # noqa: E731
+        plan = _plan_split_mm if self.plan_split else (lambda r, w: None)
+        mm = lambda a3, ws: _split_mm(a3, ws[0], plan(a3.shape[0], ws[0]))          # noqa: E731
         a3, inv_r = ops.rmsnorm_split(resid, None, self.layers[0]["ln1"], m.rms_eps)
         q = torch.empty((rows, D), device=self.device, dtype=torch.float32)
         att = torch.empty_like(q)
