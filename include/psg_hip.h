@@ -62,8 +62,9 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *        psg_train_attn_fwd / _bwd: attention-probability dropout mask; psg_split_f16x3, psg_scale_rows_cols added)
  *   401  round 4 (psg_dense_gemm_tiled, psg_interleave_gate_up added)
  *   500  round 5 (psg_decode_layer*: one persistent launch per decoder layer of the decode step; psg_qformer_cross_attn /
- *        psg_qformer_self_attn(_shared) / psg_prefill_attn accept PSG_F32 on the matrix cores) */
-#define PSG_ABI_VERSION 500
+ *        psg_qformer_self_attn(_shared) / psg_prefill_attn accept PSG_F32 on the matrix cores)
+ *   501  round 5 (psg_batch_gemm*, psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split added) */
+#define PSG_ABI_VERSION 501
 int psg_version(void);
 const char* psg_last_error(void);
 int psg_create(int device, psg_ctx** out);
@@ -279,6 +280,19 @@ int psg_skinny_gemm(psg_ctx*, const void* x, const void* w, float* part, int M, 
                     int splits, int dtype, void* stream);
 int psg_reduce_partials(psg_ctx*, const float* part, int splits, int64_t n, void* y, int dtype,
                         void* stream);
+
+/* ---- The same projections for 33..160 rows: several images' selected pairs decoded together (head.forward_batch; the
+ * reference decodes one pair at a time, V4:293-312).  16-bit operands, N % 16 == 0, K % 64 == 0.  The weight is the
+ * streamed operand (every byte from HBM once), x rides along from L2; work = (slab of 256 / 128 weight rows, K step)
+ * units dealt to the workgroups as contiguous ranges (stream-K), so that a launch is balanced whatever N is.  Writes
+ * fp32 slices part[slots][M][N] for the same consumers as psg_skinny_gemm (slices a slab did not need are written as
+ * zeros); psg_batch_gemm_plan returns the slice count for a shape and `slots` must be that number.
+ * slab_rows 256 / 128 and mode 1 (ranges aligned to the slabs: one segment per workgroup) / 2 (stream-K ranges) pick a
+ * variant, 0 leaves the choice to the library's estimate; the engine times the variants and the library GEMM per shape
+ * once and keeps the fastest (openpsg_amd/llm.py). */
+int psg_batch_gemm_plan(psg_ctx*, int64_t M, int N, int K, int dtype, int slab_rows, int mode, int* slots);
+int psg_batch_gemm(psg_ctx*, const void* x, const void* w, float* part, int64_t M, int N, int K, int slots, int dtype,
+                   int slab_rows, int mode, void* stream);
 
 /* ---- Decode-step projection with its producer row operation in the SAME launch.  The decode step alternates a
  * weight-streaming projection with a latency-bound row operation on <= 32 rows (RMSNorm HF-LL:53-67 + residual add,

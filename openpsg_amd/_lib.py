@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpsg_hip.so")
 
-PSG_ABI_VERSION = 500            # include/psg_hip.h; checked against psg_version() of the loaded library
+PSG_ABI_VERSION = 501            # include/psg_hip.h; checked against psg_version() of the loaded library
 PSG_F32, PSG_BF16, PSG_F16 = 0, 1, 2
 PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED = 0, 1
 PSG_XATTN_MFMA, PSG_XATTN_SIMPLE, PSG_XATTN_MFMA_V1 = 0, 1, 2
@@ -74,6 +74,8 @@ SIGNATURES = {
     "psg_silu_mul": [_vp, _vp, _i, _i64, _i, _vp, _i, _vp],
     "psg_skinny_gemm_plan": [_vp, _i, _i, _i, _i, C.POINTER(_i)],
     "psg_skinny_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "psg_batch_gemm_plan": [_vp, _i64, _i, _i, _i, _i, _i, C.POINTER(_i)],
+    "psg_batch_gemm": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "psg_skinny_gemm_fused": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "psg_rmsnorm_split": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp],
     "psg_rope_kvwrite_scaled": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, "libpsg_hip.so")
-SOURCES = ["psg_core.hip", "psg_rowops.hip", "psg_attn.hip", "psg_attn_f32.hip", "psg_xattn_mfma.hip", "psg_xattn_dma.hip", "psg_gemm.hip", "psg_gemm_f32.hip", "psg_decode_layer.hip", "psg_split.hip", "psg_dense_gemm.hip", "psg_patch_embed.hip", "psg_selfattn_mfma.hip", "psg_prefill_attn_mfma.hip", "psg_pool.hip", "psg_train.hip", "psg_train_bwd.hip"]
+SOURCES = ["psg_core.hip", "psg_rowops.hip", "psg_attn.hip", "psg_attn_f32.hip", "psg_xattn_mfma.hip", "psg_xattn_dma.hip", "psg_gemm.hip", "psg_gemm_f32.hip", "psg_batch_gemm.hip", "psg_decode_layer.hip", "psg_split.hip", "psg_dense_gemm.hip", "psg_patch_embed.hip", "psg_selfattn_mfma.hip", "psg_prefill_attn_mfma.hip", "psg_pool.hip", "psg_train.hip", "psg_train_bwd.hip"]
 HEADERS = ["psg_common.h", "psg_decode_math.h", os.path.join("..", "..", "include", "psg_hip.h")]
 
 

@@ -39,6 +39,11 @@ struct psg_opts {
   int llm_fuse_split = 1;       // fp32s prompt pass: operand splits / result scalings inside the row kernels (psg_split.hip)
   int decode_persistent = 0;    // fp32 decode steps: one persistent launch per decoder layer (psg_decode_layer) instead of the
                                 // chain of eight launches (bit-identical; Llama-2-7B width, 13..32 rows, 256 CUs)
+  int batch_gemm_bn = 0;        // psg_batch_gemm: forced slab height (256 or 128 weight rows); 0 = the planner's estimate
+  int batch_gemm_mode = 0;      // psg_batch_gemm: 1 = slab-aligned slices, 2 = stream-K ranges; 0 = the planner's estimate
+  int batch_gemm_grid = 0;      // psg_batch_gemm: workgroups (0 = one per CU): fewer workgroups = fewer fp32 slices
+  int batch_gemm_var = 0;       // psg_batch_gemm ablation runs (1: no slice stores, 2: no MFMA, 3: x staged for the first K step only)
+  int decode_batch_gemm = 1;    // decode steps of 33..160 rows (forward_batch): psg_batch_gemm instead of the library GEMM
   int xattn_dynamic = 1;        // LDS-DMA cross-attention: a workgroup's waves draw their tiles from an LDS counter
   int xattn_poll = 0;           // LDS-DMA cross-attention: a unit's Q tile is awaited by polling a sentinel in its LDS slot
                                 // instead of a vmcnt count (which also waits for the previous unit's stores to retire)

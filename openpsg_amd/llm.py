@@ -39,29 +39,31 @@ from .config import PSGConfig
 _SPLIT_PLANS: dict = {}
 
 
-def _split_mm(a3, w3, plan=None):
-    """a3 [rows, K'] . w3 [N, K']^T -> fp32 [rows, N] through the library, whole or in the parts `plan` names."""
+def _split_mm(a3, w3, plan=None, out_dtype=torch.float32):
+    """a3 [rows, K'] . w3 [N, K']^T -> [rows, N] through the library, whole or in the parts `plan` names.
+    out_dtype fp32: the split-fp16 products of the fp32s mode; None: the operands' 16-bit type (the 16-bit prompt pass)."""
+    kw = {} if out_dtype is None else {"out_dtype": out_dtype}
     if plan is None or plan[0] == "whole":
-        return torch.mm(a3, w3.t(), out_dtype=torch.float32)
+        return torch.mm(a3, w3.t(), **kw)
     rows, N = a3.shape[0], w3.shape[0]
-    y = torch.empty((rows, N), device=a3.device, dtype=torch.float32)
+    y = torch.empty((rows, N), device=a3.device, dtype=out_dtype or a3.dtype)
     kind, parts = plan
     if kind == "cols":                                         # ldc = N: the parts land where the whole product puts them
         h = N // parts
         for p_ in range(parts):
-            torch.mm(a3, w3[p_ * h:(p_ + 1) * h].t(), out_dtype=torch.float32, out=y[:, p_ * h:(p_ + 1) * h])
+            torch.mm(a3, w3[p_ * h:(p_ + 1) * h].t(), out=y[:, p_ * h:(p_ + 1) * h], **kw)
     else:
         h = -(-rows // (16 * parts)) * 16
         for r0 in range(0, rows, h):
-            torch.mm(a3[r0:r0 + h], w3.t(), out_dtype=torch.float32, out=y[r0:r0 + h])
+            torch.mm(a3[r0:r0 + h], w3.t(), out=y[r0:r0 + h], **kw)
     return y
 
 
-def _plan_split_mm(rows, w3):
+def _plan_split_mm(rows, w3, out_dtype=torch.float32):
     """The fastest of {whole, 2 / 3 column parts, 2 / 3 / 4 row parts} for this shape, timed on the device (7 runs each,
     minimum); a cut must win by 5 % to be taken.  Cached per process so that every engine uses the same cut."""
     N, K3 = w3.shape
-    key = (int(rows), int(N), int(K3), w3.device.index or 0)
+    key = (int(rows), int(N), int(K3), w3.device.index or 0, str(out_dtype))
     plan = _SPLIT_PLANS.get(key)
     if plan is not None:
         return plan
@@ -77,7 +79,7 @@ def _plan_split_mm(rows, w3):
         for i in range(9):
             s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s_.record()
-            _split_mm(a3, w3, c)
+            _split_mm(a3, w3, c, out_dtype)
             e_.record()
             e_.synchronize()
             if i >= 2:
@@ -91,6 +93,54 @@ def _plan_split_mm(rows, w3):
     if os.environ.get("PSG_DEBUG_PLANS"):
         print(f"[psg] split product rows={rows} N={N} K'={K3}: {best} {best_t * 1e3:.0f} us (whole {whole_t * 1e3:.0f} us)",
               file=sys.stderr, flush=True)
+    return best
+
+
+# Decode steps with 33..160 rows (several images' pairs decoded together, head.forward_batch): the library GEMM against the
+# variants of psg_batch_gemm (slab height x range mode), per (rows, N, K), timed once per process on COLD weights (the
+# layers' own weights of that shape in rotation) with the consumer's extra work - summing fp32 slices instead of reading one
+# 16-bit result - charged to the variants as a psg_reduce_partials pass.  At 160 rows the library streams o / down at 1.0-1.3
+# TB/s and wins on gate|up; at 40 rows psg_batch_gemm wins everywhere (tools/batched_decode_gemm_bench.py).
+_BATCH_PLANS: dict = {}
+
+
+def _plan_batch_mm(x, pool):
+    w = pool[0]
+    key = (int(x.shape[0]), int(w.shape[0]), int(w.shape[1]), str(x.dtype), w.device.index or 0)
+    plan = _BATCH_PLANS.get(key)
+    if plan is not None:
+        return plan
+    if torch.cuda.is_current_stream_capturing():
+        return ("lib",)
+    cands = [("lib",)] + [("own", bn, mode) for bn in (256, 128) for mode in (1, 2)]
+    best, best_t = cands[0], None
+    for c in cands:
+        if c[0] == "own":
+            try:
+                ops.batch_gemm(x, w, c[1], c[2])
+            except PsgHipError:
+                continue
+        ts = []
+        for i in range(8):                                     # a sample = 4 launches back to back on 4 different weights
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for j in range(4):
+                wi = pool[(4 * i + j) % len(pool)]
+                if c[0] == "lib":
+                    F.linear(x, wi)
+                else:
+                    ops.batch_gemm(x, wi, c[1], c[2]).reduce(x.dtype)
+            e_.record()
+            e_.synchronize()
+            if i >= 2:
+                ts.append(s_.elapsed_time(e_) / 4)
+        t = sorted(ts)[len(ts) // 2]
+        if best_t is None or t < best_t * (0.97 if best[0] == "lib" else 1.0):
+            best, best_t = c, t
+    _BATCH_PLANS[key] = best
+    if os.environ.get("PSG_DEBUG_PLANS"):
+        print(f"[psg] decode projection rows={key[0]} N={key[1]} K={key[2]}: {best} {best_t * 1e3:.0f} us", file=sys.stderr,
+              flush=True)
     return best
 
 
@@ -166,6 +216,13 @@ class LlamaDecodeEngine:
         self.fuse_split = bool(_lib.get_option(dev_i, "llm_fuse_split"))
         # fp32s prompt pass: run each library product whole or in the column / row parts measured fastest (_plan_split_mm)
         self.plan_split = True
+        # decode steps of 33..160 rows: psg_batch_gemm where it beats the library (option decode_batch_gemm)
+        self.batch_gemm = bool(_lib.get_option(dev_i, "decode_batch_gemm"))
+        self._w_pools = {}
+        for L in self.layers:
+            for k in ("wqkv", "wo", "wgu", "wdown"):
+                self._w_pools.setdefault(tuple(L[k].shape), []).append(L[k])
+        self._w_pools.setdefault(tuple(self.lm_head.shape), []).append(self.lm_head)
         self._dl_ws = {}
         self._dl_host_buf = None
         self.use_graph = True            # capture the batched decode in a HIP graph (per input shape)
@@ -191,13 +248,24 @@ class LlamaDecodeEngine:
         y = _split_mm(a3, ws[0], _plan_split_mm(a3.shape[0], ws[0]) if self.plan_split else None)
         return ops.scale_rows_cols(y, inv_r, ws[1])
 
-    def linear(self, x, w, ws=None):
+    def linear(self, x, w, ws=None, decode=False):
         """Bias-free projection.  Decode-step shapes (<= 32 rows) use the hand-written weight-streaming kernel - in
         the 16-bit modes and in the fp32 mode (the reference's own precision, V4:99-100) alike; the prompt pass goes
-        through hipBLASLt."""
+        through hipBLASLt; decode steps of 33..160 rows (several images' pairs, 16-bit modes) through whichever of
+        psg_batch_gemm's variants and the library was measured fastest for the shape (_plan_batch_mm)."""
         if (self.use_skinny and x.shape[0] <= 32 and x.dtype == w.dtype and w.shape[0] % 16 == 0
                 and w.shape[1] % 64 == 0 and w.shape[1] >= 256):
             return ops.skinny_gemm(x, w)          # fp32 split-K partials, reduced by the consumer kernel
+        if (decode and self.batch_gemm and self.use_skinny and 32 < x.shape[0] <= 160 and x.dtype == w.dtype
+                and x.dtype in (torch.bfloat16, torch.float16) and w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0):
+            plan = _plan_batch_mm(x, self._w_pools.get(tuple(w.shape), [w]))
+            if plan[0] == "own":
+                return ops.batch_gemm(x, w, plan[1], plan[2])
+        if (self.plan_split and x.shape[0] >= 1024 and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
+                and x.dim() == 2 and x.is_contiguous()):
+            # the 16-bit prompt pass of several images (forward_batch: 2 / 4 / 8 x 960 rows): the library's pick for the
+            # whole product against its column / row parts (_plan_split_mm; 7-14 % per layer at 1920-7680 rows, nothing at 960)
+            return _split_mm(x, w, _plan_split_mm(x.shape[0], w, None), None)
         if ws is not None and x.dtype == torch.float32:
             return self.linear_split(x, ws)
         return F.linear(x, w)
@@ -206,7 +274,7 @@ class LlamaDecodeEngine:
         """lm_head.  <= 32 rows: the weight-streaming kernel (fp32 split-K partials, summed inside the greedy step);
         more rows (several images' pairs decoded together): the library GEMM with an fp32 result, so that the greedy
         argmax sees unrounded logits on this path too (exact_argmax)."""
-        out = self.linear(h, self.lm_head)
+        out = self.linear(h, self.lm_head, decode=True)
         if isinstance(out, ops.Partials) or not self.exact_argmax or h.dtype == torch.float32:
             return out
         if self._mm_out_dtype is None:
@@ -246,7 +314,7 @@ class LlamaDecodeEngine:
                         and not self.prefill_attn_scalar)
         fused_rope = mfma_prefill and self.dtype in (torch.bfloat16, torch.float16)       # rotary + cache write in the launch
         for l, L in enumerate(self.layers):
-            qkv = self.linear(n, L["wqkv"], L.get("wqkv_s"))
+            qkv = self.linear(n, L["wqkv"], L.get("wqkv_s"), decode=decode)
             if decode:
                 ops.decode_attn(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, kc[l], vc[l], att)
             elif fused_rope and isinstance(qkv, torch.Tensor) and rope_pos is None:
@@ -269,11 +337,11 @@ class LlamaDecodeEngine:
                 att, resid = att_k, resid_k
                 n = torch.empty_like(att)
                 act = torch.empty((k, m.inter), device=self.device, dtype=self.dtype)
-            o = self.linear(att, L["wo"], L.get("wo_s"))
+            o = self.linear(att, L["wo"], L.get("wo_s"), decode=decode)
             ops.rmsnorm(resid, o, L["ln2"], m.rms_eps, n)                      # resid += o ; n = norm(resid)
-            gu = self.linear(n, L["wgu"], L.get("wgu_s"))
+            gu = self.linear(n, L["wgu"], L.get("wgu_s"), decode=decode)
             ops.silu_mul(gu, act)
-            d = self.linear(act, L["wdown"], L.get("wdown_s"))
+            d = self.linear(act, L["wdown"], L.get("wdown_s"), decode=decode)
             nxt = self.layers[l + 1]["ln1"] if l + 1 < len(self.layers) else self.final_norm
             ops.rmsnorm(resid, d, nxt, m.rms_eps, n)                           # resid += d ; n = norm(resid)
         return n

@@ -530,6 +530,25 @@ def skinny_gemm(x, w, splits=None) -> Partials:
     return Partials(part)
 
 
+def batch_gemm(x, w, slab_rows=0, mode=0) -> Partials:
+    """Decode-step projection for 33..160 rows (several images' pairs decoded together): fp32 split-K slices of x @ w.T
+    like `skinny_gemm`'s, the weight streamed from HBM once (psg_batch_gemm; bf16 / fp16).
+    slab_rows 256 / 128, mode 1 (slab-aligned ranges) / 2 (stream-K): a variant; 0 = the library's estimate."""
+    import ctypes
+    lib, ctx, st = _env(x)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if x.dtype not in (torch.bfloat16, torch.float16) or w.dtype != x.dtype:
+        raise PsgHipError(f"batch_gemm: x / w must both be bf16 or fp16, got {x.dtype} / {w.dtype}")
+    s = ctypes.c_int(0)
+    check(lib.psg_batch_gemm_plan(ctx, M, N, K, _dt(x), int(slab_rows), int(mode), ctypes.byref(s)), "psg_batch_gemm_plan")
+    part = torch.empty((s.value, M, N), device=x.device, dtype=torch.float32)
+    check(lib.psg_batch_gemm(ctx, _p(x, name="x"), _p(w, name="w"), _p(part), M, N, K, s.value, _dt(x), int(slab_rows),
+                             int(mode), st), "psg_batch_gemm")
+    return Partials(part)
+
+
 def skinny_gemm_fused(kind, x_out, w, sync, *, inp=None, resid=None, norm_w=None, eps=0.0, attn=None, splits=None):
     """Decode projection with its producer row operation in the same launch (psg_skinny_gemm_fused):
     the prologue `kind` computes x_out [M, K] from `inp` (Partials / activation tensor / None), then

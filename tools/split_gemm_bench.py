@@ -11,6 +11,8 @@ from openpsg_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 960
+KMUL = int(os.environ.get("PSG_SPLIT_BENCH_KMUL", "3"))       # 3: the split products (fp32 result); 1: the 16-bit prompt pass (16-bit result)
+OD = torch.float32 if KMUL == 3 else torch.float16
 shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)]
 
 
@@ -29,52 +31,52 @@ def t_us(fn, n=12):
 
 tot = {}
 for name, N, K in shapes:
-    K3 = 3 * K
+    K3 = KMUL * K
     x = (torch.randn(M, K3, device=dev) * 0.5).half()
     ws = [(torch.randn(N, K3, device=dev) / K ** 0.5).half() for _ in range(2)]
     fl = 2.0 * M * N * K3
     res = {}
-    res["lib"] = t_us(lambda i: torch.mm(x, ws[i & 1].t(), out_dtype=torch.float32))
+    res["lib"] = t_us(lambda i: torch.mm(x, ws[i & 1].t(), out_dtype=OD))
     for parts in (2, 3, 4):
         if N % (parts * 256):
             continue
         cuts = [w.view(parts, N // parts, K3) for w in ws]
-        outs = torch.empty((parts, M, N // parts), device=dev)
+        outs = torch.empty((parts, M, N // parts), device=dev, dtype=OD)
 
         def f(i, cuts=cuts, parts=parts, outs=outs):
             for p in range(parts):
-                torch.mm(x, cuts[i & 1][p].t(), out_dtype=torch.float32, out=outs[p])
+                torch.mm(x, cuts[i & 1][p].t(), out_dtype=OD, out=outs[p])
         try:
             res[f"lib/{parts}N"] = t_us(f)
         except Exception as ex:                                       # noqa: BLE001
             res[f"lib/{parts}N"] = float("nan")
             print("  (", type(ex).__name__, str(ex)[:80], ")")
     if N % 512 == 0:                                                  # two column halves written in place (ldc = N)
-        full = torch.empty((M, N), device=dev)
+        full = torch.empty((M, N), device=dev, dtype=OD)
 
         def h(i, full=full):
             for p in range(2):
-                torch.mm(x, ws[i & 1][p * (N // 2):(p + 1) * (N // 2)].t(), out_dtype=torch.float32,
+                torch.mm(x, ws[i & 1][p * (N // 2):(p + 1) * (N // 2)].t(), out_dtype=OD,
                          out=full[:, p * (N // 2):(p + 1) * (N // 2)])
         res["lib/2N in place"] = t_us(h)
-        ref = torch.mm(x, ws[0].t(), out_dtype=torch.float32)
+        ref = torch.mm(x, ws[0].t(), out_dtype=OD)
         h(0)
-        print(f"  in-place halves vs whole: max |diff| {(full - ref).abs().max().item():.3e} (|ref| max {ref.abs().max().item():.1f})")
+        print(f"  in-place halves vs whole: max |diff| {(full.float() - ref.float()).abs().max().item():.3e} (|ref| max {ref.abs().max().item():.1f})")
     for parts in (2, 3, 4):                                           # cut along the rows instead
         if M % (parts * 16):
             continue
-        outs = torch.empty((M, N), device=dev)
+        outs = torch.empty((M, N), device=dev, dtype=OD)
         mr = M // parts
 
         def g(i, parts=parts, outs=outs, mr=mr):
             for p in range(parts):
-                torch.mm(x[p * mr:(p + 1) * mr], ws[i & 1].t(), out_dtype=torch.float32, out=outs[p * mr:(p + 1) * mr])
+                torch.mm(x[p * mr:(p + 1) * mr], ws[i & 1].t(), out_dtype=OD, out=outs[p * mr:(p + 1) * mr])
         res[f"lib/{parts}M"] = t_us(g)
     xs = [x[:, j * K:(j + 1) * K].contiguous() for j in range(3)]
     wss = [[w[:, j * K:(j + 1) * K].contiguous() for j in range(3)] for w in ws]
     for tile in ("256x256",):
         try:
-            res[f"own {tile}"] = t_us(lambda i, tile=tile: ops.dense_gemm(x, ws[i & 1], None, out_dtype=torch.float32, tile=tile))
+            res[f"own {tile}"] = t_us(lambda i, tile=tile: ops.dense_gemm(x, ws[i & 1], None, out_dtype=OD, tile=tile))
         except Exception as ex:                                       # noqa: BLE001
             print("  (", tile, type(ex).__name__, str(ex)[:80], ")")
     line = "  ".join(f"{k} {v:7.1f} ({fl / v / 1e6:5.0f})" for k, v in res.items())
