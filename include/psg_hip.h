@@ -374,10 +374,14 @@ int psg_scale_rows_cols(psg_ctx*, float* y, int64_t rows, int N, const float* ro
  * y * (row_scale[m] * col_scale[n]) while loading:
  *   psg_rmsnorm_split       resid += delta * scales (delta may be NULL); RMSNorm(resid) * w -> out3 [rows][3 hidden] fp16
  *                           ([hi | hi | lo]) + inv_scale [rows]                              (HF-LL:53-67)
+ *                           delta_slices > 1: delta is [slices][rows][hidden] - the K segments of a split product run
+ *                           as ONE batched library GEMM (three times the tiles of the narrow o / down products) - summed
+ *                           in slice order before the scales
  *   psg_rope_kvwrite_scaled psg_rope_kvwrite on a raw q|k|v result                            (HF-LL:130-160)
  *   psg_silu_mul_split      silu(gate) * up of a raw gate|up result -> out3 [rows][3 inter] + inv_scale   (HF-LL:163-177) */
 int psg_rmsnorm_split(psg_ctx*, float* resid, const float* delta, const float* delta_row_scale, const float* delta_col_scale,
-                      const float* w, float eps, int64_t rows, int hidden, void* out3, float* inv_scale, void* stream);
+                      int delta_slices, const float* w, float eps, int64_t rows, int hidden, void* out3, float* inv_scale,
+                      void* stream);
 int psg_rope_kvwrite_scaled(psg_ctx*, const float* qkv, const float* row_scale, const float* col_scale,
                             const int32_t* tok_pair, const int32_t* tok_pos, const float* rope_cos, const float* rope_sin,
                             int64_t rows, int heads, int head_dim, int ctx, float* q_out, float* k_cache, float* v_cache,

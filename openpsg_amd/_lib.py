@@ -77,7 +77,7 @@ SIGNATURES = {
     "psg_batch_gemm_plan": [_vp, _i64, _i, _i, _i, _i, _i, C.POINTER(_i)],
     "psg_batch_gemm": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "psg_skinny_gemm_fused": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "psg_rmsnorm_split": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp],
+    "psg_rmsnorm_split": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _vp, _vp],
     "psg_rope_kvwrite_scaled": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp],
     "psg_silu_mul_split": [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp],
     "psg_decode_layer_workspace": [_vp, _i, _i, _i, C.POINTER(_i64), C.POINTER(_i64)],

@@ -145,7 +145,8 @@ template <int NCH>
 __global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ resid, const float* __restrict__ delta,
                                                             const float* __restrict__ d_rs, const float* __restrict__ d_cs,
                                                             const float* __restrict__ w, float eps, int hidden,
-                                                            uint16_t* __restrict__ out3, float* __restrict__ inv_scale) {
+                                                            uint16_t* __restrict__ out3, float* __restrict__ inv_scale,
+                                                            int dslices, int64_t dstride) {
   __shared__ float s_part[4], s_max[4];
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -160,7 +161,11 @@ __global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ 
       g[c] = *reinterpret_cast<const float4*>(w + col);
       v[c][0] = r.x; v[c][1] = r.y; v[c][2] = r.z; v[c][3] = r.w;
       if (delta) {
-        const float4 d = *reinterpret_cast<const float4*>(delta + row * hidden + col);
+        float4 d = *reinterpret_cast<const float4*>(delta + row * hidden + col);
+        for (int sl = 1; sl < dslices; ++sl) {                  // K segments of the product as separate slices: summed in order
+          const float4 e = *reinterpret_cast<const float4*>(delta + sl * dstride + row * hidden + col);
+          d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+        }
         const float4 cs = *reinterpret_cast<const float4*>(d_cs + col);
         v[c][0] += d.x * (rs * cs.x); v[c][1] += d.y * (rs * cs.y); v[c][2] += d.z * (rs * cs.z); v[c][3] += d.w * (rs * cs.w);
       }
@@ -202,8 +207,8 @@ __global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ 
 }
 
 extern "C" int psg_rmsnorm_split(psg_ctx* ctx, float* resid, const float* delta, const float* delta_row_scale,
-                                 const float* delta_col_scale, const float* w, float eps, int64_t rows, int hidden,
-                                 void* out3, float* inv_scale, void* stream) {
+                                 const float* delta_col_scale, int delta_slices, const float* w, float eps, int64_t rows,
+                                 int hidden, void* out3, float* inv_scale, void* stream) {
   PSG_REQUIRE(ctx && resid && w && out3 && inv_scale && (!delta || (delta_row_scale && delta_col_scale)), PSG_ERR_INVALID,
               "psg_rmsnorm_split: NULL argument");
   PSG_REQUIRE(hidden % 4 == 0 && hidden > 0 && hidden <= 8192 && rows >= 0 && rows < (1ll << 31), PSG_ERR_UNSUPPORTED,
@@ -213,7 +218,7 @@ extern "C" int psg_rmsnorm_split(psg_ctx* ctx, float* resid, const float* delta,
   hipStream_t st = (hipStream_t)stream;
 #define RNS(N)                                                                                                      \
   rmsnorm_split_kernel<N><<<(unsigned)rows, 256, 0, st>>>(resid, delta, delta_row_scale, delta_col_scale, w, eps, hidden, \
-                                                          (uint16_t*)out3, inv_scale)
+                                                          (uint16_t*)out3, inv_scale, delta_slices, rows * (int64_t)hidden)
   switch (nch) {
     case 1: RNS(1); break;
     case 2: RNS(2); break;

@@ -45,6 +45,9 @@ def _split_mm(a3, w3, plan=None, out_dtype=torch.float32):
     kw = {} if out_dtype is None else {"out_dtype": out_dtype}
     if plan is None or plan[0] == "whole":
         return torch.mm(a3, w3.t(), **kw)
+    if plan[0] == "k3":                                        # the three K segments as one batched product: [3, rows, N]
+        rows, N, K = a3.shape[0], w3.shape[0], a3.shape[1] // 3
+        return torch.bmm(a3.view(rows, 3, K).permute(1, 0, 2), w3.view(N, 3, K).permute(1, 2, 0), **kw)
     rows, N = a3.shape[0], w3.shape[0]
     y = torch.empty((rows, N), device=a3.device, dtype=out_dtype or a3.dtype)
     kind, parts = plan
@@ -59,11 +62,13 @@ def _split_mm(a3, w3, plan=None, out_dtype=torch.float32):
     return y
 
 
-def _plan_split_mm(rows, w3, out_dtype=torch.float32):
+def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False):
     """The fastest of {whole, 2 / 3 column parts, 2 / 3 / 4 row parts} for this shape, timed on the device (7 runs each,
-    minimum); a cut must win by 5 % to be taken.  Cached per process so that every engine uses the same cut."""
+    minimum); a cut must win by 5 % to be taken.  Cached per process so that every engine uses the same cut.
+    k3: the caller's reader can sum slices (psg_rmsnorm_split) - the three K segments as ONE batched product with a
+    [3, rows, N] result is a candidate too (3 x the tiles: down at 960 rows 326 -> 288 us, o 108 -> 95)."""
     N, K3 = w3.shape
-    key = (int(rows), int(N), int(K3), w3.device.index or 0, str(out_dtype))
+    key = (int(rows), int(N), int(K3), w3.device.index or 0, str(out_dtype), bool(k3))
     plan = _SPLIT_PLANS.get(key)
     if plan is not None:
         return plan
@@ -72,6 +77,8 @@ def _plan_split_mm(rows, w3, out_dtype=torch.float32):
     cands = [("whole",)]
     cands += [("cols", p_) for p_ in (2, 3) if N % (256 * p_) == 0 and N // p_ >= 2048]
     cands += [("rows", p_) for p_ in (2, 3, 4) if rows >= 128 * p_]
+    if k3 and K3 % 3 == 0 and out_dtype == torch.float32:
+        cands.append(("k3",))
     a3 = torch.randn((rows, K3), device=w3.device, generator=torch.Generator(device=w3.device).manual_seed(0)).to(w3.dtype)
     best, best_t, whole_t = cands[0], None, None
     for c in cands:
@@ -352,8 +359,8 @@ class LlamaDecodeEngine:
         until its reader applies the scales while loading.  Same arithmetic as `_forward` + linear_split, bit for bit."""
         m = self.cfg.llm
         rows, D = resid.shape
-        plan = _plan_split_mm if self.plan_split else (lambda r, w: None)
-        mm = lambda a3, ws: _split_mm(a3, ws[0], plan(a3.shape[0], ws[0]))          # noqa: E731
+        plan = _plan_split_mm if self.plan_split else (lambda r, w, k3=False: None)
+        mm = lambda a3, ws, k3=False: _split_mm(a3, ws[0], plan(a3.shape[0], ws[0], k3=k3))     # noqa: E731
         a3, inv_r = ops.rmsnorm_split(resid, None, self.layers[0]["ln1"], m.rms_eps)
         q = torch.empty((rows, D), device=self.device, dtype=torch.float32)
         att = torch.empty_like(q)
@@ -371,11 +378,11 @@ class LlamaDecodeEngine:
                 ops.gather_rows(resid, keep_rows, resid_k)
                 att, resid = att_k, resid_k
             a3o, inv_o = ops.split_f16x3(att)                   # a row's maximum spans all heads: stays a kernel of its own
-            o = ops.Scaled(mm(a3o, L["wo_s"]), inv_o, L["wo_s"][1])
+            o = ops.Scaled(mm(a3o, L["wo_s"], k3=True), inv_o, L["wo_s"][1])          # read by rmsnorm_split: may be K slices
             a3, inv_r = ops.rmsnorm_split(resid, o, L["ln2"], m.rms_eps)
             gu = ops.Scaled(mm(a3, L["wgu_s"]), inv_r, L["wgu_s"][1])
             a3a, inv_a = ops.silu_mul_split(gu, m.inter)
-            d = ops.Scaled(mm(a3a, L["wdown_s"]), inv_a, L["wdown_s"][1])
+            d = ops.Scaled(mm(a3a, L["wdown_s"], k3=True), inv_a, L["wdown_s"][1])
             if last:                                            # the lm_head reads fp32 rows
                 n = torch.empty_like(resid)
                 ops.rmsnorm(resid, d.dense(), self.final_norm, m.rms_eps, n)

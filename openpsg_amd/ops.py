@@ -735,11 +735,14 @@ class Scaled:
     __slots__ = ("y", "row_scale", "col_scale")
 
     def __init__(self, y, row_scale, col_scale):
-        assert y.dtype == torch.float32 and y.dim() == 2 and row_scale.numel() == y.shape[0] and col_scale.numel() == y.shape[1]
+        # y [rows, N], or [slices, rows, N]: the K segments of the product as separate slices (rmsnorm_split sums them)
+        assert y.dtype == torch.float32 and y.dim() in (2, 3) and y.is_contiguous()
+        assert row_scale.numel() == y.shape[-2] and col_scale.numel() == y.shape[-1]
         self.y, self.row_scale, self.col_scale = y, row_scale, col_scale
 
     def dense(self):
-        return scale_rows_cols(self.y, self.row_scale, self.col_scale)
+        y = self.y if self.y.dim() == 2 else self.y.sum(0)
+        return scale_rows_cols(y, self.row_scale, self.col_scale)
 
 
 def rmsnorm_split(resid, delta, w, eps):
@@ -750,8 +753,10 @@ def rmsnorm_split(resid, delta, w, eps):
     inv = torch.empty(rows, device=resid.device, dtype=torch.float32)
     dp, rp, cp = (None, None, None) if delta is None else (_p(delta.y), _p(delta.row_scale, torch.float32),
                                                            _p(delta.col_scale, torch.float32))
-    check(lib.psg_rmsnorm_split(ctx, _p(resid, torch.float32, "resid"), dp, rp, cp, _p(w, torch.float32), float(eps), rows,
-                                hidden, _p(out), _p(inv), st), "psg_rmsnorm_split")
+    nsl = 1 if delta is None or delta.y.dim() == 2 else delta.y.shape[0]
+    assert delta is None or delta.y.shape[-2:] == (rows, hidden)
+    check(lib.psg_rmsnorm_split(ctx, _p(resid, torch.float32, "resid"), dp, rp, cp, nsl, _p(w, torch.float32), float(eps),
+                                rows, hidden, _p(out), _p(inv), st), "psg_rmsnorm_split")
     return out, inv
 
 

@@ -206,6 +206,15 @@ def test_fused_split_kernels_equal_the_separate_kernels_bit_for_bit():
         a3, inv = ops.split_f16x3(n)
         b3, binv = ops.rmsnorm_split(rb, ops.Scaled(y.clone(), rs, cs) if with_delta else None, w, 1e-5)
         assert torch.equal(ra, rb) and torch.equal(a3, b3) and torch.equal(inv, binv)
+    # ... with the product handed over as three K-segment slices (one batched library GEMM): summed in slice order
+    y3, rs, cs = torch.randn(3, rows, D, generator=g, device=dev) * 1e3, pw2(rows), pw2(D)
+    ra, rb = resid0.clone(), resid0.clone()
+    n = torch.empty_like(ra)
+    ops.rmsnorm(ra, ops.scale_rows_cols((y3[0] + y3[1]) + y3[2], rs, cs), w, 1e-5, n)
+    a3, inv = ops.split_f16x3(n)
+    b3, binv = ops.rmsnorm_split(rb, ops.Scaled(y3.clone(), rs, cs), w, 1e-5)
+    assert torch.equal(ra, rb) and torch.equal(a3, b3) and torch.equal(inv, binv)
+    assert torch.equal(ops.Scaled(y3.clone(), rs, cs).dense(), ops.scale_rows_cols(y3.sum(0), rs, cs))
     # SwiGLU
     y, rs, cs = torch.randn(rows, 2 * I, generator=g, device=dev) * 1e3, pw2(rows), pw2(2 * I)
     act = torch.empty(rows, I, device=dev)

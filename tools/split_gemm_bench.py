@@ -62,6 +62,17 @@ for name, N, K in shapes:
         ref = torch.mm(x, ws[0].t(), out_dtype=OD)
         h(0)
         print(f"  in-place halves vs whole: max |diff| {(full.float() - ref.float()).abs().max().item():.3e} (|ref| max {ref.abs().max().item():.1f})")
+    if KMUL == 3:                                                     # the three K segments as a batched product + one sum
+        xa = x.view(M, 3, K).permute(1, 0, 2)
+
+        def k3(i):
+            y3 = torch.bmm(xa, ws[i & 1].view(N, 3, K).permute(1, 2, 0), out_dtype=torch.float32)
+            return y3.sum(0)
+        try:
+            res["bmm3+sum"] = t_us(k3)
+            res["bmm3"] = t_us(lambda i: torch.bmm(xa, ws[i & 1].view(N, 3, K).permute(1, 2, 0), out_dtype=torch.float32))
+        except Exception as ex:                                       # noqa: BLE001
+            print("  ( bmm3", type(ex).__name__, str(ex)[:80], ")")
     for parts in (2, 3, 4):                                           # cut along the rows instead
         if M % (parts * 16):
             continue
