@@ -45,9 +45,10 @@ def _split_mm(a3, w3, plan=None, out_dtype=torch.float32):
     kw = {} if out_dtype is None else {"out_dtype": out_dtype}
     if plan is None or plan[0] == "whole":
         return torch.mm(a3, w3.t(), **kw)
-    if plan[0] == "k3":                                        # the three K segments as one batched product: [3, rows, N]
-        rows, N, K = a3.shape[0], w3.shape[0], a3.shape[1] // 3
-        return torch.bmm(a3.view(rows, 3, K).permute(1, 0, 2), w3.view(N, 3, K).permute(1, 2, 0), **kw)
+    if plan[0] == "kseg":                                      # P segments of K' as ONE batched product: [P, rows, N] slices
+        rows, N, P = a3.shape[0], w3.shape[0], plan[1]
+        K = a3.shape[1] // P
+        return torch.bmm(a3.view(rows, P, K).permute(1, 0, 2), w3.view(N, P, K).permute(1, 2, 0), **kw)
     rows, N = a3.shape[0], w3.shape[0]
     y = torch.empty((rows, N), device=a3.device, dtype=out_dtype or a3.dtype)
     kind, parts = plan
@@ -65,8 +66,9 @@ def _split_mm(a3, w3, plan=None, out_dtype=torch.float32):
 def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False):
     """The fastest of {whole, 2 / 3 column parts, 2 / 3 / 4 row parts} for this shape, timed on the device (7 runs each,
     minimum); a cut must win by 5 % to be taken.  Cached per process so that every engine uses the same cut.
-    k3: the caller's reader can sum slices (psg_rmsnorm_split) - the three K segments as ONE batched product with a
-    [3, rows, N] result is a candidate too (3 x the tiles: down at 960 rows 326 -> 288 us, o 108 -> 95)."""
+    k3: the caller's reader can sum slices (psg_rmsnorm_split) - 3 / 6 / 12 segments of K' as ONE batched product with a
+    [P, rows, N] result are candidates too (P x the tiles: down at 960 rows 331 us whole, 303 as 3, 247 as 6 slices; o
+    105 -> 98); the reader's extra slice reads are charged at 4 TB/s."""
     N, K3 = w3.shape
     key = (int(rows), int(N), int(K3), w3.device.index or 0, str(out_dtype), bool(k3))
     plan = _SPLIT_PLANS.get(key)
@@ -77,8 +79,8 @@ def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False):
     cands = [("whole",)]
     cands += [("cols", p_) for p_ in (2, 3) if N % (256 * p_) == 0 and N // p_ >= 2048]
     cands += [("rows", p_) for p_ in (2, 3, 4) if rows >= 128 * p_]
-    if k3 and K3 % 3 == 0 and out_dtype == torch.float32:
-        cands.append(("k3",))
+    if k3 and out_dtype == torch.float32:
+        cands += [("kseg", p_) for p_ in (3, 6, 12) if K3 % (64 * p_) == 0]
     a3 = torch.randn((rows, K3), device=w3.device, generator=torch.Generator(device=w3.device).manual_seed(0)).to(w3.dtype)
     best, best_t, whole_t = cands[0], None, None
     for c in cands:
@@ -92,6 +94,8 @@ def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False):
             if i >= 2:
                 ts.append(s_.elapsed_time(e_))
         t = min(ts)
+        if c[0] == "kseg":
+            t += (c[1] - 1) * rows * N * 4 / 4e9               # ms: the reader sums c[1] slices instead of reading one
         if c[0] == "whole":
             whole_t = best_t = t
         elif t < best_t and t < 0.95 * whole_t:

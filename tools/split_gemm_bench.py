@@ -71,6 +71,11 @@ for name, N, K in shapes:
         try:
             res["bmm3+sum"] = t_us(k3)
             res["bmm3"] = t_us(lambda i: torch.bmm(xa, ws[i & 1].view(N, 3, K).permute(1, 2, 0), out_dtype=torch.float32))
+            for P in (6, 12):
+                if K3 % (P * 64) == 0:
+                    xp = x.view(M, P, K3 // P).permute(1, 0, 2)
+                    res[f"bmm{P}"] = t_us(lambda i, P=P, xp=xp: torch.bmm(xp, ws[i & 1].view(N, P, K3 // P).permute(1, 2, 0),
+                                                                            out_dtype=torch.float32))
         except Exception as ex:                                       # noqa: BLE001
             print("  ( bmm3", type(ex).__name__, str(ex)[:80], ")")
     for parts in (2, 3, 4):                                           # cut along the rows instead
