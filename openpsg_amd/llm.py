@@ -63,12 +63,14 @@ def _split_mm(a3, w3, plan=None, out_dtype=torch.float32):
     return y
 
 
-def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False):
+def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False, pool=None):
     """The fastest of {whole, 2 / 3 column parts, 2 / 3 / 4 row parts} for this shape, timed on the device (7 runs each,
     minimum); a cut must win by 5 % to be taken.  Cached per process so that every engine uses the same cut.
     k3: the caller's reader can sum slices (psg_rmsnorm_split) - 3 / 6 / 12 segments of K' as ONE batched product with a
     [P, rows, N] result are candidates too (P x the tiles: down at 960 rows 331 us whole, 303 as 3, 247 as 6 slices; o
-    105 -> 98); the reader's extra slice reads are charged at 4 TB/s."""
+    105 -> 98); the reader's extra slice reads are charged at 4 TB/s.
+    pool: the other weights of this shape (the layers'): timed in rotation, so that a weight small enough for the
+    Infinity Cache is as cold as it is in the pass itself."""
     N, K3 = w3.shape
     key = (int(rows), int(N), int(K3), w3.device.index or 0, str(out_dtype), bool(k3))
     plan = _SPLIT_PLANS.get(key)
@@ -83,12 +85,13 @@ def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False):
         cands += [("kseg", p_) for p_ in (3, 6, 12) if K3 % (64 * p_) == 0]
     a3 = torch.randn((rows, K3), device=w3.device, generator=torch.Generator(device=w3.device).manual_seed(0)).to(w3.dtype)
     best, best_t, whole_t = cands[0], None, None
+    pool = [w_ for w_ in (pool or [w3]) if w_.shape == w3.shape and w_.dtype == w3.dtype] or [w3]
     for c in cands:
         ts = []
         for i in range(9):
             s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s_.record()
-            _split_mm(a3, w3, c, out_dtype)
+            _split_mm(a3, pool[i % len(pool)], c, out_dtype)
             e_.record()
             e_.synchronize()
             if i >= 2:
@@ -276,7 +279,7 @@ class LlamaDecodeEngine:
                 and x.dim() == 2 and x.is_contiguous()):
             # the 16-bit prompt pass of several images (forward_batch: 2 / 4 / 8 x 960 rows): the library's pick for the
             # whole product against its column / row parts (_plan_split_mm; 7-14 % per layer at 1920-7680 rows, nothing at 960)
-            return _split_mm(x, w, _plan_split_mm(x.shape[0], w, None), None)
+            return _split_mm(x, w, _plan_split_mm(x.shape[0], w, None, pool=self._w_pools.get(tuple(w.shape))), None)
         if ws is not None and x.dtype == torch.float32:
             return self.linear_split(x, ws)
         return F.linear(x, w)
