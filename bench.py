@@ -93,6 +93,10 @@ def parse():
                          "(default of --workload rq, BASELINE config 2 names it); fp16 (BASELINE config 5)")
     ap.add_argument("--no-untruncated", action="store_true",
                     help="cpu_baseline: skip the un-truncated 32-layer fp32 decode of one pair (27 GB of host memory)")
+    ap.add_argument("--llm-values", choices=["fp32", "fp16"], default="fp32",
+                    help="fp16: the LLM's fp32 matrices hold fp16 VALUES (a frozen fp16 checkpoint upcast on load, as the "
+                         "reference's Llama-2-7b-hf is: V4:99-100, configs/psg/baseline_v4_ov.py:61-65); the engine then "
+                         "streams them as fp16 in the decode steps")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--one-phase", action="store_true",
                     help="last Q-Former layer for all 33 rows of every pair (A/B against the default cls-first path)")
@@ -131,7 +135,8 @@ def setup_head(a, dev):
     cfg = PSGConfig(qformer=QFormerConfig(), llm=LlamaConfig(layers=a.llm_layers), max_object_num=a.objects)
     dtype = getattr(a, "dtype_override", None) or a.dtype
     tdt = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp32s": torch.float32}.get(dtype, torch.float16)
-    w = make_weights_device(cfg, 0, dev, llm_dtype=tdt, with_llm=a.workload == "full")
+    vals = torch.float16 if (getattr(a, "llm_values", "fp32") == "fp16" and tdt == torch.float32) else None
+    w = make_weights_device(cfg, 0, dev, llm_dtype=tdt, with_llm=a.workload == "full", llm_values=vals)
     head = RelationTransformerHeadV4(dtype=dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
                                      llm_config=cfg.llm, on_parse_error="skip", suppress_eos=True,
                                      cls_first=not a.one_phase,

@@ -63,7 +63,8 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *   401  round 4 (psg_dense_gemm_tiled, psg_interleave_gate_up added)
  *   500  round 5 (psg_decode_layer*: one persistent launch per decoder layer of the decode step; psg_qformer_cross_attn /
  *        psg_qformer_self_attn(_shared) / psg_prefill_attn accept PSG_F32 on the matrix cores)
- *   501  round 5 (psg_batch_gemm*, psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split added) */
+ *   501  round 5 (psg_batch_gemm*, psg_skinny_gemm_w16, psg_rmsnorm_split / psg_rope_kvwrite_scaled /
+ *        psg_silu_mul_split added) */
 #define PSG_ABI_VERSION 501
 int psg_version(void);
 const char* psg_last_error(void);
@@ -280,6 +281,28 @@ int psg_skinny_gemm(psg_ctx*, const void* x, const void* w, float* part, int M, 
                     int splits, int dtype, void* stream);
 int psg_reduce_partials(psg_ctx*, const float* part, int splits, int64_t n, void* y, int dtype,
                         void* stream);
+/* The same weights (fp16 values) under fp32-GRADE arithmetic on the 16-bit matrix cores, the decode-step form of the
+ * fp32s mode: psg_split_f16x2 writes the high and low fp16 parts of M <= 32 fp32 rows as two planes [2][M][K] + the rows'
+ * inverse power-of-two scales; psg_split_gemm_w16 streams w (fp16 [N][K]) ONCE and writes fp32 slices
+ * part[slots][M][N] = (xh . w + xl . w) * inv_scale[m] for the consumers of psg_skinny_gemm (2^-22 relative: x's split
+ * residual; the weight has no low part).  Built on psg_batch_gemm's kernel (x planes as two row tiles, summed at the
+ * flush); mode 1 / 2 as there, 0 = the library's estimate. */
+int psg_split_f16x2(psg_ctx*, const float* x, int64_t rows, int K, int64_t row_stride, void* out2, float* inv_scale,
+                    void* stream);
+/* psg_rmsnorm on fp32 rows and fp32 split-K slices with the result written straight as those two planes (bit-identical to
+ * psg_rmsnorm followed by psg_split_f16x2; HF-LL:53-67) */
+int psg_rmsnorm_split2(psg_ctx*, float* resid, const float* delta, int delta_splits, const float* w, float eps, int64_t rows,
+                       int hidden, void* out2, float* inv_scale, void* stream);
+int psg_split_gemm_w16_plan(psg_ctx*, int M, int N, int K, int mode, int* slots);
+int psg_split_gemm_w16(psg_ctx*, const void* x2, const float* inv_scale, const void* w_f16, float* part, int M, int N, int K,
+                       int slots, int mode, void* stream);
+/* psg_skinny_gemm(PSG_F32) over weights STORED as fp16: x fp32 [M][K], w fp16 [N][K], the same plan (psg_skinny_gemm_plan
+ * with PSG_F32), the same f32 matrix instructions on the exactly widened weights in the same order - part is bit-identical
+ * to the fp32-weight call on w.float(), at half the weight bytes.  For weights that ARE fp16 values: the reference's LLM is
+ * the frozen Llama-2-7b-hf checkpoint (fp16 on disk; configs/psg/baseline_v4_ov.py:61-65) upcast by from_pretrained
+ * (V4:99-100).  The caller verifies the round trip (openpsg_amd/llm.py does, per tensor, at load time). */
+int psg_skinny_gemm_w16(psg_ctx*, const float* x, const void* w_f16, float* part, int M, int N, int K, int splits,
+                        void* stream);
 
 /* ---- The same projections for 33..160 rows: several images' selected pairs decoded together (head.forward_batch; the
  * reference decodes one pair at a time, V4:293-312).  16-bit operands, N % 16 == 0, K % 64 == 0.  The weight is the
@@ -380,14 +403,18 @@ int psg_scale_rows_cols(psg_ctx*, float* y, int64_t rows, int N, const float* ro
  *   psg_rope_kvwrite_scaled psg_rope_kvwrite on a raw q|k|v result                            (HF-LL:130-160)
  *   psg_silu_mul_split      silu(gate) * up of a raw gate|up result -> out3 [rows][3 inter] + inv_scale   (HF-LL:163-177) */
 int psg_rmsnorm_split(psg_ctx*, float* resid, const float* delta, const float* delta_row_scale, const float* delta_col_scale,
-                      int delta_slices, const float* w, float eps, int64_t rows, int hidden, void* out3, float* inv_scale,
-                      void* stream);
+                      int delta_slices, const float* w, float eps, int64_t rows, int hidden, void* out, float* inv_scale,
+                      int planes, void* stream);
 int psg_rope_kvwrite_scaled(psg_ctx*, const float* qkv, const float* row_scale, const float* col_scale,
                             const int32_t* tok_pair, const int32_t* tok_pos, const float* rope_cos, const float* rope_sin,
-                            int64_t rows, int heads, int head_dim, int ctx, float* q_out, float* k_cache, float* v_cache,
-                            void* stream);
-int psg_silu_mul_split(psg_ctx*, const float* gate_up, const float* row_scale, const float* col_scale, int64_t rows,
-                       int inter, void* out3, float* inv_scale, void* stream);
+                            int slices, int64_t rows, int heads, int head_dim, int ctx, float* q_out, float* k_cache,
+                            float* v_cache, void* stream);
+int psg_silu_mul_split(psg_ctx*, const float* gate_up, const float* row_scale, const float* col_scale, int slices, int64_t rows,
+                       int inter, void* out, float* inv_scale, int planes, void* stream);
+/* `slices` > 1: the raw product arrives as [slices][rows][N] and is summed in slice order before the scales (K segments of a
+ * batched library product; the two planes of a two-plane operand).  `planes` = 3: out = [rows][3 K] = [hi | hi | lo] for
+ * a weight with a low part; 2: out = [2][rows][K] (high plane, low plane) for a weight that is an fp16 value - the product
+ * is then ONE library GEMM over 2 x rows rows and K, two thirds of the three-segment form's flops. */
 
 /* ---- Q-Former dense projections with fused epilogue (HF-IB:563-596 intermediate(_query): Linear + exact-erf GELU):
  * out[M][N] = epilogue(x[M][K] . w[N][K]^T + bias[N]); x / w / out bf16 or fp16 row-major, bias fp32 (may be NULL),

@@ -76,10 +76,15 @@ SIGNATURES = {
     "psg_skinny_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "psg_batch_gemm_plan": [_vp, _i64, _i, _i, _i, _i, _i, C.POINTER(_i)],
     "psg_batch_gemm": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    "psg_split_f16x2": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp],
+    "psg_rmsnorm_split2": [_vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _vp, _vp],
+    "psg_split_gemm_w16_plan": [_vp, _i, _i, _i, _i, C.POINTER(_i)],
+    "psg_split_gemm_w16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "psg_skinny_gemm_w16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "psg_skinny_gemm_fused": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "psg_rmsnorm_split": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _vp, _vp],
-    "psg_rope_kvwrite_scaled": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "psg_silu_mul_split": [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp],
+    "psg_rmsnorm_split": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _vp, _i, _vp],
+    "psg_rope_kvwrite_scaled": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "psg_silu_mul_split": [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _i, _vp],
     "psg_decode_layer_workspace": [_vp, _i, _i, _i, C.POINTER(_i64), C.POINTER(_i64)],
     "psg_decode_layer_supported": [_vp, _i, _i, _i, _i, _i],
     "psg_decode_layers": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],

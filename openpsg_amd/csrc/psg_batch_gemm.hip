@@ -55,12 +55,17 @@ __device__ __forceinline__ bg_u32x4 bg_lds_read128(uint32_t a) {
 __host__ __device__ static inline int bg_owner(int64_t u, int64_t T, int G) { return (int)(((u + 1) * G - 1) / T); }
 
 // S_al > 0: aligned ranges (workgroup i = slab i / S_al, slice i % S_al of its K walk); 0: stream-K
-template <typename E, int MT, int TJ>
+// PAIR (psg_split_gemm_w16): x holds TWO planes of the same M <= 32 rows - the high and the low fp16 part of fp32
+// activations, [2][M][K] - staged as x tiles 0 and 1; every wave owns both tiles and ONE weight tile (8 waves along the
+// weight rows), the two accumulators are added at the flush and multiplied by the row's inverse power-of-two scale:
+// part[slot][m][n] = (xh . w + xl . w) 2^-t, M rows.
+template <typename E, int MT, int TJ, int WM = 2, bool PAIR = false>
 __global__ void __launch_bounds__(BG_WAVES * 64, 1)
 batch_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, float* __restrict__ part, int M, int N,
-                  int K, int S, int S_al, int var) {
+                  int K, int S, int S_al, int var, const float* __restrict__ row_scale) {
   using v8 = typename E::v8;
-  constexpr int WM = 2, WN = 4, TI = (MT + 1) / 2, BM = MT * 32, BN = WN * TJ * 32;
+  static_assert(!PAIR || (MT == 2 && WM == 1 && TJ == 1), "the pair form is two x tiles, one weight tile per wave");
+  constexpr int WN = BG_WAVES / WM, TI = (MT + WM - 1) / WM, BM = MT * 32, BN = WN * TJ * 32;
   constexpr int STAGE = (BM + BN) * 128;                     // one unit: [x: BM rows | w: BN rows] x 128 B
   constexpr int NST = bg_nst(STAGE);
   static_assert(NST >= 3, "the ring needs three units");
@@ -95,7 +100,8 @@ batch_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
     const int piece = sslot ^ ((r >> 1) & 7);                // (BM is a multiple of 16: the operand-local row's swizzle)
     if (idx < XI) {
       if (var == 3 && kt > 0) return;
-      const int gr = r < M ? r : M - 1;
+      int gr = r < M ? r : M - 1;
+      if (PAIR) gr = (r >> 5) * M + ((r & 31) < M ? (r & 31) : M - 1);      // plane r >> 5, row r & 31 of [2][M][K]
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(x + (int64_t)gr * K + kt * BG_BK + piece * 8),
           (__attribute__((address_space(3))) void*)(sb + idx * 1024), 16, 0, 0);
@@ -234,6 +240,22 @@ batch_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
       // D[m][n]: register r of a lane = row 8 (r >> 2) + 4 hi + (r & 3) of the tile, column lane & 31.  Row pointers are
       // wave-uniform (scalar), the lane adds ONE 32-bit offset: no per-store address registers
       const int lane_off = 4 * hi * N + l31;
+      if constexpr (PAIR) {
+        for (int s_ = slot; s_ < nslots; ++s_) {
+          float* ps = part + (int64_t)s_ * M * N;
+          const bool real = s_ == slot;
+          const int n0 = slab * BN + wn * 32;
+          if (n0 + l31 < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int mrow = 8 * (r >> 2) + (r & 3);
+              float* rowp = ps + (int64_t)mrow * N + n0;
+              if (mrow + 4 * hi < M)
+                rowp[lane_off] = real ? (acc[0][0][r] + acc[1][0][r]) * row_scale[mrow + 4 * hi] : 0.f;
+            }
+          }
+        }
+      } else
       for (int s_ = slot; s_ < nslots; ++s_) {
         float* ps = part + (int64_t)s_ * M * N;
         const bool real = s_ == slot;
@@ -286,18 +308,19 @@ static int bg_streamk_slots(int N, int K, int BN, int G) {
 // units x the unit's cost (L2 -> LDS staging of both tiles at ~40 B/clk/CU, or the unit's share of the HBM stream) + the
 // fp32 slices it leaves (written here, read by the consumer).  Aligned ranges need slabs x slices ~ the grid; stream-K
 // balances any shape at the price of a second flush per workgroup and the zero-filled slots.
-static bg_plan bg_make_plan(const psg_ctx* ctx, int64_t M, int N, int K, int bn, int mode_) {
+static bg_plan bg_make_plan(const psg_ctx* ctx, int64_t M, int N, int K, int bn, int mode_, bool pair = false) {
   bg_plan best{0, 0, 0, 0, 0};
   double best_t = 1e300;
-  const int mt = M <= 64 ? 2 : M <= 96 ? 3 : 5;
+  const int mt = (pair || M <= 64) ? 2 : M <= 96 ? 3 : 5;
   int G = ctx->num_cu;
   if (G > BG_GRID_MAX) G = BG_GRID_MAX;
   if (ctx->opt.batch_gemm_grid > 0 && ctx->opt.batch_gemm_grid < G) G = ctx->opt.batch_gemm_grid;
   const int nk = K / BG_BK;
   const int forced_bn = bn ? bn : ctx->opt.batch_gemm_bn, forced_mode = mode_ ? mode_ : ctx->opt.batch_gemm_mode;
   for (int tj = 2; tj >= 1; --tj) {
-    const int BN = 4 * tj * 32;
-    if (forced_bn && forced_bn != BN) continue;
+    const int BN = pair ? 256 : 4 * tj * 32;                 // (the pair form: 8 waves x one 32-row weight tile)
+    if (pair && tj != 1) continue;
+    if (!pair && forced_bn && forced_bn != BN) continue;
     const int NB = (N + BN - 1) / BN;
     const int64_t T = (int64_t)NB * nk;
     const double unit_us = fmax((double)(mt * 32 + BN) * 128 / (40.0 * 2.4e3), (double)BN * 128 * G / 5.8e6);
@@ -317,7 +340,7 @@ static bg_plan bg_make_plan(const psg_ctx* ctx, int64_t M, int N, int K, int bn,
         p.slots = bg_streamk_slots(N, K, BN, p.grid);
         units = (double)((T + p.grid - 1) / p.grid);
       }
-      const double slice_bytes = (double)p.slots * M * N * 4;
+      const double slice_bytes = (double)p.slots * (pair ? 32 : M) * N * 4;   // (pair form: the plan must not follow the row count)
       const double t = units * unit_us + slice_bytes / 3.5e6 + slice_bytes / 8e6 + (mode == 2 ? 3.0 : 0.0);
       if (t < best_t) {
         best_t = t;
@@ -342,20 +365,20 @@ extern "C" int psg_batch_gemm_plan(psg_ctx* ctx, int64_t M, int N, int K, int dt
   return PSG_OK;
 }
 
-template <typename E, int MT, int TJ>
+template <typename E, int MT, int TJ, int WM = 2, bool PAIR = false>
 static int bg_launch(const bg_plan& p, const void* x, const void* w, float* part, int M, int N, int K, int var,
-                     void* stream) {
-  constexpr int STAGE = (MT * 32 + 4 * TJ * 32) * 128;
+                     void* stream, const float* row_scale = nullptr) {
+  constexpr int STAGE = (MT * 32 + (BG_WAVES / WM) * TJ * 32) * 128;
   constexpr int NST_ = bg_nst(STAGE);
-  static_assert(4 * ((MT * 32 + 4 * TJ * 32) / 8 / BG_WAVES + 1) <= 63, "vmcnt field");
-  auto k = batch_gemm_kernel<E, MT, TJ>;
+  static_assert(4 * ((MT * 32 + (BG_WAVES / WM) * TJ * 32) / 8 / BG_WAVES + 1) <= 63, "vmcnt field");
+  auto k = batch_gemm_kernel<E, MT, TJ, WM, PAIR>;
   hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, NST_ * STAGE);
   if (e != hipSuccess) {
     psg_set_error("psg_batch_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
     return PSG_ERR_HIP;
   }
   k<<<(unsigned)p.grid, BG_WAVES * 64, NST_ * STAGE, (hipStream_t)stream>>>((const uint16_t*)x, (const uint16_t*)w, part, M,
-                                                                             N, K, p.slots, p.s_al, var);
+                                                                             N, K, p.slots, p.s_al, var, row_scale);
   PSG_CHECK_LAUNCH("psg_batch_gemm");
   return PSG_OK;
 }
@@ -378,4 +401,33 @@ extern "C" int psg_batch_gemm(psg_ctx* ctx, const void* x, const void* w, float*
                    });
 #undef BG_GO
   return PSG_ERR_INVALID;
+}
+
+// ---- fp32 activations x weights that are fp16 values, as TWO fp16 products on the 16-bit matrix cores -----------------
+// x 2^t = xh + xl (psg_split_f16x2: planes [2][M][K], inv_scale = 2^-t), w exactly fp16 (a frozen fp16 checkpoint that
+// the reference upcasts on load, V4:99-100 + configs/psg/baseline_v4_ov.py:61-65): x . w = (xh . w + xl . w) 2^-t with
+// every product exact in fp32 - what is lost against the fp32 product is x's split residual, 2^-22 relative, the class of
+// the fp32s prompt pass (psg_split.hip) with ONE weight segment instead of three because wl = 0.  M <= 32 rows.
+extern "C" int psg_split_gemm_w16_plan(psg_ctx* ctx, int M, int N, int K, int mode, int* slots) {
+  PSG_REQUIRE(ctx && slots, PSG_ERR_INVALID, "psg_split_gemm_w16_plan: NULL argument");
+  PSG_REQUIRE(M >= 1 && M <= 32 && N >= 16 && N % 16 == 0 && K >= BG_BK && K % BG_BK == 0 && mode >= 0 && mode <= 2,
+              PSG_ERR_UNSUPPORTED, "psg_split_gemm_w16: M=%d (1..32), N=%d (multiple of 16), K=%d (multiple of %d), mode=%d", M,
+              N, K, BG_BK, mode);
+  const bg_plan p = bg_make_plan(ctx, M, N, K, 0, mode, true);
+  PSG_REQUIRE(p.grid > 0 && p.slots <= PSG_MAX_SPLITS, PSG_ERR_UNSUPPORTED,
+              "psg_split_gemm_w16_plan: no plan with <= %d slices for M=%d N=%d K=%d", PSG_MAX_SPLITS, M, N, K);
+  *slots = p.slots;
+  return PSG_OK;
+}
+
+extern "C" int psg_split_gemm_w16(psg_ctx* ctx, const void* x2, const float* inv_scale, const void* w16, float* part, int M,
+                                  int N, int K, int slots, int mode, void* stream) {
+  PSG_REQUIRE(ctx && x2 && inv_scale && w16 && part, PSG_ERR_INVALID, "psg_split_gemm_w16: NULL argument");
+  int want = 0;
+  const int rc = psg_split_gemm_w16_plan(ctx, M, N, K, mode, &want);
+  if (rc != PSG_OK) return rc;
+  PSG_REQUIRE(slots == want, PSG_ERR_INVALID, "psg_split_gemm_w16: slots=%d, the plan for M=%d N=%d K=%d writes %d", slots, M,
+              N, K, want);
+  const bg_plan p = bg_make_plan(ctx, M, N, K, 0, mode, true);
+  return bg_launch<EF16, 2, 1, 1, true>(p, x2, w16, part, M, N, K, ctx->opt.batch_gemm_var, stream, inv_scale);
 }

@@ -581,7 +581,7 @@ static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
 // fp32 instantiation (psg_gemm_f32.hip)
 int psg_sgf_plan(const psg_ctx* ctx, int M, int N, int K);
 int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K, int splits,
-                   void* stream);
+                   void* stream, bool w16);
 
 extern "C" int psg_skinny_gemm_plan(psg_ctx* ctx, int M, int N, int K, int dtype, int* splits) {
   PSG_REQUIRE(ctx && splits, PSG_ERR_INVALID, "psg_skinny_gemm_plan: NULL argument");
@@ -729,8 +729,15 @@ static int sg_launch(psg_ctx* ctx, const void* x, const void* w, float* part, in
 
 extern "C" int psg_skinny_gemm(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K,
                                int splits, int dtype, void* stream) {
-  if (dtype == PSG_F32) return psg_sgf_launch(ctx, x, w, part, M, N, K, splits, stream);
+  if (dtype == PSG_F32) return psg_sgf_launch(ctx, x, w, part, M, N, K, splits, stream, false);
   PSG_DISPATCH_E16(dtype, "psg_skinny_gemm", return sg_launch<E>(ctx, x, w, part, M, N, K, splits, stream));
+}
+
+// fp32 activations x weights STORED as fp16 (a frozen fp16 checkpoint the reference upcasts on load, V4:99-100): the
+// arithmetic of psg_skinny_gemm(PSG_F32) on the widened weights, bit for bit, at half the weight bytes (psg_gemm_f32.hip)
+extern "C" int psg_skinny_gemm_w16(psg_ctx* ctx, const float* x, const void* w_f16, float* part, int M, int N, int K,
+                                   int splits, void* stream) {
+  return psg_sgf_launch(ctx, x, w_f16, part, M, N, K, splits, stream, true);
 }
 
 extern "C" int psg_skinny_gemm_fused(psg_ctx* ctx, const psg_prologue* pro, void* x, const void* w, float* part, int M,

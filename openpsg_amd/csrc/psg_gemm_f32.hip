@@ -34,6 +34,15 @@
 //   * x[0..M)[K range] is staged once per workgroup by LDS-DMA and reused for every slab;
 //   * K inside a block is permuted the same way for w and x: lane (n, kq) reads the 16-byte pieces 2 kq and 2 kq + 1
 //     of row n; float i of a piece is the operand of the i-th MFMA on that piece.
+//
+// W16 (psg_skinny_gemm_w16): the same kernel over weights STORED as fp16.  The reference's LLM is a frozen fp16 checkpoint
+// (configs/psg/baseline_v4_ov.py:61-65: Llama-2-7b-hf, `freeze_layers=[..., 'relation_head.language_model']`) that
+// `from_pretrained` upcasts to fp32 (V4:99-100): every weight IS an fp16 value, and reading it as 2 bytes and widening it
+// in the register (v_cvt_f32_f16: exact) feeds the same f32 MFMAs the same operands in the same order - results
+// bit-identical to the fp32-weight stream at half the HBM bytes.  The engine keeps fp16 storage only for tensors it has
+// verified to round-trip (w.half().float() == w, every element); anything trained stays fp32.  Layout differences: a K
+// block of 32 weights is 64 B per row, one DMA instruction per 16-row block (lane -> row lane >> 2, piece lane & 3,
+// source-swizzled by (row >> 1) & 3), twice the ring slots for the same bytes in flight.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -58,15 +67,15 @@ __device__ __forceinline__ void sgf_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 // wait until at most `newer` blocks (2 DMA instructions each) issued after the wanted one are outstanding
-template <int MAXN>
+template <int MAXN, int PER = 2>
 struct SgfWait {
   static __device__ __forceinline__ void go(int newer) {
-    if (newer >= MAXN) sgf_wait<(MAXN * 2 < 63 ? MAXN * 2 : 63)>();
-    else SgfWait<MAXN - 1>::go(newer);
+    if (newer >= MAXN) sgf_wait<(MAXN * PER < 63 ? MAXN * PER : 63)>();
+    else SgfWait<MAXN - 1, PER>::go(newer);
   }
 };
-template <>
-struct SgfWait<0> {
+template <int PER>
+struct SgfWait<0, PER> {
   static __device__ __forceinline__ void go(int) { sgf_wait<0>(); }
 };
 
@@ -88,14 +97,15 @@ __device__ __forceinline__ float sgf_sum_kq(float v) {
 typedef float sf32x16_t __attribute__((ext_vector_type(16)));
 
 // G16 sixteen-row groups (x rows 16 G .. 16 G + 15) followed by G4 four-row groups (x rows 16 G16 + 4 q ..)
-template <int WAVES, int SLOTS, int G16, int G4>
+template <int WAVES, int SLOTS, int G16, int G4, bool W16 = false>
 __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_f32_kernel(const float* __restrict__ x,
-                                                                     const float* __restrict__ w,
+                                                                     const void* __restrict__ w,
                                                                      float* __restrict__ part, int M, int N, int K,
                                                                      int xstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ROWS = WAVES * 16;
-  constexpr int BLOCK_BYTES = 2048;                                 // 16 rows x 128 B
+  constexpr int WROW = W16 ? 64 : 128;                              // bytes of one row of a 32-weight K block
+  constexpr int BLOCK_BYTES = 16 * WROW;                            // 16 rows
   constexpr int RING_BYTES = SLOTS * BLOCK_BYTES;
   constexpr int OT_PITCH = ROWS + 4;                                // output tile pitch (floats)
   constexpr int MP = G16 * 16 + G4 * 4;                             // x rows of the tile
@@ -115,14 +125,18 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_f32_kernel(const float
   unsigned char* xs = smem + WAVES * RING_BYTES + MP * OT_PITCH * 4;            // shared x slice [M][xstride bytes]
   const int total = nslab * nkb;                                    // flattened (slab, block) stream
   const unsigned char* wb = reinterpret_cast<const unsigned char*>(w);
-  const int64_t row_bytes = (int64_t)K * 4;
+  const int64_t row_bytes = (int64_t)K * (W16 ? 2 : 4);
+  const int64_t xrow_bytes = (int64_t)K * 4;
 
-  // DMA source of this lane: row (lane >> 3) of an 8-row group, piece (lane & 7) ^ (lane >> 3)
-  const int dr = lane >> 3, dp = (lane & 7) ^ (lane >> 3);
+  // DMA source of this lane.  fp32 weights: row (lane >> 3) of an 8-row group, piece (lane & 7) ^ (lane >> 3), two
+  // instructions per block; fp16 weights: row (lane >> 2) of the 16-row block, piece (lane & 3) ^ ((row >> 1) & 3), one
+  const int dr = W16 ? lane >> 2 : lane >> 3;
+  const int dp = W16 ? (lane & 3) ^ ((dr >> 1) & 3) : (lane & 7) ^ (lane >> 3);
   auto dma_src = [&](int t) -> const unsigned char* {
     int r = (gx + t * G) * ROWS + wid * 16 + dr;
-    r = r + 8 < N ? r : (N - 9 > 0 ? N - 9 : 0);                    // keep rows r and r + 8 in range (results dropped)
-    return wb + (int64_t)r * row_bytes + (int64_t)kbA * 128 + dp * 16;
+    if (W16) r = r < N ? r : N - 1;                                 // rows past N: clamped (results dropped)
+    else r = r + 8 < N ? r : (N - 9 > 0 ? N - 9 : 0);               // keep rows r and r + 8 in range
+    return wb + (int64_t)r * row_bytes + (int64_t)kbA * WROW + dp * 16;
   };
   int lt = 0, lb = 0, ls = 0;                                       // load cursor: slab, block, ring slot
   const unsigned char* src = dma_src(0);
@@ -130,9 +144,10 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_f32_kernel(const float
     unsigned char* dst = ring + ls * BLOCK_BYTES;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * row_bytes),
-                                     (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 2);
-    src += 128;
+    if (!W16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * row_bytes),
+                                       (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 2);
+    src += WROW;
     if (++ls == SLOTS) ls = 0;
     if (++lb == nkb) { lb = 0; ++lt; src = dma_src(lt); }
   };
@@ -148,7 +163,7 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_f32_kernel(const float
       const int c = j * 64 + lane;
       if (c < pieces)
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(xb + (int64_t)r * row_bytes + (int64_t)kbA * 128 + c * 16),
+            (const __attribute__((address_space(1))) void*)(xb + (int64_t)r * xrow_bytes + (int64_t)kbA * 128 + c * 16),
             (__attribute__((address_space(3))) void*)(xs + r * xstride + j * 1024), 16, 0, 0);
     }
   }
@@ -165,9 +180,11 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_f32_kernel(const float
   for (int g = 0; g < G16; ++g) x16[g] = xs + min(16 * g + n, M - 1) * xstride + kq * 32;
 #pragma unroll
   for (int q = 0; q < G4; ++q) x4[q] = xs + min(16 * G16 + 4 * q + (lane & 3), M - 1) * xstride + kq * 32;
-  // fragment (row n, piece c = 2 kq + j) sits at slot c ^ (n & 7) of row n
-  const int arow = (n >> 3) * 1024 + (n & 7) * 128;
-  const int a0off = arow + (((2 * kq) ^ (n & 7)) * 16), a1off = arow + (((2 * kq + 1) ^ (n & 7)) * 16);
+  // fp32 weights: fragment (row n, piece c = 2 kq + j) sits at slot c ^ (n & 7) of row n; fp16 weights: the 8 halfs of
+  // this lane's kq are ONE 16-byte piece, at slot kq ^ ((n >> 1) & 3) of the 64-byte row n
+  const int arow = W16 ? n * 64 : (n >> 3) * 1024 + (n & 7) * 128;
+  const int a0off = W16 ? arow + ((kq ^ ((n >> 1) & 3)) * 16) : arow + (((2 * kq) ^ (n & 7)) * 16);
+  const int a1off = W16 ? a0off : arow + (((2 * kq + 1) ^ (n & 7)) * 16);
   const sf32x4_t zero4 = {0, 0, 0, 0};
   const sf32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   sf32x16_t acc16[NG16];
@@ -228,14 +245,22 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_f32_kernel(const float
   }
   for (int j = 0; j < total; ++j) {
     if (j + SLOTS - 1 < total) issue();                             // refills the slot consumed at j - 1
-    SgfWait<SLOTS - 1>::go(total - 1 - j);                          // blocks issued after block j may stay in flight
+    SgfWait<SLOTS - 1, W16 ? 1 : 2>::go(total - 1 - j);             // blocks issued after block j may stay in flight
     const unsigned char* slot = ring + cs * BLOCK_BYTES;
     if (++cs == SLOTS) cs = 0;
     const int o = cb * 128;
     // k order of every output's kq partial: (block, piece 2 kq: floats 0..3, piece 2 kq + 1: floats 0..3)
+    typedef _Float16 sf16x8_t __attribute__((ext_vector_type(8)));
+    sf16x8_t a16;
+    if (W16) a16 = *reinterpret_cast<const sf16x8_t*>(slot + a0off);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const sf32x4_t a = *reinterpret_cast<const sf32x4_t*>(slot + (h ? a1off : a0off));
+      sf32x4_t a;
+      if (W16) {                                                    // exact widening: the operands of the fp32-weight stream
+        a[0] = (float)a16[4 * h]; a[1] = (float)a16[4 * h + 1]; a[2] = (float)a16[4 * h + 2]; a[3] = (float)a16[4 * h + 3];
+      } else {
+        a = *reinterpret_cast<const sf32x4_t*>(slot + (h ? a1off : a0off));
+      }
       sf32x4_t b16[NG16], b4[NG4];
 #pragma unroll
       for (int g = 0; g < G16; ++g) b16[g] = *reinterpret_cast<const sf32x4_t*>(x16[g] + o + 16 * h);
@@ -288,7 +313,7 @@ int psg_sgf_plan(const psg_ctx* ctx, int M, int N, int K) {
 }
 
 int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K, int splits,
-                   void* stream) {
+                   void* stream, bool w16) {
   PSG_REQUIRE(ctx && x && w && part, PSG_ERR_INVALID, "psg_skinny_gemm(f32): NULL argument");
   PSG_REQUIRE(M >= 1 && M <= 32, PSG_ERR_UNSUPPORTED, "psg_skinny_gemm(f32): M=%d (1..32 rows)", M);
   PSG_REQUIRE(N >= 16 && N % 16 == 0 && K >= 32 && K % 32 == 0 && K <= (1 << 20), PSG_ERR_UNSUPPORTED,
@@ -333,10 +358,16 @@ int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int 
   const int g16 = M <= 12 ? 0 : (M <= 28 ? 1 : 2), g4 = M <= 12 ? (M + 3) / 4 : (M <= 16 || M > 28 ? 0 : (M - 16 + 3) / 4);
 #define SGF_K(WV, SL, A, B)                                                                              \
   do {                                                                                                   \
-    (void)hipFuncSetAttribute((const void*)skinny_gemm_f32_kernel<WV, SL, A, B>,                         \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
-    skinny_gemm_f32_kernel<WV, SL, A, B><<<grid, WV * 64, lds, st>>>((const float*)x, (const float*)w,   \
-                                                                     part, M, N, K, xstride);            \
+    if (w16) {                                      /* fp16-stored weights: 1 KB blocks, twice the slots */ \
+      (void)hipFuncSetAttribute((const void*)skinny_gemm_f32_kernel<WV, 2 * SL, A, B, true>,             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+      skinny_gemm_f32_kernel<WV, 2 * SL, A, B, true><<<grid, WV * 64, lds, st>>>((const float*)x, w, part, M, N, K, \
+                                                                                 xstride);               \
+    } else {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)skinny_gemm_f32_kernel<WV, SL, A, B>,                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+      skinny_gemm_f32_kernel<WV, SL, A, B><<<grid, WV * 64, lds, st>>>((const float*)x, w, part, M, N, K, xstride); \
+    }                                                                                                    \
   } while (0)
 #define SGF_L(WV, A, B)                   \
   do {                                    \

@@ -78,6 +78,59 @@ extern "C" int psg_split_f16x3(psg_ctx* ctx, const float* x, int64_t rows, int K
   return PSG_OK;
 }
 
+// psg_split_f16x2: fp32 rows -> two PLANES of fp16, out[0][row][K] = xh, out[1][row][K] = xl (same row scale as above):
+// the operand of psg_split_gemm_w16, whose weight is an fp16 value and needs no low part
+__global__ void __launch_bounds__(256) split_f16x2_kernel(const float* __restrict__ x, int64_t row_stride, int K, int64_t rows,
+                                                          uint16_t* __restrict__ out, float* __restrict__ inv_scale) {
+  __shared__ float s_max[4];
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * row_stride;
+  const int tid = threadIdx.x;
+  float mx = 0.f;
+  for (int c = tid * 4; c < K; c += 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) s_max[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  int e = (int)((__float_as_uint(mx) >> 23) & 255u) - 127;
+  if (!(mx > 0.f) || e == 128) e = 13;
+  int se = 127 + 13 - e;
+  se = se < 1 ? 1 : (se > 253 ? 253 : se);
+  const float scale = __uint_as_float((uint32_t)se << 23);
+  if (tid == 0) inv_scale[row] = __uint_as_float((uint32_t)(254 - se) << 23);
+  uint16_t* oh = out + row * (int64_t)K;
+  uint16_t* ol = out + (rows + row) * (int64_t)K;
+  for (int c = tid * 4; c < K; c += 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    const float s[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+    ushort4 h, l;
+    uint16_t* hp = &h.x;
+    uint16_t* lp = &l.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint16_t hb = f32_to_f16(s[i]);
+      hp[i] = hb;
+      lp[i] = f32_to_f16(s[i] - f16_to_f32(hb));
+    }
+    *reinterpret_cast<ushort4*>(oh + c) = h;
+    *reinterpret_cast<ushort4*>(ol + c) = l;
+  }
+}
+
+extern "C" int psg_split_f16x2(psg_ctx* ctx, const float* x, int64_t rows, int K, int64_t row_stride, void* out,
+                               float* inv_scale, void* stream) {
+  PSG_REQUIRE(ctx && x && out && inv_scale, PSG_ERR_INVALID, "psg_split_f16x2: NULL argument");
+  PSG_REQUIRE(rows >= 0 && K > 0 && K % 4 == 0 && row_stride >= K && row_stride % 4 == 0 && rows < (1ll << 31),
+              PSG_ERR_INVALID, "psg_split_f16x2: rows=%lld K=%d stride=%lld", (long long)rows, K, (long long)row_stride);
+  if (rows == 0) return PSG_OK;
+  split_f16x2_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale);
+  PSG_CHECK_LAUNCH("psg_split_f16x2");
+  return PSG_OK;
+}
+
 // y[m][n] *= row_scale[m] * col_scale[n]  (powers of two: exact), in place
 __global__ void __launch_bounds__(256) scale_rows_cols_kernel(float* __restrict__ y, int64_t rows, int N,
                                                               const float* __restrict__ row_scale,
@@ -123,6 +176,7 @@ __device__ __forceinline__ float sp_row_scale(float mx, float* inv_scale_out) { 
   if (inv_scale_out) *inv_scale_out = __uint_as_float((uint32_t)(254 - se) << 23);
   return __uint_as_float((uint32_t)se << 23);
 }
+__device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, const float (&x)[4], float scale);   // two planes
 __device__ __forceinline__ void sp_store3(uint16_t* o0, int K, int c, const float (&x)[4], float scale) {   // [hi | hi | lo]
   ushort4 h, l;
   uint16_t* hp = &h.x;
@@ -146,7 +200,7 @@ __global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ 
                                                             const float* __restrict__ d_rs, const float* __restrict__ d_cs,
                                                             const float* __restrict__ w, float eps, int hidden,
                                                             uint16_t* __restrict__ out3, float* __restrict__ inv_scale,
-                                                            int dslices, int64_t dstride) {
+                                                            int dslices, int64_t dstride, int planes) {
   __shared__ float s_part[4], s_max[4];
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -199,16 +253,21 @@ __global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ 
   mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
   const float scale = sp_row_scale(mx, tid == 0 ? inv_scale + row : nullptr);
   uint16_t* o0 = out3 + row * 3 * (int64_t)hidden;
+  uint16_t* oh = out3 + row * (int64_t)hidden;                   // planes == 2: [2][rows][hidden] (dstride = rows x hidden)
+  uint16_t* ol = oh + dstride;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * 256 + tid) * 4;
-    if (col < hidden) sp_store3(o0, hidden, col, x[c], scale);
+    if (col < hidden) {
+      if (planes == 2) sp_store2(oh, ol, col, x[c], scale);
+      else sp_store3(o0, hidden, col, x[c], scale);
+    }
   }
 }
 
 extern "C" int psg_rmsnorm_split(psg_ctx* ctx, float* resid, const float* delta, const float* delta_row_scale,
                                  const float* delta_col_scale, int delta_slices, const float* w, float eps, int64_t rows,
-                                 int hidden, void* out3, float* inv_scale, void* stream) {
+                                 int hidden, void* out3, float* inv_scale, int planes, void* stream) {
   PSG_REQUIRE(ctx && resid && w && out3 && inv_scale && (!delta || (delta_row_scale && delta_col_scale)), PSG_ERR_INVALID,
               "psg_rmsnorm_split: NULL argument");
   PSG_REQUIRE(hidden % 4 == 0 && hidden > 0 && hidden <= 8192 && rows >= 0 && rows < (1ll << 31), PSG_ERR_UNSUPPORTED,
@@ -218,7 +277,7 @@ extern "C" int psg_rmsnorm_split(psg_ctx* ctx, float* resid, const float* delta,
   hipStream_t st = (hipStream_t)stream;
 #define RNS(N)                                                                                                      \
   rmsnorm_split_kernel<N><<<(unsigned)rows, 256, 0, st>>>(resid, delta, delta_row_scale, delta_col_scale, w, eps, hidden, \
-                                                          (uint16_t*)out3, inv_scale, delta_slices, rows * (int64_t)hidden)
+                                                          (uint16_t*)out3, inv_scale, delta_slices, rows * (int64_t)hidden, planes)
   switch (nch) {
     case 1: RNS(1); break;
     case 2: RNS(2); break;
@@ -238,7 +297,8 @@ extern "C" int psg_rmsnorm_split(psg_ctx* ctx, float* resid, const float* delta,
 #define SP_MAXCH 16
 __global__ void __launch_bounds__(256) silu_mul_split_kernel(const float* __restrict__ gu, const float* __restrict__ rsv,
                                                              const float* __restrict__ csv, int inter,
-                                                             uint16_t* __restrict__ out3, float* __restrict__ inv_scale) {
+                                                             uint16_t* __restrict__ out3, float* __restrict__ inv_scale,
+                                                             int slices, int64_t rows, int planes) {
   __shared__ float s_max[4];
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -250,7 +310,13 @@ __global__ void __launch_bounds__(256) silu_mul_split_kernel(const float* __rest
   for (int c = 0; c < SP_MAXCH; ++c) {
     const int col = (c * 256 + tid) * 4;
     if (col < inter) {
-      const float4 g4 = *reinterpret_cast<const float4*>(gr + col), u4 = *reinterpret_cast<const float4*>(gr + inter + col);
+      float4 g4 = *reinterpret_cast<const float4*>(gr + col), u4 = *reinterpret_cast<const float4*>(gr + inter + col);
+      for (int sl = 1; sl < slices; ++sl) {                           // the product as slices (two-plane operand): summed in order
+        const float* gs = gr + sl * rows * 2 * (int64_t)inter;
+        const float4 g5 = *reinterpret_cast<const float4*>(gs + col), u5 = *reinterpret_cast<const float4*>(gs + inter + col);
+        g4.x += g5.x; g4.y += g5.y; g4.z += g5.z; g4.w += g5.w;
+        u4.x += u5.x; u4.y += u5.y; u4.z += u5.z; u4.w += u5.w;
+      }
       const float4 cg = *reinterpret_cast<const float4*>(csv + col), cu = *reinterpret_cast<const float4*>(csv + inter + col);
       const float g[4] = {g4.x * (rs * cg.x), g4.y * (rs * cg.y), g4.z * (rs * cg.z), g4.w * (rs * cg.w)};
       const float u[4] = {u4.x * (rs * cu.x), u4.y * (rs * cu.y), u4.z * (rs * cu.z), u4.w * (rs * cu.w)};
@@ -268,22 +334,27 @@ __global__ void __launch_bounds__(256) silu_mul_split_kernel(const float* __rest
   mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
   const float scale = sp_row_scale(mx, tid == 0 ? inv_scale + row : nullptr);
   uint16_t* o0 = out3 + row * 3 * (int64_t)inter;
+  uint16_t* oh = out3 + row * (int64_t)inter;
+  uint16_t* ol = oh + rows * (int64_t)inter;
 #pragma unroll
   for (int c = 0; c < SP_MAXCH; ++c) {
     const int col = (c * 256 + tid) * 4;
-    if (col < inter) sp_store3(o0, inter, col, o[c], scale);
+    if (col < inter) {
+      if (planes == 2) sp_store2(oh, ol, col, o[c], scale);
+      else sp_store3(o0, inter, col, o[c], scale);
+    }
   }
 }
 
 extern "C" int psg_silu_mul_split(psg_ctx* ctx, const float* gate_up, const float* row_scale, const float* col_scale,
-                                  int64_t rows, int inter, void* out3, float* inv_scale, void* stream) {
+                                  int slices, int64_t rows, int inter, void* out3, float* inv_scale, int planes, void* stream) {
   PSG_REQUIRE(ctx && gate_up && row_scale && col_scale && out3 && inv_scale, PSG_ERR_INVALID,
               "psg_silu_mul_split: NULL argument");
   PSG_REQUIRE(inter > 0 && inter % 4 == 0 && inter <= SP_MAXCH * 1024 && rows >= 0 && rows < (1ll << 31),
               PSG_ERR_UNSUPPORTED, "psg_silu_mul_split: inter=%d (multiple of 4, <= %d)", inter, SP_MAXCH * 1024);
   if (rows == 0) return PSG_OK;
   silu_mul_split_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(gate_up, row_scale, col_scale, inter,
-                                                                         (uint16_t*)out3, inv_scale);
+                                                                         (uint16_t*)out3, inv_scale, slices, rows, planes);
   PSG_CHECK_LAUNCH("psg_silu_mul_split");
   return PSG_OK;
 }
@@ -293,7 +364,8 @@ __global__ void rope_kvwrite_scaled_kernel(const float* __restrict__ qkv, const 
                                            const float* __restrict__ csv, const int32_t* __restrict__ tok_pair,
                                            const int32_t* __restrict__ tok_pos, const float* __restrict__ cos_tab,
                                            const float* __restrict__ sin_tab, int64_t rows, int heads, int ctx,
-                                           float* __restrict__ q_out, float* __restrict__ kc, float* __restrict__ vc) {
+                                           float* __restrict__ q_out, float* __restrict__ kc, float* __restrict__ vc,
+                                           int slices) {
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= rows * heads) return;
@@ -306,7 +378,12 @@ __global__ void rope_kvwrite_scaled_kernel(const float* __restrict__ qkv, const 
   const int64_t base = row * 3 * hidden;
   const float rs = rsv[row];
   const float cs = cos_tab[pos * 64 + lane], sn = sin_tab[pos * 64 + lane];
-  auto ld = [&](int col) { return qkv[base + col] * (rs * csv[col]); };
+  const int64_t sstride = rows * 3 * (int64_t)hidden;
+  auto ld = [&](int col) {
+    float v = qkv[base + col];
+    for (int sl = 1; sl < slices; ++sl) v += qkv[sl * sstride + base + col];
+    return v * (rs * csv[col]);
+  };
   const float q1 = ld(c0), q2 = ld(c0 + 64), k1 = ld(hidden + c0), k2 = ld(hidden + c0 + 64);
   const float v1 = ld(2 * hidden + c0), v2 = ld(2 * hidden + c0 + 64);
   float qa, qb, ka, kb;
@@ -323,15 +400,136 @@ __global__ void rope_kvwrite_scaled_kernel(const float* __restrict__ qkv, const 
 
 extern "C" int psg_rope_kvwrite_scaled(psg_ctx* ctx_, const float* qkv, const float* row_scale, const float* col_scale,
                                        const int32_t* tok_pair, const int32_t* tok_pos, const float* rope_cos,
-                                       const float* rope_sin, int64_t rows, int heads, int head_dim, int ctx, float* q_out,
-                                       float* k_cache, float* v_cache, void* stream) {
+                                       const float* rope_sin, int slices, int64_t rows, int heads, int head_dim, int ctx,
+                                       float* q_out, float* k_cache, float* v_cache, void* stream) {
   PSG_REQUIRE(ctx_ && qkv && row_scale && col_scale && tok_pair && tok_pos && rope_cos && rope_sin && q_out && k_cache &&
                   v_cache, PSG_ERR_INVALID, "psg_rope_kvwrite_scaled: NULL argument");
   PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_rope_kvwrite_scaled: head_dim=%d (kernel is built for 128)", head_dim);
   if (rows == 0) return PSG_OK;
   const int64_t waves = rows * heads;
   rope_kvwrite_scaled_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, (hipStream_t)stream>>>(
-      qkv, row_scale, col_scale, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, q_out, k_cache, v_cache);
+      qkv, row_scale, col_scale, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, q_out, k_cache, v_cache, slices);
   PSG_CHECK_LAUNCH("psg_rope_kvwrite_scaled");
+  return PSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Decode steps of the fp32s mode over fp16-valued weights (psg_split_gemm_w16): the row kernels in front of a projection
+// write its operand straight as the two fp16 planes [2][rows][K] + the rows' inverse scales - the arithmetic of
+// psg_rmsnorm (fp32 rows, fp32 split-K slices summed in slice order) followed by psg_split_f16x2, bit for bit, in one
+// launch instead of two (HF-LL:53-67).  (The SwiGLU gate stays two launches: its row maximum spans 11008 columns, and one
+// workgroup per row took 24 us against 5.2 + 4.9 for psg_silu_mul over all CUs + psg_split_f16x2.)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, const float (&x)[4], float scale) {
+  ushort4 h, l;
+  uint16_t* hp = &h.x;
+  uint16_t* lp = &l.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float s = x[i] * scale;
+    const uint16_t hb = f32_to_f16(s);
+    hp[i] = hb;
+    lp[i] = f32_to_f16(s - f16_to_f32(hb));
+  }
+  *reinterpret_cast<ushort4*>(oh + c) = h;
+  *reinterpret_cast<ushort4*>(ol + c) = l;
+}
+
+// rmsnorm_kernel<float, NCH, float> (psg_rowops.hip: nthr threads per row, the same loads, sums and roundings) + the split
+template <int NCH>
+__global__ void __launch_bounds__(1024) rmsnorm_split2_kernel(float* __restrict__ resid, const void* __restrict__ delta,
+                                                              int dsplits, int64_t dslice, const float* __restrict__ w,
+                                                              float eps, int hidden, int64_t rows,
+                                                              uint16_t* __restrict__ out2, float* __restrict__ inv_scale) {
+  __shared__ float s_part[16], s_max[16];
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthr = blockDim.x;
+  float v[NCH][4], d[NCH][4];
+  float4 g[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden) {
+      const float4 r = *reinterpret_cast<const float4*>(resid + row * hidden + col);
+      v[c][0] = r.x; v[c][1] = r.y; v[c][2] = r.z; v[c][3] = r.w;
+      g[c] = *reinterpret_cast<const float4*>(w + col);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden && delta) ld4_in<float>(delta, dsplits, dslice, row * hidden + col, d[c]);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden) {
+      if (delta) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c][e] += d[c][e];
+      }
+      ss = psg_sumsq4(v[c], ss);
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) s_part[wid] = ss;
+  __syncthreads();
+  ss = 0.f;
+  for (int i = 0; i < (nthr >> 6); ++i) ss += s_part[i];
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  float o[NCH][4];
+  float mx = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden) {
+      if (delta) *reinterpret_cast<float4*>(resid + row * hidden + col) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+      o[c][0] = g[c].x * (v[c][0] * inv); o[c][1] = g[c].y * (v[c][1] * inv);
+      o[c][2] = g[c].z * (v[c][2] * inv); o[c][3] = g[c].w * (v[c][3] * inv);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[c][0]), fabsf(o[c][1]))), fmaxf(fabsf(o[c][2]), fabsf(o[c][3])));
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) s_max[wid] = mx;
+  __syncthreads();
+  mx = 0.f;
+  for (int i = 0; i < (nthr >> 6); ++i) mx = fmaxf(mx, s_max[i]);
+  const float scale = sp_row_scale(mx, tid == 0 ? inv_scale + row : nullptr);
+  uint16_t* oh = out2 + row * (int64_t)hidden;
+  uint16_t* ol = out2 + (rows + row) * (int64_t)hidden;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * nthr + tid) * 4;
+    if (col < hidden) sp_store2(oh, ol, col, o[c], scale);
+  }
+}
+
+extern "C" int psg_rmsnorm_split2(psg_ctx* ctx, float* resid, const float* delta, int delta_splits, const float* w, float eps,
+                                  int64_t rows, int hidden, void* out2, float* inv_scale, void* stream) {
+  PSG_REQUIRE(ctx && resid && w && out2 && inv_scale, PSG_ERR_INVALID, "psg_rmsnorm_split2: NULL argument");
+  PSG_REQUIRE(hidden % 4 == 0 && hidden > 0 && hidden <= 8192 && rows >= 0 && rows < (1ll << 31), PSG_ERR_UNSUPPORTED,
+              "psg_rmsnorm_split2: hidden=%d (multiple of 4, <= 8192)", hidden);
+  PSG_REQUIRE(delta_splits >= 0 && delta_splits <= PSG_MAX_SPLITS && (!delta || delta_splits >= 1), PSG_ERR_INVALID,
+              "psg_rmsnorm_split2: delta_splits=%d (fp32 split-K slices)", delta_splits);
+  if (rows == 0) return PSG_OK;
+  const int nthr = (rows <= 64 && hidden >= 4096) ? 1024 : 256;       // psg_rmsnorm's choice: the same summation tree
+  const int nch = (hidden + 4 * nthr - 1) / (4 * nthr);
+  hipStream_t st = (hipStream_t)stream;
+#define RS2(N)                                                                                                          \
+  rmsnorm_split2_kernel<N><<<(unsigned)rows, nthr, 0, st>>>(resid, delta, delta_splits, rows * (int64_t)hidden, w, eps, \
+                                                            hidden, rows, (uint16_t*)out2, inv_scale)
+  switch (nch) {
+    case 1: RS2(1); break;
+    case 2: RS2(2); break;
+    case 3: RS2(3); break;
+    case 4: RS2(4); break;
+    case 5: RS2(5); break;
+    case 6: RS2(6); break;
+    case 7: RS2(7); break;
+    default: RS2(8); break;
+  }
+#undef RS2
+  PSG_CHECK_LAUNCH("psg_rmsnorm_split2");
   return PSG_OK;
 }

@@ -194,6 +194,26 @@ class LlamaDecodeEngine:
                 ln1=f32(p + "input_layernorm.weight"), ln2=f32(p + "post_attention_layernorm.weight")))
         self.use_skinny = True
         self.prefill_split = bool(prefill_split) and dtype == torch.float32
+        # fp32 engines: are the projection weights fp16 VALUES?  The reference's LLM is the frozen Llama-2-7b-hf checkpoint
+        # (fp16 on disk, configs/psg/baseline_v4_ov.py:61-65) upcast by from_pretrained (V4:99-100): if every element of
+        # every projection round-trips through fp16, the decode steps stream an fp16 copy - half the HBM bytes - instead
+        # of the fp32 tensor: exact mode 'fp32' on the same f32 matrix instructions (psg_skinny_gemm_w16, bit-identical),
+        # mode 'fp32s' as two fp16 products of the split activations (psg_split_gemm_w16, 2^-22).  Anything trained in
+        # fp32 fails the check and keeps the fp32 stream.
+        self._w16 = {}
+        self._ones = {}
+        from . import _lib as _lib0
+        if dtype == torch.float32 and _lib0.get_option(self.device.index or 0, "llm_w16"):
+            tensors = [L[k] for L in self.layers for k in ("wqkv", "wo", "wgu", "wdown")] + [self.lm_head]
+            halves = []
+            for t in tensors:
+                h = t.half()
+                if not torch.equal(h.float(), t):
+                    halves = None
+                    break
+                halves.append(h)
+            if halves is not None:
+                self._w16 = {t.data_ptr(): h for t, h in zip(tensors, halves)}
         if self.prefill_split:
             # [wh | wl | wh] fp16 + the per-row power of two that undoes the row scaling, per projection (3 x 2 bytes per
             # weight next to the fp32 copy the decode steps stream: 40 GB + 27 GB for Llama-2-7B, of 288 GB)
@@ -269,6 +289,12 @@ class LlamaDecodeEngine:
         psg_batch_gemm's variants and the library was measured fastest for the shape (_plan_batch_mm)."""
         if (self.use_skinny and x.shape[0] <= 32 and x.dtype == w.dtype and w.shape[0] % 16 == 0
                 and w.shape[1] % 64 == 0 and w.shape[1] >= 256):
+            wh = self._w16.get(w.data_ptr()) if x.dtype == torch.float32 else None
+            if wh is not None and self.prefill_split:         # fp32s: two fp16 products of the split rows, 2 bytes per weight
+                x2, inv = ops.split_f16x2(x)
+                return ops.split_gemm_w16(x2, inv, wh)
+            if wh is not None:                                # exact fp32: the same f32 instructions on the widened weight
+                return ops.skinny_gemm_w16(x, wh)
             return ops.skinny_gemm(x, w)          # fp32 split-K partials, reduced by the consumer kernel
         if (decode and self.batch_gemm and self.use_skinny and 32 < x.shape[0] <= 160 and x.dtype == w.dtype
                 and x.dtype in (torch.bfloat16, torch.float16) and w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0):
@@ -367,6 +393,8 @@ class LlamaDecodeEngine:
         m = self.cfg.llm
         rows, D = resid.shape
         plan = _plan_split_mm if self.plan_split else (lambda r, w, k3=False: None)
+        if self._w16:
+            return self._forward_split_w16(resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape, keep_rows, plan)
         mm = lambda a3, ws, k3=False: _split_mm(a3, ws[0], plan(a3.shape[0], ws[0], k3=k3))     # noqa: E731
         a3, inv_r = ops.rmsnorm_split(resid, None, self.layers[0]["ln1"], m.rms_eps)
         q = torch.empty((rows, D), device=self.device, dtype=torch.float32)
@@ -395,6 +423,57 @@ class LlamaDecodeEngine:
                 ops.rmsnorm(resid, d.dense(), self.final_norm, m.rms_eps, n)
             else:
                 a3, inv_r = ops.rmsnorm_split(resid, d, self.layers[l + 1]["ln1"], m.rms_eps)
+        return n
+
+    def _forward_split_w16(self, resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape, keep_rows, plan):
+        """`_forward_split` when the LLM's matrices are fp16 values (`self._w16`): a weight has no low part, so a product is
+        ONE library GEMM of the two-plane operand [xh; xl] (2 x rows rows) against the fp16 weight over K - two thirds of
+        the three-segment form's flops, and no split copy of the weights at all; its [2, rows, N] result is summed by the
+        reader (`slices`), the only scale left is the row's."""
+        m = self.cfg.llm
+        rows, D = resid.shape
+        wh = self._w16
+        ones = self._ones
+
+        def one(n):
+            t = ones.get(n)
+            if t is None:
+                t = ones[n] = torch.ones(n, device=self.device, dtype=torch.float32)
+            return t
+
+        def mm(a2, w, k3=False):                               # a2 [2, r, K] -> raw product slices [S, r, N]
+            r = a2.shape[1]
+            w16 = wh[w.data_ptr()]
+            y = _split_mm(a2.view(2 * r, a2.shape[2]), w16, plan(2 * r, w16, k3=k3))
+            return y.view(-1, r, w16.shape[0])
+
+        a2, inv_r = ops.rmsnorm_split(resid, None, self.layers[0]["ln1"], m.rms_eps, planes=2)
+        q = torch.empty((rows, D), device=self.device, dtype=torch.float32)
+        att = torch.empty_like(q)
+        n = None
+        for l, L in enumerate(self.layers):
+            qkv = ops.Scaled(mm(a2, L["wqkv"]), inv_r, one(3 * D))
+            ops.rope_kvwrite_scaled(qkv, tok_pair, tok_pos, self.rope, m.heads, m.head_dim, ctx_len, q, kc[l], vc[l])
+            ops.prefill_attn(q, kc[l], vc[l], tok_pos, prefill_shape[0], prefill_shape[1], m.heads, m.head_dim, ctx_len, att)
+            last = l == len(self.layers) - 1
+            if keep_rows is not None and last:
+                k = keep_rows.numel()
+                att_k = torch.empty((k, D), device=self.device, dtype=torch.float32)
+                resid_k = torch.empty((k, D), device=self.device, dtype=torch.float32)
+                ops.gather_rows(att, keep_rows, att_k)
+                ops.gather_rows(resid, keep_rows, resid_k)
+                att, resid = att_k, resid_k
+            a2o, inv_o = ops.split_f16x2(att)
+            o = ops.Scaled(mm(a2o, L["wo"], k3=True), inv_o, one(D))
+            a2, inv_r = ops.rmsnorm_split(resid, o, L["ln2"], m.rms_eps, planes=2)
+            gu = ops.Scaled(mm(a2, L["wgu"]), inv_r, one(2 * m.inter))
+            a2a, inv_a = ops.silu_mul_split(gu, m.inter, planes=2)
+            d = ops.Scaled(mm(a2a, L["wdown"], k3=True), inv_a, one(D))
+            if last:
+                n = torch.empty_like(resid)
+                ops.rmsnorm(resid, d.dense(), self.final_norm, m.rms_eps, n)
+            else:
+                a2, inv_r = ops.rmsnorm_split(resid, d, self.layers[l + 1]["ln1"], m.rms_eps, planes=2)
         return n
 
     def _can_persist(self, rows, slot):
@@ -428,6 +507,38 @@ class LlamaDecodeEngine:
         n = torch.empty_like(x)
         ops.rmsnorm(x, delta, self.final_norm, m.rms_eps, n)
         return self.logits(n)
+
+    def _can_w16(self, rows):
+        """fp32s decode steps over fp16-valued weights: every projection as psg_split_gemm_w16, the row kernels writing
+        its two-plane operand directly (`_decode_step_w16`)."""
+        m = self.cfg.llm
+        return (bool(self._w16) and self.prefill_split and self.use_skinny and self.fuse_split and rows <= 32
+                and self.dtype == torch.float32 and m.hidden % 64 == 0 and m.inter % 64 == 0 and m.inter <= 16384
+                and m.hidden <= 8192 and m.vocab % 16 == 0)
+
+    def _decode_step_w16(self, st):
+        """One decode step of the fp32s mode when the LLM's matrices are fp16 values (`self._w16`): 2 bytes per weight
+        from HBM, two fp16 products per projection (high and low part of the fp32 rows) on the 16-bit matrix cores."""
+        m = self.cfg.llm
+        x, wh = st["x"], self._w16
+        K, D = x.shape
+        att = torch.empty((K, D), device=self.device, dtype=torch.float32)
+        a2, inv = ops.rmsnorm_split2(x, None, self.layers[0]["ln1"], m.rms_eps)
+        for l, L in enumerate(self.layers):
+            qkv = ops.split_gemm_w16(a2, inv, wh[L["wqkv"].data_ptr()])
+            ops.decode_attn(qkv, st["dec_pair"], st["dec_pos"], self.rope, m.heads, m.head_dim, st["ctx_len"], st["kc"][l],
+                            st["vc"][l], att)
+            a2o, invo = ops.split_f16x2(att)                   # a row's maximum spans all heads: a launch of its own
+            o = ops.split_gemm_w16(a2o, invo, wh[L["wo"].data_ptr()])
+            a2, inv = ops.rmsnorm_split2(x, o, L["ln2"], m.rms_eps)
+            gu = ops.split_gemm_w16(a2, inv, wh[L["wgu"].data_ptr()])
+            act = torch.empty((K, m.inter), device=self.device, dtype=torch.float32)
+            ops.silu_mul(gu, act)                              # (one workgroup per row for the row maximum was measured at
+            a2a, inva = ops.split_f16x2(act)                   # 24 us against 5.2 + 4.9 for these two launches)
+            d = ops.split_gemm_w16(a2a, inva, wh[L["wdown"].data_ptr()])
+            nxt = self.layers[l + 1]["ln1"] if l + 1 < len(self.layers) else self.final_norm
+            a2, inv = ops.rmsnorm_split2(x, d, nxt, m.rms_eps)
+        return ops.split_gemm_w16(a2, inv, wh[self.lm_head.data_ptr()])
 
     def _can_fuse(self, rows):
         m = self.cfg.llm
@@ -660,7 +771,8 @@ class LlamaDecodeEngine:
         """Decode steps lo .. hi-1 (step s writes tokens[:, s])."""
         m = self.cfg.llm
         persist = hi > lo and self._can_persist(st["x"].shape[0], st.get("slot", 0))
-        fused = not persist and self._can_fuse(st["x"].shape[0]) and hi > lo
+        w16 = not persist and self._can_w16(st["x"].shape[0])
+        fused = not persist and not w16 and self._can_fuse(st["x"].shape[0]) and hi > lo
         if persist:                                            # one counter block per layer launch, zeroed once per call
             per_step = ops.decode_layer_counters(self.device) * len(self.layers)
             sync = torch.zeros((hi - lo) * per_step, device=self.device, dtype=torch.int32)
@@ -670,6 +782,8 @@ class LlamaDecodeEngine:
         for step in range(lo, hi):
             if persist:
                 logits = self._decode_step_persistent(st, sync[(step - lo) * per_step:(step - lo + 1) * per_step])
+            elif w16:
+                logits = self._decode_step_w16(st)
             elif fused:
                 logits = self._decode_step_fused(st, sync[(step - lo) * per_step:(step - lo + 1) * per_step])
             else:

@@ -530,6 +530,68 @@ def skinny_gemm(x, w, splits=None) -> Partials:
     return Partials(part)
 
 
+def skinny_gemm_w16(x, w16, splits=None) -> Partials:
+    """`skinny_gemm` of fp32 rows against weights STORED as fp16 (values that are fp16 numbers: a frozen fp16 checkpoint
+    upcast on load): bit-identical to skinny_gemm(x, w16.float()) at half the weight bytes (psg_skinny_gemm_w16)."""
+    import ctypes
+    lib, ctx, st = _env(x)
+    M, K = x.shape
+    N = w16.shape[0]
+    assert w16.shape[1] == K
+    if x.dtype != torch.float32 or w16.dtype != torch.float16:
+        raise PsgHipError(f"skinny_gemm_w16: x must be fp32 and w fp16, got {x.dtype} / {w16.dtype}")
+    if splits is None:
+        s = ctypes.c_int(0)
+        check(lib.psg_skinny_gemm_plan(ctx, M, N, K, _DT[torch.float32], ctypes.byref(s)), "psg_skinny_gemm_plan")
+        splits = s.value
+    part = torch.empty((splits, M, N), device=x.device, dtype=torch.float32)
+    check(lib.psg_skinny_gemm_w16(ctx, _p(x, name="x"), _p(w16, name="w"), _p(part), M, N, K, splits, st),
+          "psg_skinny_gemm_w16")
+    return Partials(part)
+
+
+def split_f16x2(x):
+    """fp32 rows -> (fp16 planes [2, rows, K]: high and low parts, inv_scale fp32 [rows]) - the operand of `split_gemm_w16`."""
+    lib, ctx, st = _env(x)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    rows, K = x.shape
+    out = torch.empty((2, rows, K), device=x.device, dtype=torch.float16)
+    inv = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(lib.psg_split_f16x2(ctx, x.data_ptr(), rows, K, x.stride(0), _p(out), _p(inv), st), "psg_split_f16x2")
+    return out, inv
+
+
+def rmsnorm_split2(resid, delta, w, eps):
+    """resid (fp32) += delta (Partials or None); RMSNorm(resid) * w as the two fp16 planes of `split_f16x2`:
+    (fp16 [2, rows, hidden], inv_scale) - psg_rmsnorm + psg_split_f16x2 in one launch, bit-identical."""
+    lib, ctx, st = _env(resid)
+    rows, hidden = resid.shape
+    assert resid.dtype == torch.float32 and (delta is None or isinstance(delta, Partials))
+    out = torch.empty((2, rows, hidden), device=resid.device, dtype=torch.float16)
+    inv = torch.empty(rows, device=resid.device, dtype=torch.float32)
+    dp, ds = (None, 0) if delta is None else (_p(delta.t, torch.float32), delta.splits)
+    check(lib.psg_rmsnorm_split2(ctx, _p(resid), dp, ds, _p(w, torch.float32), float(eps), rows, hidden, _p(out), _p(inv), st),
+          "psg_rmsnorm_split2")
+    return out, inv
+
+
+def split_gemm_w16(x2, inv_scale, w16, mode=0) -> Partials:
+    """Decode-step projection of fp32 rows against a weight that is an fp16 value (frozen fp16 checkpoint): two fp16
+    products (high and low part of x) on the 16-bit matrix cores, fp32 slices [S, M, N] like `skinny_gemm`'s;
+    2^-22 relative against the fp32 product (psg_split_gemm_w16).  x2, inv_scale from `split_f16x2`."""
+    import ctypes
+    lib, ctx, st = _env(x2)
+    _, M, K = x2.shape
+    N = w16.shape[0]
+    assert x2.shape[0] == 2 and w16.shape[1] == K and x2.dtype == torch.float16 and w16.dtype == torch.float16
+    s = ctypes.c_int(0)
+    check(lib.psg_split_gemm_w16_plan(ctx, M, N, K, int(mode), ctypes.byref(s)), "psg_split_gemm_w16_plan")
+    part = torch.empty((s.value, M, N), device=x2.device, dtype=torch.float32)
+    check(lib.psg_split_gemm_w16(ctx, _p(x2), _p(inv_scale, torch.float32), _p(w16), _p(part), M, N, K, s.value, int(mode), st),
+          "psg_split_gemm_w16")
+    return Partials(part)
+
+
 def batch_gemm(x, w, slab_rows=0, mode=0) -> Partials:
     """Decode-step projection for 33..160 rows (several images' pairs decoded together): fp32 split-K slices of x @ w.T
     like `skinny_gemm`'s, the weight streamed from HBM once (psg_batch_gemm; bf16 / fp16).
@@ -745,38 +807,42 @@ class Scaled:
         return scale_rows_cols(y, self.row_scale, self.col_scale)
 
 
-def rmsnorm_split(resid, delta, w, eps):
-    """resid += delta (a `Scaled` or None); RMSNorm(resid) * w as split-fp16 segments: (fp16 [rows, 3 hidden], inv_scale)."""
+def rmsnorm_split(resid, delta, w, eps, planes=3):
+    """resid += delta (a `Scaled` or None); RMSNorm(resid) * w as split-fp16 segments: (fp16 [rows, 3 hidden], inv_scale);
+    planes=2: as two planes (fp16 [2, rows, hidden]: high, low) for a weight that is an fp16 value."""
     lib, ctx, st = _env(resid)
     rows, hidden = resid.shape
-    out = torch.empty((rows, 3 * hidden), device=resid.device, dtype=torch.float16)
+    out = torch.empty((rows, 3 * hidden) if planes == 3 else (2, rows, hidden), device=resid.device, dtype=torch.float16)
     inv = torch.empty(rows, device=resid.device, dtype=torch.float32)
     dp, rp, cp = (None, None, None) if delta is None else (_p(delta.y), _p(delta.row_scale, torch.float32),
                                                            _p(delta.col_scale, torch.float32))
     nsl = 1 if delta is None or delta.y.dim() == 2 else delta.y.shape[0]
     assert delta is None or delta.y.shape[-2:] == (rows, hidden)
     check(lib.psg_rmsnorm_split(ctx, _p(resid, torch.float32, "resid"), dp, rp, cp, nsl, _p(w, torch.float32), float(eps),
-                                rows, hidden, _p(out), _p(inv), st), "psg_rmsnorm_split")
+                                rows, hidden, _p(out), _p(inv), int(planes), st), "psg_rmsnorm_split")
     return out, inv
 
 
 def rope_kvwrite_scaled(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, q_out, k_cache, v_cache):
     lib, ctx, st = _env(q_out)
     rows = q_out.shape[0]
-    assert isinstance(qkv, Scaled) and qkv.y.shape == (rows, 3 * heads * head_dim)
+    assert isinstance(qkv, Scaled) and qkv.y.shape[-2:] == (rows, 3 * heads * head_dim)
+    nsl = 1 if qkv.y.dim() == 2 else qkv.y.shape[0]
     check(lib.psg_rope_kvwrite_scaled(ctx, _p(qkv.y), _p(qkv.row_scale, torch.float32), _p(qkv.col_scale, torch.float32),
                                       _p(tok_pair, torch.int32), _p(tok_pos, torch.int32), _p(rope[0], torch.float32),
-                                      _p(rope[1], torch.float32), rows, heads, head_dim, ctx_len, _p(q_out, torch.float32),
+                                      _p(rope[1], torch.float32), nsl, rows, heads, head_dim, ctx_len, _p(q_out, torch.float32),
                                       _p(k_cache, torch.float32), _p(v_cache, torch.float32), st), "psg_rope_kvwrite_scaled")
 
 
-def silu_mul_split(gate_up, inter):
-    """silu(gate) * up of a `Scaled` gate|up result as split-fp16 segments: (fp16 [rows, 3 inter], inv_scale)."""
+def silu_mul_split(gate_up, inter, planes=3):
+    """silu(gate) * up of a `Scaled` gate|up result as split-fp16 segments: (fp16 [rows, 3 inter], inv_scale);
+    planes=2: as two planes (fp16 [2, rows, inter])."""
     lib, ctx, st = _env(gate_up.y)
-    rows = gate_up.y.shape[0]
-    assert gate_up.y.shape[1] == 2 * inter
-    out = torch.empty((rows, 3 * inter), device=gate_up.y.device, dtype=torch.float16)
+    rows = gate_up.y.shape[-2]
+    nsl = 1 if gate_up.y.dim() == 2 else gate_up.y.shape[0]
+    assert gate_up.y.shape[-1] == 2 * inter
+    out = torch.empty((rows, 3 * inter) if planes == 3 else (2, rows, inter), device=gate_up.y.device, dtype=torch.float16)
     inv = torch.empty(rows, device=gate_up.y.device, dtype=torch.float32)
     check(lib.psg_silu_mul_split(ctx, _p(gate_up.y), _p(gate_up.row_scale, torch.float32), _p(gate_up.col_scale, torch.float32),
-                                 rows, inter, _p(out), _p(inv), st), "psg_silu_mul_split")
+                                 nsl, rows, inter, _p(out), _p(inv), int(planes), st), "psg_silu_mul_split")
     return out, inv

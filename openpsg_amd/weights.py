@@ -124,8 +124,11 @@ def make_weights_numpy(cfg: PSGConfig, seed: int = 0, with_llm: bool = True) -> 
 
 
 def make_weights_device(cfg: PSGConfig, seed: int, device, head_dtype=torch.float32,
-                        llm_dtype=torch.bfloat16, with_llm: bool = True) -> dict:
-    """Random-init weights generated directly in HBM (benchmark use: 7B-shaped LLM)."""
+                        llm_dtype=torch.bfloat16, with_llm: bool = True, llm_values=None) -> dict:
+    """Random-init weights generated directly in HBM (benchmark use: 7B-shaped LLM).
+    llm_values=torch.float16 with an fp32 `llm_dtype`: the LLM's matrices hold fp16 VALUES in fp32 tensors - what
+    `from_pretrained` makes of the fp16 Llama-2-7b-hf checkpoint the reference loads and freezes (V4:99-100,
+    configs/psg/baseline_v4_ov.py:61-65)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     out = {}
@@ -142,6 +145,11 @@ def make_weights_device(cfg: PSGConfig, seed: int, device, head_dtype=torch.floa
             step = 1 << 26
             for o in range(0, flat.numel(), step):
                 n = min(step, flat.numel() - o)
-                flat[o:o + n] = torch.empty(n, device=device).normal_(mean, std, generator=g).to(dt)
+                chunk = torch.empty(n, device=device).normal_(mean, std, generator=g)
+                if llm_values is not None and key.startswith("language_model."):
+                    chunk = chunk.to(llm_values).float()
+                flat[o:o + n] = chunk.to(dt)
+        if t.dtype == torch.float32 and len(shapes[key]) >= 2 and llm_values is not None and key.startswith("language_model."):
+            t = t.to(llm_values).float()
         out[key] = t.to(dt) if len(shapes[key]) >= 2 else t
     return out

@@ -1,0 +1,116 @@
+"""Weights stored as fp16 under fp32 arithmetic (`-m gpu`): the reference's LLM is the frozen Llama-2-7b-hf checkpoint -
+fp16 on disk, upcast by `from_pretrained` (V4:99-100; configs/psg/baseline_v4_ov.py:61-65 freezes
+`relation_head.language_model`) - so every LLM weight is an fp16 value.  psg_skinny_gemm_w16 streams such a weight as
+2 bytes and widens it in the register: bit-identical to psg_skinny_gemm(PSG_F32) on the widened tensor."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("M", [1, 4, 12, 13, 16, 20, 24, 29, 32])
+def test_w16_stream_equals_the_fp32_weight_stream_bit_for_bit(M):
+    from openpsg_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(50 + M)
+    for N, K in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008), (32000, 4096), (272, 320), (16, 32), (1040, 96)):
+        x = torch.randn(M, K, generator=g, device=DEV)
+        w16 = (torch.randn(N, K, generator=g, device=DEV) / K ** 0.5).half()
+        a = ops.skinny_gemm(x, w16.float().contiguous())
+        b = ops.skinny_gemm_w16(x, w16)
+        assert a.t.shape == b.t.shape
+        assert torch.equal(a.t, b.t), f"M={M} N={N} K={K}: max diff {(a.t - b.t).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M", [1, 5, 16, 20, 32])
+def test_split_gemm_w16_is_fp32_grade(M, mode):
+    """psg_split_f16x2 + psg_split_gemm_w16 (fp32 rows = high + low fp16 part, weight an fp16 value, two products on the
+    16-bit matrix cores) against the exact product: the error class of an fp32 GEMM (<= 2e-6 of |x|.|w|), rows of very
+    different magnitudes included (per-row power-of-two scale); rows do not depend on their neighbours."""
+    from openpsg_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(90 + M)
+    for N, K in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008), (32000, 4096), (272, 320), (16, 64)):
+        x = torch.randn(M, K, generator=g, device=DEV) * torch.logspace(-6, 3, M, device=DEV)[:, None]
+        w16 = (torch.randn(N, K, generator=g, device=DEV) / K ** 0.5).half()
+        x2, inv = ops.split_f16x2(x)
+        assert torch.equal((x2[0].double() + x2[1].double()) * inv.double()[:, None], x.double()) or \
+            ((x2[0].double() + x2[1].double()) * inv.double()[:, None] - x.double()).abs().max() <= 2.0 ** -21 * x.abs().max(1)[0].max()
+        part = ops.split_gemm_w16(x2, inv, w16, mode)
+        assert part.t.shape[1:] == (M, N) and part.splits <= 16
+        got = part.t.sum(0).double()
+        ref = x.double() @ w16.double().t()
+        bound = (x.abs().double() @ w16.abs().double().t())
+        assert ((got - ref).abs() <= 2e-6 * bound + 1e-30).all(), \
+            f"M={M} N={N} K={K}: worst {((got - ref).abs() / bound.clamp_min(1e-30)).max().item():.3e}"
+        if M >= 5:
+            x_ = x.clone()
+            x_[2:] = torch.randn(M - 2, K, generator=g, device=DEV)
+            x2b, invb = ops.split_f16x2(x_)
+            assert torch.equal(ops.split_gemm_w16(x2b, invb, w16, mode).t[:, :2], part.t[:, :2])
+
+
+def _g6_head(dtype, w, cfg, g, flag):
+    from openpsg_amd import _lib
+    from openpsg_amd.head import RelationTransformerHeadV4
+    _lib.set_option(0, "llm_w16", flag)
+    try:
+        head = RelationTransformerHeadV4(dtype=dtype, device=DEV, qformer_vocab_size=cfg.qformer.vocab, llm_config=cfg.llm,
+                                         llm_feature_size=cfg.llm.hidden, tokenizers="word", max_object_num=cfg.max_object_num,
+                                         on_parse_error="skip", suppress_eos=bool(g["suppress_eos"]))
+        head.load_weights(w)
+    finally:
+        _lib.set_option(0, "llm_w16", 1)
+    return head
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp32s"])
+def test_engine_streams_fp16_valued_weights_as_fp16(dtype):
+    """G6 (Llama-2-7B width, 2 layers, 20 selected pairs) with the LLM's matrices rounded through fp16 - the values a frozen
+    fp16 checkpoint has after `from_pretrained` upcast it (V4:99-100).  The engine finds that every projection round-trips
+    and streams fp16 copies in the decode steps: exact mode bit-identical to the fp32 stream (tokens AND first-step
+    logits), fp32s mode token-identical with logits within 1e-4; weights that are NOT fp16 values keep the fp32 stream."""
+    import numpy as np
+    from tests import helpers as H
+    g, cfg, w, scene = H.load_case("G6_llm_7b_width_n6")
+    w16 = {k: (torch.as_tensor(v).half().float() if k.startswith("language_model.") and torch.as_tensor(v).dim() >= 2 else v)
+           for k, v in w.items()}
+    dev = torch.device(DEV)
+    ids = [int(i) for i in scene["object_id_list"]]
+    names = H.object_names(scene)
+    sel = torch.from_numpy(g["selected"].astype(np.int32)).to(dev)
+    outs = {}
+    for flag in (0, 1):
+        head = _g6_head(dtype, w16, cfg, g, flag)
+        assert bool(head.llm_engine._w16) == bool(flag)
+        rq = head.run_relation_query(scene["mask_features"].to(dev), scene["img_meta"], ids, names, scene["pan_results"].to(dev))
+        dec = head.decode_selected(rq, names, selected=sel)
+        dec2 = head.decode_selected(rq, names, selected=sel)                 # graph replay
+        assert np.array_equal(dec["tokens_host"], dec2["tokens_host"])
+        outs[flag] = (dec["tokens_host"].copy(), dec["first_logits"].float().cpu())
+        del head
+        torch.cuda.empty_cache()
+    assert np.array_equal(outs[0][0], outs[1][0]), "tokens differ between the fp32 and the fp16 weight stream"
+    if dtype == "fp32":
+        assert torch.equal(outs[0][1], outs[1][1])
+    else:
+        assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-4
+    head = _g6_head(dtype, w, cfg, g, 1)                                       # generic fp32 weights: nothing to narrow
+    assert not head.llm_engine._w16
+
+
+def test_two_plane_rmsnorm_equals_the_row_kernel_followed_by_the_split_bit_for_bit():
+    """psg_rmsnorm_split2 (decode steps: fp32 rows, fp32 split-K slices) against psg_rmsnorm + psg_split_f16x2."""
+    from openpsg_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for rows, D, I in ((20, 4096, 11008), (32, 4096, 11008), (3, 512, 1024), (7, 1024, 2816)):
+        w = 1.0 + 0.1 * torch.randn(D, generator=g, device=DEV)
+        for S in (0, 1, 4, 16):
+            resid = torch.randn(rows, D, generator=g, device=DEV) * 3
+            delta = ops.Partials(torch.randn(S, rows, D, generator=g, device=DEV).contiguous()) if S else None
+            ra, rb = resid.clone(), resid.clone()
+            n = torch.empty_like(ra)
+            ops.rmsnorm(ra, delta, w, 1e-5, n)
+            a2, ainv = ops.split_f16x2(n)
+            b2, binv = ops.rmsnorm_split2(rb, delta, w, 1e-5)
+            assert torch.equal(ra, rb) and torch.equal(a2, b2) and torch.equal(ainv, binv), (rows, D, S)

@@ -27,9 +27,10 @@ def timeit(fn, iters=30, warm=5, flush=None):
     return ts[len(ts) // 2], ts[0]
 
 
-def skinny(M, dtype=torch.bfloat16):
+def skinny(M, dtype=torch.bfloat16, w16=False):
+    """w16: fp32 rows against weights stored as fp16 (psg_skinny_gemm_w16)"""
     dev = torch.device("cuda:0")
-    esz = torch.empty(0, dtype=dtype).element_size()
+    esz = 2 if w16 else torch.empty(0, dtype=dtype).element_size()
     shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008),
               ("lm_head", 32000, 4096)]
     tot_b, tot_s, tot_l = 0, 0.0, 0.0
@@ -40,22 +41,30 @@ def skinny(M, dtype=torch.bfloat16):
     for name, N, K in shapes:
         x = torch.randn(M, K, device=dev).to(dtype)
         ncopy = max(2, int(800e6 / (N * K * esz)) + 1)     # rotate > MALL-size of weights: always cold
-        ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(dtype) for _ in range(ncopy)]
+        ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(torch.float16 if w16 else dtype) for _ in range(ncopy)]
         it = [0]
+        xs2 = ops.split_f16x2(x) if w16 == "split" else None
+        split_in_loop = os.environ.get("PSG_BENCH_SPLIT_IN_LOOP") == "1"
 
         REP = 16                                            # back-to-back launches per timing sample
 
         def run_s():
             for _ in range(REP):
                 it[0] += 1
-                ops.skinny_gemm(x, ws[it[0] % ncopy])
+                if w16 == "split":
+                    x2, inv = ops.split_f16x2(x) if split_in_loop else xs2
+                    ops.split_gemm_w16(x2, inv, ws[it[0] % ncopy])
+                elif w16:
+                    ops.skinny_gemm_w16(x, ws[it[0] % ncopy])
+                else:
+                    ops.skinny_gemm(x, ws[it[0] % ncopy])
 
         def run_l():
             for _ in range(REP):
                 it[0] += 1
                 torch.nn.functional.linear(x, ws[it[0] % ncopy])
         ts, _ = timeit(run_s, iters=12, warm=2)
-        tl = None if nolib else timeit(run_l, iters=12, warm=2)[0] / REP   # PSG_BENCH_NOLIB=1: no library column at all
+        tl = None if (nolib or w16) else timeit(run_l, iters=12, warm=2)[0] / REP   # PSG_BENCH_NOLIB=1: no library column at all
         ts = ts / REP
         gb = N * K * esz / 1e9
         lib = "" if tl is None else f" | library (F.linear) {tl:8.1f} us = {gb / tl * 1e6:7.0f} GB/s"
@@ -65,7 +74,7 @@ def skinny(M, dtype=torch.bfloat16):
         tot_b += gb * mult
         tot_s += ts * mult
         tot_l += (tl or 0.0) * mult
-    lib = "" if nolib else f", library {tot_l / 1e3:.2f} ms ({tot_b / tot_l * 1e6:.0f} GB/s)"
+    lib = "" if (nolib or w16) else f", library {tot_l / 1e3:.2f} ms ({tot_b / tot_l * 1e6:.0f} GB/s)"
     print(f"  one decode step (32 layers + lm_head): {tot_b:.2f} GB, skinny {tot_s / 1e3:.2f} ms "
           f"({tot_b / tot_s * 1e6:.0f} GB/s){lib}")
 
@@ -134,6 +143,12 @@ if __name__ == "__main__":
     for wname in a.what:
         if wname.startswith("skinny32_m"):
             skinny(int(wname[10:]), torch.float32)
+    for wname in a.what:
+        if wname.startswith("skinnysplit"):   # fp32 rows as two fp16 planes x fp16-valued weights (psg_split_gemm_w16)
+            skinny(int(wname[13:]) if wname.startswith("skinnysplit_m") else 20, torch.float32, w16="split")
+    for wname in a.what:
+        if wname.startswith("skinnyw16"):     # skinnyw16 or skinnyw16_m<M>
+            skinny(int(wname[11:]) if wname.startswith("skinnyw16_m") else 20, torch.float32, w16=True)
     if "mall" in a.what:
         mall()
     if "xattn" in a.what:
