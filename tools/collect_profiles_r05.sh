@@ -11,7 +11,7 @@ run() { local d=$1; shift; rm -rf "$d"; rocprofv3 "$@" > "$d.log" 2>&1; }
 # 1. the default command, as the driver runs it
 python bench.py --steps 20 --warmup 5 2> "$OUT/bench_default.err" | grep '^{"metric"' | tail -1 > "$OUT/${TAG}_bench_default_line.json"
 # 2. per-kernel durations of the headline path (kernel trace + stats; no counters in this pass)
-run /tmp/p_full --kernel-trace --stats -d /tmp/p_full -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-mixed --no-exact
+run /tmp/p_full --kernel-trace --stats -d /tmp/p_full -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-mixed --no-exact --no-frozen16
 python tools/prof_summary.py "$(db /tmp/p_full)" "$OUT/${TAG}_bench_full_kernel_stats.csv" > /dev/null
 grep '^{"metric"' /tmp/p_full.log | tail -1 > "$OUT/${TAG}_bench_full_line.json"
 # 3. dominant kernel (fp32 decode GEMM): HBM traffic, two PMC passes

@@ -10,6 +10,6 @@ export TMPDIR=/tmp
 db() { ls "$1"/*/*_results.db 2>/dev/null | head -1; }
 for n in 2 10; do
   rm -rf /tmp/pi_$n
-  rocprofv3 --kernel-trace -d /tmp/pi_$n -- python bench.py --steps $n --warmup 1 --no-cpu-baseline --no-parity --no-batched --no-mixed --no-exact "$@" > /tmp/pi_$n.log 2>&1
+  rocprofv3 --kernel-trace -d /tmp/pi_$n -- python bench.py --steps $n --warmup 1 --no-cpu-baseline --no-parity --no-batched --no-mixed --no-exact --no-frozen16 "$@" > /tmp/pi_$n.log 2>&1
 done
 python tools/per_image_diff.py "$(db /tmp/pi_2)" "$(db /tmp/pi_10)" 8 "$OUT" > /dev/null
