@@ -53,7 +53,7 @@ def skinny(M, dtype=torch.bfloat16, w16=False):
                 it[0] += 1
                 if w16 == "split":
                     x2, inv = ops.split_f16x2(x) if split_in_loop else xs2
-                    ops.split_gemm_w16(x2, inv, ws[it[0] % ncopy])
+                    ops.split_gemm_w16(x2, inv, ws[it[0] % ncopy], int(os.environ.get("PSG_BENCH_PAIR_MODE", "0")))
                 elif w16:
                     ops.skinny_gemm_w16(x, ws[it[0] % ncopy])
                 else:
