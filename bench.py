@@ -482,6 +482,12 @@ DTYPE_LABEL = {"fp32s": "fp32", "fp32": "fp32", "mixed": "fp16", "fp16": "fp16",
 MATRIX_PEAK = {"fp32s": (2.5e15, 3), "fp32": (157.3e12, 1), "mixed": (2.5e15, 1), "fp16": (2.5e15, 1), "bf16": (2.5e15, 1)}
 
 
+def pmc_traffic(pmc_file):
+    """HBM bytes per launch from the committed PMC summary of a kernel (profiles/README.md: not re-measured in the run)."""
+    pmc = os.path.join(REPO, "profiles", pmc_file)
+    return json.load(open(pmc)).get("hbm_bytes_per_launch") if os.path.exists(pmc) else None
+
+
 def decode_roofline(head, N, pmc_file, kernel):
     bpl, spl, n = measure_decode_gemm(head, min(20, N * N))
     ach = bpl / spl / 1e9
@@ -866,7 +872,8 @@ def main():
                         t_rq = base.get("relation_query", 0.0) / 1e3
                         fz["roofline"] = {"bound": "hbm", "kernel": "batch_gemm_kernel<EF16, 2, 1, 1, PAIR> (psg_split_gemm_w16)",
                                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(bpl),
+                                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("pmc_split_gemm_w16.json"),
+                                          "bytes_per_launch": int(bpl),
                                           "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": nl,
                                           "bytes_per_decode_step": int(bpl * nl),
                                           "image": {"floor_ms": round((t_dec + t_pp + t_rq) * 1e3, 2),

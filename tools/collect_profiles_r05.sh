@@ -18,6 +18,13 @@ grep '^{"metric"' /tmp/p_full.log | tail -1 > "$OUT/${TAG}_bench_full_line.json"
 run /tmp/p_fetch32 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch32 -- env PSG_BENCH_NOLIB=1 python tools/bench_kernels.py skinny32
 run /tmp/p_write32 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_write32 -- env PSG_BENCH_NOLIB=1 python tools/bench_kernels.py skinny32
 python tools/pmc_summary.py "$(db /tmp/p_fetch32)" "$(db /tmp/p_write32)" "$OUT/pmc_skinny_gemm_f32.json" 4 > /dev/null
+# 3b. the same for the 2-byte stream of fp16-valued weights (psg_split_gemm_w16) + kernel stats of that configuration
+run /tmp/p_fetchw --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetchw -- env PSG_BENCH_NOLIB=1 python tools/bench_kernels.py skinnysplit
+run /tmp/p_writew --pmc WRITE_SIZE --kernel-trace -d /tmp/p_writew -- env PSG_BENCH_NOLIB=1 python tools/bench_kernels.py skinnysplit
+python tools/pmc_summary.py "$(db /tmp/p_fetchw)" "$(db /tmp/p_writew)" "$OUT/pmc_split_gemm_w16.json" 2 batch_gemm > /dev/null
+run /tmp/p_fullw --kernel-trace --stats -d /tmp/p_fullw -- python bench.py --steps 5 --warmup 2 --llm-values fp16 --no-cpu-baseline --no-parity --no-mixed --no-exact --no-frozen16
+python tools/prof_summary.py "$(db /tmp/p_fullw)" "$OUT/${TAG}_bench_w16_kernel_stats.csv" > /dev/null
+grep '^{"metric"' /tmp/p_fullw.log | tail -1 > "$OUT/${TAG}_bench_w16_line.json"
 # 4. BASELINE C2 (bf16 relation query) per step, and the 16-bit cross-attention counters at C2
 bash tools/per_image_profile.sh "$OUT/${TAG}_per_step_rq_kernels.csv" --workload rq
 f="$OUT/${TAG}_xattn_pmc_n50.txt"

@@ -14,13 +14,16 @@ SHAPES = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("d
           ("lm_head", 32000, 4096)]
 
 
+PREFIX = ["skinny_gemm"]                                   # kernel-name prefix of the runs (argv[5] overrides)
+
+
 def runs(db, counter):
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select dispatch_id, name, counter_value from pmc_events where counter_name = ? "
                             "order by dispatch_id", (counter,)))
     out, cur_run = [], []
     for _, name, val in rows:
-        if name.startswith("void skinny_gemm") or name.startswith("skinny_gemm"):
+        if name.startswith("void " + PREFIX[0]) or name.startswith(PREFIX[0]):
             cur_run.append(val)
         elif cur_run:
             out.append(cur_run)
@@ -46,9 +49,11 @@ def main(fetch_db, write_db, out=None, esz=2):
         mult = 1 if name == "lm_head" else 32
         tot_a += alg * mult
         tot_h += hbm * mult
-    res = dict(kernel="skinny_gemm_dma_kernel<8, 1, 3, 2>" if esz == 2 else "skinny_gemm_f32_kernel (psg_gemm_f32.hip)",
+    res = dict(kernel=("batch_gemm_kernel<EF16, 2, 1, 1, PAIR> (psg_split_gemm_w16, psg_batch_gemm.hip; bench_kernels.py skinnysplit)"
+                       if PREFIX[0] != "skinny_gemm" else
+                       "skinny_gemm_dma_kernel<8, 1, 3, 2>" if esz == 2 else "skinny_gemm_f32_kernel (psg_gemm_f32.hip)"),
                method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/bench_kernels.py "
-                      + ("skinny" if esz == 2 else "skinny32") + " (M=20); hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction per "
+                      + ("skinnysplit" if PREFIX[0] != "skinny_gemm" else "skinny" if esz == 2 else "skinny32") + " (M=20); hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction per "
                       "MI355X_MICROARCH.md); summarised by tools/pmc_summary.py",
                per_shape=per, launches_per_decode_step=129, hbm_bytes_per_launch=int(tot_h / 129),
                algorithmic_bytes_per_launch=int(tot_a / 129), ratio=round(tot_h / tot_a, 3))
@@ -59,4 +64,6 @@ def main(fetch_db, write_db, out=None, esz=2):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 5:
+        PREFIX[0] = sys.argv[5]
     print(main(*sys.argv[1:5]))
