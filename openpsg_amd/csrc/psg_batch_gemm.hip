@@ -32,7 +32,7 @@
 #define BG_GRID_MAX 1024
 // ring depth.  Deeper rings where the LDS would hold them (4-6 units for the 128-row slabs / <= 96 rows of x) were measured
 // SLOWER (down projection at 160 rows: 35.0 -> 38.1 us, q|k|v at 40 rows: 26.3 -> 30.1): three units everywhere
-constexpr int bg_nst(int stage_bytes) { return stage_bytes > 0 ? 3 : 3; }
+constexpr int bg_nst(int) { return 3; }
 
 template <int N_>
 __device__ __forceinline__ void bg_vmwait() {

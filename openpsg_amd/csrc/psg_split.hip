@@ -120,12 +120,58 @@ __global__ void __launch_bounds__(256) split_f16x2_kernel(const float* __restric
   }
 }
 
+__device__ __forceinline__ float sp_row_scale(float mx, float* inv_scale_out);
+__device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, const float (&x)[4], float scale);
+// decode steps (<= 64 rows): 1024 threads per row, the row held in registers between the maximum and the stores - one
+// read of x and one barrier instead of two passes (the launch is latency, not bytes)
+template <int NCH>
+__global__ void __launch_bounds__(1024) split_f16x2_small_kernel(const float* __restrict__ x, int64_t row_stride, int K,
+                                                                 int64_t rows, uint16_t* __restrict__ out,
+                                                                 float* __restrict__ inv_scale) {
+  __shared__ float s_max[16];
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * row_stride;
+  const int tid = threadIdx.x;
+  float v[NCH][4];
+  float mx = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 1024 + tid) * 4;
+    if (col < K) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + col);
+      v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
+    }
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) s_max[tid >> 6] = mx;
+  __syncthreads();
+  mx = 0.f;
+  for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s_max[i]);
+  const float scale = sp_row_scale(mx, tid == 0 ? inv_scale + row : nullptr);     // the scale of split_f16x2_kernel
+  uint16_t* oh = out + row * (int64_t)K;
+  uint16_t* ol = out + (rows + row) * (int64_t)K;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 1024 + tid) * 4;
+    if (col < K) sp_store2(oh, ol, col, v[c], scale);
+  }
+}
+
 extern "C" int psg_split_f16x2(psg_ctx* ctx, const float* x, int64_t rows, int K, int64_t row_stride, void* out,
                                float* inv_scale, void* stream) {
   PSG_REQUIRE(ctx && x && out && inv_scale, PSG_ERR_INVALID, "psg_split_f16x2: NULL argument");
   PSG_REQUIRE(rows >= 0 && K > 0 && K % 4 == 0 && row_stride >= K && row_stride % 4 == 0 && rows < (1ll << 31),
               PSG_ERR_INVALID, "psg_split_f16x2: rows=%lld K=%d stride=%lld", (long long)rows, K, (long long)row_stride);
   if (rows == 0) return PSG_OK;
+  if (rows <= 64 && K <= 16384) {
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 4096) split_f16x2_small_kernel<1><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale);
+    else if (K <= 12288) split_f16x2_small_kernel<3><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale);
+    else split_f16x2_small_kernel<4><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale);
+    PSG_CHECK_LAUNCH("psg_split_f16x2");
+    return PSG_OK;
+  }
   split_f16x2_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale);
   PSG_CHECK_LAUNCH("psg_split_f16x2");
   return PSG_OK;
