@@ -448,7 +448,7 @@ def parity_block(a, dev, scene, oracle_part):
         h.load_weights(oracle_part["w16"])
         part16 = dict(oracle_part, decodes=oracle_part["decodes16"])
         modes["fp32s_frozen_fp16_checkpoint"] = dict(
-            weights_streamed_as_fp16=bool(h.llm_engine._w16),
+            weights_streamed_as_fp16=bool(h.llm_engine._w16_all),
             decode_7b_width_2_layers=decode_parity(h, part16, scene, names_, ocfg.llm.eos))
         del h
         torch.cuda.empty_cache()
@@ -854,7 +854,7 @@ def main():
                           "weights": "random-init fp32 LLM matrices holding fp16 VALUES (what from_pretrained makes of the "
                                      "frozen fp16 Llama-2-7b-hf checkpoint the reference loads: V4:99-100, "
                                      "configs/psg/baseline_v4_ov.py:61-65); every tensor verified to round-trip at load",
-                          "weights_streamed_as_fp16": bool(h.llm_engine._w16),
+                          "weights_streamed_as_fp16": bool(h.llm_engine._w16_all),
                           "precision": "as the headline (fp32-grade): decode projections = two fp16 products of the split "
                                        "fp32 rows against the fp16-valued weight (2^-22 relative), prompt pass = ONE library "
                                        "GEMM of the two-plane operand per projection",
@@ -862,7 +862,7 @@ def main():
                                                   "unit": "pairs/s", "steps": kf},
                           "two_in_flight": {"ms_per_image": round(el_p * 1e3, 3), "value": round(pairs_per_image / el_p, 1),
                                             "unit": "pairs/s", "steps": kf}}
-                    if not a.no_roofline and h.llm_engine._w16:
+                    if not a.no_roofline and h.llm_engine._w16_all:
                         bpl, spl, nl = measure_decode_gemm_w16(h, min(20, N * N))
                         ach = bpl / spl / 1e9
                         steps_ = h.cfg.max_new_tokens - 1

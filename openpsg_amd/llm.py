@@ -201,19 +201,16 @@ class LlamaDecodeEngine:
         # mode 'fp32s' as two fp16 products of the split activations (psg_split_gemm_w16, 2^-22).  Anything trained in
         # fp32 fails the check and keeps the fp32 stream.
         self._w16 = {}
+        self._w16_all = False
         self._ones = {}
         from . import _lib as _lib0
         if dtype == torch.float32 and _lib0.get_option(self.device.index or 0, "llm_w16"):
             tensors = [L[k] for L in self.layers for k in ("wqkv", "wo", "wgu", "wdown")] + [self.lm_head]
-            halves = []
-            for t in tensors:
+            for t in tensors:                                   # per tensor: a fine-tuned lm_head keeps its fp32 stream alone
                 h = t.half()
-                if not torch.equal(h.float(), t):
-                    halves = None
-                    break
-                halves.append(h)
-            if halves is not None:
-                self._w16 = {t.data_ptr(): h for t, h in zip(tensors, halves)}
+                if torch.equal(h.float(), t):
+                    self._w16[t.data_ptr()] = h
+            self._w16_all = len(self._w16) == len(tensors)      # the fused decode step / two-plane prompt pass need all of them
         if self.prefill_split:
             # [wh | wl | wh] fp16 + the per-row power of two that undoes the row scaling, per projection (3 x 2 bytes per
             # weight next to the fp32 copy the decode steps stream: 40 GB + 27 GB for Llama-2-7B, of 288 GB)
@@ -393,7 +390,7 @@ class LlamaDecodeEngine:
         m = self.cfg.llm
         rows, D = resid.shape
         plan = _plan_split_mm if self.plan_split else (lambda r, w, k3=False: None)
-        if self._w16:
+        if self._w16_all:
             return self._forward_split_w16(resid, tok_pair, tok_pos, kc, vc, ctx_len, prefill_shape, keep_rows, plan)
         mm = lambda a3, ws, k3=False: _split_mm(a3, ws[0], plan(a3.shape[0], ws[0], k3=k3))     # noqa: E731
         a3, inv_r = ops.rmsnorm_split(resid, None, self.layers[0]["ln1"], m.rms_eps)
@@ -512,7 +509,7 @@ class LlamaDecodeEngine:
         """fp32s decode steps over fp16-valued weights: every projection as psg_split_gemm_w16, the row kernels writing
         its two-plane operand directly (`_decode_step_w16`)."""
         m = self.cfg.llm
-        return (bool(self._w16) and self.prefill_split and self.use_skinny and self.fuse_split and rows <= 32
+        return (self._w16_all and self.prefill_split and self.use_skinny and self.fuse_split and rows <= 32
                 and self.dtype == torch.float32 and m.hidden % 64 == 0 and m.inter % 64 == 0 and m.inter <= 16384
                 and m.hidden <= 8192 and m.vocab % 16 == 0)
 

@@ -97,6 +97,21 @@ def test_engine_streams_fp16_valued_weights_as_fp16(dtype):
         assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-4
     head = _g6_head(dtype, w, cfg, g, 1)                                       # generic fp32 weights: nothing to narrow
     assert not head.llm_engine._w16
+    # one matrix that is NOT an fp16 value (a fine-tuned lm_head): it alone keeps the fp32 stream, tokens unchanged
+    del head
+    torch.cuda.empty_cache()
+    wm = dict(w16)
+    wm["language_model.lm_head.weight"] = torch.as_tensor(w["language_model.lm_head.weight"]).clone()
+    outs_m = {}
+    for flag in (0, 1):
+        head = _g6_head(dtype, wm, cfg, g, flag)
+        eng = head.llm_engine
+        assert (not eng._w16_all) and (len(eng._w16) == 4 * len(eng.layers) if flag else not eng._w16)
+        rq = head.run_relation_query(scene["mask_features"].to(dev), scene["img_meta"], ids, names, scene["pan_results"].to(dev))
+        outs_m[flag] = head.decode_selected(rq, names, selected=sel)["tokens_host"].copy()
+        del head
+        torch.cuda.empty_cache()
+    assert np.array_equal(outs_m[0], outs_m[1])
 
 
 def test_two_plane_rmsnorm_equals_the_row_kernel_followed_by_the_split_bit_for_bit():
