@@ -391,12 +391,13 @@ static int dg_launch(psg_ctx* ctx, const void* x, const void* w, const float* bi
 }
 
 // tile that fills the CUs best for [M, N]: cost = rounds x tile area, ties to the larger tile (less operand traffic)
-static int dg_auto_tile(const psg_ctx* ctx, int64_t M, int N) {
+static int dg_auto_tile(const psg_ctx* ctx, int64_t M, int N, bool o32 = false) {
   int best = PSG_TILE_256x256;
   double best_cost = 1e300;
   const int cus = ctx->num_cu / 8 * 8;
   for (const dg_geom& g : DG_GEOMS) {
     if (g.id == PSG_TILE_128x128) continue;                  // 4-wave tile: explicit requests only
+    if (o32 && g.id == PSG_TILE_256x192) continue;           // (not built with the fp32 output)
     const int BM = g.wm * g.ti * 32, BN = g.wn * g.tj * 32;
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int64_t rounds = (tiles + cus - 1) / cus;
@@ -443,16 +444,22 @@ extern "C" int psg_dense_gemm_tiled(psg_ctx* ctx, const void* x, const void* w, 
   PSG_REQUIRE(epilogue != PSG_EPI_SWIGLU || (out_dtype == dtype && !bias), PSG_ERR_UNSUPPORTED,
               "psg_dense_gemm: the SwiGLU epilogue takes no bias and writes the operand dtype");
   if (M == 0) return PSG_OK;
-  if (tile == PSG_TILE_AUTO) tile = dg_auto_tile(ctx, M, N);
+  if (tile == PSG_TILE_AUTO) tile = dg_auto_tile(ctx, M, N, out_dtype == PSG_F32 && dtype != PSG_F32);
   const int var = ctx->opt.dense_gemm_var;
   const bool o32 = out_dtype == PSG_F32 && dtype != PSG_F32;
-  PSG_REQUIRE(tile == PSG_TILE_256x256 || (!o32 && epilogue != PSG_EPI_GELU && var == 0), PSG_ERR_UNSUPPORTED,
-              "psg_dense_gemm: tile %d is built for the plain and SwiGLU epilogues with 16-bit output", tile);
+  PSG_REQUIRE(tile == PSG_TILE_256x256 || var == 0, PSG_ERR_UNSUPPORTED, "psg_dense_gemm: ablation builds exist for the 256 x 256 tile");
+  PSG_REQUIRE(tile == PSG_TILE_256x256 || epilogue != PSG_EPI_GELU || o32, PSG_ERR_UNSUPPORTED,
+              "psg_dense_gemm: tile %d with the GELU epilogue is built for the fp32 output (the split products)", tile);
+  PSG_REQUIRE(!(o32 && tile == PSG_TILE_256x192), PSG_ERR_UNSUPPORTED, "psg_dense_gemm: the 256 x 192 tile has no fp32 output");
 #define DGL(EPI, V, O, WM, WN, TI, TJ) \
   return dg_launch<E, EPI, V, O, WM, WN, TI, TJ>(ctx, x, w, bias, out, M, N, K, row_scale, col_scale, stream)
 #define DG_TILE(WM, WN, TI, TJ)                                                        \
   PSG_DISPATCH_E16(dtype, "psg_dense_gemm", if (epilogue == PSG_EPI_SWIGLU) DGL(PSG_EPI_SWIGLU, 0, 0, WM, WN, TI, TJ); \
                    else DGL(PSG_EPI_NONE, 0, 0, WM, WN, TI, TJ))
+  // fp32 output (split products of the fp32s mode): the small-M projections of the Q-Former fill the CUs with smaller tiles
+#define DG_TILE32(WM, WN, TI, TJ)                                                      \
+  PSG_DISPATCH_E16(dtype, "psg_dense_gemm", if (epilogue == PSG_EPI_GELU) DGL(PSG_EPI_GELU, 0, 1, WM, WN, TI, TJ); \
+                   else DGL(PSG_EPI_NONE, 0, 1, WM, WN, TI, TJ))
   switch (tile) {
     case PSG_TILE_256x256:
       if (o32) {
@@ -468,12 +475,22 @@ extern "C" int psg_dense_gemm_tiled(psg_ctx* ctx, const void* x, const void* w, 
       }
       break;
     case PSG_TILE_256x192: DG_TILE(4, 2, 2, 3); break;
-    case PSG_TILE_256x128: DG_TILE(4, 2, 2, 2); break;
-    case PSG_TILE_256x64: DG_TILE(8, 1, 1, 2); break;
-    case PSG_TILE_128x128: DG_TILE(2, 2, 2, 2); break;
+    case PSG_TILE_256x128:
+      if (o32) { PSG_REQUIRE(epilogue != PSG_EPI_SWIGLU, PSG_ERR_UNSUPPORTED, "psg_dense_gemm: SwiGLU with fp32 output"); DG_TILE32(4, 2, 2, 2); }
+      else DG_TILE(4, 2, 2, 2);
+      break;
+    case PSG_TILE_256x64:
+      if (o32) { PSG_REQUIRE(epilogue != PSG_EPI_SWIGLU, PSG_ERR_UNSUPPORTED, "psg_dense_gemm: SwiGLU with fp32 output"); DG_TILE32(8, 1, 1, 2); }
+      else DG_TILE(8, 1, 1, 2);
+      break;
+    case PSG_TILE_128x128:
+      if (o32) { PSG_REQUIRE(epilogue != PSG_EPI_SWIGLU, PSG_ERR_UNSUPPORTED, "psg_dense_gemm: SwiGLU with fp32 output"); DG_TILE32(2, 2, 2, 2); }
+      else DG_TILE(2, 2, 2, 2);
+      break;
     default: break;
   }
 #undef DG_TILE
+#undef DG_TILE32
 #undef DGL
   psg_set_error("psg_dense_gemm: unknown tile %d", tile);
   return PSG_ERR_INVALID;

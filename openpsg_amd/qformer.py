@@ -465,7 +465,10 @@ class RelationQueryEngine:
             if ws is None:
                 ws = self._split_w[key] = ops.split_f16x3(w, weights=True)
             a3, inv_r = ops.split_f16x3(x)
-            return ops.dense_gemm(a3, ws[0], b, gelu=gelu, out_dtype=torch.float32, row_scale=inv_r, col_scale=ws[1])
+            # (a row's result does not depend on the tile: below ~30 k rows the 256 x 256 tile leaves most CUs idle -
+            # 2500 x 768 is 30 tiles - and the geometry that fills them in the fewest rounds is taken instead)
+            return ops.dense_gemm(a3, ws[0], b, gelu=gelu, out_dtype=torch.float32, row_scale=inv_r, col_scale=ws[1],
+                                  tile="auto" if x.shape[0] < 16384 else "256x256")
         if self.own_gemm >= 2 and fits and x.dtype != torch.float32 and x.is_contiguous():
             if b is not None and b.dtype != torch.float32:
                 key = (b.data_ptr(), N)

@@ -70,3 +70,22 @@ def test_auto_tile_and_argument_checks():
     b = torch.zeros(256, device="cuda")
     with pytest.raises(Exception):
         ops.dense_gemm(x, w, bias=b, swiglu=True)
+
+
+@pytest.mark.parametrize("gelu", [False, True])
+def test_fp32_output_tiles_give_the_same_bits(gelu):
+    """The split products of the fp32s Q-Former (fp16 operands, fp32 output with row / column scales, bias, optional GELU):
+    the small-M projections run on smaller tiles - every geometry built with the fp32 output gives the bits of the
+    256 x 256 tile (HF-IB:519-596)."""
+    from openpsg_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    for M, N, K in ((2500, 768, 2304), (660, 3072, 2304), (33, 2304, 2304), (920, 768, 9216)):
+        x = torch.randn(M, K, generator=g, device="cuda:0").half()
+        w = (torch.randn(N, K, generator=g, device="cuda:0") / K ** 0.5).half()
+        b = torch.randn(N, generator=g, device="cuda:0")
+        rs = torch.exp2(torch.randint(-8, 4, (M,), generator=g, device="cuda:0").float())
+        cs = torch.exp2(torch.randint(-8, 4, (N,), generator=g, device="cuda:0").float())
+        base = ops.dense_gemm(x, w, b, gelu=gelu, out_dtype=torch.float32, row_scale=rs, col_scale=cs, tile="256x256")
+        for t in ("256x128", "256x64", "128x128", "auto"):
+            got = ops.dense_gemm(x, w, b, gelu=gelu, out_dtype=torch.float32, row_scale=rs, col_scale=cs, tile=t)
+            assert torch.equal(got, base), f"tile {t} differs at {M}x{N}x{K}"
