@@ -63,7 +63,8 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *   401  round 4 (psg_dense_gemm_tiled, psg_interleave_gate_up added)
  *   500  round 5 (psg_decode_layer*: one persistent launch per decoder layer of the decode step; psg_qformer_cross_attn /
  *        psg_qformer_self_attn(_shared) / psg_prefill_attn accept PSG_F32 on the matrix cores)
- *   501  round 5 (psg_batch_gemm*, psg_skinny_gemm_w16, psg_rmsnorm_split / psg_rope_kvwrite_scaled /
+ *   501  round 5 (psg_batch_gemm*, psg_qformer_cross_attn_indexed, psg_skinny_gemm_w16, psg_split_f16x2, psg_split_gemm_w16,
+ *        psg_rmsnorm_split2, psg_rmsnorm_split / psg_rope_kvwrite_scaled /
  *        psg_silu_mul_split added) */
 #define PSG_ABI_VERSION 501
 int psg_version(void);
@@ -185,6 +186,12 @@ int psg_qformer_cross_attn(psg_ctx*, const void* q, const void* k, const void* v
                            const uint64_t* bits, int words, const int32_t* pair_index, int N, int P,
                            int L, int nq, int heads, int empty_policy, int variant, void* out,
                            int dtype, void* stream);
+/* The same with the queries stored once per PROMPT (the prompt-deduplicated layer 0): q_u [U][33][hidden], q_index [P] =
+ * prompt of each pair, q_cls [P][hidden] = the cls row of every pair.  LDS-DMA kernel only: PSG_ERR_UNSUPPORTED otherwise
+ * (the caller expands q and uses psg_qformer_cross_attn). */
+int psg_qformer_cross_attn_indexed(psg_ctx*, const void* q_u, const int32_t* q_index, const void* q_cls, const void* k,
+                                   const void* v, const uint64_t* bits, int words, const int32_t* pair_index, int N, int P,
+                                   int L, int heads, int empty_policy, void* out, int dtype, void* stream);
 
 /* ---- K8: pair-existence scoring head, V4:206-209: logit = w . x[p*nq] + b, prob = sigmoid. */
 int psg_exist_head(psg_ctx*, const void* x, const float* w, const float* b, int P, int nq, int hidden,

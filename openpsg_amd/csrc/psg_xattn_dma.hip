@@ -68,7 +68,11 @@ __global__ void __launch_bounds__(XD_WAVES * 64, (XD_WAVES + 3) / 4)
 cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                       const uint64_t* __restrict__ bits, int words, const int32_t* __restrict__ pair_index, int N,
                       int64_t R, int L, int nq, int heads, int policy, uint16_t* __restrict__ out,
-                      long long* __restrict__ trace, int poll, int dyn) {
+                      long long* __restrict__ trace, int poll, int dyn, const int32_t* __restrict__ q_index,
+                      const uint16_t* __restrict__ q_cls) {
+  // q_index != nullptr (nq == 33 only): q holds the 33 projected query rows per PROMPT, pair p reads block q_index[p] - the
+  // pair tiles look the block up with one scalar load (the pair is wave-uniform), the cls tiles (row 0 of 32 different
+  // pairs) read q_cls [P][hidden], which the caller gathered (P rows instead of 33 P: psg_qformer_cross_attn_indexed)
   // trace != nullptr (psg_set_trace_buffer(PSG_TRACE_CROSS_ATTN), debugging only): 32 stamps per wave:
   // [0] start, [1] K/V staged, [2] = [1], [3 + i] end of unit i, [31] unit count
   long long* tr = trace ? trace + ((int64_t)blockIdx.x * XD_WAVES + (threadIdx.x >> 6)) * 32 : nullptr;
@@ -141,6 +145,14 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
       bool valid;
       tile_row(tile, 8 * i + r8, row, valid, pair);
       const uint16_t* src = q + row * hidden + h * 64 + ((pc ^ r8) * 8);
+      if (q_index) {
+        if (tile >= NCLS) {
+          const int qi = q_index[__builtin_amdgcn_readfirstlane((int)pair)];
+          src = q + ((int64_t)qi * 33 + 1 + 8 * i + r8) * hidden + h * 64 + ((pc ^ r8) * 8);
+        } else {
+          src = q_cls + pair * hidden + h * 64 + ((pc ^ r8) * 8);
+        }
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
     }
@@ -520,7 +532,7 @@ extern "C" int psg_cross_attn_dma_lds_bytes(int N, int words, int L) { return (i
 template <typename E>
 static int xd_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits, int words,
                      const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy, void* out,
-                     hipStream_t st) {
+                     hipStream_t st, const int32_t* q_index, const void* q_cls) {
   const int Lpad = (L + 31) & ~31;
   // 8 waves per CU, ten for launches with few tiles per wave when the K/V image leaves room for ten slot pairs
   // (L <= 256): with the tiles drawn from the LDS counter, BASELINE C2 (2579 tiles per head, 15 per wave) runs 6 % faster
@@ -553,7 +565,7 @@ static int xd_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, 
     }                                                                                                              \
     cross_attn_dma_kernel<E, NC_, W_><<<(unsigned)(G * heads), W_ * 64, lds, st>>>(                                   \
         (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads,   \
-        policy, (uint16_t*)out, trace, ctx->opt.xattn_poll, dyn);                                                  \
+        policy, (uint16_t*)out, trace, ctx->opt.xattn_poll, dyn, q_index, (const uint16_t*)q_cls);                 \
   } while (0)
   if (waves == 10) {
     if (NC == 1) XDLAUNCH(1, 10);
@@ -570,7 +582,8 @@ static int xd_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, 
 
 int psg_cross_attn_dma_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
                               int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy,
-                              void* out, int dtype, hipStream_t st) {
+                              void* out, int dtype, hipStream_t st, const int32_t* q_index, const void* q_cls) {
   PSG_DISPATCH_E16(dtype, "psg_qformer_cross_attn(dma)",
-                   return xd_launch<E>(ctx, q, k, v, bits, words, pair_index, N, P, L, nq, heads, policy, out, st));
+                   return xd_launch<E>(ctx, q, k, v, bits, words, pair_index, N, P, L, nq, heads, policy, out, st, q_index,
+                                       q_cls));
 }

@@ -463,7 +463,8 @@ cross_attn_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
 
 int psg_cross_attn_dma_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, const uint64_t* bits,
                               int words, const int32_t* pair_index, int N, int P, int L, int nq, int heads, int policy,
-                              void* out, int dtype, hipStream_t st);
+                              void* out, int dtype, hipStream_t st, const int32_t* q_index = nullptr,
+                              const void* q_cls = nullptr);
 extern "C" int psg_cross_attn_dma_lds_bytes(int N, int words, int L);
 
 int psg_cross_attn_simple_launch(const void* q, const void* k, const void* v, const uint64_t* bits, int words,
@@ -546,3 +547,26 @@ extern "C" int psg_qformer_cross_attn(psg_ctx* ctx, const void* q, const void* k
                                                                             heads, empty_policy, out, st));
 }
 
+
+// psg_qformer_cross_attn with the queries stored ONCE PER PROMPT (HF-IB:464-496 over the prompt-deduplicated layer 0):
+// q_u [U][33][hidden] = the projected query rows of the U distinct prompts, q_index [P] = the prompt of each pair, q_cls
+// [P][hidden] = row 0 of every pair (gathered by the caller: P rows).  Saves the [P x 33][hidden] expansion of q (127 MB
+// written and read again at BASELINE C2).  Only the LDS-DMA kernel takes the index: PSG_ERR_UNSUPPORTED when it cannot run
+// (fp32, L > 384, LDS image too large, option xattn_dma = 0) - the caller then expands q and calls psg_qformer_cross_attn.
+extern "C" int psg_qformer_cross_attn_indexed(psg_ctx* ctx, const void* q_u, const int32_t* q_index, const void* q_cls,
+                                              const void* k, const void* v, const uint64_t* bits, int words,
+                                              const int32_t* pair_index, int N, int P, int L, int heads, int empty_policy,
+                                              void* out, int dtype, void* stream) {
+  PSG_REQUIRE(ctx && q_u && q_index && q_cls && k && v && bits && pair_index && out, PSG_ERR_INVALID,
+              "psg_qformer_cross_attn_indexed: NULL argument");
+  PSG_REQUIRE(N > 0 && P >= 0 && L > 0 && heads > 0 && words * 64 >= L, PSG_ERR_INVALID,
+              "psg_qformer_cross_attn_indexed: N=%d P=%d L=%d heads=%d words=%d", N, P, L, heads, words);
+  PSG_REQUIRE(empty_policy == PSG_EMPTY_UNIFORM || empty_policy == PSG_EMPTY_UNMASKED, PSG_ERR_INVALID,
+              "psg_qformer_cross_attn_indexed: empty_policy=%d", empty_policy);
+  PSG_REQUIRE((dtype == PSG_BF16 || dtype == PSG_F16) && ctx->opt.xattn_dma && L <= 384 &&
+                  psg_cross_attn_dma_lds_bytes(N, words, L) <= 160 * 1024,
+              PSG_ERR_UNSUPPORTED, "psg_qformer_cross_attn_indexed: needs the LDS-DMA kernel (16-bit, L <= 384, image in LDS)");
+  if (P == 0) return PSG_OK;
+  return psg_cross_attn_dma_launch(ctx, q_u, k, v, bits, words, pair_index, N, P, L, 33, heads, empty_policy, out, dtype,
+                                   (hipStream_t)stream, q_index, q_cls);
+}

@@ -248,6 +248,27 @@ def qformer_cross_attn(q, k, v, bits, pair_index, N, nq, heads, out=None, empty_
     return out
 
 
+def qformer_cross_attn_indexed(q_u, q_index, q_cls, k, v, bits, pair_index, N, heads, out=None,
+                               empty_policy=PSG_EMPTY_UNIFORM):
+    """`qformer_cross_attn` (33 query rows per pair) with the queries stored once per prompt: q_u [U * 33, hidden], q_index
+    int32 [P] (prompt of each pair), q_cls [P, hidden] (row 0 of every pair).  Returns the context [P * 33, hidden], or
+    None when the LDS-DMA kernel cannot run on these inputs (the caller then expands q)."""
+    PSG_ERR_UNSUPPORTED = -2                                # include/psg_hip.h
+    lib, ctx, st = _env(q_u)
+    P = pair_index.numel()
+    L, hidden = k.shape
+    assert q_cls.shape == (P, hidden) and q_index.numel() == P and q_u.shape[1] == hidden and q_u.dtype == k.dtype == v.dtype
+    out = torch.empty((P * 33, hidden), device=q_u.device, dtype=q_u.dtype) if out is None else out
+    rc = lib.psg_qformer_cross_attn_indexed(ctx, _p(q_u), _p(q_index, torch.int32, "q_index"), _p(q_cls, q_u.dtype),
+                                            _p(k), _p(v), _p(bits, torch.int64, "bits"), bits.shape[1],
+                                            _p(pair_index, torch.int32, "pair_index"), int(N), P, L, heads, int(empty_policy),
+                                            _p(out, q_u.dtype), _dt(q_u), st)
+    if rc == PSG_ERR_UNSUPPORTED:
+        return None
+    check(rc, "psg_qformer_cross_attn_indexed")
+    return out
+
+
 def exist_head(x, w, b, P, nq):
     lib, ctx, st = _env(x)
     hidden = x.shape[1]

@@ -41,6 +41,8 @@ class RelationQueryEngine:
         self._split_w, self._bias32 = {}, {}
         self.own_gemm = int(_lib.get_option(self.device.index or 0, "qformer_own_gemm"))
         self.xattn_variant = xattn_variant
+        self._xidx_cache = {}
+        self.index_xattn = True          # layer 0: the cross-attention reads the per-prompt queries through an index
         q = cfg.qformer
         f32 = lambda k: weights[k].to(device=self.device, dtype=torch.float32).contiguous()  # noqa: E731
         act = lambda t: t.to(device=self.device, dtype=dtype).contiguous()                   # noqa: E731
@@ -357,12 +359,29 @@ class RelationQueryEngine:
             rows = prompts[3]
         else:
             rows = (inv.to(torch.int64)[:, None] * nq + torch.arange(nq, device=self.device)[None, :]).reshape(-1).to(torch.int32)
-        qx = torch.empty((P * nq, H), device=self.device, dtype=self.dtype)
-        ops.gather_rows(qx_u, rows, qx)
-        cx = self._cross(0, qx, nq, kv, bits, num_objects, pair_index, None)
+        cx = None
+        if (self.index_xattn and self.dtype in (torch.bfloat16, torch.float16) and nq == 33
+                and self.xattn_variant in (None, ops.PSG_XATTN_MFMA)):
+            # the LDS-DMA kernel looks the prompt's block up itself (pair tiles: one scalar load; cls tiles: the P cls
+            # rows gathered here) - no [P x 33, H] expansion of the queries (127 MB written and read again at C2)
+            key = (rows.data_ptr(), inv.data_ptr(), P)
+            ent = self._xidx_cache.get(key)
+            if ent is None:                                               # (index tensors of a cached prompt table: built once)
+                if len(self._xidx_cache) > 64:
+                    self._xidx_cache.clear()
+                ent = self._xidx_cache[key] = (rows[::nq].contiguous(), inv.to(torch.int32).contiguous(), rows, inv)
+            q_cls = torch.empty((P, H), device=self.device, dtype=self.dtype)
+            ops.gather_rows(qx_u, ent[0], q_cls)
+            cx = ops.qformer_cross_attn_indexed(qx_u, ent[1], q_cls, kv[0][0], kv[0][1], bits, pair_index,
+                                                num_objects, q.heads, empty_policy=self.empty_policy)
+        if cx is None:
+            qx = torch.empty((P * nq, H), device=self.device, dtype=self.dtype)
+            ops.gather_rows(qx_u, rows, qx)
+            cx = self._cross(0, qx, nq, kv, bits, num_objects, pair_index, None)
+            del qx
         Cq = self._lin(cx, L["wo_x"])
         _, Cq32 = self._ln(Cq, A[:RQu], self._s(A32, 0, RQu), L["bo_x"], L["ln_x"], period=nq, index=inv)
-        del qx, cx, qx_u
+        del cx, qx_u
         iq = self._ffn1(Cq, L["w1q"], L["b1q"])
         hq = self._lin(iq, L["w2q"])
         Xq, Xq32 = self._ln(hq, Cq, Cq32, L["b2q"], L["ln_q"])

@@ -390,3 +390,30 @@ def test_skinny_gemm_fp16_vs_fp32_reference(M, N, K):
     err = (y.float() - ref).abs().max().item()
     print(f"fp16 skinny GEMM M={M} N={N} K={K}: err {err:.3e}")
     assert err < 4e-3
+
+
+def test_indexed_cross_attention_equals_the_expanded_queries_bit_for_bit():
+    """psg_qformer_cross_attn_indexed (queries stored once per prompt, looked up through the pair -> prompt index by the
+    LDS-DMA kernel) against psg_qformer_cross_attn on the expanded [P x 33] query rows (HF-IB:464-496)."""
+    from openpsg_amd import ops
+    from openpsg_amd.synthetic import make_scene
+    dev = "cuda:0"
+    N, L, H, heads, nq = 23, 256, 768, 12, 33
+    sc = make_scene((1024, 1024), N, seed=2, device=dev, features=False)
+    grid = ops.mask_grid(sc["pan_results"], (1024, 1024), (1024, 1024), (16, 16))
+    bits = ops.object_bitmasks(grid, torch.tensor([int(i) for i in sc["object_id_list"]], dtype=torch.int32, device=dev))
+    P, U = N * N, 37
+    g = torch.Generator(device=dev).manual_seed(0)
+    for dt in (torch.bfloat16, torch.float16):
+        q_u = torch.randn(U * nq, H, generator=g, device=dev).to(dt)
+        k = torch.randn(L, H, generator=g, device=dev).to(dt)
+        v = torch.randn(L, H, generator=g, device=dev).to(dt)
+        inv = torch.randint(0, U, (P,), generator=g, device=dev).to(torch.int32)
+        pidx = torch.arange(P, device=dev, dtype=torch.int32)
+        rows = (inv.long()[:, None] * nq + torch.arange(nq, device=dev)[None, :]).reshape(-1)
+        q_full = q_u[rows].contiguous()
+        want = ops.qformer_cross_attn(q_full, k, v, bits, pidx, N, nq, heads)
+        q_cls = q_u[inv.long() * nq].contiguous()
+        got = ops.qformer_cross_attn_indexed(q_u, inv, q_cls, k, v, bits, pidx, N, heads)
+        assert got is not None and torch.equal(got, want)
+    assert ops.qformer_cross_attn_indexed(q_u.float(), inv, q_cls.float(), k.float(), v.float(), bits, pidx, N, heads) is None

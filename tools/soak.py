@@ -12,7 +12,7 @@ import bench  # noqa: E402
 from openpsg_amd.synthetic import make_scene  # noqa: E402
 
 n_img = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 60
-sys.argv = sys.argv[:1] + ["--no-cpu-baseline", "--no-parity"]
+sys.argv = sys.argv[:1] + ["--no-cpu-baseline", "--no-parity"] + [x for x in sys.argv[2:] if x.startswith("--") or x in ("fp16", "fp32")]
 a = bench.parse()
 dev = torch.device("cuda:0")
 head = bench.setup_head(a, dev)
