@@ -332,12 +332,18 @@ static bg_plan bg_make_plan(const psg_ctx* ctx, int64_t M, int N, int K, int bn,
         int s_al = G / NB;
         if (s_al < 1) continue;
         if (s_al > nk) s_al = nk;
+        if (s_al > PSG_MAX_SPLITS) s_al = PSG_MAX_SPLITS;    // what a consumer kernel sums
         p.s_al = p.slots = s_al;
         p.grid = NB * s_al;
         units = (double)((nk + s_al - 1) / s_al);
       } else {
         p.grid = T < G ? (int)T : G;                         // every workgroup gets at least one unit: slot ranks are contiguous
         p.slots = bg_streamk_slots(N, K, BN, p.grid);
+        while (p.slots > PSG_MAX_SPLITS && p.grid > NB) {    // few slabs, long K walks: fewer workgroups = longer segments
+          p.grid = p.grid * 7 / 8 > NB ? p.grid * 7 / 8 : NB;
+          p.slots = bg_streamk_slots(N, K, BN, p.grid);
+        }
+        if (p.slots > PSG_MAX_SPLITS) continue;
         units = (double)((T + p.grid - 1) / p.grid);
       }
       const double slice_bytes = (double)p.slots * (pair ? 32 : M) * N * 4;   // (pair form: the plan must not follow the row count)

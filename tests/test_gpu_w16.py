@@ -129,3 +129,32 @@ def test_two_plane_rmsnorm_equals_the_row_kernel_followed_by_the_split_bit_for_b
             a2, ainv = ops.split_f16x2(n)
             b2, binv = ops.rmsnorm_split2(rb, delta, w, 1e-5)
             assert torch.equal(ra, rb) and torch.equal(a2, b2) and torch.equal(ainv, binv), (rows, D, S)
+
+
+def test_plans_never_exceed_the_slices_a_consumer_can_sum():
+    """Other widths than Llama-2-7B's (13B: 5120 / 13824; 70B-like: 8192 / 28672; narrow N) must still plan <= 16 slices."""
+    from openpsg_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for N, K in ((5120, 5120), (5120, 13824), (8192, 8192), (1024, 28672), (4096, 16384), (256, 8192)):
+        x = torch.randn(20, K, generator=g, device=DEV)
+        w16 = (torch.randn(N, K, generator=g, device=DEV) / K ** 0.5).half()
+        x2, inv = ops.split_f16x2(x)
+        for mode in (0, 1, 2):
+            try:
+                part = ops.split_gemm_w16(x2, inv, w16, mode)
+            except Exception as exc:                                   # a forced mode may have no plan; the estimate must
+                assert mode != 0, exc
+                continue
+            assert part.splits <= 16
+            ref = x.double() @ w16.double().t()
+            bound = x.abs().double() @ w16.abs().double().t()
+            assert ((part.t.sum(0).double() - ref).abs() <= 2e-6 * bound + 1e-30).all()
+        xb = torch.randn(96, K, generator=g, device=DEV).half()
+        for bn in (0, 128, 256):
+            for mode in (0, 1, 2):
+                try:
+                    pb = ops.batch_gemm(xb, w16, bn, mode)
+                except Exception as exc:
+                    assert mode != 0 or bn != 0, exc
+                    continue
+                assert pb.splits <= 16
