@@ -158,3 +158,39 @@ def test_plans_never_exceed_the_slices_a_consumer_can_sum():
                     assert mode != 0 or bn != 0, exc
                     continue
                 assert pb.splits <= 16
+
+
+def test_small_llm_with_fp16_valued_weights_decodes_the_same_tokens_with_and_without_the_fp16_stream():
+    """A small LLM shape (hidden 512, inter 1024, vocab 512, 2 layers: other kernel instantiations than the 7B width) through
+    the whole head in fp32s: llm_w16 = 1 (fp16 stream: psg_split_gemm_w16 decode steps, two-plane prompt pass) against
+    llm_w16 = 0 (fp32 stream, three-segment prompt pass) on the same fp16-valued weights - identical tokens, existence
+    logits identical (the Q-Former does not change), first-step logits within 1e-4."""
+    import numpy as np
+    from openpsg_amd import _lib
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from openpsg_amd.synthetic import make_scene
+    from openpsg_amd.weights import make_weights_device
+    dev = torch.device(DEV)
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=30522), llm=tiny_llm(512, 2, 1024, 512), max_object_num=50)
+    w = make_weights_device(cfg, 7, dev, llm_dtype=torch.float32, llm_values=torch.float16)
+    sc = make_scene((512, 768), 12, seed=4, device=DEV)
+    inp = dict(mask_features=sc["mask_features"], img_metas=[sc["img_meta"]],
+               object_info=[dict(object_id_list=sc["object_id_list"], pan_results=sc["pan_results"])])
+    res = {}
+    for flag in (0, 1):
+        _lib.set_option(0, "llm_w16", flag)
+        try:
+            head = RelationTransformerHeadV4(dtype="fp32s", device=DEV, llm_config=cfg.llm, llm_feature_size=512,
+                                             tokenizers="word", max_object_num=50, on_parse_error="skip", suppress_eos=True)
+            head.load_weights(w)
+        finally:
+            _lib.set_option(0, "llm_w16", 1)
+        assert head.llm_engine._w16_all == bool(flag)
+        out = head(inp)
+        out2 = head(inp)                                               # graph replay
+        assert out == out2
+        res[flag] = (head.last["tokens_host"].copy(), head.last["exist_logit"].float().cpu().clone(), out)
+        del head
+        torch.cuda.empty_cache()
+    assert np.array_equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
