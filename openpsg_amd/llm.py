@@ -83,6 +83,9 @@ def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False, pool=None):
     cands += [("rows", p_) for p_ in (2, 3, 4) if rows >= 128 * p_]
     if k3 and out_dtype == torch.float32:
         cands += [("kseg", p_) for p_ in (3, 6, 12) if K3 % (64 * p_) == 0]
+    # (drain the device first: the timing loop is EAGER library work, and an eager library GEMM beside one inside another
+    # slot's replaying graph is the combination that hung the GPU in round 4, tools/inflight_stress.py)
+    torch.cuda.synchronize(w3.device)
     a3 = torch.randn((rows, K3), device=w3.device, generator=torch.Generator(device=w3.device).manual_seed(0)).to(w3.dtype)
     best, best_t, whole_t = cands[0], None, None
     pool = [w_ for w_ in (pool or [w3]) if w_.shape == w3.shape and w_.dtype == w3.dtype] or [w3]
@@ -126,6 +129,7 @@ def _plan_batch_mm(x, pool):
         return plan
     if torch.cuda.is_current_stream_capturing():
         return ("lib",)
+    torch.cuda.synchronize(w.device)                           # (as in _plan_split_mm: no eager library work beside a replaying graph)
     cands = [("lib",)] + [("own", bn, mode) for bn in (256, 128) for mode in (1, 2)]
     best, best_t = cands[0], None
     for c in cands:
