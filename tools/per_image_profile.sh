@@ -3,6 +3,8 @@
 # steps; the difference of the per-kernel totals divided by the extra steps is what ONE step (image) costs (setup,
 # warm-up, graph capture and the roofline leg cancel).  Run on the MI355X box from the repo root:
 #   tools/per_image_profile.sh [out.csv] [extra bench.py arguments, e.g. --workload rq]
+# (The library products of the prompt pass run in parts measured per PROCESS, llm._plan_split_mm: if the two traces picked
+# different parts for a shape, its library kernel rows shift between names - the TOTAL row stays right; rerun then.)
 set -u
 OUT=${1:-gpurun_out/per_image_kernels.csv}
 shift || true
