@@ -367,7 +367,7 @@ int psg_skinny_gemm_fused(psg_ctx*, const psg_prologue* pro, void* x, const void
  * layer's down-projection partials, delta_splits slices, or NULL) and whose last projection leaves its 16 split-K slices
  * in down_part [16][M][hidden] for the next layer (or for the final psg_rmsnorm).  256 workgroups stay resident and keep
  * their weight rings filled across the row operations (csrc/psg_decode_layer.hip).  fp32 weights / activations / caches,
- * hidden = 4096 = 32 heads x 128, inter % 128 == 0, 13..32 rows, a 256-CU device: psg_decode_layer_supported() says
+ * hidden = 4096 = 32 heads x 128, inter % 128 == 0, 13..24 rows, a 256-CU device: psg_decode_layer_supported() says
  * whether a shape qualifies (else keep the chain).  workspace: psg_decode_layer_workspace() floats, contents
  * irrelevant; counters: that many uint32 words ZEROED by the caller before every launch (one block per launch inside a
  * captured graph); word [255 * 64] != 0 afterwards = a bounded poll gave up.  At most ONE of these launches may run on a

@@ -38,7 +38,7 @@ struct psg_opts {
   int prefill_attn_scalar = 0;  // prompt pass: scalar cache-attention kernel instead of the matrix-core one
   int llm_fuse_split = 1;       // fp32s prompt pass: operand splits / result scalings inside the row kernels (psg_split.hip)
   int decode_persistent = 0;    // fp32 decode steps: one persistent launch per decoder layer (psg_decode_layer) instead of the
-                                // chain of eight launches (bit-identical; Llama-2-7B width, 13..32 rows, 256 CUs)
+                                // chain of eight launches (bit-identical; Llama-2-7B width, 13..24 rows, 256 CUs)
   int llm_w16 = 1;              // fp32 engines: stream projection weights that are fp16 VALUES (verified per tensor) as fp16
   int batch_gemm_bn = 0;        // psg_batch_gemm: forced slab height (256 or 128 weight rows); 0 = the planner's estimate
   int batch_gemm_mode = 0;      // psg_batch_gemm: 1 = slab-aligned slices, 2 = stream-K ranges; 0 = the planner's estimate

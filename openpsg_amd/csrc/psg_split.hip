@@ -240,14 +240,15 @@ __device__ __forceinline__ void sp_store3(uint16_t* o0, int K, int c, const floa
 }
 
 // resid += delta * (d_rs[row] * d_cs[col]);  x = RMSNorm(resid) * w  ->  out3 [rows][3 hidden] fp16, inv_scale [rows].
-// One 256-thread workgroup per row in the arithmetic order of rmsnorm_kernel<float, NCH, float> launched with 256 threads.
-template <int NCH>
-__global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ resid, const float* __restrict__ delta,
+// One NTHR-thread workgroup per row in the arithmetic order of rmsnorm_kernel<float, NCH, float> launched with NTHR threads
+// (psg_rmsnorm's rule: 1024 threads for <= 64 rows of >= 4096 columns, else 256 - the same sum-of-squares tree either way).
+template <int NCH, int NTHR>
+__global__ void __launch_bounds__(NTHR) rmsnorm_split_kernel(float* __restrict__ resid, const float* __restrict__ delta,
                                                             const float* __restrict__ d_rs, const float* __restrict__ d_cs,
                                                             const float* __restrict__ w, float eps, int hidden,
                                                             uint16_t* __restrict__ out3, float* __restrict__ inv_scale,
                                                             int dslices, int64_t dstride, int planes) {
-  __shared__ float s_part[4], s_max[4];
+  __shared__ float s_part[NTHR / 64], s_max[NTHR / 64];
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float v[NCH][4];
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ 
   const float rs = delta ? d_rs[row] : 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int col = (c * 256 + tid) * 4;
+    const int col = (c * NTHR + tid) * 4;
     if (col < hidden) {
       const float4 r = *reinterpret_cast<const float4*>(resid + row * hidden + col);
       g[c] = *reinterpret_cast<const float4*>(w + col);
@@ -274,18 +275,18 @@ __global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ 
   float ss = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
-    if ((c * 256 + tid) * 4 < hidden) ss = psg_sumsq4(v[c], ss);
+    if ((c * NTHR + tid) * 4 < hidden) ss = psg_sumsq4(v[c], ss);
   ss = wave_sum(ss);
   if (lane == 0) s_part[wid] = ss;
   __syncthreads();
   ss = 0.f;
-  for (int i = 0; i < 4; ++i) ss += s_part[i];
+  for (int i = 0; i < NTHR / 64; ++i) ss += s_part[i];
   const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
   float x[NCH][4];
   float mx = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int col = (c * 256 + tid) * 4;
+    const int col = (c * NTHR + tid) * 4;
     if (col < hidden) {
       if (delta) *reinterpret_cast<float4*>(resid + row * hidden + col) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
       x[c][0] = g[c].x * (v[c][0] * inv); x[c][1] = g[c].y * (v[c][1] * inv);
@@ -296,14 +297,16 @@ __global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ 
   mx = wave_max(mx);
   if (lane == 0) s_max[wid] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  mx = s_max[0];
+#pragma unroll
+  for (int i = 1; i < NTHR / 64; ++i) mx = fmaxf(mx, s_max[i]);
   const float scale = sp_row_scale(mx, tid == 0 ? inv_scale + row : nullptr);
   uint16_t* o0 = out3 + row * 3 * (int64_t)hidden;
   uint16_t* oh = out3 + row * (int64_t)hidden;                   // planes == 2: [2][rows][hidden] (dstride = rows x hidden)
   uint16_t* ol = oh + dstride;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int col = (c * 256 + tid) * 4;
+    const int col = (c * NTHR + tid) * 4;
     if (col < hidden) {
       if (planes == 2) sp_store2(oh, ol, col, x[c], scale);
       else sp_store3(o0, hidden, col, x[c], scale);
@@ -319,20 +322,24 @@ extern "C" int psg_rmsnorm_split(psg_ctx* ctx, float* resid, const float* delta,
   PSG_REQUIRE(hidden % 4 == 0 && hidden > 0 && hidden <= 8192 && rows >= 0 && rows < (1ll << 31), PSG_ERR_UNSUPPORTED,
               "psg_rmsnorm_split: hidden=%d rows=%lld", hidden, (long long)rows);
   if (rows == 0) return PSG_OK;
-  const int nch = (hidden + 1023) / 1024;
+  const int nthr = (rows <= 64 && hidden >= 4096) ? 1024 : 256;       // psg_rmsnorm's choice: the same summation tree
+  const int nch = (hidden + 4 * nthr - 1) / (4 * nthr);
   hipStream_t st = (hipStream_t)stream;
-#define RNS(N)                                                                                                      \
-  rmsnorm_split_kernel<N><<<(unsigned)rows, 256, 0, st>>>(resid, delta, delta_row_scale, delta_col_scale, w, eps, hidden, \
+#define RNS(N, T)                                                                                                   \
+  rmsnorm_split_kernel<N, T><<<(unsigned)rows, T, 0, st>>>(resid, delta, delta_row_scale, delta_col_scale, w, eps, hidden, \
                                                           (uint16_t*)out3, inv_scale, delta_slices, rows * (int64_t)hidden, planes)
-  switch (nch) {
-    case 1: RNS(1); break;
-    case 2: RNS(2); break;
-    case 3: RNS(3); break;
-    case 4: RNS(4); break;
-    case 5: RNS(5); break;
-    case 6: RNS(6); break;
-    case 7: RNS(7); break;
-    default: RNS(8); break;
+  if (nthr == 1024) {
+    if (nch <= 1) RNS(1, 1024);
+    else RNS(2, 1024);
+  } else switch (nch) {
+    case 1: RNS(1, 256); break;
+    case 2: RNS(2, 256); break;
+    case 3: RNS(3, 256); break;
+    case 4: RNS(4, 256); break;
+    case 5: RNS(5, 256); break;
+    case 6: RNS(6, 256); break;
+    case 7: RNS(7, 256); break;
+    default: RNS(8, 256); break;
   }
 #undef RNS
   PSG_CHECK_LAUNCH("psg_rmsnorm_split");

@@ -16,6 +16,8 @@ Differences that are deliberate and documented:
 """
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -40,8 +42,8 @@ _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.flo
 class _Pending:
     """An image submitted with `head.submit`: its kernels are enqueued on `stream`; `result()` is the only host wait."""
 
-    def __init__(self, head, stream, rq, out, num_objects, inputs=None):
-        self.head, self.stream, self.rq, self.out, self.N = head, stream, rq, out, num_objects
+    def __init__(self, head, stream, rq, out, num_objects, inputs=None, slot=None):
+        self.head, self.stream, self.rq, self.out, self.N, self.slot = head, stream, rq, out, num_objects, slot
         # the caller's input tensors are read on `stream`, possibly long after `submit` returned: they stay referenced
         # here until the result is taken (and carry a record_stream mark in case the handle is dropped first)
         self.inputs = inputs
@@ -58,6 +60,11 @@ class _Pending:
             sel = self.rq["selected"]
             if "_finish" in out:                                           # natural EOS: the chunks behind the first
                 out.pop("_finish")()
+                # the deferred chunks were enqueued only now: `_decode_done` of this image (recorded at submit, behind the
+                # first chunk) must cover them, or `serialize_decodes` / `_wait_front` would let the next decode start early
+                if h._decode_done_slot == self.slot:
+                    h._decode_done = torch.cuda.Event()
+                    h._decode_done.record(self.stream)
             out["tokens_host"] = out["tokens"].cpu().numpy()               # waits for this stream's work only
             out["selected_host"] = sel.cpu().numpy()
         self.rq.update(out)
@@ -66,6 +73,10 @@ class _Pending:
         self.rq = self.out = self.inputs = None
         self._result = dict(rel_pred=rel_pred, rel_score=rel_score)
         return self._result
+
+    @property
+    def taken(self):
+        return self._result is not None
 
 
 class _PendingBatch:
@@ -291,6 +302,8 @@ class RelationTransformerHeadV4(nn.Module):
             for slot in (0, 1):
                 self._slot_stream(slot)
         self._decode_done = None
+        self._decode_done_slot = None
+        self._slot_pending = {}
         self._front_done = None
         # submit(): image k+1's decode steps wait for image k's (its relation query and prompt pass do not).  Measured A/B
         # at BASELINE C3, two slots: serialised 67.4 ms per image = no gain over one image at a time; free-running 56.6.
@@ -497,13 +510,19 @@ class RelationTransformerHeadV4(nn.Module):
         static buffers; `forward` has its own) and must not be re-submitted before its pending result was taken."""
         if self.training:
             raise PsgHipError("submit: inference only")
+        live = self._slot_pending.get(slot)
+        live = live() if live is not None else None
+        if live is not None and not live.taken and live.rq is not None:
+            # the slot's decode graphs hand out their static token buffers at result(): a second image on the slot would
+            # silently return ITS tokens for the first handle
+            raise PsgHipError(f"submit: slot {slot} still holds an image whose result() was not taken")
         st = self._slot_stream(slot)
         st.wait_stream(torch.cuda.current_stream(self.device))          # the inputs were produced on the caller's stream
         with torch.cuda.stream(st):
             feat, meta, info, obj_ids, names = self._unpack(inputs)
             N = len(obj_ids)
             if N == 0:
-                return _Pending(self, st, None, None, 0)
+                return _Pending(self, st, None, None, 0, slot=slot)
             # the caller may drop its tensors as soon as this returns (a detector's mask_features are a temporary): the
             # caching allocator must not hand their blocks out again before the slot stream has read them
             for t in (feat, info["pan_results"], *[x for x in info['object_id_list'] if torch.is_tensor(x)]):
@@ -518,7 +537,9 @@ class RelationTransformerHeadV4(nn.Module):
             self._wait_front(st)
             rq = self.run_relation_query(feat, meta, obj_ids, names, info["pan_results"])
             out = self._enqueue_decode(st, rq, names, slot, defer=True)
-        return _Pending(self, st, rq, out, N, inputs=inputs)
+        pend = _Pending(self, st, rq, out, N, inputs=inputs, slot=slot)
+        self._slot_pending[slot] = weakref.ref(pend)                   # (a dropped handle frees its slot)
+        return pend
 
     def _slot_stream(self, slot):
         st = self._slot_streams.get(slot)
@@ -557,6 +578,7 @@ class RelationTransformerHeadV4(nn.Module):
         self._front_done = front_done
         self._decode_done = torch.cuda.Event()
         self._decode_done.record(st)
+        self._decode_done_slot = slot
         return out
 
     def decode_concurrent(self, items):

@@ -32,11 +32,30 @@ from ._lib import PsgHipError
 from .config import PSGConfig
 
 
-# How the library runs one split-fp16 product [rows, K'] x [N, K']^T -> fp32 best, per (rows, N, K', device): whole, or cut
-# into column / row parts written in place.  hipBLASLt's pick for a shape is a heuristic, and at K' = 3K it is erratic
-# (Llama-2-7B gate|up at 960 rows: 694 us whole, 480 us as two column halves; q|k|v at 1440 rows: 635 whole, 397 as halves;
-# tools/split_gemm_bench.py), so the cut is MEASURED once per shape and process, outside any graph capture.
-_SPLIT_PLANS: dict = {}
+# How the library runs one split-fp16 product [rows, K'] x [N, K']^T -> fp32: whole, or cut into column / row parts written
+# in place, or as a batched product over K segments.  hipBLASLt's pick for a shape is a heuristic, and at K' = 3K it is erratic
+# (Llama-2-7B gate|up at 960 rows: 694 us whole, 480 us as two column halves; tools/split_gemm_bench.py), so a cut pays.
+# The forms are NOT numerically equivalent (K segments change the fp32 summation order, parts can make the library pick
+# another kernel), so the choice must not depend on anything a process measures: it comes from the FIXED table below - the
+# measured winners for the Llama-2-7B shapes on gfx950 (gpurun_out/plans_run*.txt of round 6: two runs of the old per-process
+# timing disagreed on 3 of 12 shapes at near-ties, which is exactly what the table retires).  Every rank, every box and every
+# process then runs the same arithmetic on the same input (tests/test_gpu_plans.py: two fresh processes, identical logits
+# and tokens).  `PSG_PLAN=measure` brings the timing back as a TOOL: it times the candidates and prints table lines.
+#   key: (N, K', result is fp32, the reader sums [P, rows, N] slices)  ->  [(rows from, rows below, plan), ...]; else whole
+_SPLIT_PLAN_TABLE = {
+    # fp32s prompt pass, generic fp32 weights: [xh | xh | xl] . [wh | wl | wh]^T over K' = 3K (960 rows at BASELINE C3)
+    (22016, 12288, True, False): [(512, 2048, ("cols", 2))],      # gate|up: 702-709 us whole, 466-494 as two column halves
+    (4096, 33024, True, True): [(512, 2048, ("kseg", 6))],        # down: 335-347 us whole, 283-293 as six K segments
+    # fp32s prompt pass, fp16-valued weights: the two-plane operand [xh; xl] (2 x rows) against the fp16 weight over K
+    (22016, 4096, True, False): [(1024, 6144, ("cols", 2))],      # gate|up: 375 us whole, 326-332 in halves (1920 rows)
+    # 16-bit prompt pass of several images (forward_batch: 1920 / 3840 rows; 7680: whole)
+    (22016, 4096, False, False): [(1024, 6144, ("cols", 2))],     # 598-604 us whole, 534-539 in halves (3840 rows)
+}
+_SPLIT_PLANS: dict = {}                                            # PSG_PLAN=measure only: what this process measured
+
+
+def _plan_measuring() -> bool:
+    return os.environ.get("PSG_PLAN", "") == "measure"
 
 
 def _split_mm(a3, w3, plan=None, out_dtype=torch.float32):
@@ -64,15 +83,28 @@ def _split_mm(a3, w3, plan=None, out_dtype=torch.float32):
 
 
 def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False, pool=None):
-    """The fastest of {whole, 2 / 3 column parts, 2 / 3 / 4 row parts} for this shape, timed on the device (7 runs each,
-    minimum); a cut must win by 5 % to be taken.  Cached per process so that every engine uses the same cut.
+    """The form the library product of this shape runs in: a pure function of the shape (`_SPLIT_PLAN_TABLE`; 'whole' for
+    every shape the table does not name), unless PSG_PLAN=measure."""
+    if _plan_measuring():
+        return _measure_split_plan(rows, w3, out_dtype, k3, pool)
+    N, K3 = w3.shape
+    for lo, hi, plan in _SPLIT_PLAN_TABLE.get((int(N), int(K3), out_dtype == torch.float32, bool(k3)), ()):
+        if lo <= rows < hi:
+            return plan
+    return ("whole",)
+
+
+def _measure_split_plan(rows, w3, out_dtype=torch.float32, k3=False, pool=None):
+    """PSG_PLAN=measure (a tool, not the product path: its result depends on timing noise).
+    The fastest of {whole, 2 / 3 column parts, 2 / 3 / 4 row parts} for this shape, timed on the device (7 runs each,
+    minimum); a cut must win by 5 % to be taken.  Cached per process; prints the line `_SPLIT_PLAN_TABLE` would carry.
     k3: the caller's reader can sum slices (psg_rmsnorm_split) - 3 / 6 / 12 segments of K' as ONE batched product with a
     [P, rows, N] result are candidates too (P x the tiles: down at 960 rows 331 us whole, 303 as 3, 247 as 6 slices; o
     105 -> 98); the reader's extra slice reads are charged at 4 TB/s.
     pool: the other weights of this shape (the layers'): timed in rotation, so that a weight small enough for the
     Infinity Cache is as cold as it is in the pass itself."""
     N, K3 = w3.shape
-    key = (int(rows), int(N), int(K3), w3.device.index or 0, str(out_dtype), bool(k3))
+    key = (int(rows), int(N), int(K3), w3.device.index or 0, str(out_dtype), bool(k3), str(w3.dtype))
     plan = _SPLIT_PLANS.get(key)
     if plan is not None:
         return plan
@@ -107,29 +139,48 @@ def _plan_split_mm(rows, w3, out_dtype=torch.float32, k3=False, pool=None):
         elif t < best_t and t < 0.95 * whole_t:
             best, best_t = c, t
     _SPLIT_PLANS[key] = best
-    if os.environ.get("PSG_DEBUG_PLANS"):
-        print(f"[psg] split product rows={rows} N={N} K'={K3}: {best} {best_t * 1e3:.0f} us (whole {whole_t * 1e3:.0f} us)",
-              file=sys.stderr, flush=True)
+    print(f"[psg plan] ({N}, {K3}, {out_dtype == torch.float32}, {bool(k3)}): rows={rows} -> {best}  # {best_t * 1e3:.0f} us "
+          f"(whole {whole_t * 1e3:.0f} us)", file=sys.stderr, flush=True)
     return best
 
 
 # Decode steps with 33..160 rows (several images' pairs decoded together, head.forward_batch): the library GEMM against the
-# variants of psg_batch_gemm (slab height x range mode), per (rows, N, K), timed once per process on COLD weights (the
-# layers' own weights of that shape in rotation) with the consumer's extra work - summing fp32 slices instead of reading one
-# 16-bit result - charged to the variants as a psg_reduce_partials pass.  At 160 rows the library streams o / down at 1.0-1.3
-# TB/s and wins on gate|up; at 40 rows psg_batch_gemm wins everywhere (tools/batched_decode_gemm_bench.py).
-_BATCH_PLANS: dict = {}
+# variants of psg_batch_gemm (slab height x range mode) per (rows, N, K).  'own' hands fp32 slices to the consumer where 'lib'
+# hands a 16-bit-rounded result, so - like the split products above - the choice is a FIXED table of the measured winners at
+# the Llama-2-7B shapes (COLD weights, the consumer's slice sums charged to the variants; profiles/r05_batch_gemm_ab.txt,
+# gpurun_out/plans_run*.txt of round 6), never a per-process measurement.  At 160 rows the library streams o / down at
+# 1.0-1.3 TB/s and wins on gate|up; at 40 rows psg_batch_gemm wins everywhere but the lm_head.
+#   key: (N, K) -> [(rows from, rows below, plan), ...]; anything else: the library
+_BATCH_PLAN_TABLE = {
+    (12288, 4096): [(33, 49, ("own", 128, 2))],                                        # q|k|v: 80 / 160 rows library (32 / 40 us)
+    (4096, 4096): [(33, 49, ("own", 128, 1)), (113, 161, ("own", 128, 1))],            # o: 80 rows library 22 us; 160: 29 vs 31
+    (22016, 4096): [(33, 49, ("own", 128, 2))],                                        # gate|up
+    (4096, 11008): [(33, 113, ("own", 128, 1)), (113, 161, ("own", 256, 1))],          # down: 160 rows 42 us vs library 72
+}
+_BATCH_PLANS: dict = {}                                            # PSG_PLAN=measure only
 
 
 def _plan_batch_mm(x, pool):
+    if _plan_measuring():
+        return _measure_batch_plan(x, pool)
+    w, rows = pool[0], int(x.shape[0])
+    for lo, hi, plan in _BATCH_PLAN_TABLE.get((int(w.shape[0]), int(w.shape[1])), ()):
+        if lo <= rows < hi:
+            return plan
+    return ("lib",)
+
+
+def _measure_batch_plan(x, pool):
+    """PSG_PLAN=measure (a tool): library vs the psg_batch_gemm variants, timed once per process on COLD weights (the layers'
+    own weights of that shape in rotation) with a psg_reduce_partials pass charged to the variants."""
     w = pool[0]
-    key = (int(x.shape[0]), int(w.shape[0]), int(w.shape[1]), str(x.dtype), w.device.index or 0)
+    key = (int(x.shape[0]), int(w.shape[0]), int(w.shape[1]), str(x.dtype), str(w.dtype), w.device.index or 0)
     plan = _BATCH_PLANS.get(key)
     if plan is not None:
         return plan
     if torch.cuda.is_current_stream_capturing():
         return ("lib",)
-    torch.cuda.synchronize(w.device)                           # (as in _plan_split_mm: no eager library work beside a replaying graph)
+    torch.cuda.synchronize(w.device)                           # (as in _measure_split_plan: no eager library work beside a replaying graph)
     cands = [("lib",)] + [("own", bn, mode) for bn in (256, 128) for mode in (1, 2)]
     best, best_t = cands[0], None
     for c in cands:
@@ -156,9 +207,8 @@ def _plan_batch_mm(x, pool):
         if best_t is None or t < best_t * (0.97 if best[0] == "lib" else 1.0):
             best, best_t = c, t
     _BATCH_PLANS[key] = best
-    if os.environ.get("PSG_DEBUG_PLANS"):
-        print(f"[psg] decode projection rows={key[0]} N={key[1]} K={key[2]}: {best} {best_t * 1e3:.0f} us", file=sys.stderr,
-              flush=True)
+    print(f"[psg plan] decode projection ({key[1]}, {key[2]}): rows={key[0]} -> {best}  # {best_t * 1e3:.0f} us", file=sys.stderr,
+          flush=True)
     return best
 
 
@@ -243,7 +293,7 @@ class LlamaDecodeEngine:
         self.fuse_rowops = frozenset({"rmsnorm"}) if _lib.get_option(dev_i, "llm_fuse_rmsnorm") else frozenset()
         self.prefill_attn_scalar = bool(_lib.get_option(dev_i, "prefill_attn_scalar"))
         # decode steps as ONE persistent launch per layer (psg_decode_layer; fp32 engines at Llama-2-7B width on a 256-CU
-        # device, 13..32 rows): bit-identical to the launch chain, so every other shape - and the in-flight slots, since
+        # device, 13..24 rows): bit-identical to the launch chain, so every other shape - and the in-flight slots, since
         # only one persistent launch may run on a device at a time - simply keeps the chain
         self.persistent_layer = bool(_lib.get_option(dev_i, "decode_persistent"))
         # fp32s prompt pass: the split of a projection's operand and the un-scaling of its result inside the row kernels
@@ -716,6 +766,7 @@ class LlamaDecodeEngine:
 
         def finish():
             advance(None)
+            self._check_persistent(st)
             # the graph's static buffers are overwritten by the next replay: hand out copies
             fl = st["first_logits"]
             return self._finish((st["tokens"].clone(), None if fl is None else fl.clone()), return_first_logits)
@@ -729,9 +780,22 @@ class LlamaDecodeEngine:
     def _finish(outs, want_first):
         return outs if want_first else outs[0]
 
+    def _check_persistent(self, st):
+        """psg_decode_layer bounds every hand-off poll and reports a producer that never arrived through word
+        PSG_DL_TIMEOUT of the launch's counter block (256-byte slots: word 255 * 64).  Raises if any launch of this
+        generation set it - its tokens are not to be trusted; the caller can switch `persistent_layer` off (the launch
+        chain computes the same bits)."""
+        for sync in st.get("dl_counters", ()):
+            ncnt = ops.decode_layer_counters(self.device)
+            if bool((sync.view(-1, ncnt)[:, 255 * 64] != 0).any().item()):
+                raise PsgHipError("psg_decode_layer: a hand-off poll timed out (cnt[PSG_DL_TIMEOUT] set); the tokens of this "
+                                  "generation are invalid - disable option decode_persistent")
+
     def _generate_eager(self, X, prompt_len, max_new, suppress_eos, return_first_logits, slot=0):
         st = self._prefill(X, prompt_len, max_new, suppress_eos, return_first_logits, slot=slot)
         self._steps(st, 1, max_new)
+        if not torch.cuda.is_current_stream_capturing():
+            self._check_persistent(st)
         return st["tokens"], st["first_logits"]
 
     def _prefill(self, X, prompt_len, max_new, suppress_eos, return_first_logits, slot=0):
@@ -777,6 +841,9 @@ class LlamaDecodeEngine:
         if persist:                                            # one counter block per layer launch, zeroed once per call
             per_step = ops.decode_layer_counters(self.device) * len(self.layers)
             sync = torch.zeros((hi - lo) * per_step, device=self.device, dtype=torch.int32)
+            # kept in the decode state: a hand-off poll that gave up reports through the block's time-out word, which
+            # `generate` reads back with the tokens (`_check_persistent`) - a dead producer must not yield silent garbage
+            st.setdefault("dl_counters", []).append(sync)
         if fused:                                              # two counter words per fused launch, zeroed once per call
             per_step = 2 * (4 * len(self.layers) + 1)
             sync = torch.zeros((hi - lo) * per_step, device=self.device, dtype=torch.int32)

@@ -364,12 +364,15 @@ class RelationQueryEngine:
                 and self.xattn_variant in (None, ops.PSG_XATTN_MFMA)):
             # the LDS-DMA kernel looks the prompt's block up itself (pair tiles: one scalar load; cls tiles: the P cls
             # rows gathered here) - no [P x 33, H] expansion of the queries (127 MB written and read again at C2)
-            key = (rows.data_ptr(), inv.data_ptr(), P)
-            ent = self._xidx_cache.get(key)
-            if ent is None:                                               # (index tensors of a cached prompt table: built once)
-                if len(self._xidx_cache) > 64:
-                    self._xidx_cache.clear()
-                ent = self._xidx_cache[key] = (rows[::nq].contiguous(), inv.to(torch.int32).contiguous(), rows, inv)
+            if len(prompts) > 3:                                          # index tensors of a cached prompt table: built once
+                key = (rows.data_ptr(), inv.data_ptr(), P)               # (the entry keeps both tensors alive: the pointers
+                ent = self._xidx_cache.get(key)                          # cannot be handed out again while it exists)
+                if ent is None:
+                    if len(self._xidx_cache) > 64:
+                        self._xidx_cache.clear()
+                    ent = self._xidx_cache[key] = (rows[::nq].contiguous(), inv.to(torch.int32).contiguous(), rows, inv)
+            else:                                                         # `rows` is a temporary of this call: nothing to key on
+                ent = (rows[::nq].contiguous(), inv.to(torch.int32).contiguous())
             q_cls = torch.empty((P, H), device=self.device, dtype=self.dtype)
             ops.gather_rows(qx_u, ent[0], q_cls)
             cx = ops.qformer_cross_attn_indexed(qx_u, ent[1], q_cls, kv[0][0], kv[0][1], bits, pair_index,

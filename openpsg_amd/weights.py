@@ -123,6 +123,48 @@ def make_weights_numpy(cfg: PSGConfig, seed: int = 0, with_llm: bool = True) -> 
     return out
 
 
+def extend_llm_weights_numpy(w: dict, cfg: PSGConfig, seed_base: int = 1000, threads: int = 8) -> dict:
+    """`w` plus every `language_model.*` tensor of `cfg` it lacks (the layers behind a truncated model's), fp32 CPU
+    tensors.  ONE numpy PCG64 generator PER TENSOR, seeded `seed_base + i` with i = the tensor's index in the sorted
+    schema of `cfg`: bit-reproducible on any box whatever the thread count, and fast enough for the un-truncated
+    Llama-2-7B shape (27 GB; `make_weights_numpy`'s single stream would take minutes).  The CPU oracle and the GPU head
+    of the 32-layer decode parity check (bench.py `parity...decode_7b_32_layers`, tests/test_gpu_llm7b.py) are both
+    fed from this dict, so they hold the same values."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = dict(w)
+    todo = [(i, key, shp) for i, (key, shp) in enumerate(sorted(llm_shapes(cfg).items())) if key not in out]
+
+    def fill(job):                                          # numpy releases the GIL while it draws
+        i, key, shp = job
+        mean, std = _std_for(key, shp)
+        arr = np.random.default_rng(seed_base + i).standard_normal(shp, dtype=np.float32)
+        arr *= np.float32(std)
+        arr += np.float32(mean)
+        return key, torch.from_numpy(arr)
+    with ThreadPoolExecutor(max_workers=max(1, int(threads))) as ex:
+        out.update(ex.map(fill, todo))
+    return out
+
+
+def llm_matrices_as_fp16_values(w: dict, in_place=()) -> dict:
+    """A dict in which every `language_model.*` matrix is the fp32 image of its fp16 rounding - the values the
+    reference's frozen fp16 Llama-2-7b-hf checkpoint has after `from_pretrained` upcast it (V4:99-100,
+    configs/psg/baseline_v4_ov.py:61-65).  Norm vectors and the head's own tensors are passed through.  Keys named in
+    `in_place` are rounded inside their storage (the 27 GB of an un-truncated model are not held twice); every other
+    matrix is a new tensor, so a dict sharing tensors with `w` keeps its values."""
+    out, in_place = {}, set(in_place)
+    for k, v in w.items():
+        if k.startswith("language_model.") and v.dim() >= 2:
+            if k in in_place:
+                v.copy_(v.half().float())
+                out[k] = v
+            else:
+                out[k] = v.half().float()
+        else:
+            out[k] = v
+    return out
+
+
 def make_weights_device(cfg: PSGConfig, seed: int, device, head_dtype=torch.float32,
                         llm_dtype=torch.bfloat16, with_llm: bool = True, llm_values=None) -> dict:
     """Random-init weights generated directly in HBM (benchmark use: 7B-shaped LLM).

@@ -96,14 +96,15 @@ def test_forward_batch_on_the_planned_projections_reproduces_the_per_image_decod
                object_info=[dict(object_id_list=scene["object_id_list"], pan_results=scene["pan_results"].to(dev))])
     single = head(inp)
     tok1 = head.last["tokens_host"].copy()
-    llm_mod._BATCH_PLANS.clear()
     batched = head.forward_batch([inp, inp, inp])
     toks = [head.last_batch[i]["tokens_host"] for i in range(3)]
     assert np.array_equal(toks[0], toks[1]) and np.array_equal(toks[0], toks[2])
     assert batched[0] == batched[1] == batched[2]
     same = int((toks[0] == tok1).sum())
     assert same >= 0.95 * tok1.size, f"{same} of {tok1.size} tokens equal the single-image decode"
-    plans = {k: v for k, v in llm_mod._BATCH_PLANS.items() if k[0] == 60}
-    assert plans and any(v[0] == "own" for v in plans.values()), plans
+    # 60 rows: the fixed plan table (llm._BATCH_PLAN_TABLE) puts the down projection on psg_batch_gemm
+    eng = head.llm_engine
+    x60 = torch.zeros((60, cfg.llm.inter), device=dev, dtype=eng.dtype)
+    assert llm_mod._plan_batch_mm(x60, [eng.layers[0]["wdown"]])[0] == "own"
     again = head.forward_batch([inp, inp, inp])                        # graph replay
     assert again == batched and single is not None

@@ -206,6 +206,19 @@ def test_fused_split_kernels_equal_the_separate_kernels_bit_for_bit():
         a3, inv = ops.split_f16x3(n)
         b3, binv = ops.rmsnorm_split(rb, ops.Scaled(y.clone(), rs, cs) if with_delta else None, w, 1e-5)
         assert torch.equal(ra, rb) and torch.equal(a3, b3) and torch.equal(inv, binv)
+    # <= 64 rows of >= 4096 columns (the last layer's kept rows, a 33..64-row prompt pass): psg_rmsnorm spreads a row over
+    # 1024 threads there - another sum-of-squares tree - and psg_rmsnorm_split must follow it
+    for small in (20, 64):
+        y, rs, cs = torch.randn(small, D, generator=g, device=dev) * 1e3, pw2(small), pw2(D)
+        ra, rb, rc = resid0[:small].clone(), resid0[:small].clone(), resid0[:small].clone()
+        n = torch.empty_like(ra)
+        ops.rmsnorm(ra, ops.scale_rows_cols(y.clone(), rs, cs), w, 1e-5, n)
+        a3, inv = ops.split_f16x3(n)
+        b3, binv = ops.rmsnorm_split(rb, ops.Scaled(y.clone(), rs, cs), w, 1e-5)
+        assert torch.equal(ra, rb) and torch.equal(a3, b3) and torch.equal(inv, binv)
+        a2, inv2 = ops.split_f16x2(n)
+        b2, binv2 = ops.rmsnorm_split(rc, ops.Scaled(y.clone(), rs, cs), w, 1e-5, planes=2)
+        assert torch.equal(ra, rc) and torch.equal(a2, b2) and torch.equal(inv2, binv2)
     # ... with the product handed over as three K-segment slices (one batched library GEMM): summed in slice order
     y3, rs, cs = torch.randn(3, rows, D, generator=g, device=dev) * 1e3, pw2(rows), pw2(D)
     ra, rb = resid0.clone(), resid0.clone()

@@ -192,6 +192,18 @@ def test_two_images_in_flight_give_the_results_of_forward():
             assert np.array_equal(sel, ws) and np.array_equal(toks, wt) and r == wr, f"{dtype}: image {k} differs"
         empty = head.submit(dict(ins[0], object_info=[dict(object_id_list=[], pan_results=scenes[0]["pan_results"])]), slot=0)
         assert empty.result() == dict(rel_pred=[], rel_score=[])
+        # a slot whose result was not taken cannot be submitted again (its static token buffers would be overwritten and the
+        # first handle would silently return the second image's tokens); a taken or dropped handle frees the slot
+        from openpsg_amd._lib import PsgHipError
+        first = head.submit(ins[0], slot=0)
+        with pytest.raises(PsgHipError, match="slot 0"):
+            head.submit(ins[1], slot=0)
+        assert first.result() == want[0][0]
+        second = head.submit(ins[1], slot=0)
+        del second                                                     # dropped without a result
+        import gc
+        gc.collect()
+        assert head.submit(ins[2], slot=0).result() == want[2][0]
 
 
 def test_submit_keeps_the_callers_temporaries_alive_until_they_are_read():
