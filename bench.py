@@ -614,6 +614,28 @@ def time_in_flight(head, inputs, warmup, steps, slots=2):
     return time.perf_counter() - t0
 
 
+def batched_decode_figures(head, a, dev, pairs_per_image, steps):
+    """head.forward_batch on 4 and on 8 images per step (BASELINE C5's batch): the images' 80 / 160 selected pairs decoded
+    together, so that the Llama weights stream once per decode step for all of them."""
+    from openpsg_amd.synthetic import make_scene
+    N = a.objects
+    try:
+        B3 = 4
+        batch = [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev))) for m in range(B3)]
+        k = max(2, min(steps, 5))
+        elb = time_steps(lambda: head.forward_batch(batch), 1, k)
+        out = {"images_per_step": B3, "value": round(B3 * k * pairs_per_image / elb, 1), "unit": "pairs/s",
+               "ms_per_step": round(elb / k * 1e3, 3), "steps": k}
+        B8 = 8                                                         # BASELINE C5's batch: 160 decode rows per step
+        batch += [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev))) for m in range(B3, B8)]
+        el8 = time_steps(lambda: head.forward_batch(batch), 1, 2)
+        out["eight_images"] = {"value": round(B8 * 2 * pairs_per_image / el8, 1), "ms_per_step": round(el8 / 2 * 1e3, 3),
+                               "steps": 2}
+        return out
+    except Exception as exc:                                           # never lose the line
+        return {"error": f"{type(exc).__name__}: {exc}"[:200]}
+
+
 def median_step(step, warmup, steps):
     """Median seconds of `steps` individually timed calls (a one-off stall - an allocator refill, a library kernel
     selection - does not move it)."""
@@ -923,6 +945,13 @@ def main():
                     del scene4, inputs4
                 except Exception as exc:                               # never lose the headline line
                     line["c4_single_gpu"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            # throughput mode at the headline's precision (round 6): several images per step, decode rows 80 / 160 on the
+            # library SGEMM (generic fp32 weights: 4 bytes per weight once per step for all rows)
+            if a.dtype in ("fp32s", "fp32") and not a.no_batched:
+                bd = batched_decode_figures(head, a, dev, pairs_per_image, a.steps)
+                bd["mode"] = a.dtype
+                bd["decode_projections"] = "library SGEMM over the fp32 weights (exact), 33..160 rows"
+                line["batched_decode"] = bd
         # ---- sub-objects measured with their own heads: the headline head is released first -------------------------
         if plain:
             import copy
@@ -986,6 +1015,11 @@ def main():
                                           "traffic_source": "profiles/pmc_split_gemm_w16.json (not re-measured in this run)",
                                           # the same three terms as the headline's roofline.image, from this head's own shapes
                                           "image": image_floor(h, a, "fp32s", int(bpl * nl), el * 1e3, prompt_mult=2)}
+                    if not a.no_batched:
+                        bd = batched_decode_figures(h, a, dev, pairs_per_image, a.steps)
+                        bd["decode_projections"] = ("one library product of the two fp16 planes of the fp32 rows against the fp16 "
+                                                    "weight per projection (2 bytes per weight, fp32 result), 33..160 rows")
+                        fz["batched_decode"] = bd
                     line["frozen_fp16_checkpoint"] = fz
                     del h
                     torch.cuda.empty_cache()
@@ -1009,24 +1043,7 @@ def main():
                         r["image"] = image_floor(h, a, "mixed", r["bytes_per_decode_step"], el * 1e3)
                         mx["roofline"] = r
                     if not a.no_batched:
-                        # four / eight such images per step, their 80 / 160 selected pairs decoded together so that the
-                        # Llama weights stream once per decode step for all of them (head.forward_batch)
-                        try:
-                            B3 = 4
-                            batch = [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev))) for m in range(B3)]
-                            k = max(2, min(a.steps, 5))
-                            elb = time_steps(lambda: h.forward_batch(batch), 1, k)
-                            mx["batched_decode"] = {"images_per_step": B3, "value": round(B3 * k * pairs_per_image / elb, 1),
-                                                    "unit": "pairs/s", "ms_per_step": round(elb / k * 1e3, 3), "steps": k}
-                            B8 = 8                                     # BASELINE C5's batch: 160 decode rows per step
-                            batch += [scene_inputs(make_scene((a.size, a.size), N, seed=m, device=str(dev)))
-                                      for m in range(B3, B8)]
-                            el8 = time_steps(lambda: h.forward_batch(batch), 1, 2)
-                            mx["batched_decode"]["eight_images"] = {"value": round(B8 * 2 * pairs_per_image / el8, 1),
-                                                                    "ms_per_step": round(el8 / 2 * 1e3, 3), "steps": 2}
-                            del batch
-                        except Exception as exc:
-                            mx["batched_decode"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+                        mx["batched_decode"] = batched_decode_figures(h, a, dev, pairs_per_image, a.steps)
                     line["mixed"] = mx
                     del h
                     torch.cuda.empty_cache()

@@ -65,8 +65,9 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *        psg_qformer_self_attn(_shared) / psg_prefill_attn accept PSG_F32 on the matrix cores)
  *   501  round 5 (psg_batch_gemm*, psg_qformer_cross_attn_indexed, psg_skinny_gemm_w16, psg_split_f16x2, psg_split_gemm_w16,
  *        psg_rmsnorm_split2, psg_rmsnorm_split / psg_rope_kvwrite_scaled /
- *        psg_silu_mul_split added) */
-#define PSG_ABI_VERSION 501
+ *        psg_silu_mul_split added)
+ *   600  round 6 (psg_dense_gemm_split, psg_decode_attn_split2, psg_silu_mul_split2 added; psg_split_f16x3 order 2) */
+#define PSG_ABI_VERSION 600
 int psg_version(void);
 const char* psg_last_error(void);
 int psg_create(int device, psg_ctx** out);
@@ -300,6 +301,18 @@ int psg_split_f16x2(psg_ctx*, const float* x, int64_t rows, int K, int64_t row_s
  * psg_rmsnorm followed by psg_split_f16x2; HF-LL:53-67) */
 int psg_rmsnorm_split2(psg_ctx*, float* resid, const float* delta, int delta_splits, const float* w, float eps, int64_t rows,
                        int hidden, void* out2, float* inv_scale, void* stream);
+/* Round 6: the two other producers of such planes in a decode step - the attention output (HF-LL:191-214; its row maximum
+ * spans the heads) and the SwiGLU gate (HF-LL:163-177; 11 008 columns) - write them directly: the workgroups of a row meet
+ * at four device-scope words per row (maximum bits, arrivals, departures; zero before the first launch, zeroed again by
+ * the last workgroup out), so no psg_split_f16x2 launch follows.  Planes and inv_scale are bit-identical to
+ * psg_decode_attn(PSG_F32) / psg_silu_mul(PSG_F32) + psg_split_f16x2.  rows <= 32 / 64: every workgroup of the launch is
+ * resident, which the rendezvous needs; a poll that gives up (~seconds) writes NaN to inv_scale[row].
+ * sync: uint32 [4 rows] per launch in flight (a decode state owns one for each of the two kernels). */
+int psg_decode_attn_split2(psg_ctx*, const void* qkv, int qkv_splits, const int32_t* tok_pair, const int32_t* tok_pos,
+                           const float* rope_cos, const float* rope_sin, int rows, int heads, int head_dim, int ctx_len,
+                           float* k_cache, float* v_cache, void* out2, float* inv_scale, uint32_t* sync, void* stream);
+int psg_silu_mul_split2(psg_ctx*, const float* gate_up_parts, int splits, int64_t rows, int inter, void* out2,
+                        float* inv_scale, uint32_t* sync, void* stream);
 int psg_split_gemm_w16_plan(psg_ctx*, int M, int N, int K, int mode, int* slots);
 int psg_split_gemm_w16(psg_ctx*, const void* x2, const float* inv_scale, const void* w_f16, float* part, int M, int N, int K,
                        int slots, int mode, void* stream);
@@ -392,7 +405,8 @@ int psg_decode_layers(psg_ctx*, void* resid, const void* delta, int delta_splits
  * HF-LL:163-177): an fp32 row, scaled by a power of two so that its largest magnitude lies in [2^13, 2^14), is written as
  * three fp16 K segments - order 0 (activations): [hi | hi | lo], order 1 (weights): [hi | lo | hi], hi = fp16(v),
  * lo = fp16(v - hi) - so that ONE fp16 GEMM over K' = 3K computes xh.wh + xh.wl + xl.wh with fp32 accumulation
- * (error ~3 * 2^-22 per product; psg_split.hip).  inv_scale[row] = the power of two that undoes the row's scaling;
+ * (error ~3 * 2^-22 per product; psg_split.hip).  order 2 (round 6, either operand of psg_dense_gemm_split; K % 32 == 0):
+ * out [rows][2 K], per 32 k [hi(32) | lo(32)] - every value once.  inv_scale[row] = the power of two that undoes the row's scaling;
  * psg_scale_rows_cols applies y[m][n] *= row_scale[m] * col_scale[n] in place (exact). */
 int psg_split_f16x3(psg_ctx*, const float* x, int64_t rows, int K, int64_t row_stride, int order, void* out,
                     float* inv_scale, void* stream);
@@ -450,6 +464,14 @@ int psg_dense_gemm_tiled(psg_ctx*, const void* x, const void* w, const float* bi
                          int N, int K, int dtype, int out_dtype, const float* row_scale, const float* col_scale, int tile,
                          void* stream);
 int psg_interleave_gate_up(psg_ctx*, const void* gate_up, void* out, int inter, int K, void* stream);
+/* Round 6: the split-fp16 product with every operand value staged ONCE.  x2 [M][K2], w2 [N][K2] fp16 are
+ * psg_split_f16x3(order = 2) images of fp32 matrices - per 32 k [hi(32) | lo(32)], K2 = 2 K - and
+ * out[m][n] = epilogue((xh.wh + xh.wl + xl.wh)[m][n] * row_scale[m] * col_scale[n] + bias[n]) in fp32: the three products
+ * of psg_dense_gemm_ex's K' = 3K form (HF-IB / HF-LL nn.Linear at the reference's fp32, V4:78-84, 99-100) from one
+ * staging of each part, 2/3 of the operand bytes per flop.  One k-ordered accumulation per element (row-count and tile
+ * invariant).  epilogue: PSG_EPI_NONE | PSG_EPI_GELU; tile: PSG_TILE_AUTO, 256x256, 256x128, 256x64, 128x128. */
+int psg_dense_gemm_split(psg_ctx*, const void* x2, const void* w2, const float* bias, int epilogue, float* out, int64_t M,
+                         int N, int K2, const float* row_scale, const float* col_scale, int tile, void* stream);
 
 /* ---- K16: greedy step (HF generate, num_beams=1, do_sample=False; V4:305-312).
  * logits [K][vocab] (dtype); token = argmax (first maximal index); suppress_token >= 0 is

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpsg_hip.so")
 
-PSG_ABI_VERSION = 501            # include/psg_hip.h; checked against psg_version() of the loaded library
+PSG_ABI_VERSION = 600            # include/psg_hip.h; checked against psg_version() of the loaded library
 PSG_F32, PSG_BF16, PSG_F16 = 0, 1, 2
 PSG_EMPTY_UNIFORM, PSG_EMPTY_UNMASKED = 0, 1
 PSG_XATTN_MFMA, PSG_XATTN_SIMPLE, PSG_XATTN_MFMA_V1 = 0, 1, 2
@@ -78,6 +78,8 @@ SIGNATURES = {
     "psg_batch_gemm": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "psg_split_f16x2": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp],
     "psg_rmsnorm_split2": [_vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _vp, _vp],
+    "psg_decode_attn_split2": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "psg_silu_mul_split2": [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp],
     "psg_split_gemm_w16_plan": [_vp, _i, _i, _i, _i, C.POINTER(_i)],
     "psg_split_gemm_w16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "psg_qformer_cross_attn_indexed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
@@ -100,6 +102,7 @@ SIGNATURES = {
     "psg_dense_gemm_ex": [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp],
     "psg_dense_gemm_tiled": [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "psg_interleave_gate_up": [_vp, _vp, _vp, _i, _i, _vp],
+    "psg_dense_gemm_split": [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _i, _vp],
     "psg_train_layernorm_fwd": [_vp, _vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp, _vp],
     "psg_train_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp],
     "psg_train_rmsnorm_fwd": [_vp, _vp, _vp, _f, _i64, _i, _vp, _vp, _vp],

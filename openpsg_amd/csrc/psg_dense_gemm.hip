@@ -79,7 +79,15 @@ __device__ __forceinline__ dg_u32x4 dg_lds_read128(uint32_t a) {
 // (w[16 p + r] = gate[8 p + r], w[16 p + 8 + r] = up[8 p + r], r < 8: psg_interleave_gate_up), so a lane's accumulator
 // chunks alternate gate / up of the SAME 4 columns; out[m][8 p + r] = silu(gate) * up, N / 2 columns, with the
 // roundings of the separate kernels (GEMM output, act_fn(gate), product: psg_silu_mul).
-template <typename E, int EPI, int VAR, int OUT32, int WM, int WN, int TI, int TJ>
+//
+// SPL (psg_dense_gemm_split, fp32s mode): BOTH operands are psg_split_f16x3(order 2) images of fp32 matrices - per 32 k
+// [hi(32) | lo(32)], 2K elements per row - so a 64-element K tile is one 32-wide block of the original K with its high
+// parts in 16-byte pieces 0..3 and its low parts in pieces 4..7.  The tile is staged ONCE and feeds three products,
+//     acc += xh.wh + xh.wl + xl.wh        (6 MFMA groups per K tile: A pieces (0,1) x B (0,1), A (0,1) x B (2,3), A (2,3) x B (0,1))
+// against the K' = 3K form's [xh | xh | xl] . [wh | wl | wh]^T, which stages xh and wh twice: 3 products from 64 KB of
+// operand tiles instead of 2 - this kernel waits for its operand tiles, not for the matrix pipe (see above), so that is
+// its speed.  Still ONE k-ordered accumulation per output element (per block: hh, hl, lh), independent of M and tile.
+template <typename E, int EPI, int VAR, int OUT32, int WM, int WN, int TI, int TJ, int SPL = 0>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 2 : 1))
 dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
                   uint16_t* __restrict__ out, int M, int N, int K, const float* __restrict__ row_scale,
@@ -219,6 +227,52 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
       acc[i][j] = E::mfma32(BF[j].v, AF[i].v, acc[i][j]);   /* D[n][m]: swapped operands */       \
     }                                                                                             \
   }
+      if constexpr (SPL) {
+        // pieces 2 s + hi: s = 0, 1 high parts (k 0..15, 16..31 of the block), s = 2, 3 low parts.  Reads return in order
+        Frag bl[2][TJ];
+        auto read_a = [&](int sub, Frag (&a_)[TI]) {
+          const uint32_t piece = (uint32_t)(2 * sub + hi);
+#pragma unroll
+          for (int i = 0; i < TI; ++i) a_[i].u = dg_lds_read128(base + arow[i] + ((piece ^ aswz[i]) << 4));
+        };
+        auto read_b = [&](int sub, Frag (&b_)[TJ]) {
+          const uint32_t piece = (uint32_t)(2 * sub + hi);
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) b_[j].u = dg_lds_read128(base + brow[j] + ((piece ^ bswz[j]) << 4));
+        };
+        read_frags(0, af[0], bf[0]);
+        read_frags(1, af[1], bf[1]);
+        if (pf) stage_x(pm0, pkt, buf ^ 1);
+        dg_lgkmwait<TI + TJ>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        DG_MMA(af[0], bf[0])                                  // xh . wh, k 0..15
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(2, bl[0]);
+        if (pf) stage_w(pn0, pkt, buf ^ 1);
+        dg_lgkmwait<TJ>();
+        __builtin_amdgcn_sched_barrier(0);
+        DG_MMA(af[1], bf[1])                                  // xh . wh, k 16..31
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(3, bl[1]);
+        dg_lgkmwait<TJ>();
+        __builtin_amdgcn_sched_barrier(0);
+        DG_MMA(af[0], bl[0])                                  // xh . wl, k 0..15
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(2, af[0]);
+        dg_lgkmwait<TI>();
+        __builtin_amdgcn_sched_barrier(0);
+        DG_MMA(af[1], bl[1])                                  // xh . wl, k 16..31
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(3, af[1]);
+        dg_lgkmwait<TI>();
+        __builtin_amdgcn_sched_barrier(0);
+        DG_MMA(af[0], bf[0])                                  // xl . wh, k 0..15
+        dg_lgkmwait<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        DG_MMA(af[1], bf[1])                                  // xl . wh, k 16..31
+        __builtin_amdgcn_s_setprio(0);
+      } else {
       read_frags(0, af[0], bf[0]);
       read_frags(1, af[1], bf[1]);
       if (pf) stage_x(pm0, pkt, buf ^ 1);
@@ -241,6 +295,7 @@ dense_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
       __builtin_amdgcn_sched_barrier(0);
       DG_MMA(af[1], bf[1])
       __builtin_amdgcn_s_setprio(0);
+      }
 #undef DG_MMA
       // no barrier here: this buffer is refilled by DMAs that are issued after the NEXT K step's barrier, which
       // every wave reaches only after its own lgkmcnt(0) above, i.e. after its last read of this buffer
@@ -369,7 +424,7 @@ static const dg_geom DG_GEOMS[] = {
     {PSG_TILE_256x64, 8, 1, 1, 2},  {PSG_TILE_128x128, 2, 2, 2, 2},
 };
 
-template <typename E, int EPI, int VAR, int OUT32, int WM, int WN, int TI, int TJ>
+template <typename E, int EPI, int VAR, int OUT32, int WM, int WN, int TI, int TJ, int SPL = 0>
 static int dg_launch(psg_ctx* ctx, const void* x, const void* w, const float* bias, void* out, int64_t M, int N, int K,
                      const float* row_scale, const float* col_scale, void* stream) {
   constexpr int BM = WM * TI * 32, BN = WN * TJ * 32;
@@ -378,7 +433,7 @@ static int dg_launch(psg_ctx* ctx, const void* x, const void* w, const float* bi
   int grid_i = ctx->num_cu / 8 * 8;                          // persistent: one workgroup per CU, a multiple of 8 (XCD map)
   if (grid_i > ntile) grid_i = ntile;
   const size_t lds = 2 * (size_t)(BM + BN) * 128;
-  auto k = dense_gemm_kernel<E, EPI, VAR, OUT32, WM, WN, TI, TJ>;
+  auto k = dense_gemm_kernel<E, EPI, VAR, OUT32, WM, WN, TI, TJ, SPL>;
   hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     psg_set_error("psg_dense_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -493,6 +548,40 @@ extern "C" int psg_dense_gemm_tiled(psg_ctx* ctx, const void* x, const void* w, 
 #undef DG_TILE32
 #undef DGL
   psg_set_error("psg_dense_gemm: unknown tile %d", tile);
+  return PSG_ERR_INVALID;
+}
+
+// ---- fp32-grade product of two fp32 matrices given as interleaved hi / lo fp16 images (psg_split_f16x3 order 2) ---------
+extern "C" int psg_dense_gemm_split(psg_ctx* ctx, const void* x2, const void* w2, const float* bias, int epilogue, float* out,
+                                    int64_t M, int N, int K2, const float* row_scale, const float* col_scale, int tile,
+                                    void* stream) {
+  PSG_REQUIRE(ctx && x2 && w2 && out && row_scale && col_scale, PSG_ERR_INVALID, "psg_dense_gemm_split: NULL argument");
+  PSG_REQUIRE(M >= 0 && N > 0 && K2 > 0 && M < (1ll << 31), PSG_ERR_INVALID, "psg_dense_gemm_split: M=%lld N=%d K2=%d",
+              (long long)M, N, K2);
+  PSG_REQUIRE(N % 16 == 0 && K2 % DG_BK == 0, PSG_ERR_UNSUPPORTED,
+              "psg_dense_gemm_split: N=%d must be a multiple of 16 and K2=%d (= 2 K) of %d", N, K2, DG_BK);
+  PSG_REQUIRE(epilogue == PSG_EPI_NONE || epilogue == PSG_EPI_GELU, PSG_ERR_INVALID, "psg_dense_gemm_split: epilogue=%d",
+              epilogue);
+  if (M == 0) return PSG_OK;
+  if (tile == PSG_TILE_AUTO) tile = dg_auto_tile(ctx, M, N, true);
+  const void* x = x2;
+  const void* w = w2;
+  const int K = K2;
+#define DGS(WM, WN, TI, TJ)                                                                                              \
+  do {                                                                                                                   \
+    if (epilogue == PSG_EPI_GELU)                                                                                        \
+      return dg_launch<EF16, PSG_EPI_GELU, 0, 1, WM, WN, TI, TJ, 1>(ctx, x, w, bias, out, M, N, K, row_scale, col_scale, stream); \
+    return dg_launch<EF16, PSG_EPI_NONE, 0, 1, WM, WN, TI, TJ, 1>(ctx, x, w, bias, out, M, N, K, row_scale, col_scale, stream);   \
+  } while (0)
+  switch (tile) {
+    case PSG_TILE_256x256: DGS(2, 4, 4, 2);
+    case PSG_TILE_256x128: DGS(4, 2, 2, 2);
+    case PSG_TILE_256x64: DGS(8, 1, 1, 2);
+    case PSG_TILE_128x128: DGS(2, 2, 2, 2);
+    default: break;
+  }
+#undef DGS
+  psg_set_error("psg_dense_gemm_split: tile %d (256x256, 256x128, 256x64, 128x128 or auto)", tile);
   return PSG_ERR_INVALID;
 }
 

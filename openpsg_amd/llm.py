@@ -277,6 +277,8 @@ class LlamaDecodeEngine:
         # job) then gives the bits it gives in the batch of 20.  ~1.3x the prompt pass's GEMM time: the sharded
         # pipeline switches it on, a single GPU does not need it
         self.row_invariant = False
+        self.split_i2 = bool(_lib0.get_option(self.device.index or 0, "split_i2"))
+        self._i2_w = {}
         self.proj_s = ops.split_f16x3(self.proj_w, weights=True) if self.prefill_split else None
         # greedy argmax over the fp32 split-K sums of the lm_head, NOT over their 16-bit rounding: HF computes the logits of
         # a model cast to 16 bits in 16 bits, but the reference runs the LLM in fp32 (V4:99-100), and a 16-bit logit has
@@ -299,6 +301,7 @@ class LlamaDecodeEngine:
         # fp32s prompt pass: the split of a projection's operand and the un-scaling of its result inside the row kernels
         # next to it (psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split; bit-identical, 7 launches per layer less)
         self.fuse_split = bool(_lib.get_option(dev_i, "llm_fuse_split"))
+        self.fuse_split2 = bool(_lib.get_option(dev_i, "decode_fuse_split2"))
         # fp32s prompt pass: run each library product whole or in the column / row parts measured fastest (_plan_split_mm)
         self.plan_split = True
         # decode steps of 33..160 rows: psg_batch_gemm where it beats the library (option decode_batch_gemm)
@@ -322,16 +325,30 @@ class LlamaDecodeEngine:
         ang = torch.arange(4096, dtype=torch.float32)[:, None] * inv_freq[None, :]
         self.rope = (ang.cos().contiguous().to(self.device), ang.sin().contiguous().to(self.device))
 
-    def linear_split(self, x, ws):
+    def linear_split(self, x, ws, w=None):
         """x [rows, K] fp32 @ w.T as ONE fp16 matrix-core GEMM over 3K: [xh | xh | xl] . [wh | wl | wh]^T with fp32
         accumulation, rows and columns rescaled by their powers of two afterwards (exact).  Products of fp16 values
         are exact in fp32, so what is lost against an fp32 GEMM is the xl.wl term and the split residuals: ~7e-7
         relative per product (fp32 rounds each product to 6e-8), at 3/16 of the fp32 matrix time."""
-        a3, inv_r = ops.split_f16x3(x)
         if self.row_invariant and ws[0].shape[0] % 256 == 0 and ws[0].shape[1] % 64 == 0:
+            if self.split_i2 and w is not None and w.shape[1] % 32 == 0:
+                # round 6: interleaved hi / lo images, the three products from one staging (psg_dense_gemm_split)
+                w2 = self._i2_weight(w)
+                a2, inv_r = ops.split_f16i2(x)
+                return ops.dense_gemm_split(a2, w2[0], None, inv_r, w2[1], tile="256x256")
+            a3, inv_r = ops.split_f16x3(x)
             return ops.dense_gemm(a3, ws[0], None, out_dtype=torch.float32, row_scale=inv_r, col_scale=ws[1])
+        a3, inv_r = ops.split_f16x3(x)
         y = _split_mm(a3, ws[0], _plan_split_mm(a3.shape[0], ws[0]) if self.plan_split else None)
         return ops.scale_rows_cols(y, inv_r, ws[1])
+
+    def _i2_weight(self, w):
+        """The interleaved hi / lo image of a projection weight (+ its rows' inverse scales), made at first use: only the
+        row-invariant path (the dealt decodes of a pair-sharded job) reads it - 4 bytes per weight next to the fp32 tensor."""
+        ent = self._i2_w.get(w.data_ptr())
+        if ent is None:
+            ent = self._i2_w[w.data_ptr()] = ops.split_f16i2(w)
+        return ent
 
     def linear(self, x, w, ws=None, decode=False):
         """Bias-free projection.  Decode-step shapes (<= 32 rows) use the hand-written weight-streaming kernel - in
@@ -357,8 +374,24 @@ class LlamaDecodeEngine:
             # the 16-bit prompt pass of several images (forward_batch: 2 / 4 / 8 x 960 rows): the library's pick for the
             # whole product against its column / row parts (_plan_split_mm; 7-14 % per layer at 1920-7680 rows, nothing at 960)
             return _split_mm(x, w, _plan_split_mm(x.shape[0], w, None, pool=self._w_pools.get(tuple(w.shape))), None)
+        if decode and x.dtype == torch.float32 and x.shape[0] > 32:
+            # fp32 engines, decode steps of 33..160 rows (several images' pairs, head.forward_batch - BASELINE C5's batch of 8
+            # at the reference's precision): the weight leaves HBM ONCE per step for all rows.  fp16-valued weights of an
+            # fp32s engine: the two planes of the split rows [xh; xl] against the fp16 copy in ONE library product with an
+            # fp32 result (2 bytes per weight, 2^-22 per product - the arithmetic of psg_split_gemm_w16); generic fp32
+            # weights: the library SGEMM, exact (4 bytes per weight) - NOT the three-segment split product of the prompt
+            # pass, which would stream 6 bytes per weight for flops a 160-row step does not need to save
+            wh = self._w16.get(w.data_ptr()) if self.prefill_split else None
+            if wh is not None and w.shape[1] % 8 == 0:
+                a2, inv = ops.split_f16x2(x)
+                y2 = torch.mm(a2.view(2 * x.shape[0], x.shape[1]), wh.t(), out_dtype=torch.float32)
+                ones = self._ones.get(w.shape[0])
+                if ones is None:
+                    ones = self._ones[w.shape[0]] = torch.ones(w.shape[0], device=self.device, dtype=torch.float32)
+                return ops.Scaled(y2.view(2, x.shape[0], w.shape[0]), inv, ones).dense()
+            return F.linear(x, w)
         if ws is not None and x.dtype == torch.float32:
-            return self.linear_split(x, ws)
+            return self.linear_split(x, ws, w)
         return F.linear(x, w)
 
     def logits(self, h):
@@ -574,18 +607,31 @@ class LlamaDecodeEngine:
         x, wh = st["x"], self._w16
         K, D = x.shape
         att = torch.empty((K, D), device=self.device, dtype=torch.float32)
+        # round 6 (option decode_fuse_split2): the attention output and the SwiGLU gate leave their kernels as planes - the
+        # workgroups of a row meet at a device word for the row maximum (psg_decode_attn_split2 / psg_silu_mul_split2)
+        # instead of a psg_split_f16x2 launch each; bit-identical.  The decode state owns the rendezvous words
+        fuse2 = self.fuse_split2 and K <= 32 and m.heads <= 64
+        if fuse2 and "sync2" not in st:
+            st["sync2"] = torch.zeros(2 * 4 * 32, device=self.device, dtype=torch.int32)
         a2, inv = ops.rmsnorm_split2(x, None, self.layers[0]["ln1"], m.rms_eps)
         for l, L in enumerate(self.layers):
             qkv = ops.split_gemm_w16(a2, inv, wh[L["wqkv"].data_ptr()])
-            ops.decode_attn(qkv, st["dec_pair"], st["dec_pos"], self.rope, m.heads, m.head_dim, st["ctx_len"], st["kc"][l],
-                            st["vc"][l], att)
-            a2o, invo = ops.split_f16x2(att)                   # a row's maximum spans all heads: a launch of its own
+            if fuse2:
+                a2o, invo = ops.decode_attn_split2(qkv, st["dec_pair"], st["dec_pos"], self.rope, m.heads, m.head_dim,
+                                                   st["ctx_len"], st["kc"][l], st["vc"][l], st["sync2"][:128])
+            else:
+                ops.decode_attn(qkv, st["dec_pair"], st["dec_pos"], self.rope, m.heads, m.head_dim, st["ctx_len"], st["kc"][l],
+                                st["vc"][l], att)
+                a2o, invo = ops.split_f16x2(att)               # a row's maximum spans all heads: a launch of its own
             o = ops.split_gemm_w16(a2o, invo, wh[L["wo"].data_ptr()])
             a2, inv = ops.rmsnorm_split2(x, o, L["ln2"], m.rms_eps)
             gu = ops.split_gemm_w16(a2, inv, wh[L["wgu"].data_ptr()])
-            act = torch.empty((K, m.inter), device=self.device, dtype=torch.float32)
-            ops.silu_mul(gu, act)                              # (one workgroup per row for the row maximum was measured at
-            a2a, inva = ops.split_f16x2(act)                   # 24 us against 5.2 + 4.9 for these two launches)
+            if fuse2:
+                a2a, inva = ops.silu_mul_split2(gu, m.inter, st["sync2"][128:])
+            else:
+                act = torch.empty((K, m.inter), device=self.device, dtype=torch.float32)
+                ops.silu_mul(gu, act)                          # (one workgroup per row for the row maximum was measured at
+                a2a, inva = ops.split_f16x2(act)               # 24 us against 5.2 + 4.9 for these two launches)
             d = ops.split_gemm_w16(a2a, inva, wh[L["wdown"].data_ptr()])
             nxt = self.layers[l + 1]["ln1"] if l + 1 < len(self.layers) else self.final_norm
             a2, inv = ops.rmsnorm_split2(x, d, nxt, m.rms_eps)
@@ -643,9 +689,14 @@ class LlamaDecodeEngine:
         nv = self.cfg.qformer.num_query
         X = torch.empty((K, nv + Tp, m.hidden), device=self.device, dtype=self.dtype)
         if self.row_invariant and self.proj_s is not None and m.hidden % 256 == 0 and pair_feature_rows.shape[1] % 64 == 0:
-            a3, inv_r = ops.split_f16x3(pair_feature_rows.contiguous())
-            vis = ops.dense_gemm(a3, self.proj_s[0], self.proj_b, out_dtype=torch.float32, row_scale=inv_r,
-                                 col_scale=self.proj_s[1]).view(K, nv, m.hidden)
+            if self.split_i2 and pair_feature_rows.shape[1] % 32 == 0:
+                w2 = self._i2_weight(self.proj_w)
+                a2, inv_r = ops.split_f16i2(pair_feature_rows.contiguous())
+                vis = ops.dense_gemm_split(a2, w2[0], self.proj_b, inv_r, w2[1], tile="256x256").view(K, nv, m.hidden)
+            else:
+                a3, inv_r = ops.split_f16x3(pair_feature_rows.contiguous())
+                vis = ops.dense_gemm(a3, self.proj_s[0], self.proj_b, out_dtype=torch.float32, row_scale=inv_r,
+                                     col_scale=self.proj_s[1]).view(K, nv, m.hidden)
         else:
             vis = F.linear(pair_feature_rows, self.proj_w, self.proj_b).view(K, nv, m.hidden)
         X[:, :nv] = vis

@@ -596,6 +596,39 @@ def rmsnorm_split2(resid, delta, w, eps):
     return out, inv
 
 
+def decode_attn_split2(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, k_cache, v_cache, sync):
+    """`decode_attn` on an fp32 cache with the output written as the two fp16 planes of `split_f16x2` (fp16
+    [2, rows, hidden], inv_scale [rows]): the head workgroups of a row meet at `sync` (int32 [4 rows], zero before the
+    first launch, zero again afterwards) for the row maximum - no split launch.  Bit-identical to decode_attn + split_f16x2."""
+    lib, ctx, st = _env(k_cache)
+    assert k_cache.dtype == torch.float32 and sync.dtype == torch.int32
+    if isinstance(qkv, Partials):
+        qp, qs, rows = _p(qkv.t, torch.float32), qkv.splits, qkv.shape[0]
+    else:
+        qp, qs, rows = _p(qkv, torch.float32), 0, qkv.shape[0]
+    assert sync.numel() >= 4 * rows
+    out = torch.empty((2, rows, heads * head_dim), device=k_cache.device, dtype=torch.float16)
+    inv = torch.empty(rows, device=k_cache.device, dtype=torch.float32)
+    check(lib.psg_decode_attn_split2(ctx, qp, qs, _p(tok_pair, torch.int32), _p(tok_pos, torch.int32), _p(rope[0], torch.float32),
+                                     _p(rope[1], torch.float32), rows, heads, head_dim, ctx_len, _p(k_cache), _p(v_cache), _p(out),
+                                     _p(inv), _p(sync), st), "psg_decode_attn_split2")
+    return out, inv
+
+
+def silu_mul_split2(gate_up: Partials, inter, sync):
+    """silu(gate) * up of the gate|up split-K slices as the two fp16 planes of `split_f16x2` (fp16 [2, rows, inter],
+    inv_scale [rows]); row rendezvous at `sync` as in `decode_attn_split2`.  Bit-identical to silu_mul + split_f16x2."""
+    lib, ctx, st = _env(gate_up.t)
+    assert isinstance(gate_up, Partials) and sync.dtype == torch.int32
+    rows = gate_up.shape[0]
+    assert gate_up.shape[1] == 2 * inter and sync.numel() >= 4 * rows
+    out = torch.empty((2, rows, inter), device=gate_up.t.device, dtype=torch.float16)
+    inv = torch.empty(rows, device=gate_up.t.device, dtype=torch.float32)
+    check(lib.psg_silu_mul_split2(ctx, _p(gate_up.t, torch.float32), gate_up.splits, rows, inter, _p(out), _p(inv), _p(sync), st),
+          "psg_silu_mul_split2")
+    return out, inv
+
+
 def split_gemm_w16(x2, inv_scale, w16, mode=0) -> Partials:
     """Decode-step projection of fp32 rows against a weight that is an fp16 value (frozen fp16 checkpoint): two fp16
     products (high and low part of x) on the 16-bit matrix cores, fp32 slices [S, M, N] like `skinny_gemm`'s;
@@ -779,6 +812,22 @@ def dense_gemm(x, w, bias=None, gelu=False, out=None, out_dtype=None, row_scale=
     return out
 
 
+def dense_gemm_split(x2, w2, bias, row_scale, col_scale, gelu=False, out=None, tile="auto"):
+    """fp32 out = [gelu]((xh.wh + xh.wl + xl.wh) * row_scale[:, None] * col_scale[None, :] + bias) for two fp32 matrices
+    given as `split_f16i2` images ([rows, 2K] fp16: per 32 k the high parts, then the low parts): the fp32-grade product
+    of the fp32s mode with every operand value staged once (psg_dense_gemm_split).  Row-count and tile invariant."""
+    lib, ctx, st = _env(x2)
+    M, K2 = x2.shape
+    N = w2.shape[0]
+    assert w2.shape[1] == K2 and x2.dtype == torch.float16 and w2.dtype == torch.float16
+    out = torch.empty((M, N), device=x2.device, dtype=torch.float32) if out is None else out
+    assert out.shape == (M, N) and out.dtype == torch.float32
+    check(lib.psg_dense_gemm_split(ctx, _p(x2, name="x2"), _p(w2, name="w2"), _p(bias, torch.float32, "bias"),
+                                   1 if gelu else 0, _p(out, torch.float32), M, N, K2, _p(row_scale, torch.float32, "row_scale"),
+                                   _p(col_scale, torch.float32, "col_scale"), TILES[tile], st), "psg_dense_gemm_split")
+    return out
+
+
 def interleave_gate_up(w_gate_up):
     """[2 inter, K] (gate rows, then up rows) -> the row order the SwiGLU epilogue of `dense_gemm` reads: groups of 16
     rows = 8 gate rows, then the 8 up rows of the same columns."""
@@ -799,6 +848,18 @@ def split_f16x3(x, weights=False):
     inv = torch.empty(rows, device=x.device, dtype=torch.float32)
     check(lib.psg_split_f16x3(ctx, x.data_ptr(), rows, K, x.stride(0), 1 if weights else 0, _p(out), _p(inv), st),
           "psg_split_f16x3")
+    return out, inv
+
+
+def split_f16i2(x):
+    """fp32 rows -> (fp16 [rows, 2K]: per 32 k [hi(32) | lo(32)], inv_scale fp32 [rows]) - an operand of
+    `dense_gemm_split` (activations and weights alike; psg_split_f16x3 order 2).  K % 32 == 0."""
+    lib, ctx, st = _env(x)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] % 32 == 0
+    rows, K = x.shape
+    out = torch.empty((rows, 2 * K), device=x.device, dtype=torch.float16)
+    inv = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(lib.psg_split_f16x3(ctx, x.data_ptr(), rows, K, x.stride(0), 2, _p(out), _p(inv), st), "psg_split_f16x3")
     return out, inv
 
 

@@ -38,6 +38,7 @@ class RelationQueryEngine:
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.res32 = resid_dtype == torch.float32 and dtype != torch.float32
         self.split = bool(split) and dtype == torch.float32
+        self.split_i2 = bool(_lib.get_option(self.device.index or 0, "split_i2")) if self.split else False
         self._split_w, self._bias32 = {}, {}
         self.own_gemm = int(_lib.get_option(self.device.index or 0, "qformer_own_gemm"))
         self.xattn_variant = xattn_variant
@@ -482,15 +483,20 @@ class RelationQueryEngine:
         N, K = w.shape
         fits = N % 256 == 0 and K % 64 == 0 and x.shape[0] > 0
         if self.split and fits and x.dtype == torch.float32:
-            key = (w.data_ptr(), N, K)
+            i2 = self.split_i2 and K % 32 == 0                 # round 6: every operand value staged once (psg_dense_gemm_split)
+            key = (w.data_ptr(), N, K, i2)
             ws = self._split_w.get(key)
             if ws is None:
-                ws = self._split_w[key] = ops.split_f16x3(w, weights=True)
-            a3, inv_r = ops.split_f16x3(x)
+                ws = self._split_w[key] = ops.split_f16i2(w) if i2 else ops.split_f16x3(w, weights=True)
             # (a row's result does not depend on the tile: below ~30 k rows the 256 x 256 tile leaves most CUs idle -
             # 2500 x 768 is 30 tiles - and the geometry that fills them in the fewest rounds is taken instead)
+            tile = "auto" if x.shape[0] < 16384 else "256x256"
+            if i2:
+                a2, inv_r = ops.split_f16i2(x)
+                return ops.dense_gemm_split(a2, ws[0], b, inv_r, ws[1], gelu=gelu, tile=tile)
+            a3, inv_r = ops.split_f16x3(x)
             return ops.dense_gemm(a3, ws[0], b, gelu=gelu, out_dtype=torch.float32, row_scale=inv_r, col_scale=ws[1],
-                                  tile="auto" if x.shape[0] < 16384 else "256x256")
+                                  tile=tile)
         if self.own_gemm >= 2 and fits and x.dtype != torch.float32 and x.is_contiguous():
             if b is not None and b.dtype != torch.float32:
                 key = (b.data_ptr(), N)

@@ -231,6 +231,53 @@ def test_decode_attn_split_inputs_vs_fp32_torch(splits, rows, heads, ctx):
         assert torch.equal(kc[r, :, :p].cpu(), kc0[r, :, :p]) and torch.isnan(kc[r, :, p + 1:].float()).all()
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
+def test_decode_attn_every_dtype_long_contexts_and_poisoned_rows(dtype, tol):
+    """psg_decode_attn in the three cache types (fp32 = the headline's KV cache) over contexts of 0 .. 199 cached
+    positions - the 64-key passes of the round-6 layout (two whole cache rows per load instruction, a 32-lane
+    transposing sum per key) with full, partial and empty last passes - with every unwritten cache row set to NaN:
+    against fp32 torch (HF-LL:130-160, 191-214)."""
+    from openpsg_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(7)
+    heads, ctx = 4, 200
+    D = heads * 128
+    pos = torch.tensor([0, 1, 2, 15, 16, 17, 31, 33, 47, 48, 63, 64, 65, 79, 80, 127, 128, 129, 150, 199])
+    rows = pos.numel()
+    qkv = torch.randn(rows, 3 * D, generator=gen)
+    kc0 = torch.randn(rows, heads, ctx, 128, generator=gen).to(dtype)
+    vc0 = torch.randn(rows, heads, ctx, 128, generator=gen).to(dtype)
+    ang = torch.arange(ctx, dtype=torch.float32)[:, None] / (10000 ** (torch.arange(0, 128, 2).float() / 128))[None]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    kc, vc = kc0.clone().to(dev), vc0.clone().to(dev)
+    for r in range(rows):
+        kc[r, :, int(pos[r]):] = float("nan")
+        vc[r, :, int(pos[r]):] = float("nan")
+    pair = torch.arange(rows, dtype=torch.int32, device=dev)
+    x_in = ops.Partials(_split(qkv.to(dev), 4, gen))
+    qkv_eff = x_in.t.sum(0).cpu()
+    out = torch.empty(rows, D, device=dev, dtype=dtype)
+    ops.decode_attn(x_in, pair, pos.to(torch.int32).to(dev), (cos, sin), heads, 128, ctx, kc, vc, out)
+    torch.cuda.synchronize()
+    q, k, v = [t.view(rows, heads, 128) for t in qkv_eff.split(D, dim=1)]
+    c, s_ = cos.cpu()[pos][:, None, :], sin.cpu()[pos][:, None, :]
+    qr, kr = _rope_ref(q, c, s_), _rope_ref(k, c, s_)
+    worst = 0.0
+    for r in range(rows):
+        p = int(pos[r])
+        K_ = torch.cat([kc0[r, :, :p].float(), kr[r][:, None].to(dtype).float()], dim=1)
+        V_ = torch.cat([vc0[r, :, :p].float(), v[r][:, None].to(dtype).float()], dim=1)
+        sc = torch.einsum("hd,hjd->hj", qr[r].to(dtype).float(), K_) / 128 ** 0.5
+        ref = torch.einsum("hj,hjd->hd", torch.softmax(sc, -1), V_)
+        got = out[r].float().cpu().view(heads, 128)
+        assert torch.isfinite(got).all(), f"row {r} (pos {p}) read an unwritten cache row"
+        worst = max(worst, (got - ref).abs().max().item())
+        assert torch.equal(kc[r, :, :p].cpu(), kc0[r, :, :p]) and torch.isnan(kc[r, :, p + 1:].float()).all()
+        assert torch.isfinite(kc[r, :, p].float()).all() and torch.isfinite(vc[r, :, p].float()).all()
+    print(f"decode_attn {dtype}: max |out - fp32 torch| = {worst:.3e} over contexts 0..199")
+    assert worst < tol
+
+
 @pytest.mark.parametrize("splits", [0, 4, 8])
 @pytest.mark.parametrize("rows,D", [(20, 4096), (900, 4096), (5, 512)])
 def test_rmsnorm_split_delta_vs_fp32_torch(splits, rows, D):

@@ -187,6 +187,44 @@ def test_dense_gemm_fp32_output_with_split_scales(M, N, K, gelu):
         assert torch.equal(y2, y[:m2])
 
 
+@pytest.mark.parametrize("M,N,K,gelu", [(2500 * 3, 768, 768, False), (980, 4096, 4096, False), (515, 3072, 768, True),
+                                        (33, 2304, 768, False), (700, 768, 3072, False), (260, 4096, 11008, False)])
+def test_dense_gemm_split_three_products_from_one_staging(M, N, K, gelu):
+    """psg_dense_gemm_split (round 6): both operands as interleaved hi / lo fp16 images (psg_split_f16x3 order 2), the
+    three products xh.wh + xh.wl + xl.wh formed from ONE staging of each part - the Q-Former's / the row-invariant
+    prompt pass's Linear layers in the fp32s mode (HF-IB:519-596, HF-LL:163-177 at V4:99-100's fp32): against fp64 with
+    the bound of the K' = 3K form, row-count invariance bit for bit, tile invariance bit for bit, and the layout of the
+    split image itself."""
+    from openpsg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    x = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 6, (M, 1), generator=g).float())).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    a2, inv_r = ops.split_f16i2(x)
+    b2, inv_c = ops.split_f16i2(w)
+    # the image: per 32 k [hi | lo], the same row scale as the three-segment form
+    a3, inv3 = ops.split_f16x3(x)
+    assert torch.equal(inv_r, inv3)
+    blocks = a2.view(M, K // 32, 2, 32)
+    assert torch.equal(blocks[:, :, 0].reshape(M, K), a3[:, :K]) and torch.equal(blocks[:, :, 1].reshape(M, K), a3[:, 2 * K:])
+    y = ops.dense_gemm_split(a2, b2, b, inv_r, inv_c, gelu=gelu)
+    ref = x.double() @ w.double().t() + b.double()
+    bound = (x.double().abs() @ w.double().abs().t()) + b.double().abs() + 1e-300
+    if gelu:
+        err = (y.double() - torch.nn.functional.gelu(ref)).abs().max().item()
+        assert err < 2e-5
+    else:
+        rel = ((y.double() - ref).abs() / bound).max().item()
+        print(f"M={M} N={N} K={K}: {rel:.2e} x sum|x w|")
+        assert rel < 1.5e-6
+    for m2 in (1, min(M, 257)):                                          # a row does not depend on the rows beside it
+        s2, r2 = ops.split_f16i2(x[:m2].contiguous())
+        assert torch.equal(ops.dense_gemm_split(s2, b2, b, r2, inv_c, gelu=gelu), y[:m2])
+    for tile in ("256x256", "256x128", "256x64", "128x128"):             # ... nor on the tile it falls into
+        assert torch.equal(ops.dense_gemm_split(a2, b2, b, inv_r, inv_c, gelu=gelu, tile=tile), y), tile
+
+
 def test_fused_split_kernels_equal_the_separate_kernels_bit_for_bit():
     """psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split against psg_scale_rows_cols + psg_rmsnorm /
     psg_rope_kvwrite / psg_silu_mul + psg_split_f16x3 on the prompt pass's shapes: identical bits (no GEMM involved)."""

@@ -71,10 +71,13 @@ def _inputs(scene):
                 object_info=[dict(object_id_list=scene["object_id_list"], pan_results=scene["pan_results"])])
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp32s", "fp32s_w16"])
 def test_forward_batch_matches_per_image(setup, dtype):
     """Several images decoded together (60 LLM rows per step) give each image the triplets of its own
-    forward() call; images of different object counts and prompt lengths share one batch."""
+    forward() call; images of different object counts and prompt lengths share one batch.
+    fp32s / fp32s_w16 (round 6): the throughput mode at the reference's precision - decode steps of 60 rows on the
+    library SGEMM (generic fp32 weights) or on one two-plane fp16 product per projection (fp16-valued weights, streamed
+    as fp16): the tokens of each image are those of its single-image decode (V4:112 lifted; V4:293-312)."""
     from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
     from openpsg_amd.head import RelationTransformerHeadV4
     from openpsg_amd.synthetic import make_scene
@@ -83,10 +86,12 @@ def test_forward_batch_matches_per_image(setup, dtype):
         head = setup[0]
     else:
         cfg = PSGConfig(qformer=QFormerConfig(vocab=30522), llm=tiny_llm(512, 2, 1024, 512), max_object_num=50)
-        head = RelationTransformerHeadV4(dtype="fp32", device="cuda:0", llm_config=cfg.llm, llm_feature_size=512,
+        head = RelationTransformerHeadV4(dtype=dtype.split("_")[0], device="cuda:0", llm_config=cfg.llm, llm_feature_size=512,
                                          tokenizers="word", max_object_num=50, on_parse_error="skip",
                                          suppress_eos=True)
-        head.load_weights(make_weights_device(cfg, 7, torch.device("cuda:0"), llm_dtype=torch.float32))
+        head.load_weights(make_weights_device(cfg, 7, torch.device("cuda:0"), llm_dtype=torch.float32,
+                                              llm_values=torch.float16 if dtype.endswith("_w16") else None))
+        assert head.llm_engine._w16_all == dtype.endswith("_w16")
     scenes = [make_scene((1024, 1024), 50, seed=3, device="cuda:0", tiny_object=True),
               make_scene((512, 768), 12, seed=4, device="cuda:0"),
               make_scene((1024, 1024), 30, seed=5, device="cuda:0")]
@@ -107,6 +112,10 @@ def test_forward_batch_matches_per_image(setup, dtype):
     print(f"{dtype}: {same}/{total} generated tokens identical between forward_batch and forward")
     if dtype == "fp32":
         assert same == total and all(batched[i] == single[i] for i in range(3))
+    elif dtype.startswith("fp32s"):
+        # fp32-grade on both sides; the batch's prompt pass and decode projections sum in another order than the
+        # single image's (library vs weight-streaming kernels): a near-tie of a RANDOM model may move
+        assert same >= 0.97 * total
     else:
         assert same >= 0.9 * total                                     # bf16 GEMM rounding differs with the row count
 

@@ -160,26 +160,31 @@ if __name__ == "__main__":
 
 def decode_attn():
     dev = torch.device("cuda:0")
-    K, heads, ctx, D = 20, 32, 68, 4096
-    kc = torch.randn(K, heads, ctx, 128, device=dev).bfloat16()
-    vc = torch.randn(K, heads, ctx, 128, device=dev).bfloat16()
-    out = torch.empty(K, D, device=dev, dtype=torch.bfloat16)
+    K, heads, ctx, D, layers = 20, 32, 64, 4096, 32
     pair = torch.arange(K, device=dev, dtype=torch.int32)
     ang = torch.arange(128, dtype=torch.float32)[:, None] / (10000.0 ** (torch.arange(0, 128, 2) / 128))[None, :]
     inv = (ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous())
-    for pos_v in (1, 50, 64):
-        pos = torch.full((K,), pos_v, device=dev, dtype=torch.int32)
-        for splits in (0, 4):
-            if splits:
-                qkv = ops.Partials(torch.randn(splits, K, 3 * D, device=dev))
-            else:
-                qkv = torch.randn(K, 3 * D, device=dev).bfloat16()
+    for dt in (torch.float32, torch.float16):
+        # one cache per layer, rotated: as cold as in the decode step (32 x 2 x 21 MB of fp32 >> L2; the Infinity Cache holds
+        # part of it, as it does in situ)
+        kcs = [torch.randn(K, heads, ctx, 128, device=dev).to(dt) for _ in range(layers)]
+        vcs = [torch.randn(K, heads, ctx, 128, device=dev).to(dt) for _ in range(layers)]
+        out = torch.empty(K, D, device=dev, dtype=dt)
+        for pos_v in (1, 50, 60):
+            pos = torch.full((K,), pos_v, device=dev, dtype=torch.int32)
+            for splits in (0, 8):
+                if splits:
+                    qkv = ops.Partials(torch.randn(splits, K, 3 * D, device=dev))
+                else:
+                    qkv = torch.randn(K, 3 * D, device=dev).to(dt)
 
-            def run():
-                for _ in range(32):
-                    ops.decode_attn(qkv, pair, pos, inv, heads, 128, ctx, kc, vc, out)
-            t, _ = timeit(run, iters=8, warm=2)
-            print(f"decode_attn pos={pos_v} splits={splits}: {t / 32:.2f} us")
+                def run():
+                    for l in range(layers):
+                        ops.decode_attn(qkv, pair, pos, inv, heads, 128, ctx, kcs[l], vcs[l], out)
+                t, _ = timeit(run, iters=8, warm=2)
+                nbytes = 2 * K * heads * pos_v * 128 * kcs[0].element_size()
+                print(f"decode_attn {str(dt)[6:]} pos={pos_v} splits={splits}: {t / layers:.2f} us per launch, {nbytes / 1e6:.1f} MB of "
+                      f"K/V = {nbytes / (t / layers) / 1e6:.2f} TB/s")
 
 
 if __name__ == "__main__" and "decode_attn" in sys.argv:

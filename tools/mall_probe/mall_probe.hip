@@ -28,6 +28,14 @@ __global__ void __launch_bounds__(512) rd(const u32x4* __restrict__ p, size_t n1
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+// one 64-byte line per `step` bytes of the slice: warms the address translation (and nothing else worth mentioning)
+__global__ void __launch_bounds__(256) touch(const unsigned char* __restrict__ p, size_t bytes, size_t step, unsigned* __restrict__ out) {
+  unsigned acc = 0;
+  for (size_t o = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * step; o < bytes; o += (size_t)gridDim.x * blockDim.x * step)
+    acc ^= *reinterpret_cast<const unsigned*>(p + o);
+  if (acc == 0x12345678u) out[0] = 1;
+}
+
 int main() {
   const size_t POOL = (size_t)6 << 30;
   unsigned char* buf;
@@ -86,6 +94,57 @@ int main() {
       printf("S=%4zu MB %s: P %7.1f us, G %7.1f us = %7.1f GB/s\n", mb,
              mode == 0 ? "G alone (cold)     " : mode == 1 ? "P(default) then G  " : "P(nt) then G       ", p, g, bytes / (g * 1e-6) / 1e9);
     }
+  }
+  printf("# (3) cold slice: what a preceding TOUCH of one line per step bytes (address translation only) buys pass G; us of G\n");
+  for (size_t mb : {64, 200}) {
+    const size_t bytes = mb << 20;
+    for (size_t step : {(size_t)0, (size_t)4096, (size_t)65536, (size_t)(2 << 20), (size_t)1}) {   // 0: none; 1: P over the first 16 MB only
+      float tot = 0, totp = 0;
+      const int reps = 12;
+      size_t off = 0;
+      for (int r = 0; r < reps; ++r) {
+        off = (off + ((size_t)512 << 20)) % (POOL - bytes);
+        hipEvent_t a, b, c;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); CK(hipEventCreate(&c));
+        CK(hipEventRecord(a, st));
+        if (step == 1) pass(false, off, (size_t)16 << 20);
+        else if (step) touch<<<64, 256, 0, st>>>(buf + off, bytes, step, out);
+        CK(hipEventRecord(b, st));
+        pass(true, off, bytes);
+        CK(hipEventRecord(c, st));
+        CK(hipEventSynchronize(c));
+        float mp, mg;
+        CK(hipEventElapsedTime(&mp, a, b));
+        CK(hipEventElapsedTime(&mg, b, c));
+        if (r >= 2) { tot += mg; totp += mp; }
+        CK(hipEventDestroy(a)); CK(hipEventDestroy(b)); CK(hipEventDestroy(c));
+      }
+      const float g = tot / (reps - 2) * 1e3f, pp = totp / (reps - 2) * 1e3f;
+      printf("S=%4zu MB step %8zu: touch %7.1f us, G %7.1f us = %7.1f GB/s\n", mb, step, pp, g, bytes / (g * 1e-6) / 1e9);
+    }
+  }
+  printf("# (4) G twice over the same cold slice (second pass: translation warm, data > L2): us\n");
+  for (size_t mb : {64, 200, 360}) {
+    const size_t bytes = mb << 20;
+    float t1 = 0, t2 = 0;
+    size_t off = 0;
+    for (int r = 0; r < 12; ++r) {
+      off = (off + ((size_t)512 << 20)) % (POOL - bytes);
+      hipEvent_t a, b, c;
+      CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); CK(hipEventCreate(&c));
+      CK(hipEventRecord(a, st));
+      pass(true, off, bytes);
+      CK(hipEventRecord(b, st));
+      pass(true, off, bytes);
+      CK(hipEventRecord(c, st));
+      CK(hipEventSynchronize(c));
+      float m1, m2;
+      CK(hipEventElapsedTime(&m1, a, b));
+      CK(hipEventElapsedTime(&m2, b, c));
+      if (r >= 2) { t1 += m1; t2 += m2; }
+      CK(hipEventDestroy(a)); CK(hipEventDestroy(b)); CK(hipEventDestroy(c));
+    }
+    printf("S=%4zu MB: first %7.1f us, second %7.1f us\n", mb, t1 * 100.f, t2 * 100.f);
   }
   return 0;
 }
