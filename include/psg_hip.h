@@ -66,7 +66,7 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *   501  round 5 (psg_batch_gemm*, psg_qformer_cross_attn_indexed, psg_skinny_gemm_w16, psg_split_f16x2, psg_split_gemm_w16,
  *        psg_rmsnorm_split2, psg_rmsnorm_split / psg_rope_kvwrite_scaled /
  *        psg_silu_mul_split added)
- *   600  round 6 (psg_dense_gemm_split, psg_decode_attn_split2, psg_silu_mul_split2 added; psg_split_f16x3 order 2) */
+ *   600  round 6 (psg_dense_gemm_split added; psg_split_f16x3 order 2) */
 #define PSG_ABI_VERSION 600
 int psg_version(void);
 const char* psg_last_error(void);
@@ -301,18 +301,6 @@ int psg_split_f16x2(psg_ctx*, const float* x, int64_t rows, int K, int64_t row_s
  * psg_rmsnorm followed by psg_split_f16x2; HF-LL:53-67) */
 int psg_rmsnorm_split2(psg_ctx*, float* resid, const float* delta, int delta_splits, const float* w, float eps, int64_t rows,
                        int hidden, void* out2, float* inv_scale, void* stream);
-/* Round 6: the two other producers of such planes in a decode step - the attention output (HF-LL:191-214; its row maximum
- * spans the heads) and the SwiGLU gate (HF-LL:163-177; 11 008 columns) - write them directly: the workgroups of a row meet
- * at four device-scope words per row (maximum bits, arrivals, departures; zero before the first launch, zeroed again by
- * the last workgroup out), so no psg_split_f16x2 launch follows.  Planes and inv_scale are bit-identical to
- * psg_decode_attn(PSG_F32) / psg_silu_mul(PSG_F32) + psg_split_f16x2.  rows <= 32 / 64: every workgroup of the launch is
- * resident, which the rendezvous needs; a poll that gives up (~seconds) writes NaN to inv_scale[row].
- * sync: uint32 [4 rows] per launch in flight (a decode state owns one for each of the two kernels). */
-int psg_decode_attn_split2(psg_ctx*, const void* qkv, int qkv_splits, const int32_t* tok_pair, const int32_t* tok_pos,
-                           const float* rope_cos, const float* rope_sin, int rows, int heads, int head_dim, int ctx_len,
-                           float* k_cache, float* v_cache, void* out2, float* inv_scale, uint32_t* sync, void* stream);
-int psg_silu_mul_split2(psg_ctx*, const float* gate_up_parts, int splits, int64_t rows, int inter, void* out2,
-                        float* inv_scale, uint32_t* sync, void* stream);
 int psg_split_gemm_w16_plan(psg_ctx*, int M, int N, int K, int mode, int* slots);
 int psg_split_gemm_w16(psg_ctx*, const void* x2, const float* inv_scale, const void* w_f16, float* part, int M, int N, int K,
                        int slots, int mode, void* stream);

@@ -78,8 +78,6 @@ SIGNATURES = {
     "psg_batch_gemm": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "psg_split_f16x2": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp],
     "psg_rmsnorm_split2": [_vp, _vp, _vp, _i, _vp, _f, _i64, _i, _vp, _vp, _vp],
-    "psg_decode_attn_split2": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "psg_silu_mul_split2": [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp],
     "psg_split_gemm_w16_plan": [_vp, _i, _i, _i, _i, C.POINTER(_i)],
     "psg_split_gemm_w16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "psg_qformer_cross_attn_indexed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],

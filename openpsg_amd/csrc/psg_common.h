@@ -37,8 +37,6 @@ struct psg_opts {
   int llm_fuse_rmsnorm = 0;     // decode step: RMSNorm as the prologue of the projection it feeds (psg_skinny_gemm_fused)
   int prefill_attn_scalar = 0;  // prompt pass: scalar cache-attention kernel instead of the matrix-core one
   int llm_fuse_split = 1;       // fp32s prompt pass: operand splits / result scalings inside the row kernels (psg_split.hip)
-  int decode_fuse_split2 = 1;   // fp32s decode over fp16-valued weights: attention / SwiGLU write their fp16 planes themselves
-                                // (row rendezvous, psg_decode_attn_split2 / psg_silu_mul_split2) - no psg_split_f16x2 launch
   int split_i2 = 1;             // fp32s own-GEMM products (Q-Former, row-invariant Llama prompt pass): interleaved hi / lo
                                 // operands through psg_dense_gemm_split (3 products from one staging; 0: the K' = 3K form)
   int decode_persistent = 0;    // fp32 decode steps: one persistent launch per decoder layer (psg_decode_layer) instead of the

@@ -595,162 +595,3 @@ extern "C" int psg_rmsnorm_split2(psg_ctx* ctx, float* resid, const float* delta
   PSG_CHECK_LAUNCH("psg_rmsnorm_split2");
   return PSG_OK;
 }
-
-// ---- round 6: the decode step's two remaining split launches folded into their producers ------------------------------
-// fp32s decode over fp16-valued weights (psg_split_gemm_w16): the attention output and the SwiGLU gate must reach the next
-// projection as two fp16 planes under ONE power-of-two scale per row, and a row's maximum spans 32 heads / 11 008 columns -
-// i.e. 32 / 11 workgroups of the producing kernel.  Round 5 paid a launch for it (psg_split_f16x2: 993 launches, 6.4 ms per
-// image).  Here the workgroups of a row meet at a device-scope word instead:
-//     sync[4 row + 0]  bits of the row's largest |value| so far (atomicMax on the uint pattern: monotone for values >= 0)
-//     sync[4 row + 1]  arrivals;   sync[4 row + 2]  departures - the last one out zeroes the row's three words
-// A workgroup publishes its own maximum, arrives, waits until all `parts` workgroups of the row have arrived (one lane
-// polls, s_sleep between polls; every workgroup of the launch is resident: 220 / 640 of <= 256 threads), reads the row
-// maximum and writes its share of the planes.  The scale is the one psg_split_f16x2 derives from the same maximum, so the
-// planes and inv_scale are BIT-IDENTICAL to producer + psg_split_f16x2 (tests/test_gpu_w16.py).  sync must be zero at
-// the first launch; it is zero again when the launch ends.  A poll that gives up (a producer never arrived: ~0.1 s)
-// poisons inv_scale[row] with NaN - every logit of the row turns NaN instead of being silently wrong.
-// Called by ONE lane of the workgroup; returns the row maximum (NaN if the rendezvous gave up).
-__device__ __forceinline__ float sp_row_rendezvous(uint32_t* sync, int row, int parts, float wg_max) {
-  uint32_t* s = sync + 4 * row;
-  __hip_atomic_fetch_max(s, __float_as_uint(wg_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add(s + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  bool ok = false;
-  for (int it = 0; it < (1 << 21); ++it) {
-    if (__hip_atomic_load(s + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)parts) {
-      ok = true;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  const uint32_t bits = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (__hip_atomic_fetch_add(s + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)parts - 1) {
-    __hip_atomic_store(s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // everyone has read the maximum
-    __hip_atomic_store(s + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(s + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return ok ? __uint_as_float(bits) : __uint_as_float(0x7fc00000u);
-}
-
-// act = silu(g) * u of the gate|up split-K slices (psg_silu_mul<float>'s arithmetic) -> planes [2][rows][inter] + inv_scale.
-// grid (ceil(inter / 1024), rows), 256 threads x 4 columns.
-__global__ void __launch_bounds__(256) silu_mul_split2_kernel(const float* __restrict__ gu, int S, int64_t rows, int inter,
-                                                              uint16_t* __restrict__ out2, float* __restrict__ inv_scale,
-                                                              uint32_t* __restrict__ sync) {
-  __shared__ float s_max[4], s_b;
-  const int row = blockIdx.y, tid = threadIdx.x;
-  const int c = (blockIdx.x * 256 + tid) * 4;
-  float o[4] = {0.f, 0.f, 0.f, 0.f};
-  float mx = 0.f;
-  if (c < inter) {
-    const int64_t idx[2] = {(int64_t)row * 2 * inter + c, (int64_t)row * 2 * inter + inter + c};
-    float4 gu4[2];
-    ldn_splits<float4, 2>(gu, S, rows * 2 * inter, idx, gu4);
-    const float g[4] = {gu4[0].x, gu4[0].y, gu4[0].z, gu4[0].w}, u[4] = {gu4[1].x, gu4[1].y, gu4[1].z, gu4[1].w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float s = g[e] / (1.0f + expf(-g[e]));
-      o[e] = s * u[e];
-      mx = fmaxf(mx, fabsf(o[e]));
-    }
-  }
-  mx = wave_max(mx);
-  if ((tid & 63) == 0) s_max[tid >> 6] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-  if (tid == 0) s_b = sp_row_rendezvous(sync, row, (int)gridDim.x, mx);
-  __syncthreads();
-  const float row_mx = s_b;
-  float scale;
-  if (row_mx != row_mx) {                                       // the rendezvous gave up
-    if (tid == 0 && blockIdx.x == 0) inv_scale[row] = row_mx;
-    scale = 1.f;
-  } else {
-    scale = sp_row_scale(row_mx, (tid == 0 && blockIdx.x == 0) ? inv_scale + row : nullptr);
-  }
-  if (c < inter) sp_store2(out2 + (int64_t)row * inter, out2 + (rows + row) * (int64_t)inter, c, o, scale);
-}
-
-extern "C" int psg_silu_mul_split2(psg_ctx* ctx, const float* gate_up, int splits, int64_t rows, int inter, void* out2,
-                                   float* inv_scale, uint32_t* sync, void* stream) {
-  PSG_REQUIRE(ctx && gate_up && out2 && inv_scale && sync, PSG_ERR_INVALID, "psg_silu_mul_split2: NULL argument");
-  PSG_REQUIRE(inter > 0 && inter % 4 == 0 && rows >= 0 && rows <= 64 && splits >= 1 && splits <= PSG_MAX_SPLITS,
-              PSG_ERR_UNSUPPORTED, "psg_silu_mul_split2: rows=%lld (<= 64: every workgroup of a row must be resident), inter=%d, "
-              "splits=%d (1..%d slices)", (long long)rows, inter, splits, PSG_MAX_SPLITS);
-  if (rows == 0) return PSG_OK;
-  const dim3 grid((unsigned)((inter + 1023) / 1024), (unsigned)rows);
-  silu_mul_split2_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gate_up, splits, rows, inter, (uint16_t*)out2, inv_scale, sync);
-  PSG_CHECK_LAUNCH("psg_silu_mul_split2");
-  return PSG_OK;
-}
-
-// psg_decode_attn<float> (rotary, cache append, attention: psg_decode_attn4_unit) writing the head's 128 outputs as its share
-// of the row's two fp16 planes: the 32 head workgroups of a row meet at sync[4 row ..] for the row maximum.
-__global__ void __launch_bounds__(256) decode_attn4_split2_kernel(const void* __restrict__ qkv, int qs,
-                                                                  const int32_t* __restrict__ tok_pair,
-                                                                  const int32_t* __restrict__ tok_pos,
-                                                                  const float* __restrict__ cos_tab,
-                                                                  const float* __restrict__ sin_tab, int rows, int heads,
-                                                                  int ctx, float* __restrict__ kc, float* __restrict__ vc,
-                                                                  uint16_t* __restrict__ out2, float* __restrict__ inv_scale,
-                                                                  uint32_t* __restrict__ sync) {
-  __shared__ PsgDecodeAttnScratch sc;
-  const int unit = blockIdx.x;
-  const int row = unit / heads, h = unit % heads;
-  const int pos = tok_pos[row];
-  const int hidden = heads * 128;
-  if (pos < 0) return;                                        // a dead row: all of its head workgroups leave (uniform)
-  const int64_t sl = (int64_t)rows * 3 * hidden;
-  auto ld = [&](const int64_t (&idx)[6], float (&x)[6]) {
-    if (qs > 0) {
-      ldn_splits<float, 6>(qkv, qs, sl, idx, x);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 6; ++e) x[e] = reinterpret_cast<const float*>(qkv)[idx[e]];
-    }
-  };
-  float vals[2] = {0.f, 0.f};
-  int nv = 0;
-  auto st = [&](int64_t, float v) { vals[nv++] = v; };      // dims (lane, lane + 64) of the head, in that order
-  psg_decode_attn4_unit<float>(true, (int)threadIdx.x, row, h, pos, tok_pair[row], heads, ctx, cos_tab, sin_tab, kc, vc, ld,
-                               st, &sc);
-  if (threadIdx.x >= 64) return;                              // wave 0 holds the head's outputs
-  const int lane = threadIdx.x;
-  const float mx = wave_max(fmaxf(fabsf(vals[0]), fabsf(vals[1])));
-  float row_mx = 0.f;
-  if (lane == 0) row_mx = sp_row_rendezvous(sync, row, heads, mx);
-  row_mx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(row_mx)));
-  float scale;
-  if (row_mx != row_mx) {
-    if (lane == 0 && h == 0) inv_scale[row] = row_mx;
-    scale = 1.f;
-  } else {
-    scale = sp_row_scale(row_mx, (lane == 0 && h == 0) ? inv_scale + row : nullptr);
-  }
-  uint16_t* oh = out2 + (int64_t)row * hidden + h * 128;
-  uint16_t* ol = out2 + ((int64_t)rows + row) * hidden + h * 128;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const float sv = vals[e] * scale;
-    const uint16_t hb = f32_to_f16(sv);
-    oh[lane + 64 * e] = hb;
-    ol[lane + 64 * e] = f32_to_f16(sv - f16_to_f32(hb));
-  }
-}
-
-extern "C" int psg_decode_attn_split2(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
-                                      const int32_t* tok_pos, const float* rope_cos, const float* rope_sin, int rows,
-                                      int heads, int head_dim, int ctx, float* k_cache, float* v_cache, void* out2,
-                                      float* inv_scale, uint32_t* sync, void* stream) {
-  PSG_REQUIRE(ctx_ && qkv && tok_pair && tok_pos && rope_cos && rope_sin && k_cache && v_cache && out2 && inv_scale && sync,
-              PSG_ERR_INVALID, "psg_decode_attn_split2: NULL argument");
-  PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_decode_attn_split2: head_dim=%d (kernel is built for 128)", head_dim);
-  PSG_REQUIRE(qkv_splits >= 0 && qkv_splits <= PSG_MAX_SPLITS && rows >= 0 && rows <= 32 && heads >= 1 && heads <= 64,
-              PSG_ERR_UNSUPPORTED, "psg_decode_attn_split2: rows=%d (<= 32: every workgroup of the launch must be resident), "
-              "heads=%d, qkv_splits=%d", rows, heads, qkv_splits);
-  if (rows == 0) return PSG_OK;
-  decode_attn4_split2_kernel<<<rows * heads, 256, 0, (hipStream_t)stream>>>(qkv, qkv_splits, tok_pair, tok_pos, rope_cos,
-                                                                            rope_sin, rows, heads, ctx, k_cache, v_cache,
-                                                                            (uint16_t*)out2, inv_scale, sync);
-  PSG_CHECK_LAUNCH("psg_decode_attn_split2");
-  return PSG_OK;
-}

@@ -301,7 +301,6 @@ class LlamaDecodeEngine:
         # fp32s prompt pass: the split of a projection's operand and the un-scaling of its result inside the row kernels
         # next to it (psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split; bit-identical, 7 launches per layer less)
         self.fuse_split = bool(_lib.get_option(dev_i, "llm_fuse_split"))
-        self.fuse_split2 = bool(_lib.get_option(dev_i, "decode_fuse_split2"))
         # fp32s prompt pass: run each library product whole or in the column / row parts measured fastest (_plan_split_mm)
         self.plan_split = True
         # decode steps of 33..160 rows: psg_batch_gemm where it beats the library (option decode_batch_gemm)
@@ -607,31 +606,21 @@ class LlamaDecodeEngine:
         x, wh = st["x"], self._w16
         K, D = x.shape
         att = torch.empty((K, D), device=self.device, dtype=torch.float32)
-        # round 6 (option decode_fuse_split2): the attention output and the SwiGLU gate leave their kernels as planes - the
-        # workgroups of a row meet at a device word for the row maximum (psg_decode_attn_split2 / psg_silu_mul_split2)
-        # instead of a psg_split_f16x2 launch each; bit-identical.  The decode state owns the rendezvous words
-        fuse2 = self.fuse_split2 and K <= 32 and m.heads <= 64
-        if fuse2 and "sync2" not in st:
-            st["sync2"] = torch.zeros(2 * 4 * 32, device=self.device, dtype=torch.int32)
         a2, inv = ops.rmsnorm_split2(x, None, self.layers[0]["ln1"], m.rms_eps)
         for l, L in enumerate(self.layers):
             qkv = ops.split_gemm_w16(a2, inv, wh[L["wqkv"].data_ptr()])
-            if fuse2:
-                a2o, invo = ops.decode_attn_split2(qkv, st["dec_pair"], st["dec_pos"], self.rope, m.heads, m.head_dim,
-                                                   st["ctx_len"], st["kc"][l], st["vc"][l], st["sync2"][:128])
-            else:
-                ops.decode_attn(qkv, st["dec_pair"], st["dec_pos"], self.rope, m.heads, m.head_dim, st["ctx_len"], st["kc"][l],
-                                st["vc"][l], att)
-                a2o, invo = ops.split_f16x2(att)               # a row's maximum spans all heads: a launch of its own
+            ops.decode_attn(qkv, st["dec_pair"], st["dec_pos"], self.rope, m.heads, m.head_dim, st["ctx_len"], st["kc"][l],
+                            st["vc"][l], att)
+            # a row's maximum spans all heads / 11 008 columns: a split launch of its own behind attention and SwiGLU.  Folding
+            # it into the producers needs a rendezvous of the row's 32 / 11 workgroups - built and measured in round 6
+            # (profiles/r06_split2_rendezvous_ab.txt): inside a graph the launch costs 2.6 / 3.5 us, the rendezvous 9.3 / 3.4
+            a2o, invo = ops.split_f16x2(att)
             o = ops.split_gemm_w16(a2o, invo, wh[L["wo"].data_ptr()])
             a2, inv = ops.rmsnorm_split2(x, o, L["ln2"], m.rms_eps)
             gu = ops.split_gemm_w16(a2, inv, wh[L["wgu"].data_ptr()])
-            if fuse2:
-                a2a, inva = ops.silu_mul_split2(gu, m.inter, st["sync2"][128:])
-            else:
-                act = torch.empty((K, m.inter), device=self.device, dtype=torch.float32)
-                ops.silu_mul(gu, act)                          # (one workgroup per row for the row maximum was measured at
-                a2a, inva = ops.split_f16x2(act)               # 24 us against 5.2 + 4.9 for these two launches)
+            act = torch.empty((K, m.inter), device=self.device, dtype=torch.float32)
+            ops.silu_mul(gu, act)
+            a2a, inva = ops.split_f16x2(act)
             d = ops.split_gemm_w16(a2a, inva, wh[L["wdown"].data_ptr()])
             nxt = self.layers[l + 1]["ln1"] if l + 1 < len(self.layers) else self.final_norm
             a2, inv = ops.rmsnorm_split2(x, d, nxt, m.rms_eps)

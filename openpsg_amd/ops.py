@@ -596,39 +596,6 @@ def rmsnorm_split2(resid, delta, w, eps):
     return out, inv
 
 
-def decode_attn_split2(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, k_cache, v_cache, sync):
-    """`decode_attn` on an fp32 cache with the output written as the two fp16 planes of `split_f16x2` (fp16
-    [2, rows, hidden], inv_scale [rows]): the head workgroups of a row meet at `sync` (int32 [4 rows], zero before the
-    first launch, zero again afterwards) for the row maximum - no split launch.  Bit-identical to decode_attn + split_f16x2."""
-    lib, ctx, st = _env(k_cache)
-    assert k_cache.dtype == torch.float32 and sync.dtype == torch.int32
-    if isinstance(qkv, Partials):
-        qp, qs, rows = _p(qkv.t, torch.float32), qkv.splits, qkv.shape[0]
-    else:
-        qp, qs, rows = _p(qkv, torch.float32), 0, qkv.shape[0]
-    assert sync.numel() >= 4 * rows
-    out = torch.empty((2, rows, heads * head_dim), device=k_cache.device, dtype=torch.float16)
-    inv = torch.empty(rows, device=k_cache.device, dtype=torch.float32)
-    check(lib.psg_decode_attn_split2(ctx, qp, qs, _p(tok_pair, torch.int32), _p(tok_pos, torch.int32), _p(rope[0], torch.float32),
-                                     _p(rope[1], torch.float32), rows, heads, head_dim, ctx_len, _p(k_cache), _p(v_cache), _p(out),
-                                     _p(inv), _p(sync), st), "psg_decode_attn_split2")
-    return out, inv
-
-
-def silu_mul_split2(gate_up: Partials, inter, sync):
-    """silu(gate) * up of the gate|up split-K slices as the two fp16 planes of `split_f16x2` (fp16 [2, rows, inter],
-    inv_scale [rows]); row rendezvous at `sync` as in `decode_attn_split2`.  Bit-identical to silu_mul + split_f16x2."""
-    lib, ctx, st = _env(gate_up.t)
-    assert isinstance(gate_up, Partials) and sync.dtype == torch.int32
-    rows = gate_up.shape[0]
-    assert gate_up.shape[1] == 2 * inter and sync.numel() >= 4 * rows
-    out = torch.empty((2, rows, inter), device=gate_up.t.device, dtype=torch.float16)
-    inv = torch.empty(rows, device=gate_up.t.device, dtype=torch.float32)
-    check(lib.psg_silu_mul_split2(ctx, _p(gate_up.t, torch.float32), gate_up.splits, rows, inter, _p(out), _p(inv), _p(sync), st),
-          "psg_silu_mul_split2")
-    return out, inv
-
-
 def split_gemm_w16(x2, inv_scale, w16, mode=0) -> Partials:
     """Decode-step projection of fp32 rows against a weight that is an fp16 value (frozen fp16 checkpoint): two fp16
     products (high and low part of x) on the 16-bit matrix cores, fp32 slices [S, M, N] like `skinny_gemm`'s;

@@ -171,6 +171,34 @@ def test_step_with_unequal_images_over_fake_ranks(world, selector, per_rank):
         assert len(set(ks)) > 1, "the threshold case should exercise different K per image"
 
 
+@pytest.mark.parametrize("world,per_rank", [(4, 1), (2, 2)])
+def test_step_in_the_headline_mode_is_bit_exact_with_the_single_gpu_head(world, per_rank):
+    """Weak-scaling `step` in fp32s (bench.py's N > 1 job): the Q-Former's projections are the repo's own row-count-invariant
+    GEMM and - round 6 - the library products of the prompt pass run in a form that is a pure function of the shape
+    (llm._SPLIT_PLAN_TABLE), so an image's probabilities, selection and EVERY decoded token equal the single-GPU head's,
+    bit for bit, on whichever rank it is decoded (SURVEY 8e "bit-exactness across R"; round 5 could only assert this for
+    `step_one_image`)."""
+    from openpsg_amd.dist import HipBackend, LoopbackWorld
+    from openpsg_amd.synthetic import make_scene
+    head = _mk_head("fp32s", 50)
+    geo = [((1024, 1024), 50), ((768, 1024), 23), ((512, 512), 9), ((1024, 1344), 31)][:world * per_rank]
+    scenes = [make_scene(hw, n, seed=80 + m, device="cuda:0", tiny_object=True) for m, (hw, n) in enumerate(geo)]
+    refs = []
+    for s in scenes:
+        head(_inputs(s))
+        torch.cuda.synchronize()
+        refs.append(dict(prob=head.last["exist_prob"].clone(), sel=head.last["selected"].clone(),
+                         tokens=head.last["tokens_host"].copy()))
+    fw = LoopbackWorld(world)
+    outs = fw.run([p.step_gen(scenes) for p in fw.pipelines(HipBackend(head))])
+    torch.cuda.synchronize()
+    for m in range(len(scenes)):
+        for r in range(world):
+            assert torch.equal(outs[r]["exist_prob"][m], refs[m]["prob"]), (r, m)
+            assert torch.equal(outs[r]["selected"][m], refs[m]["sel"]), (r, m)
+            assert np.array_equal(outs[r]["tokens"][m].cpu().numpy(), refs[m]["tokens"]), (r, m)
+
+
 def test_infer_tool_image_dealing_through_the_fake_world(tmp_path):
     """BASELINE C5's multi-GPU form (`torch.distributed.run ... tools/infer.py`): whole images dealt round-robin to the
     ranks, results merged in image order.  8 images at the C5 geometry (480x640 -> 1000x1333 -> pad 1024x1344), fp16,

@@ -198,7 +198,10 @@ def test_dense_gemm_split_three_products_from_one_staging(M, N, K, gelu):
     from openpsg_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(M + N + K + 1)
-    x = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 6, (M, 1), generator=g).float())).to(dev)
+    x = torch.randn(M, K, generator=g)
+    if not gelu:                                    # rows of very different magnitude (the GELU bound below is absolute)
+        x = x * torch.exp2(torch.randint(-6, 6, (M, 1), generator=g).float())
+    x = x.to(dev)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev)
     a2, inv_r = ops.split_f16i2(x)

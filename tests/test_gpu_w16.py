@@ -131,87 +131,6 @@ def test_two_plane_rmsnorm_equals_the_row_kernel_followed_by_the_split_bit_for_b
             assert torch.equal(ra, rb) and torch.equal(a2, b2) and torch.equal(ainv, binv), (rows, D, S)
 
 
-def test_attention_and_swiglu_write_their_planes_themselves_bit_for_bit():
-    """Round 6: psg_decode_attn_split2 / psg_silu_mul_split2 - the decode step's attention output (HF-LL:191-214) and SwiGLU
-    gate (HF-LL:163-177) leave their kernels as the two fp16 planes of the next projection's operand; the workgroups of a
-    row (32 heads / 11 column chunks) meet at a device word for the row maximum.  Against psg_decode_attn / psg_silu_mul
-    followed by psg_split_f16x2: planes, scales AND the appended cache rows identical, the rendezvous words zero again
-    after every launch (they are re-used without a memset), repeated 20 times on the same words."""
-    from openpsg_amd import ops
-    g = torch.Generator(device=DEV).manual_seed(9)
-    heads, ctx = 32, 64
-    D = heads * 128
-    ang = torch.arange(ctx, dtype=torch.float32)[:, None] / (10000 ** (torch.arange(0, 128, 2).float() / 128))[None]
-    rope = (ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV))
-    for rows in (20, 32, 1, 5):
-        sync = torch.zeros(2 * 4 * 32, device=DEV, dtype=torch.int32)
-        for rep in range(20 if rows == 20 else 2):
-            pos = torch.randint(0, ctx - 1, (rows,), generator=g, device=DEV, dtype=torch.int32)
-            pos[0] = ctx - 1
-            pair = torch.arange(rows, device=DEV, dtype=torch.int32)
-            qkv = ops.Partials((torch.randn(8, rows, 3 * D, generator=g, device=DEV) * (1.0 + rep)).contiguous())
-            kc = torch.randn(rows, heads, ctx, 128, generator=g, device=DEV)
-            vc = torch.randn(rows, heads, ctx, 128, generator=g, device=DEV) * torch.exp2(
-                torch.randint(-8, 8, (rows, 1, 1, 1), generator=g, device=DEV).float())
-            kc_b, vc_b = kc.clone(), vc.clone()
-            att = torch.empty(rows, D, device=DEV)
-            ops.decode_attn(qkv, pair, pos, rope, heads, 128, ctx, kc, vc, att)
-            a2, ainv = ops.split_f16x2(att)
-            b2, binv = ops.decode_attn_split2(qkv, pair, pos, rope, heads, 128, ctx, kc_b, vc_b, sync[:128])
-            assert torch.equal(a2, b2) and torch.equal(ainv, binv), (rows, rep)
-            assert torch.equal(kc, kc_b) and torch.equal(vc, vc_b)
-            I = 11008
-            gu = ops.Partials((torch.randn(8, rows, 2 * I, generator=g, device=DEV) * (0.5 + rep)).contiguous())
-            act = torch.empty(rows, I, device=DEV)
-            ops.silu_mul(gu, act)
-            c2, cinv = ops.split_f16x2(act)
-            d2, dinv = ops.silu_mul_split2(gu, I, sync[128:])
-            assert torch.equal(c2, d2) and torch.equal(cinv, dinv), (rows, rep)
-            assert int(sync.abs().max()) == 0, "the rendezvous words were not returned to zero"
-    # a smaller geometry (2 heads, 1000 columns: one column chunk, ragged)
-    sync = torch.zeros(256, device=DEV, dtype=torch.int32)
-    gu = ops.Partials(torch.randn(3, 4, 2 * 1000, generator=g, device=DEV).contiguous())
-    act = torch.empty(4, 1000, device=DEV)
-    ops.silu_mul(gu, act)
-    c2, cinv = ops.split_f16x2(act)
-    d2, dinv = ops.silu_mul_split2(gu, 1000, sync[128:])
-    assert torch.equal(c2, d2) and torch.equal(cinv, dinv) and int(sync.abs().max()) == 0
-
-
-def test_decode_steps_with_fused_plane_producers_equal_the_separate_split_launches():
-    """The fp32s engine over fp16-valued weights with option decode_fuse_split2 on / off: the same tokens and first-step
-    logits bit for bit, through the HIP graph and eagerly (G6, Llama-2-7B width, 20 pairs)."""
-    import numpy as np
-    from openpsg_amd import _lib
-    from tests import helpers as H
-    g, cfg, w, scene = H.load_case("G6_llm_7b_width_n6")
-    w16 = {k: (torch.as_tensor(v).half().float() if k.startswith("language_model.") and torch.as_tensor(v).dim() >= 2 else v)
-           for k, v in w.items()}
-    dev = torch.device(DEV)
-    ids = [int(i) for i in scene["object_id_list"]]
-    names = H.object_names(scene)
-    sel = torch.from_numpy(g["selected"].astype(np.int32)).to(dev)
-    outs = {}
-    for flag in (0, 1):
-        _lib.set_option(0, "decode_fuse_split2", flag)
-        try:
-            head = _g6_head("fp32s", w16, cfg, g, 1)
-            assert head.llm_engine.fuse_split2 == bool(flag) and head.llm_engine._w16_all
-            rq = head.run_relation_query(scene["mask_features"].to(dev), scene["img_meta"], ids, names, scene["pan_results"].to(dev))
-            dec = head.decode_selected(rq, names, selected=sel)
-            dec2 = head.decode_selected(rq, names, selected=sel)             # graph replay on the same rendezvous words
-            assert np.array_equal(dec["tokens_host"], dec2["tokens_host"])
-            head.llm_engine.use_graph = False
-            dec3 = head.decode_selected(rq, names, selected=sel)
-            assert np.array_equal(dec["tokens_host"], dec3["tokens_host"])
-            outs[flag] = (dec["tokens_host"].copy(), dec["first_logits"].float().cpu())
-        finally:
-            _lib.set_option(0, "decode_fuse_split2", 1)
-        del head
-        torch.cuda.empty_cache()
-    assert np.array_equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-
-
 def test_plans_never_exceed_the_slices_a_consumer_can_sum():
     """Other widths than Llama-2-7B's (13B: 5120 / 13824; 70B-like: 8192 / 28672; narrow N) must still plan <= 16 slices."""
     from openpsg_amd import ops

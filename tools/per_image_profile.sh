@@ -3,8 +3,8 @@
 # steps; the difference of the per-kernel totals divided by the extra steps is what ONE step (image) costs (setup,
 # warm-up, graph capture and the roofline leg cancel).  Run on the MI355X box from the repo root:
 #   tools/per_image_profile.sh [out.csv] [extra bench.py arguments, e.g. --workload rq]
-# (The library products of the prompt pass run in parts measured per PROCESS, llm._plan_split_mm: if the two traces picked
-# different parts for a shape, its library kernel rows shift between names - the TOTAL row stays right; rerun then.)
+# (Round 6: the library products of the prompt pass run in parts fixed per SHAPE - llm._SPLIT_PLAN_TABLE - so the two
+# traces run the same kernels.)
 set -u
 OUT=${1:-gpurun_out/per_image_kernels.csv}
 shift || true
@@ -12,6 +12,6 @@ export TMPDIR=/tmp
 db() { ls "$1"/*/*_results.db 2>/dev/null | head -1; }
 for n in 2 10; do
   rm -rf /tmp/pi_$n
-  rocprofv3 --kernel-trace -d /tmp/pi_$n -- python bench.py --steps $n --warmup 1 --no-cpu-baseline --no-parity --no-batched --no-mixed --no-exact --no-frozen16 "$@" > /tmp/pi_$n.log 2>&1
+  rocprofv3 --kernel-trace -d /tmp/pi_$n -- python bench.py --steps $n --warmup 1 --no-cpu-baseline --no-parity --no-batched --no-mixed --no-exact --no-frozen16 --no-c4 "$@" > /tmp/pi_$n.log 2>&1
 done
 python tools/per_image_diff.py "$(db /tmp/pi_2)" "$(db /tmp/pi_10)" 8 "$OUT" > /dev/null
