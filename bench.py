@@ -26,6 +26,13 @@ multi-GPU line measures is the cost of the four collectives per step.  The line 
 dealt round-robin - its latency is bounded below by the 16 weight passes of the decode (no tensor parallelism in
 scope), which is stated next to the number.
 
+Round 6 additions to the line: `frozen_fp16_checkpoint` is timed exactly like the headline (same steps / warm-up, its
+own roofline.image terms): the same mode over LLM matrices that hold fp16 VALUES, as the reference's frozen checkpoint does;
+`c4_single_gpu` = BASELINE C4 (100 masks) on this one GPU; `batched_decode` = head.forward_batch at 4 / 8 images per step in
+the headline mode (BASELINE C5's batch at the reference's precision); `parity.modes.*.decode_7b_32_layers` = the oracle's
+UN-TRUNCATED 32-layer fp32 decode of a pair (the one cpu_baseline times) against the fp32s head on the same weights, both
+weight kinds; multi-GPU lines add `strong_scaling_rq` (C4's sharded part alone) beside `strong_scaling`.
+
 The JSON line also carries
   roofline     - the dominant kernel (skinny_gemm_f32_kernel: HBM stream of the fp32 LLM weights in the decode
                  steps), timed with HIP events on the launch stream right after the timed region with the
