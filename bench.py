@@ -795,7 +795,7 @@ def main():
         inputs4 = scene_inputs(scene4)
         ref1 = time_steps(lambda: head(inputs4) if a.workload == "full" else head.run_relation_query(
             scene4["mask_features"], scene4["img_meta"], [int(i) for i in scene4["object_id_list"]],
-            pipe1.be._names(scene4), scene4["pan_results"]), 1, 3) / 3
+            pipe1.be._names(scene4), scene4["pan_results"]), 2, 5) / 5
         barrier()
         wbytes = 26.4 if a.dtype in ("fp32", "fp32s") else 13.2
         strong = {"workload": f"ONE {a.size}x{a.size} image, {n4} masks ({n4 * (n4 - 1)} pairs), pairs sharded over "
