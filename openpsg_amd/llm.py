@@ -822,12 +822,12 @@ class LlamaDecodeEngine:
 
     def _check_persistent(self, st):
         """psg_decode_layer bounds every hand-off poll and reports a producer that never arrived through word
-        PSG_DL_TIMEOUT of the launch's counter block (256-byte slots: word 255 * 64).  Raises if any launch of this
+        PSG_DL_TIMEOUT of the launch's counter block (`ops.DL_TIMEOUT_WORD`).  Raises if any launch of this
         generation set it - its tokens are not to be trusted; the caller can switch `persistent_layer` off (the launch
         chain computes the same bits)."""
         for sync in st.get("dl_counters", ()):
             ncnt = ops.decode_layer_counters(self.device)
-            if bool((sync.view(-1, ncnt)[:, 255 * 64] != 0).any().item()):
+            if bool((sync.view(-1, ncnt)[:, ops.DL_TIMEOUT_WORD] != 0).any().item()):
                 raise PsgHipError("psg_decode_layer: a hand-off poll timed out (cnt[PSG_DL_TIMEOUT] set); the tokens of this "
                                   "generation are invalid - disable option decode_persistent")
 

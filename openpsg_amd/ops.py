@@ -433,6 +433,9 @@ def decode_layer_supported(rows, hidden, inter, heads, dtype, device) -> bool:
     return bool(lib.psg_decode_layer_supported(ctx, int(rows), int(hidden), int(inter), int(heads), _DT[dtype]))
 
 
+DL_TIMEOUT_WORD = 255 * 64         # csrc/psg_decode_layer.hip: PSG_DL_TIMEOUT * PSG_DL_SLOT - set by a hand-off poll that gave up
+
+
 def decode_layer_counters(device) -> int:
     """int32 words of one psg_decode_layer launch's counter block (to be zeroed by the caller)."""
     import ctypes

@@ -36,7 +36,7 @@ def parser():
                     help="original H W; with it and without --size the pipeline's shape arithmetic is applied")
     ap.add_argument("--out", default="work_dirs/demo")
     ap.add_argument("--llm-layers", type=int, default=2)
-    ap.add_argument("--dtype", default="mixed", help="mixed | fp16 | bf16 | fp32 (RelationTransformerHeadV4 dtype)")
+    ap.add_argument("--dtype", default="mixed", help="mixed | fp16 | bf16 | fp32 | fp32s (RelationTransformerHeadV4 dtype; fp32s = the reference's precision)")
     ap.add_argument("--selector", choices=["topk", "threshold"], default="topk")
     ap.add_argument("--batch", type=int, default=1,
                     help="images per head call; > 1 decodes their selected pairs together (throughput mode)")
