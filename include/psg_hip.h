@@ -66,8 +66,7 @@ enum psg_xattn_variant { PSG_XATTN_MFMA = 0, PSG_XATTN_SIMPLE = 1, PSG_XATTN_MFM
  *   501  round 5 (psg_batch_gemm*, psg_qformer_cross_attn_indexed, psg_skinny_gemm_w16, psg_split_f16x2, psg_split_gemm_w16,
  *        psg_rmsnorm_split2, psg_rmsnorm_split / psg_rope_kvwrite_scaled /
  *        psg_silu_mul_split added)
- *   600  round 6 (psg_dense_gemm_split, psg_rmsnorm_pre(_parts), psg_decode_attn_ex, psg_silu_mul_ex added; psg_split_f16x3
- *        order 2) */
+ *   600  round 6 (psg_dense_gemm_split added; psg_split_f16x3 order 2) */
 #define PSG_ABI_VERSION 600
 int psg_version(void);
 const char* psg_last_error(void);
@@ -225,17 +224,6 @@ int psg_gather_pair_rows(psg_ctx*, const void* xq, const void* xt, const int32_t
 int psg_rmsnorm(psg_ctx*, void* resid, const void* delta, int delta_splits, const float* w, float eps,
                 int64_t rows, int hidden, void* out, int dtype, int resid_dtype, void* stream);
 
-/* Round 6, decode steps in fp32: the RMSNorm row scale applied BEHIND the projection it feeds (HF-LL:53-67 with
- * HF-LL:243-281: x_n W = ((w . x) W) / rms(x)).  psg_rmsnorm_pre: resid += sum of delta's slices (as psg_rmsnorm);
- * out = w . resid WITHOUT the 1 / rms; ssq[row][part] = sum of squares of the row's part-th 512-column chunk
- * (psg_rmsnorm_pre_parts(hidden) parts per row).  No row-wide reduction, so a row is spread over `parts` workgroups instead
- * of one.  The consumers of a projection of `out` - psg_decode_attn_ex, psg_silu_mul_ex - take (ssq, parts, eps) and multiply
- * the slice sums by 1 / sqrt(sum(ssq[row]) / hidden + eps); the greedy step's argmax is indifferent to a positive row
- * factor.  Agrees with psg_rmsnorm + projection to fp32 rounding, not bit for bit. */
-int psg_rmsnorm_pre_parts(int hidden);
-int psg_rmsnorm_pre(psg_ctx*, float* resid, const float* delta, int delta_splits, const float* w, int64_t rows, int hidden,
-                    float* out, float* ssq, void* stream);
-
 /* ---- K13: rotary embedding (half-split, HF-LL:130-160) + KV-cache write.
  * qkv [rows][3*hidden]; tok_pair / tok_pos int32 [rows] give the cache row (pair) and the
  * position (= cache slot = cumsum(mask)-1, V4 left-padding removed by compaction); tok_pos < 0
@@ -277,18 +265,11 @@ int psg_prefill_attn_rope(psg_ctx*, const void* qkv, const int32_t* tok_pos, con
 int psg_decode_attn(psg_ctx*, const void* qkv, int qkv_splits, const int32_t* tok_pair, const int32_t* tok_pos,
                     const float* rope_cos, const float* rope_sin, int rows, int heads, int head_dim, int ctx, void* k_cache,
                     void* v_cache, void* out, int dtype, void* stream);
-/* ... with the q|k|v slices being a projection of psg_rmsnorm_pre's rows: ssq [rows][ssq_parts] (NULL: psg_decode_attn) */
-int psg_decode_attn_ex(psg_ctx*, const void* qkv, int qkv_splits, const int32_t* tok_pair, const int32_t* tok_pos,
-                       const float* rope_cos, const float* rope_sin, int rows, int heads, int head_dim, int ctx, void* k_cache,
-                       void* v_cache, void* out, int dtype, const float* ssq, int ssq_parts, float eps, void* stream);
 
 /* ---- SwiGLU gate, HF-LL:163-177: out = silu(gate_up[:, :inter]) * gate_up[:, inter:].
  * splits > 0: gate_up is fp32 split-K partials [splits][rows][2*inter]. */
 int psg_silu_mul(psg_ctx*, const void* gate_up, int splits, int64_t rows, int inter, void* out, int dtype,
                  void* stream);
-/* ... with the gate|up slices being a projection of psg_rmsnorm_pre's rows (hidden = that row length) */
-int psg_silu_mul_ex(psg_ctx*, const void* gate_up, int splits, int64_t rows, int inter, void* out, int dtype, const float* ssq,
-                    int ssq_parts, int hidden, float eps, void* stream);
 
 /* ---- K15: weight-streaming skinny GEMM of the batched decode step (HF-LL q/k/v/o/gate/up/down
  * projections and lm_head, all bias-free Linear layers): y[M][N] = x[M][K] . w[N][K]^T with

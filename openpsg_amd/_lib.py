@@ -71,11 +71,7 @@ SIGNATURES = {
     "psg_prefill_attn": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "psg_prefill_attn_rope": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "psg_decode_attn": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
-    "psg_decode_attn_ex": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _f, _vp],
     "psg_silu_mul": [_vp, _vp, _i, _i64, _i, _vp, _i, _vp],
-    "psg_silu_mul_ex": [_vp, _vp, _i, _i64, _i, _vp, _i, _vp, _i, _i, _f, _vp],
-    "psg_rmsnorm_pre": [_vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _vp, _vp],
-    "psg_rmsnorm_pre_parts": [_i],
     "psg_skinny_gemm_plan": [_vp, _i, _i, _i, _i, C.POINTER(_i)],
     "psg_skinny_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "psg_batch_gemm_plan": [_vp, _i64, _i, _i, _i, _i, _i, C.POINTER(_i)],

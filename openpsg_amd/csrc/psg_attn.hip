@@ -816,8 +816,7 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
                                                            const float* __restrict__ cos_tab,
                                                            const float* __restrict__ sin_tab, int rows, int heads,
                                                            int ctx, T* __restrict__ kc, T* __restrict__ vc,
-                                                           T* __restrict__ out, const float* __restrict__ ssq = nullptr,
-                                                           int ssq_parts = 0, float eps = 0.f) {
+                                                           T* __restrict__ out) {
   __shared__ PsgDecodeAttnScratch sc;
   const int unit = blockIdx.x;
   const int row = unit / heads, h = unit % heads;
@@ -828,13 +827,6 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
   auto ld = [&](const int64_t (&idx)[6], float (&x)[6]) {
     if (qs > 0) {                                             // split-K partials: all slices of q, k, v in one pass
       ldn_splits<float, 6>(qkv, qs, sl, idx, x);
-      if (ssq) {                                              // a projection of psg_rmsnorm_pre's rows: 1 / rms applied here
-        float t = 0.f;
-        for (int c = 0; c < ssq_parts; ++c) t += ssq[(int64_t)row * ssq_parts + c];
-        const float inv = 1.0f / sqrtf(t / (float)hidden + eps);
-#pragma unroll
-        for (int e = 0; e < 6; ++e) x[e] *= inv;
-      }
 #pragma unroll
       for (int e = 0; e < 6; ++e) x[e] = Act<T>::rnd(x[e]);
     } else {
@@ -848,39 +840,23 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
                            st, &sc);
 }
 
-extern "C" int psg_decode_attn_ex(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
-                                  const int32_t* tok_pos, const float* rope_cos, const float* rope_sin, int rows, int heads,
-                                  int head_dim, int ctx, void* k_cache, void* v_cache, void* out, int dtype, const float* ssq,
-                                  int ssq_parts, float eps, void* stream);
 extern "C" int psg_decode_attn(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
                                const int32_t* tok_pos, const float* rope_cos, const float* rope_sin, int rows,
                                int heads, int head_dim, int ctx, void* k_cache, void* v_cache, void* out, int dtype,
                                void* stream) {
-  return psg_decode_attn_ex(ctx_, qkv, qkv_splits, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, head_dim, ctx, k_cache,
-                            v_cache, out, dtype, nullptr, 0, 0.f, stream);
-}
-
-extern "C" int psg_decode_attn_ex(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
-                                  const int32_t* tok_pos, const float* rope_cos, const float* rope_sin, int rows, int heads,
-                                  int head_dim, int ctx, void* k_cache, void* v_cache, void* out, int dtype, const float* ssq,
-                                  int ssq_parts, float eps, void* stream) {
   PSG_REQUIRE(ctx_ && qkv && tok_pair && tok_pos && rope_cos && rope_sin && k_cache && v_cache && out, PSG_ERR_INVALID,
               "psg_decode_attn: NULL argument");
-  PSG_REQUIRE(!ssq || (qkv_splits > 0 && ssq_parts >= 1 && ssq_parts <= 16), PSG_ERR_INVALID,
-              "psg_decode_attn_ex: the row scale needs split-K slices (qkv_splits=%d) and 1..16 chunk sums (%d)", qkv_splits,
-              ssq_parts);
   PSG_REQUIRE(head_dim == 128, PSG_ERR_UNSUPPORTED, "psg_decode_attn: head_dim=%d (kernel is built for 128)", head_dim);
   PSG_REQUIRE(qkv_splits >= 0 && qkv_splits <= PSG_MAX_SPLITS, PSG_ERR_INVALID, "psg_decode_attn: qkv_splits=%d",
               qkv_splits);
   if (rows == 0) return PSG_OK;
   const int waves = rows * heads;
   const int single = ctx_->opt.decode_attn_1wave;    // option decode_attn_1wave: the one-wave-per-head kernel
-  PSG_REQUIRE(!ssq || !single, PSG_ERR_UNSUPPORTED, "psg_decode_attn_ex: the one-wave kernel takes no row scale");
   if (!single) {
     PSG_DISPATCH_DTYPE(dtype, "psg_decode_attn",
                        (decode_attn4_kernel<T><<<waves, 256, 0, (hipStream_t)stream>>>(
                            qkv, qkv_splits, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, (T*)k_cache,
-                           (T*)v_cache, (T*)out, ssq, ssq_parts, eps)));
+                           (T*)v_cache, (T*)out)));
     PSG_CHECK_LAUNCH("psg_decode_attn");
     return PSG_OK;
   }

@@ -37,8 +37,6 @@ struct psg_opts {
   int llm_fuse_rmsnorm = 0;     // decode step: RMSNorm as the prologue of the projection it feeds (psg_skinny_gemm_fused)
   int prefill_attn_scalar = 0;  // prompt pass: scalar cache-attention kernel instead of the matrix-core one
   int llm_fuse_split = 1;       // fp32s prompt pass: operand splits / result scalings inside the row kernels (psg_split.hip)
-  int decode_norm_commute = 1;  // fp32 decode steps: RMSNorm's 1 / rms applied behind the projection (psg_rmsnorm_pre + the _ex
-                                // consumers): fp32-rounding-level different from the chain, 8 workgroups per row instead of 1
   int split_i2 = 1;             // fp32s own-GEMM products (Q-Former, row-invariant Llama prompt pass): interleaved hi / lo
                                 // operands through psg_dense_gemm_split (3 products from one staging; 0: the K' = 3K form)
   int decode_persistent = 0;    // fp32 decode steps: one persistent launch per decoder layer (psg_decode_layer) instead of the

@@ -718,85 +718,9 @@ extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, int qkv_splits, 
   return PSG_OK;
 }
 
-// ---- Round 6: RMSNorm with the row scale applied BEHIND the projection (decode steps, fp32) --------------------------
-// HF-LL:53-67: x_n = w . (x / rms(x)), then q|k|v = x_n W (HF-LL:243-281).  The row scalar commutes with the projection:
-//     x_n W = ((w . x) W) / rms(x)
-// so this kernel writes x' = w . (resid + delta) WITHOUT normalising and the sums of squares of its column chunk; the
-// projection runs on x', and the kernels that sum its split-K slices (psg_decode_attn_ex, psg_silu_mul_ex; the greedy step's
-// argmax does not care about a positive row factor) multiply by 1 / sqrt(sum of the chunks' sums / hidden + eps).
-// Why: psg_rmsnorm needs the whole row before it can write anything, i.e. ONE workgroup per row - 20 compute units pulling
-// 16 slices x 16 KB each; inside the decode graph that launch costs 4.3 us behind the o projection (8 slices) and 7.6 us
-// behind the down projection (16 slices; tools/rowkernel_graph_bench.py), where a kernel of one round trip costs 2.3.
-// Without the row-wide reduction a row is RP_CHUNK-column chunks on as many workgroups (160 for 20 x 4096).
-// Arithmetic against psg_rmsnorm: the slices are summed in the same order and the residual stream gets the same bits;
-// the normalised operand is never rounded on its own (one rounding less), the scale meets the PRODUCT instead of the
-// operand: results agree to fp32 rounding (~1e-7 relative), not bit for bit - the oracle is the gate (tests/test_gpu_*).
-#define RP_CHUNK 512
-__global__ void __launch_bounds__(RP_CHUNK / 4) rmsnorm_pre_kernel(float* __restrict__ resid, const float* __restrict__ delta,
-                                                                  int dsplits, int64_t dslice, const float* __restrict__ w,
-                                                                  int hidden, float* __restrict__ out,
-                                                                  float* __restrict__ ssq) {
-  __shared__ float s_part[RP_CHUNK / 4 / 64];
-  const int64_t row = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int col = blockIdx.x * RP_CHUNK + tid * 4;
-  float ss = 0.f;
-  if (col < hidden) {
-    const float4 r = *reinterpret_cast<const float4*>(resid + row * hidden + col);
-    const float4 g = *reinterpret_cast<const float4*>(w + col);
-    float v[4] = {r.x, r.y, r.z, r.w};
-    if (delta) {
-      float d[4];
-      ld4_in<float>(delta, dsplits, dslice, row * hidden + col, d);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += d[e];
-      *reinterpret_cast<float4*>(resid + row * hidden + col) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    ss = psg_sumsq4(v, 0.f);
-    *reinterpret_cast<float4*>(out + row * hidden + col) = make_float4(g.x * v[0], g.y * v[1], g.z * v[2], g.w * v[3]);
-  }
-  ss = wave_sum(ss);
-  if (lane == 0) s_part[wid] = ss;
-  __syncthreads();
-  if (tid == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < RP_CHUNK / 4 / 64; ++i) t += s_part[i];
-    ssq[row * gridDim.x + blockIdx.x] = t;
-  }
-}
-
-extern "C" int psg_rmsnorm_pre_parts(int hidden) { return hidden > 0 ? (hidden + RP_CHUNK - 1) / RP_CHUNK : 0; }
-
-extern "C" int psg_rmsnorm_pre(psg_ctx* ctx, float* resid, const float* delta, int delta_splits, const float* w, int64_t rows,
-                               int hidden, float* out, float* ssq, void* stream) {
-  PSG_REQUIRE(ctx && resid && w && out && ssq, PSG_ERR_INVALID, "psg_rmsnorm_pre: NULL argument");
-  PSG_REQUIRE(delta_splits >= 0 && (delta || delta_splits == 0) && delta_splits <= PSG_MAX_SPLITS, PSG_ERR_INVALID,
-              "psg_rmsnorm_pre: delta_splits=%d", delta_splits);
-  PSG_REQUIRE(hidden % 4 == 0 && hidden > 0 && hidden <= 16 * RP_CHUNK && rows >= 0 && rows < 65536, PSG_ERR_UNSUPPORTED,
-              "psg_rmsnorm_pre: hidden=%d (multiple of 4, <= %d), rows=%lld", hidden, 16 * RP_CHUNK, (long long)rows);
-  if (rows == 0) return PSG_OK;
-  const dim3 grid((unsigned)psg_rmsnorm_pre_parts(hidden), (unsigned)rows);
-  rmsnorm_pre_kernel<<<grid, RP_CHUNK / 4, 0, (hipStream_t)stream>>>(resid, delta, delta_splits, rows * (int64_t)hidden, w, hidden,
-                                                                      out, ssq);
-  PSG_CHECK_LAUNCH("psg_rmsnorm_pre");
-  return PSG_OK;
-}
-
-// 1 / rms of a row from the chunk sums psg_rmsnorm_pre left (the consumers of a projection of its output)
-__device__ __forceinline__ float psg_inv_rms(const float* __restrict__ ssq, int parts, int64_t row, int hidden, float eps) {
-  float t = 0.f;
-  for (int c = 0; c < parts; ++c) t += ssq[row * parts + c];
-  return 1.0f / sqrtf(t / (float)hidden + eps);
-}
-
 // ---- SwiGLU gate ------------------------------------------------------------------------------
-// ssq != nullptr (psg_silu_mul_ex): the slices are a projection of psg_rmsnorm_pre's un-normalised rows - gate and up sums
-// take the row's 1 / rms here
 template <typename T>
-__global__ void __launch_bounds__(256) silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows, int inter, T* __restrict__ out,
-                                                       const float* __restrict__ ssq = nullptr, int ssq_parts = 0, int hidden = 0,
-                                                       float eps = 0.f) {
+__global__ void __launch_bounds__(256) silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows, int inter, T* __restrict__ out) {
   const int64_t n4 = rows * inter / 4;
   const int i4 = inter / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -807,11 +731,6 @@ __global__ void __launch_bounds__(256) silu_mul_kernel(const void* __restrict__ 
       const int64_t idx[2] = {r * 2 * inter + c, r * 2 * inter + inter + c};
       float4 gu4[2];
       ldn_splits<float4, 2>(gu, S, rows * 2 * inter, idx, gu4);
-      if (ssq) {
-        const float inv = psg_inv_rms(ssq, ssq_parts, r, hidden, eps);
-        gu4[0].x *= inv; gu4[0].y *= inv; gu4[0].z *= inv; gu4[0].w *= inv;
-        gu4[1].x *= inv; gu4[1].y *= inv; gu4[1].z *= inv; gu4[1].w *= inv;
-      }
       g[0] = Act<T>::rnd(gu4[0].x); g[1] = Act<T>::rnd(gu4[0].y); g[2] = Act<T>::rnd(gu4[0].z); g[3] = Act<T>::rnd(gu4[0].w);
       u[0] = Act<T>::rnd(gu4[1].x); u[1] = Act<T>::rnd(gu4[1].y); u[2] = Act<T>::rnd(gu4[1].z); u[3] = Act<T>::rnd(gu4[1].w);
     } else {
@@ -853,22 +772,12 @@ __global__ void __launch_bounds__(256) silu_mul_rows_bf16_kernel(const uint16_t*
   }
 }
 
-extern "C" int psg_silu_mul_ex(psg_ctx* ctx, const void* gate_up, int splits, int64_t rows, int inter, void* out, int dtype,
-                               const float* ssq, int ssq_parts, int hidden, float eps, void* stream);
 extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int splits, int64_t rows, int inter, void* out,
                             int dtype, void* stream) {
-  return psg_silu_mul_ex(ctx, gate_up, splits, rows, inter, out, dtype, nullptr, 0, 0, 0.f, stream);
-}
-
-extern "C" int psg_silu_mul_ex(psg_ctx* ctx, const void* gate_up, int splits, int64_t rows, int inter, void* out, int dtype,
-                               const float* ssq, int ssq_parts, int hidden, float eps, void* stream) {
   PSG_REQUIRE(ctx && gate_up && out, PSG_ERR_INVALID, "psg_silu_mul: NULL argument");
   PSG_REQUIRE(inter > 0 && inter % 4 == 0, PSG_ERR_INVALID, "psg_silu_mul: inter=%d must be a multiple of 4", inter);
-  PSG_REQUIRE(!ssq || (splits > 0 && ssq_parts >= 1 && ssq_parts <= 16 && hidden > 0), PSG_ERR_INVALID,
-              "psg_silu_mul_ex: the row scale needs split-K slices (splits=%d), 1..16 chunk sums (%d) and hidden=%d", splits,
-              ssq_parts, hidden);
   if (rows == 0) return PSG_OK;
-  if (!ssq && (dtype == PSG_BF16 || dtype == PSG_F16) && splits == 0 && rows > 64 && inter % 8 == 0) {
+  if ((dtype == PSG_BF16 || dtype == PSG_F16) && splits == 0 && rows > 64 && inter % 8 == 0) {
     const dim3 grid((unsigned)((inter / 8 + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
     PSG_DISPATCH_E16(dtype, "psg_silu_mul",
                      (silu_mul_rows_bf16_kernel<E><<<grid, 256, 0, (hipStream_t)stream>>>(
@@ -879,8 +788,8 @@ extern "C" int psg_silu_mul_ex(psg_ctx* ctx, const void* gate_up, int splits, in
   int64_t blocks = (rows * inter / 4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   PSG_DISPATCH_DTYPE(dtype, "psg_silu_mul",
-                     (silu_mul_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(gate_up, splits, rows, inter,
-                                                                                          (T*)out, ssq, ssq_parts, hidden, eps)));
+                     (silu_mul_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(gate_up, splits, rows,
+                                                                                          inter, (T*)out)));
   PSG_CHECK_LAUNCH("psg_silu_mul");
   return PSG_OK;
 }

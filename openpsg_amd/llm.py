@@ -301,9 +301,6 @@ class LlamaDecodeEngine:
         # fp32s prompt pass: the split of a projection's operand and the un-scaling of its result inside the row kernels
         # next to it (psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split; bit-identical, 7 launches per layer less)
         self.fuse_split = bool(_lib.get_option(dev_i, "llm_fuse_split"))
-        # fp32 decode steps: the RMSNorm row scale applied behind the projection (psg_rmsnorm_pre: no row-wide reduction in
-        # front of the projection, a row on 8 workgroups instead of one - 4.3 / 7.6 us per launch become ~2.5 in the graph)
-        self.norm_commute = bool(_lib.get_option(dev_i, "decode_norm_commute"))
         # fp32s prompt pass: run each library product whole or in the column / row parts measured fastest (_plan_split_mm)
         self.plan_split = True
         # decode steps of 33..160 rows: psg_batch_gemm where it beats the library (option decode_batch_gemm)
@@ -629,38 +626,6 @@ class LlamaDecodeEngine:
             a2, inv = ops.rmsnorm_split2(x, d, nxt, m.rms_eps)
         return ops.split_gemm_w16(a2, inv, wh[self.lm_head.data_ptr()])
 
-    def _can_commute(self, rows):
-        m = self.cfg.llm
-        return (self.norm_commute and self.use_skinny and self.dtype == torch.float32 and self.resid_dtype == torch.float32
-                and rows <= 32 and m.hidden % 64 == 0 and m.hidden >= 256 and m.hidden <= 8192 and m.inter % 64 == 0
-                and m.inter >= 256 and m.vocab % 16 == 0 and m.head_dim == 128)
-
-    def _decode_step_commute(self, st):
-        """One fp32 decode step with every RMSNorm's row scale applied behind the projection it feeds (HF-LL:53-67 with
-        243-281: x_n W = ((w . x) W) / rms(x)): `rmsnorm_pre` sums the previous projection's slices into the residual stream
-        and writes w . x for the next one, the attention / SwiGLU kernels that sum THAT projection's slices multiply by
-        1 / rms; the lm_head's slices go to the greedy step as they are (its argmax is indifferent to a positive row
-        factor).  Same weight-streaming projections as the chain (`linear`: fp32 stream, or the exact fp16-stored stream)."""
-        m = self.cfg.llm
-        x = st["x"]
-        K, D = x.shape
-        n = torch.empty_like(x)
-        att = torch.empty_like(x)
-        act = torch.empty((K, m.inter), device=self.device, dtype=torch.float32)
-        sc = ops.rmsnorm_pre(x, None, self.layers[0]["ln1"], m.rms_eps, n)
-        for l, L in enumerate(self.layers):
-            qkv = self.linear(n, L["wqkv"], decode=True)
-            ops.decode_attn(qkv, st["dec_pair"], st["dec_pos"], self.rope, m.heads, m.head_dim, st["ctx_len"], st["kc"][l],
-                            st["vc"][l], att, scale=sc)
-            o = self.linear(att, L["wo"], decode=True)
-            sc = ops.rmsnorm_pre(x, o, L["ln2"], m.rms_eps, n)
-            gu = self.linear(n, L["wgu"], decode=True)
-            ops.silu_mul(gu, act, scale=sc)
-            d = self.linear(act, L["wdown"], decode=True)
-            nxt = self.layers[l + 1]["ln1"] if l + 1 < len(self.layers) else self.final_norm
-            sc = ops.rmsnorm_pre(x, d, nxt, m.rms_eps, n)
-        return self.linear(n, self.lm_head, decode=True)
-
     def _can_fuse(self, rows):
         m = self.cfg.llm
         D = m.hidden
@@ -912,8 +877,7 @@ class LlamaDecodeEngine:
         m = self.cfg.llm
         persist = hi > lo and self._can_persist(st["x"].shape[0], st.get("slot", 0))
         w16 = not persist and self._can_w16(st["x"].shape[0])
-        commute = not persist and not w16 and self._can_commute(st["x"].shape[0])
-        fused = not persist and not w16 and not commute and self._can_fuse(st["x"].shape[0]) and hi > lo
+        fused = not persist and not w16 and self._can_fuse(st["x"].shape[0]) and hi > lo
         if persist:                                            # one counter block per layer launch, zeroed once per call
             per_step = ops.decode_layer_counters(self.device) * len(self.layers)
             sync = torch.zeros((hi - lo) * per_step, device=self.device, dtype=torch.int32)
@@ -928,8 +892,6 @@ class LlamaDecodeEngine:
                 logits = self._decode_step_persistent(st, sync[(step - lo) * per_step:(step - lo + 1) * per_step])
             elif w16:
                 logits = self._decode_step_w16(st)
-            elif commute:
-                logits = self._decode_step_commute(st)
             elif fused:
                 logits = self._decode_step_fused(st, sync[(step - lo) * per_step:(step - lo + 1) * per_step])
             else:

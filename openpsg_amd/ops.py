@@ -364,31 +364,6 @@ def rmsnorm(resid, delta, w, eps, out):
     return out
 
 
-class RowSumSq:
-    """What `rmsnorm_pre` leaves for the consumers of a projection of its output: the sums of squares of every row's
-    512-column chunks ([rows, parts] fp32), the row length and eps - they multiply by 1 / sqrt(sum / hidden + eps)."""
-
-    def __init__(self, ssq, hidden, eps):
-        self.ssq, self.hidden, self.eps = ssq, int(hidden), float(eps)
-
-    @property
-    def parts(self):
-        return self.ssq.shape[1]
-
-
-def rmsnorm_pre(resid, delta, w, eps, out):
-    """resid (fp32) += delta (Partials or None); out = w * resid WITHOUT the 1 / rms, which commutes with the projection
-    that reads `out` (psg_rmsnorm_pre).  Returns the `RowSumSq` for `decode_attn` / `silu_mul` (argument `scale`)."""
-    lib, ctx, st = _env(resid)
-    rows, hidden = resid.shape
-    assert resid.dtype == torch.float32 and out.dtype == torch.float32 and (delta is None or isinstance(delta, Partials))
-    parts = lib.psg_rmsnorm_pre_parts(int(hidden))
-    ssq = torch.empty((rows, parts), device=resid.device, dtype=torch.float32)
-    dp, ds = (None, 0) if delta is None else (_p(delta.t, torch.float32), delta.splits)
-    check(lib.psg_rmsnorm_pre(ctx, _p(resid), dp, ds, _p(w, torch.float32), rows, hidden, _p(out), _p(ssq), st), "psg_rmsnorm_pre")
-    return RowSumSq(ssq, hidden, eps)
-
-
 def rope_kvwrite(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, q_out, k_cache, v_cache, rope_pos=None):
     """rope = (cos, sin) fp32 tables [>= ctx_len, head_dim/2].  rope_pos int32 [rows]: rotary positions when they
     differ from the cache slots (training forward)."""
@@ -438,19 +413,11 @@ def prefill_attn_rope(qkv, tok_pos, rope, pairs, rows_per_pair, heads, head_dim,
     return out
 
 
-def decode_attn(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, k_cache, v_cache, out, scale=None):
-    """Fused rotary + KV append + attention for rows that each hold the newest token of their pair.
-    scale (a `RowSumSq`): qkv are split-K slices of a projection of `rmsnorm_pre`'s rows - the 1 / rms is applied here."""
+def decode_attn(qkv, tok_pair, tok_pos, rope, heads, head_dim, ctx_len, k_cache, v_cache, out):
+    """Fused rotary + KV append + attention for rows that each hold the newest token of their pair."""
     lib, ctx, st = _env(out)
     qp, qs = _in(qkv, out.dtype)
     assert rope[0].shape[0] >= ctx_len and rope[0].shape[1] == head_dim // 2
-    if scale is not None:
-        assert scale.hidden == heads * head_dim and scale.ssq.shape[0] == out.shape[0]
-        check(lib.psg_decode_attn_ex(ctx, qp, qs, _p(tok_pair, torch.int32), _p(tok_pos, torch.int32), _p(rope[0], torch.float32),
-                                     _p(rope[1], torch.float32), out.shape[0], heads, head_dim, ctx_len, _p(k_cache, out.dtype),
-                                     _p(v_cache, out.dtype), _p(out), _dt(out), _p(scale.ssq, torch.float32), scale.parts,
-                                     scale.eps, st), "psg_decode_attn_ex")
-        return out
     check(lib.psg_decode_attn(ctx, qp, qs, _p(tok_pair, torch.int32), _p(tok_pos, torch.int32),
                               _p(rope[0], torch.float32), _p(rope[1], torch.float32), out.shape[0], heads, head_dim, ctx_len,
                               _p(k_cache, out.dtype), _p(v_cache, out.dtype), _p(out), _dt(out), st), "psg_decode_attn")
@@ -539,16 +506,10 @@ def decode_layers(resid, delta, table, n_layers, tok_pair, tok_pos, rope, heads,
     return Partials(down_parts[(n_layers - 1) & 1])
 
 
-def silu_mul(gate_up, out, scale=None):
-    """out = silu(gate) * up.  scale (a `RowSumSq`): gate_up are split-K slices of a projection of `rmsnorm_pre`'s rows."""
+def silu_mul(gate_up, out):
     lib, ctx, st = _env(out)
     rows, inter = out.shape
     gp, gs = _in(gate_up, out.dtype)
-    if scale is not None:
-        assert scale.ssq.shape[0] == rows
-        check(lib.psg_silu_mul_ex(ctx, gp, gs, rows, inter, _p(out), _dt(out), _p(scale.ssq, torch.float32), scale.parts,
-                                  scale.hidden, scale.eps, st), "psg_silu_mul_ex")
-        return out
     check(lib.psg_silu_mul(ctx, gp, gs, rows, inter, _p(out), _dt(out), st), "psg_silu_mul")
     return out
 

@@ -228,108 +228,6 @@ def test_dense_gemm_split_three_products_from_one_staging(M, N, K, gelu):
         assert torch.equal(ops.dense_gemm_split(a2, b2, b, inv_r, inv_c, gelu=gelu, tile=tile), y), tile
 
 
-def test_rmsnorm_row_scale_behind_the_projection():
-    """Round 6 (psg_rmsnorm_pre, psg_decode_attn_ex, psg_silu_mul_ex): HF-LL:53-67 followed by a bias-free projection
-    (HF-LL:243-281) is ((w . x) W) / rms(x).  The pre kernel must leave the residual stream psg_rmsnorm leaves (bit for
-    bit), w . x exactly, and chunk sums that add up to the row's sum of squares; the consumers with the scale must agree
-    with the consumers fed normalised slices to fp32 rounding."""
-    from openpsg_amd import ops
-    dev = _dev()
-    g = torch.Generator(device=dev).manual_seed(21)
-    eps = 1e-5
-    for rows, D in ((20, 4096), (1, 4096), (32, 4096), (5, 512), (7, 1280)):
-        w = 1.0 + 0.1 * torch.randn(D, generator=g, device=dev)
-        for S in (0, 8, 16):
-            resid = torch.randn(rows, D, generator=g, device=dev) * 3
-            delta = ops.Partials(torch.randn(S, rows, D, generator=g, device=dev).contiguous()) if S else None
-            ra, rb = resid.clone(), resid.clone()
-            n = torch.empty_like(ra)
-            ops.rmsnorm(ra, delta, w, eps, n)
-            out = torch.empty_like(rb)
-            sc = ops.rmsnorm_pre(rb, delta, w, eps, out)
-            assert torch.equal(ra, rb), (rows, D, S)
-            assert torch.equal(out, rb * w)
-            assert sc.ssq.shape == (rows, -(-D // 512)) and sc.hidden == D
-            ss = rb.double().pow(2).sum(1)
-            assert ((sc.ssq.double().sum(1) - ss).abs() / ss).max().item() < 1e-6
-            inv = torch.rsqrt(sc.ssq.sum(1) / D + eps)
-            assert ((out * inv[:, None] - n).abs().max() / n.abs().max()).item() < 1e-6
-    # consumers: slices of a projection of the un-normalised rows + the scale == slices of the normalised rows' projection
-    rows, heads, ctx, I = 20, 32, 64, 11008
-    D = heads * 128
-    x = torch.randn(rows, D, generator=g, device=dev) * 2
-    w = torch.ones(D, device=dev)
-    out = torch.empty_like(x)
-    sc = ops.rmsnorm_pre(x.clone(), None, w, eps, out)
-    inv = torch.rsqrt(sc.ssq.sum(1) / D + eps)
-    gu_raw = torch.randn(8, rows, 2 * I, generator=g, device=dev)
-    a_ref, a_new = torch.empty(rows, I, device=dev), torch.empty(rows, I, device=dev)
-    ops.silu_mul(ops.Partials((gu_raw * inv[None, :, None]).contiguous()), a_ref)
-    ops.silu_mul(ops.Partials(gu_raw), a_new, scale=sc)
-    rel = ((a_ref - a_new).abs().max() / a_ref.abs().max()).item()
-    print(f"silu_mul with the row scale: {rel:.2e} of the largest value")
-    assert rel < 2e-6
-    ang = torch.arange(ctx, dtype=torch.float32)[:, None] / (10000 ** (torch.arange(0, 128, 2).float() / 128))[None]
-    rope = (ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev))
-    pos = torch.randint(1, ctx - 1, (rows,), generator=g, device=dev, dtype=torch.int32)
-    pair = torch.arange(rows, device=dev, dtype=torch.int32)
-    qkv_raw = torch.randn(8, rows, 3 * D, generator=g, device=dev)
-    kc = torch.randn(rows, heads, ctx, 128, generator=g, device=dev)
-    vc = torch.randn(rows, heads, ctx, 128, generator=g, device=dev)
-    outs = []
-    for scaled in (False, True):
-        kc_, vc_ = kc.clone(), vc.clone()
-        att = torch.empty(rows, D, device=dev)
-        if scaled:
-            ops.decode_attn(ops.Partials(qkv_raw), pair, pos, rope, heads, 128, ctx, kc_, vc_, att, scale=sc)
-        else:
-            ops.decode_attn(ops.Partials((qkv_raw * inv[None, :, None]).contiguous()), pair, pos, rope, heads, 128, ctx, kc_, vc_, att)
-        outs.append((att, kc_, vc_))
-    for a, b in zip(*outs):
-        d = ((a - b).abs().max() / a.abs().max()).item()
-        assert d < 5e-6, d
-
-
-def test_decode_steps_with_the_row_scale_behind_the_projection_decode_the_reference_tokens():
-    """G6 (Llama-2-7B width, the real reference's 20 x 16 greedy tokens) through the fp32 and fp32s heads with option
-    decode_norm_commute on (default) and off: both reproduce every reference token; the two arithmetics agree token for
-    token (they differ by fp32 roundings of the decode steps only: the prompt pass is the same)."""
-    import numpy as np
-    from openpsg_amd import _lib
-    from openpsg_amd.head import RelationTransformerHeadV4
-    from tests import helpers as H
-    g, cfg, w, scene = H.load_case("G6_llm_7b_width_n6")
-    dev = torch.device("cuda:0")
-    ids = [int(i) for i in scene["object_id_list"]]
-    names = H.object_names(scene)
-    sel = torch.from_numpy(g["selected"].astype(np.int32)).to(dev)
-    for dtype in ("fp32", "fp32s"):
-        outs = {}
-        for flag in (0, 1):
-            _lib.set_option(0, "decode_norm_commute", flag)
-            try:
-                head = RelationTransformerHeadV4(dtype=dtype, device="cuda:0", qformer_vocab_size=cfg.qformer.vocab,
-                                                 llm_config=cfg.llm, llm_feature_size=cfg.llm.hidden, tokenizers="word",
-                                                 max_object_num=cfg.max_object_num, on_parse_error="skip",
-                                                 suppress_eos=bool(g["suppress_eos"]))
-                head.load_weights(w)
-                assert head.llm_engine.norm_commute == bool(flag)
-                rq = head.run_relation_query(scene["mask_features"].to(dev), scene["img_meta"], ids, names,
-                                             scene["pan_results"].to(dev))
-                dec = head.decode_selected(rq, names, selected=sel)
-                dec2 = head.decode_selected(rq, names, selected=sel)         # graph replay
-                assert np.array_equal(dec["tokens_host"], dec2["tokens_host"])
-                outs[flag] = dec["tokens_host"].copy()
-            finally:
-                _lib.set_option(0, "decode_norm_commute", 1)
-            del head
-            torch.cuda.empty_cache()
-        assert np.array_equal(outs[0], outs[1]), dtype
-        for i in range(outs[1].shape[0]):
-            want = g["gen_tokens"][i]
-            assert [int(t) for t in outs[1][i] if t >= 0] == want[want >= 0].tolist(), (dtype, i)
-
-
 def test_fused_split_kernels_equal_the_separate_kernels_bit_for_bit():
     """psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split against psg_scale_rows_cols + psg_rmsnorm /
     psg_rope_kvwrite / psg_silu_mul + psg_split_f16x3 on the prompt pass's shapes: identical bits (no GEMM involved)."""

@@ -49,11 +49,6 @@ def main():
             for i in range(n):
                 ops.rmsnorm(resid, parts[i], w, 1e-5, out)
         print(f"rmsnorm, {S:2d} slices of [20, 4096]: {graph_time(norm) / n:5.2f} us per launch in a graph")
-
-        def pre():
-            for i in range(n):
-                ops.rmsnorm_pre(resid, parts[i], w, 1e-5, out)
-        print(f"rmsnorm_pre (row scale behind the projection), {S:2d} slices: {graph_time(pre) / n:5.2f} us")
     gus = [ops.Partials(torch.randn(8, K, 2 * I, device=dev)) for _ in range(n)]
 
     def silu():
