@@ -1,5 +1,7 @@
-"""What a decode step's row kernels cost INSIDE a HIP graph (kernel-trace durations overlap their neighbours' fill and drain):
-graph replays of 64 launches each.   python tools/rowkernel_graph_bench.py"""
+"""What a decode step's row kernels cost as INDEPENDENT launches inside a HIP graph (replays of 64 launches each on cold
+slices).  Caveat learnt in round 6 (profiles/r06_norm_commute_ab.txt): behind a weight-streaming launch a DEPENDENT kernel
+lasts ~5 us whatever these figures say - its first loads wait for the producer's slices to become visible across the eight
+L2s - so a kernel that is 3x cheaper here can buy nothing in the chain.   python tools/rowkernel_graph_bench.py"""
 import os
 import sys
 
