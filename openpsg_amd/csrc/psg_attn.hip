@@ -4,6 +4,8 @@
 //   K14 Llama attention over the KV cache, prefill + decode (head_dim 128)    HF-LL:191-214
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "psg_common.h"
 #include "psg_decode_math.h"
 
@@ -816,7 +818,7 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
                                                            const float* __restrict__ cos_tab,
                                                            const float* __restrict__ sin_tab, int rows, int heads,
                                                            int ctx, T* __restrict__ kc, T* __restrict__ vc,
-                                                           T* __restrict__ out) {
+                                                           T* __restrict__ out, int wt = 0) {
   __shared__ PsgDecodeAttnScratch sc;
   const int unit = blockIdx.x;
   const int row = unit / heads, h = unit % heads;
@@ -834,7 +836,15 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
       for (int e = 0; e < 6; ++e) x[e] = Act<T>::ld(reinterpret_cast<const T*>(qkv), idx[e]);
     }
   };
-  auto st = [&](int64_t i, float v) { Act<T>::st(out, i, v); };
+  auto st = [&](int64_t i, float v) {
+    if constexpr (std::is_same<T, float>::value) {
+      if (wt) {                                                 // option wt_stores: 4-byte agent-scope store = write-through
+        __hip_atomic_store(reinterpret_cast<unsigned*>(out) + i, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
+    Act<T>::st(out, i, v);
+  };
   // the arithmetic lives in psg_decode_math.h: the persistent decoder layer (psg_decode_layer.hip) runs the same unit
   psg_decode_attn4_unit<T>(true, (int)threadIdx.x, row, h, pos, tok_pair[row], heads, ctx, cos_tab, sin_tab, kc, vc, ld,
                            st, &sc);
@@ -856,7 +866,7 @@ extern "C" int psg_decode_attn(psg_ctx* ctx_, const void* qkv, int qkv_splits, c
     PSG_DISPATCH_DTYPE(dtype, "psg_decode_attn",
                        (decode_attn4_kernel<T><<<waves, 256, 0, (hipStream_t)stream>>>(
                            qkv, qkv_splits, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, (T*)k_cache,
-                           (T*)v_cache, (T*)out)));
+                           (T*)v_cache, (T*)out, ctx_->opt.wt_stores)));
     PSG_CHECK_LAUNCH("psg_decode_attn");
     return PSG_OK;
   }

@@ -37,6 +37,8 @@ struct psg_opts {
   int llm_fuse_rmsnorm = 0;     // decode step: RMSNorm as the prologue of the projection it feeds (psg_skinny_gemm_fused)
   int prefill_attn_scalar = 0;  // prompt pass: scalar cache-attention kernel instead of the matrix-core one
   int llm_fuse_split = 1;       // fp32s prompt pass: operand splits / result scalings inside the row kernels (psg_split.hip)
+  int wt_stores = 0;            // decode-step kernels (fp32 chain) store their outputs write-through (sc1): nothing dirty in
+                                // the eight L2s when the launch ends (experiment of round 6)
   int split_i2 = 1;             // fp32s own-GEMM products (Q-Former, row-invariant Llama prompt pass): interleaved hi / lo
                                 // operands through psg_dense_gemm_split (3 products from one staging; 0: the K' = 3K form)
   int decode_persistent = 0;    // fp32 decode steps: one persistent launch per decoder layer (psg_decode_layer) instead of the
@@ -334,6 +336,14 @@ __device__ __forceinline__ void ldn_splits(const void* __restrict__ in, int S, i
 #pragma unroll
       for (int v = 0; v < NV; ++v) psg_acc(o[v], t[s][v]);
     }
+}
+
+// 16-byte store written through the L2 (agent scope: sc1) - a kernel whose outputs are all stored this way leaves no dirty
+// line behind for the release at its end
+__device__ __forceinline__ void psg_st4_wt(float* p, float a, float b, float c, float d) {
+  typedef float psg_wt_f4 __attribute__((ext_vector_type(4)));
+  const psg_wt_f4 v = {a, b, c, d};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
 // dispatch on the activation dtype enum

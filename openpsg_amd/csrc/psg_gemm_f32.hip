@@ -101,7 +101,7 @@ template <int WAVES, int SLOTS, int G16, int G4, bool W16 = false>
 __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_f32_kernel(const float* __restrict__ x,
                                                                      const void* __restrict__ w,
                                                                      float* __restrict__ part, int M, int N, int K,
-                                                                     int xstride) {
+                                                                     int xstride, int wt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ROWS = WAVES * 16;
   constexpr int WROW = W16 ? 64 : 128;                              // bytes of one row of a 32-weight K block
@@ -228,7 +228,9 @@ __global__ void __launch_bounds__(WAVES * 64) skinny_gemm_f32_kernel(const float
         const int m = e / C4, c4 = e - m * C4;
         if (nblk + c4 * 4 + 4 <= N) {
           const sf32x4_t v = sgf_ds_read128(otile_lds + (uint32_t)(m * OT_PITCH + c4 * 4) * 4u);
-          *reinterpret_cast<float4*>(part + ((int64_t)by * M + m) * N + nblk + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          float* dst = part + ((int64_t)by * M + m) * N + nblk + c4 * 4;
+          if (wt) psg_st4_wt(dst, v[0], v[1], v[2], v[3]);         // option wt_stores: the slices leave the L2 as they are written
+          else *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
@@ -354,6 +356,7 @@ int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int 
   if (G < 1) G = 1;
   const dim3 grid(G, splits);
   hipStream_t st = (hipStream_t)stream;
+  const int wt = ctx->opt.wt_stores;
   // x rows: 16-row groups (16x16x1_4b) then 4-row groups (4x4x1_16b); up to 12 rows go through 4-row groups only
   const int g16 = M <= 12 ? 0 : (M <= 28 ? 1 : 2), g4 = M <= 12 ? (M + 3) / 4 : (M <= 16 || M > 28 ? 0 : (M - 16 + 3) / 4);
 #define SGF_K(WV, SL, A, B)                                                                              \
@@ -362,11 +365,11 @@ int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int 
       (void)hipFuncSetAttribute((const void*)skinny_gemm_f32_kernel<WV, 2 * SL, A, B, true>,             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
       skinny_gemm_f32_kernel<WV, 2 * SL, A, B, true><<<grid, WV * 64, lds, st>>>((const float*)x, w, part, M, N, K, \
-                                                                                 xstride);               \
+                                                                                 xstride, wt);           \
     } else {                                                                                             \
       (void)hipFuncSetAttribute((const void*)skinny_gemm_f32_kernel<WV, SL, A, B>,                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-      skinny_gemm_f32_kernel<WV, SL, A, B><<<grid, WV * 64, lds, st>>>((const float*)x, w, part, M, N, K, xstride); \
+      skinny_gemm_f32_kernel<WV, SL, A, B><<<grid, WV * 64, lds, st>>>((const float*)x, w, part, M, N, K, xstride, wt); \
     }                                                                                                    \
   } while (0)
 #define SGF_L(WV, A, B)                   \

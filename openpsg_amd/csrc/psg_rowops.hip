@@ -8,6 +8,8 @@
 //   K13 rotary + KV-cache write                (HF-LL:130-160)
 //       SwiGLU gate                            (HF-LL:163-177)
 //   K16 greedy argmax step                     (V4:305-312)
+#include <type_traits>
+
 #include "psg_common.h"
 #include "psg_decode_math.h"
 
@@ -462,7 +464,7 @@ extern "C" int psg_exist_head(psg_ctx* ctx, const void* x, const float* w, const
 template <typename T, int NCH, typename R = T>
 __global__ void __launch_bounds__(1024) rmsnorm_kernel(R* __restrict__ resid, const void* __restrict__ delta,
                                                       int dsplits, int64_t dslice, const float* __restrict__ w,
-                                                      float eps, int hidden, T* __restrict__ out) {
+                                                      float eps, int hidden, T* __restrict__ out, int wt = 0) {
   __shared__ float s_part[16];
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthr = blockDim.x;
@@ -513,9 +515,16 @@ __global__ void __launch_bounds__(1024) rmsnorm_kernel(R* __restrict__ resid, co
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * nthr + tid) * 4;
     if (col < hidden) {
-      if (delta) Act<R>::st4(resid, row * hidden + col, v[c]);
       float o[4] = {g[c].x * (v[c][0] * inv), g[c].y * (v[c][1] * inv), g[c].z * (v[c][2] * inv),
                     g[c].w * (v[c][3] * inv)};
+      if constexpr (std::is_same<T, float>::value && std::is_same<R, float>::value) {
+        if (wt) {                                             // option wt_stores (fp32 decode chain)
+          if (delta) psg_st4_wt(reinterpret_cast<float*>(resid) + row * hidden + col, v[c][0], v[c][1], v[c][2], v[c][3]);
+          psg_st4_wt(reinterpret_cast<float*>(out) + row * hidden + col, o[0], o[1], o[2], o[3]);
+          continue;
+        }
+      }
+      if (delta) Act<R>::st4(resid, row * hidden + col, v[c]);
       Act<T>::st4(out, row * hidden + col, o);
     }
   }
@@ -633,6 +642,7 @@ extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int del
     return PSG_OK;
   }
   // decode-sized launches (a handful of rows) are latency bound: spread each row over 16 waves
+  const int wt = (ctx->opt.wt_stores && rows <= 64) ? 1 : 0;
   const int nthr = (rows <= 64 && hidden >= 4096) ? 1024 : 256;
   const int nch = (hidden + 4 * nthr - 1) / (4 * nthr);
 #define RN(N)                                                                                                        \
@@ -643,7 +653,7 @@ extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int del
   } else                                                                                                             \
     PSG_DISPATCH_DTYPE(dtype, "psg_rmsnorm",                                                                         \
                        (rmsnorm_kernel<T, N><<<grid, nthr, 0, st>>>((T*)resid, delta, delta_splits, rows * hidden, w, \
-                                                                   eps, hidden, (T*)out)))
+                                                                   eps, hidden, (T*)out, wt)))
   switch (nch) {
     case 1: RN(1); break;
     case 2: RN(2); break;
@@ -720,7 +730,8 @@ extern "C" int psg_rope_kvwrite(psg_ctx* ctx_, const void* qkv, int qkv_splits, 
 
 // ---- SwiGLU gate ------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows, int inter, T* __restrict__ out) {
+__global__ void __launch_bounds__(256) silu_mul_kernel(const void* __restrict__ gu, int S, int64_t rows, int inter, T* __restrict__ out,
+                                                       int wt = 0) {
   const int64_t n4 = rows * inter / 4;
   const int i4 = inter / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -742,6 +753,12 @@ __global__ void __launch_bounds__(256) silu_mul_kernel(const void* __restrict__ 
       float s = g[e] / (1.0f + expf(-g[e]));
       s = Act<T>::rnd(s);  // HF rounds act_fn(gate) before the product
       o[e] = s * u[e];
+    }
+    if constexpr (std::is_same<T, float>::value) {
+      if (wt) {
+        psg_st4_wt(reinterpret_cast<float*>(out) + r * inter + c, o[0], o[1], o[2], o[3]);
+        continue;
+      }
     }
     Act<T>::st4(out, r * inter + c, o);
   }
@@ -788,8 +805,8 @@ extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int splits, int64
   int64_t blocks = (rows * inter / 4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   PSG_DISPATCH_DTYPE(dtype, "psg_silu_mul",
-                     (silu_mul_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(gate_up, splits, rows,
-                                                                                          inter, (T*)out)));
+                     (silu_mul_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(
+                         gate_up, splits, rows, inter, (T*)out, (ctx->opt.wt_stores && rows <= 64) ? 1 : 0)));
   PSG_CHECK_LAUNCH("psg_silu_mul");
   return PSG_OK;
 }
