@@ -62,7 +62,7 @@ __host__ __device__ static inline int bg_owner(int64_t u, int64_t T, int G) { re
 template <typename E, int MT, int TJ, int WM = 2, bool PAIR = false>
 __global__ void __launch_bounds__(BG_WAVES * 64, 1)
 batch_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, float* __restrict__ part, int M, int N,
-                  int K, int S, int S_al, int var, const float* __restrict__ row_scale) {
+                  int K, int S, int S_al, int var, const float* __restrict__ row_scale, int wt) {
   using v8 = typename E::v8;
   static_assert(!PAIR || (MT == 2 && WM == 1 && TJ == 1), "the pair form is two x tiles, one weight tile per wave");
   constexpr int WN = BG_WAVES / WM, TI = (MT + WM - 1) / WM, BM = MT * 32, BN = WN * TJ * 32;
@@ -250,8 +250,13 @@ batch_gemm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w
             for (int r = 0; r < 16; ++r) {
               const int mrow = 8 * (r >> 2) + (r & 3);
               float* rowp = ps + (int64_t)mrow * N + n0;
-              if (mrow + 4 * hi < M)
-                rowp[lane_off] = real ? (acc[0][0][r] + acc[1][0][r]) * row_scale[mrow + 4 * hi] : 0.f;
+              if (mrow + 4 * hi < M) {
+                const float val = real ? (acc[0][0][r] + acc[1][0][r]) * row_scale[mrow + 4 * hi] : 0.f;
+                if (wt)                                      // option wt_stores: agent-scope store = written through the L2
+                  __hip_atomic_store(reinterpret_cast<unsigned*>(rowp + lane_off), __float_as_uint(val), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+                else rowp[lane_off] = val;
+              }
             }
           }
         }
@@ -373,7 +378,7 @@ extern "C" int psg_batch_gemm_plan(psg_ctx* ctx, int64_t M, int N, int K, int dt
 
 template <typename E, int MT, int TJ, int WM = 2, bool PAIR = false>
 static int bg_launch(const bg_plan& p, const void* x, const void* w, float* part, int M, int N, int K, int var,
-                     void* stream, const float* row_scale = nullptr) {
+                     void* stream, const float* row_scale = nullptr, int wt = 0) {
   constexpr int STAGE = (MT * 32 + (BG_WAVES / WM) * TJ * 32) * 128;
   constexpr int NST_ = bg_nst(STAGE);
   static_assert(4 * ((MT * 32 + (BG_WAVES / WM) * TJ * 32) / 8 / BG_WAVES + 1) <= 63, "vmcnt field");
@@ -384,7 +389,7 @@ static int bg_launch(const bg_plan& p, const void* x, const void* w, float* part
     return PSG_ERR_HIP;
   }
   k<<<(unsigned)p.grid, BG_WAVES * 64, NST_ * STAGE, (hipStream_t)stream>>>((const uint16_t*)x, (const uint16_t*)w, part, M,
-                                                                             N, K, p.slots, p.s_al, var, row_scale);
+                                                                             N, K, p.slots, p.s_al, var, row_scale, wt);
   PSG_CHECK_LAUNCH("psg_batch_gemm");
   return PSG_OK;
 }
@@ -435,5 +440,6 @@ extern "C" int psg_split_gemm_w16(psg_ctx* ctx, const void* x2, const float* inv
   PSG_REQUIRE(slots == want, PSG_ERR_INVALID, "psg_split_gemm_w16: slots=%d, the plan for M=%d N=%d K=%d writes %d", slots, M,
               N, K, want);
   const bg_plan p = bg_make_plan(ctx, M, N, K, 0, mode, true);
-  return bg_launch<EF16, 2, 1, 1, true>(p, x2, w16, part, M, N, K, ctx->opt.batch_gemm_var, stream, inv_scale);
+  return bg_launch<EF16, 2, 1, 1, true>(p, x2, w16, part, M, N, K, ctx->opt.batch_gemm_var, stream, inv_scale,
+                                        ctx->opt.wt_stores);
 }

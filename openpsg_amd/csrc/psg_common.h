@@ -37,8 +37,8 @@ struct psg_opts {
   int llm_fuse_rmsnorm = 0;     // decode step: RMSNorm as the prologue of the projection it feeds (psg_skinny_gemm_fused)
   int prefill_attn_scalar = 0;  // prompt pass: scalar cache-attention kernel instead of the matrix-core one
   int llm_fuse_split = 1;       // fp32s prompt pass: operand splits / result scalings inside the row kernels (psg_split.hip)
-  int wt_stores = 0;            // decode-step kernels (fp32 chain) store their outputs write-through (sc1): nothing dirty in
-                                // the eight L2s when the launch ends (experiment of round 6)
+  int wt_stores = 1;            // decode-step kernels of the fp32 modes store their outputs write-through (sc1): nothing dirty
+                                // in the eight L2s when a launch ends - 0.5 us per kernel boundary, -2 ms per image
   int split_i2 = 1;             // fp32s own-GEMM products (Q-Former, row-invariant Llama prompt pass): interleaved hi / lo
                                 // operands through psg_dense_gemm_split (3 products from one staging; 0: the K' = 3K form)
   int decode_persistent = 0;    // fp32 decode steps: one persistent launch per decoder layer (psg_decode_layer) instead of the

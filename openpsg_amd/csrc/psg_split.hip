@@ -130,13 +130,13 @@ __global__ void __launch_bounds__(256) split_f16x2_kernel(const float* __restric
 }
 
 __device__ __forceinline__ float sp_row_scale(float mx, float* inv_scale_out);
-__device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, const float (&x)[4], float scale);
+__device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, const float (&x)[4], float scale, int wt = 0);
 // decode steps (<= 64 rows): 1024 threads per row, the row held in registers between the maximum and the stores - one
 // read of x and one barrier instead of two passes (the launch is latency, not bytes)
 template <int NCH>
 __global__ void __launch_bounds__(1024) split_f16x2_small_kernel(const float* __restrict__ x, int64_t row_stride, int K,
                                                                  int64_t rows, uint16_t* __restrict__ out,
-                                                                 float* __restrict__ inv_scale) {
+                                                                 float* __restrict__ inv_scale, int wt) {
   __shared__ float s_max[16];
   const int64_t row = blockIdx.x;
   const float* xr = x + row * row_stride;
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(1024) split_f16x2_small_kernel(const float* __
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * 1024 + tid) * 4;
-    if (col < K) sp_store2(oh, ol, col, v[c], scale);
+    if (col < K) sp_store2(oh, ol, col, v[c], scale, wt);
   }
 }
 
@@ -175,9 +175,9 @@ extern "C" int psg_split_f16x2(psg_ctx* ctx, const float* x, int64_t rows, int K
   if (rows == 0) return PSG_OK;
   if (rows <= 64 && K <= 16384) {
     hipStream_t st = (hipStream_t)stream;
-    if (K <= 4096) split_f16x2_small_kernel<1><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale);
-    else if (K <= 12288) split_f16x2_small_kernel<3><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale);
-    else split_f16x2_small_kernel<4><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale);
+    if (K <= 4096) split_f16x2_small_kernel<1><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale, ctx->opt.wt_stores);
+    else if (K <= 12288) split_f16x2_small_kernel<3><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale, ctx->opt.wt_stores);
+    else split_f16x2_small_kernel<4><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale, ctx->opt.wt_stores);
     PSG_CHECK_LAUNCH("psg_split_f16x2");
     return PSG_OK;
   }
@@ -231,7 +231,7 @@ __device__ __forceinline__ float sp_row_scale(float mx, float* inv_scale_out) { 
   if (inv_scale_out) *inv_scale_out = __uint_as_float((uint32_t)(254 - se) << 23);
   return __uint_as_float((uint32_t)se << 23);
 }
-__device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, const float (&x)[4], float scale);   // two planes
+__device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, const float (&x)[4], float scale, int wt);   // two planes
 __device__ __forceinline__ void sp_store3(uint16_t* o0, int K, int c, const float (&x)[4], float scale) {   // [hi | hi | lo]
   ushort4 h, l;
   uint16_t* hp = &h.x;
@@ -482,7 +482,8 @@ extern "C" int psg_rope_kvwrite_scaled(psg_ctx* ctx_, const float* qkv, const fl
 // launch instead of two (HF-LL:53-67).  (The SwiGLU gate stays two launches: its row maximum spans 11008 columns, and one
 // workgroup per row took 24 us against 5.2 + 4.9 for psg_silu_mul over all CUs + psg_split_f16x2.)
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, const float (&x)[4], float scale) {
+// wt (option wt_stores, decode steps): the two 8-byte stores written through the L2 (agent-scope stores = sc1)
+__device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, const float (&x)[4], float scale, int wt) {
   ushort4 h, l;
   uint16_t* hp = &h.x;
   uint16_t* lp = &l.x;
@@ -493,6 +494,13 @@ __device__ __forceinline__ void sp_store2(uint16_t* oh, uint16_t* ol, int c, con
     hp[i] = hb;
     lp[i] = f32_to_f16(s - f16_to_f32(hb));
   }
+  if (wt) {
+    const uint64_t hw = (uint64_t)h.x | ((uint64_t)h.y << 16) | ((uint64_t)h.z << 32) | ((uint64_t)h.w << 48);
+    const uint64_t lw = (uint64_t)l.x | ((uint64_t)l.y << 16) | ((uint64_t)l.z << 32) | ((uint64_t)l.w << 48);
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(oh + c), hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(ol + c), lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   *reinterpret_cast<ushort4*>(oh + c) = h;
   *reinterpret_cast<ushort4*>(ol + c) = l;
 }
@@ -502,7 +510,8 @@ template <int NCH>
 __global__ void __launch_bounds__(1024) rmsnorm_split2_kernel(float* __restrict__ resid, const void* __restrict__ delta,
                                                               int dsplits, int64_t dslice, const float* __restrict__ w,
                                                               float eps, int hidden, int64_t rows,
-                                                              uint16_t* __restrict__ out2, float* __restrict__ inv_scale) {
+                                                              uint16_t* __restrict__ out2, float* __restrict__ inv_scale,
+                                                              int wt) {
   __shared__ float s_part[16], s_max[16];
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthr = blockDim.x;
@@ -546,7 +555,10 @@ __global__ void __launch_bounds__(1024) rmsnorm_split2_kernel(float* __restrict_
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * nthr + tid) * 4;
     if (col < hidden) {
-      if (delta) *reinterpret_cast<float4*>(resid + row * hidden + col) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+      if (delta) {
+        if (wt) psg_st4_wt(resid + row * hidden + col, v[c][0], v[c][1], v[c][2], v[c][3]);
+        else *reinterpret_cast<float4*>(resid + row * hidden + col) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+      }
       o[c][0] = g[c].x * (v[c][0] * inv); o[c][1] = g[c].y * (v[c][1] * inv);
       o[c][2] = g[c].z * (v[c][2] * inv); o[c][3] = g[c].w * (v[c][3] * inv);
       mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[c][0]), fabsf(o[c][1]))), fmaxf(fabsf(o[c][2]), fabsf(o[c][3])));
@@ -563,7 +575,7 @@ __global__ void __launch_bounds__(1024) rmsnorm_split2_kernel(float* __restrict_
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * nthr + tid) * 4;
-    if (col < hidden) sp_store2(oh, ol, col, o[c], scale);
+    if (col < hidden) sp_store2(oh, ol, col, o[c], scale, wt);
   }
 }
 
@@ -580,7 +592,7 @@ extern "C" int psg_rmsnorm_split2(psg_ctx* ctx, float* resid, const float* delta
   hipStream_t st = (hipStream_t)stream;
 #define RS2(N)                                                                                                          \
   rmsnorm_split2_kernel<N><<<(unsigned)rows, nthr, 0, st>>>(resid, delta, delta_splits, rows * (int64_t)hidden, w, eps, \
-                                                            hidden, rows, (uint16_t*)out2, inv_scale)
+                                                            hidden, rows, (uint16_t*)out2, inv_scale, ctx->opt.wt_stores)
   switch (nch) {
     case 1: RS2(1); break;
     case 2: RS2(2); break;
