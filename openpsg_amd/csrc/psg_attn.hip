@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(256) decode_attn4_kernel(const void* __restric
   };
   // the arithmetic lives in psg_decode_math.h: the persistent decoder layer (psg_decode_layer.hip) runs the same unit
   psg_decode_attn4_unit<T>(true, (int)threadIdx.x, row, h, pos, tok_pair[row], heads, ctx, cos_tab, sin_tab, kc, vc, ld,
-                           st, &sc);
+                           st, &sc, wt != 0);
 }
 
 extern "C" int psg_decode_attn(psg_ctx* ctx_, const void* qkv, int qkv_splits, const int32_t* tok_pair,
@@ -866,7 +866,7 @@ extern "C" int psg_decode_attn(psg_ctx* ctx_, const void* qkv, int qkv_splits, c
     PSG_DISPATCH_DTYPE(dtype, "psg_decode_attn",
                        (decode_attn4_kernel<T><<<waves, 256, 0, (hipStream_t)stream>>>(
                            qkv, qkv_splits, tok_pair, tok_pos, rope_cos, rope_sin, rows, heads, ctx, (T*)k_cache,
-                           (T*)v_cache, (T*)out, ctx_->opt.wt_stores)));
+                           (T*)v_cache, (T*)out, ctx_->opt.wt_stores & 1)));
     PSG_CHECK_LAUNCH("psg_decode_attn");
     return PSG_OK;
   }

@@ -441,5 +441,5 @@ extern "C" int psg_split_gemm_w16(psg_ctx* ctx, const void* x2, const float* inv
               N, K, want);
   const bg_plan p = bg_make_plan(ctx, M, N, K, 0, mode, true);
   return bg_launch<EF16, 2, 1, 1, true>(p, x2, w16, part, M, N, K, ctx->opt.batch_gemm_var, stream, inv_scale,
-                                        ctx->opt.wt_stores);
+                                        (ctx->opt.wt_stores >> 1) & 1);
 }

@@ -38,7 +38,10 @@ struct psg_opts {
   int prefill_attn_scalar = 0;  // prompt pass: scalar cache-attention kernel instead of the matrix-core one
   int llm_fuse_split = 1;       // fp32s prompt pass: operand splits / result scalings inside the row kernels (psg_split.hip)
   int wt_stores = 1;            // decode-step kernels of the fp32 modes store their outputs write-through (sc1): nothing dirty
-                                // in the eight L2s when a launch ends - 0.5 us per kernel boundary, -2 ms per image
+                                // in the eight L2s when a launch ends - 0.5-0.8 us per kernel boundary.  Bits:
+                                // 1 = fp32 weight-streaming GEMM + rmsnorm / silu / attention (16-byte stores: -3 ms per
+                                // image), 2 = the PAIR GEMM of fp16-valued weights (4-byte stores: measured +4 ms, off),
+                                // 4 = rmsnorm_split2 / split_f16x2 (8-byte stores)
   int split_i2 = 1;             // fp32s own-GEMM products (Q-Former, row-invariant Llama prompt pass): interleaved hi / lo
                                 // operands through psg_dense_gemm_split (3 products from one staging; 0: the K' = 3K form)
   int decode_persistent = 0;    // fp32 decode steps: one persistent launch per decoder layer (psg_decode_layer) instead of the

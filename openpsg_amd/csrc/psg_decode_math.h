@@ -56,7 +56,7 @@ __device__ __forceinline__ void psg_decode_attn4_unit(bool live, int tid, int ro
                                                       int ctx, const float* __restrict__ cos_tab,
                                                       const float* __restrict__ sin_tab, T* __restrict__ kc,
                                                       T* __restrict__ vc, const LoadQKV& ld, const StoreOut& st,
-                                                      PsgDecodeAttnScratch* sc) {
+                                                      PsgDecodeAttnScratch* sc, bool wt = false) {
 #pragma clang fp contract(off)
   const int lane = tid & 63, wid = tid >> 6;
   const int hidden = heads * 128;
@@ -94,10 +94,20 @@ __device__ __forceinline__ void psg_decode_attn4_unit(bool live, int tid, int ro
     psg_rope_pair(q1, q2, cs, sn, qa, qb);
     psg_rope_pair(k1, k2, cs, sn, ka, kb);
     qa = rnd(qa); qb = rnd(qb); ka = rnd(ka); kb = rnd(kb);
-    Act<T>::st(kc, cbase + (int64_t)pos * 128 + lane, ka);
-    Act<T>::st(kc, cbase + (int64_t)pos * 128 + lane + 64, kb);
-    Act<T>::st(vc, cbase + (int64_t)pos * 128 + lane, v1);
-    Act<T>::st(vc, cbase + (int64_t)pos * 128 + lane + 64, v2);
+    // wt (fp32 caches, option wt_stores): the appended rows written through the L2 like the kernel's output
+    auto app = [&](T* base, int64_t i, float v) {
+      if constexpr (sizeof(T) == 4) {
+        if (wt) {
+          __hip_atomic_store(reinterpret_cast<unsigned*>(base) + i, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+      }
+      Act<T>::st(base, i, v);
+    };
+    app(kc, cbase + (int64_t)pos * 128 + lane, ka);
+    app(kc, cbase + (int64_t)pos * 128 + lane + 64, kb);
+    app(vc, cbase + (int64_t)pos * 128 + lane, v1);
+    app(vc, cbase + (int64_t)pos * 128 + lane + 64, v2);
     sc->q[lane] = qa;
     sc->q[lane + 64] = qb;
     const float dot = __builtin_fmaf(qa, ka, qb * kb);

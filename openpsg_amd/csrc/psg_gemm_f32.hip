@@ -356,7 +356,7 @@ int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int 
   if (G < 1) G = 1;
   const dim3 grid(G, splits);
   hipStream_t st = (hipStream_t)stream;
-  const int wt = ctx->opt.wt_stores;
+  const int wt = ctx->opt.wt_stores & 1;
   // x rows: 16-row groups (16x16x1_4b) then 4-row groups (4x4x1_16b); up to 12 rows go through 4-row groups only
   const int g16 = M <= 12 ? 0 : (M <= 28 ? 1 : 2), g4 = M <= 12 ? (M + 3) / 4 : (M <= 16 || M > 28 ? 0 : (M - 16 + 3) / 4);
 #define SGF_K(WV, SL, A, B)                                                                              \

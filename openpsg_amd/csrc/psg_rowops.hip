@@ -642,7 +642,7 @@ extern "C" int psg_rmsnorm(psg_ctx* ctx, void* resid, const void* delta, int del
     return PSG_OK;
   }
   // decode-sized launches (a handful of rows) are latency bound: spread each row over 16 waves
-  const int wt = (ctx->opt.wt_stores && rows <= 64) ? 1 : 0;
+  const int wt = ((ctx->opt.wt_stores & 1) && rows <= 64) ? 1 : 0;
   const int nthr = (rows <= 64 && hidden >= 4096) ? 1024 : 256;
   const int nch = (hidden + 4 * nthr - 1) / (4 * nthr);
 #define RN(N)                                                                                                        \
@@ -806,7 +806,7 @@ extern "C" int psg_silu_mul(psg_ctx* ctx, const void* gate_up, int splits, int64
   if (blocks > 256 * 16) blocks = 256 * 16;
   PSG_DISPATCH_DTYPE(dtype, "psg_silu_mul",
                      (silu_mul_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(
-                         gate_up, splits, rows, inter, (T*)out, (ctx->opt.wt_stores && rows <= 64) ? 1 : 0)));
+                         gate_up, splits, rows, inter, (T*)out, ((ctx->opt.wt_stores & 1) && rows <= 64) ? 1 : 0)));
   PSG_CHECK_LAUNCH("psg_silu_mul");
   return PSG_OK;
 }

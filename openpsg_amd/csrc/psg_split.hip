@@ -175,9 +175,9 @@ extern "C" int psg_split_f16x2(psg_ctx* ctx, const float* x, int64_t rows, int K
   if (rows == 0) return PSG_OK;
   if (rows <= 64 && K <= 16384) {
     hipStream_t st = (hipStream_t)stream;
-    if (K <= 4096) split_f16x2_small_kernel<1><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale, ctx->opt.wt_stores);
-    else if (K <= 12288) split_f16x2_small_kernel<3><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale, ctx->opt.wt_stores);
-    else split_f16x2_small_kernel<4><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale, ctx->opt.wt_stores);
+    if (K <= 4096) split_f16x2_small_kernel<1><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale, (ctx->opt.wt_stores >> 2) & 1);
+    else if (K <= 12288) split_f16x2_small_kernel<3><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale, (ctx->opt.wt_stores >> 2) & 1);
+    else split_f16x2_small_kernel<4><<<(unsigned)rows, 1024, 0, st>>>(x, row_stride, K, rows, (uint16_t*)out, inv_scale, (ctx->opt.wt_stores >> 2) & 1);
     PSG_CHECK_LAUNCH("psg_split_f16x2");
     return PSG_OK;
   }
@@ -592,7 +592,7 @@ extern "C" int psg_rmsnorm_split2(psg_ctx* ctx, float* resid, const float* delta
   hipStream_t st = (hipStream_t)stream;
 #define RS2(N)                                                                                                          \
   rmsnorm_split2_kernel<N><<<(unsigned)rows, nthr, 0, st>>>(resid, delta, delta_splits, rows * (int64_t)hidden, w, eps, \
-                                                            hidden, rows, (uint16_t*)out2, inv_scale, ctx->opt.wt_stores)
+                                                            hidden, rows, (uint16_t*)out2, inv_scale, (ctx->opt.wt_stores >> 2) & 1)
   switch (nch) {
     case 1: RS2(1); break;
     case 2: RS2(2); break;
