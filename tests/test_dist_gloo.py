@@ -219,6 +219,11 @@ def _one_image_worker(rank, world, port, n_obj, ret):
         mine = deal_indices(len(sel), world, rank)              # this rank decoded exactly its dealt pairs
         rows = (torch.tensor([sel[i] for i in mine])[:, None] * 33 + 1 + torch.arange(32)[None, :]).reshape(-1)
         ok &= torch.allclose(be.received, h[rows], atol=1e-4)
+        # the relation query alone (bench.py's `strong_scaling_rq`: C4's sharded part): the same probabilities and the same
+        # selection on every rank, no feature exchange, no decode
+        rq_only = PairShardedPipeline(be, dist.group.WORLD, decode=False).step_one_image(scene)
+        ok &= torch.equal(rq_only["exist_prob"], out["exist_prob"]) and torch.equal(rq_only["selected"], out["selected"])
+        ok &= "tokens" not in rq_only
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
