@@ -228,6 +228,66 @@ def test_dense_gemm_split_three_products_from_one_staging(M, N, K, gelu):
         assert torch.equal(ops.dense_gemm_split(a2, b2, b, inv_r, inv_c, gelu=gelu, tile=tile), y), tile
 
 
+def _g6_decode(dtype, options):
+    """G6 through a fresh head built under the given context options; returns (existence logits, tokens, first logits)."""
+    import numpy as np
+    from openpsg_amd import _lib
+    from openpsg_amd.head import RelationTransformerHeadV4
+    from tests import helpers as H
+    g, cfg, w, scene = H.load_case("G6_llm_7b_width_n6")
+    dev = torch.device("cuda:0")
+    ids = [int(i) for i in scene["object_id_list"]]
+    names = H.object_names(scene)
+    sel = torch.from_numpy(g["selected"].astype(np.int32)).to(dev)
+    old = {k: _lib.get_option(0, k) for k in options}
+    for k, v in options.items():
+        _lib.set_option(0, k, v)
+    try:
+        head = RelationTransformerHeadV4(dtype=dtype, device="cuda:0", qformer_vocab_size=cfg.qformer.vocab, llm_config=cfg.llm,
+                                         llm_feature_size=cfg.llm.hidden, tokenizers="word", max_object_num=cfg.max_object_num,
+                                         on_parse_error="skip", suppress_eos=bool(g["suppress_eos"]))
+        head.load_weights(w)
+        rq = head.run_relation_query(scene["mask_features"].to(dev), scene["img_meta"], ids, names, scene["pan_results"].to(dev))
+        dec = head.decode_selected(rq, names, selected=sel)
+        out = (rq["exist_logit"].cpu().clone(), dec["tokens_host"].copy(), dec["first_logits"].float().cpu().clone())
+    finally:
+        for k, v in old.items():
+            _lib.set_option(0, k, v)
+    del head
+    torch.cuda.empty_cache()
+    return g, out
+
+
+def test_write_through_output_stores_change_no_value():
+    """Option wt_stores (round 6: the fp32 decode chain's outputs stored write-through) is a cache policy: the
+    existence logits, first-step logits and all 20 x 16 tokens of G6 are bit-identical with it on and off, in fp32 and fp32s."""
+    import numpy as np
+    for dtype in ("fp32", "fp32s"):
+        _, off = _g6_decode(dtype, {"wt_stores": 0})
+        _, on = _g6_decode(dtype, {"wt_stores": 1})
+        _, every = _g6_decode(dtype, {"wt_stores": 7})
+        for a in (on, every):
+            assert torch.equal(off[0], a[0]) and np.array_equal(off[1], a[1]) and torch.equal(off[2], a[2]), dtype
+
+
+def test_split_products_in_both_operand_layouts_agree_with_the_reference():
+    """Option split_i2 (round 6): the Q-Former's fp32s products on psg_dense_gemm_split (interleaved hi / lo operands, three
+    products from one staging) against the K' = 3K form of round 5: both inside 1e-3 of the reference's existence logits
+    on G6, within 2e-5 of each other, the same selection, and the reference's tokens."""
+    import numpy as np
+    g, new = _g6_decode("fp32s", {"split_i2": 1})
+    _, old = _g6_decode("fp32s", {"split_i2": 0})
+    ref = torch.from_numpy(g["exist_logit"])
+    e_new, e_old = (new[0] - ref).abs().max().item(), (old[0] - ref).abs().max().item()
+    print(f"G6 existence logits vs the reference: split form {e_new:.2e}, K' = 3K form {e_old:.2e}; "
+          f"between them {(new[0] - old[0]).abs().max().item():.2e}")
+    assert e_new < 1e-3 and e_old < 1e-3 and (new[0] - old[0]).abs().max().item() < 2e-5
+    assert np.array_equal(new[1], old[1])
+    for i in range(new[1].shape[0]):
+        want = g["gen_tokens"][i]
+        assert [int(t) for t in new[1][i] if t >= 0] == want[want >= 0].tolist()
+
+
 def test_fused_split_kernels_equal_the_separate_kernels_bit_for_bit():
     """psg_rmsnorm_split / psg_rope_kvwrite_scaled / psg_silu_mul_split against psg_scale_rows_cols + psg_rmsnorm /
     psg_rope_kvwrite / psg_silu_mul + psg_split_f16x3 on the prompt pass's shapes: identical bits (no GEMM involved)."""
