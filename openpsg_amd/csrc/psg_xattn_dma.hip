@@ -68,8 +68,9 @@ __global__ void __launch_bounds__(XD_WAVES * 64, (XD_WAVES + 3) / 4)
 cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                       const uint64_t* __restrict__ bits, int words, const int32_t* __restrict__ pair_index, int N,
                       int64_t R, int L, int nq, int heads, int policy, uint16_t* __restrict__ out,
-                      long long* __restrict__ trace, int poll, int dyn, const int32_t* __restrict__ q_index,
+                      long long* __restrict__ trace, int poll_wt, int dyn, const int32_t* __restrict__ q_index,
                       const uint16_t* __restrict__ q_cls) {
+  const int poll = poll_wt & 1, wt = poll_wt & 2;            // bit 1: output rows stored write-through (option xattn_wt)
   // q_index != nullptr (nq == 33 only): q holds the 33 projected query rows per PROMPT, pair p reads block q_index[p] - the
   // pair tiles look the block up with one scalar load (the pair is wave-uniform), the cls tiles (row 0 of 32 different
   // pairs) read q_cls [P][hidden], which the caller gathered (P rows instead of 33 P: psg_qformer_cross_attn_indexed)
@@ -483,9 +484,11 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
       int64_t row, pair;
       bool valid;
       tile_row(tile, 8 * i + r8, row, valid, pair);
-      if (AL || valid)
-        *reinterpret_cast<uint4*>(out + row * hidden + h * 64 + pc * 8) =
-            make_uint4(orow[i][0], orow[i][1], orow[i][2], orow[i][3]);
+      if (AL || valid) {
+        uint16_t* dst = out + row * hidden + h * 64 + pc * 8;
+        if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(orow[i]) : "memory");
+        else *reinterpret_cast<uint4*>(dst) = make_uint4(orow[i][0], orow[i][1], orow[i][2], orow[i][3]);
+      }
     }
   };
 
@@ -565,7 +568,8 @@ static int xd_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, 
     }                                                                                                              \
     cross_attn_dma_kernel<E, NC_, W_><<<(unsigned)(G * heads), W_ * 64, lds, st>>>(                                   \
         (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads,   \
-        policy, (uint16_t*)out, trace, ctx->opt.xattn_poll, dyn, q_index, (const uint16_t*)q_cls);                 \
+        policy, (uint16_t*)out, trace, (ctx->opt.xattn_poll & 1) | (ctx->opt.xattn_wt ? 2 : 0), dyn, q_index,       \
+        (const uint16_t*)q_cls);                                                                                    \
   } while (0)
   if (waves == 10) {
     if (NC == 1) XDLAUNCH(1, 10);
