@@ -36,7 +36,6 @@ static const OptName kOpts[] = {
     {"dense_gemm_var", &psg_opts::dense_gemm_var},     {"qformer_own_gemm", &psg_opts::qformer_own_gemm},
     {"ln_half_wave", &psg_opts::ln_half_wave},         {"xattn_poll", &psg_opts::xattn_poll},
     {"xattn_wt", &psg_opts::xattn_wt},
-    {"xattn_qnt", &psg_opts::xattn_qnt},
     {"xattn_dynamic", &psg_opts::xattn_dynamic},
     {"llm_w16", &psg_opts::llm_w16},
     {"batch_gemm_bn", &psg_opts::batch_gemm_bn},       {"decode_batch_gemm", &psg_opts::decode_batch_gemm},

@@ -70,9 +70,9 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
                       int64_t R, int L, int nq, int heads, int policy, uint16_t* __restrict__ out,
                       long long* __restrict__ trace, int poll_wt, int dyn, const int32_t* __restrict__ q_index,
                       const uint16_t* __restrict__ q_cls) {
-  // bit 0: poll mode; bits 1-2: cache policy of the output stores (option xattn_wt: 0 default, 1 sc1 = write-through, 2 nt,
-  // 3 sc1 nt); bit 3: the Q tiles fetched non-temporal (option xattn_qnt)
-  const int poll = poll_wt & 1, wt = (poll_wt >> 1) & 3, qnt = poll_wt & 8;
+  // bit 0: poll mode; bit 1: output rows stored write-through (option xattn_wt: no dirty L2 lines to flush when the launch
+  // ends: 70.0 -> 67.6 us in situ at C2; `nt` stores measured no better, non-temporal Q tiles 1-4 us WORSE - round 6)
+  const int poll = poll_wt & 1, wt = poll_wt & 2;
   // q_index != nullptr (nq == 33 only): q holds the 33 projected query rows per PROMPT, pair p reads block q_index[p] - the
   // pair tiles look the block up with one scalar load (the pair is wave-uniform), the cls tiles (row 0 of 32 different
   // pairs) read q_cls [P][hidden], which the caller gathered (P rows instead of 33 P: psg_qformer_cross_attn_indexed)
@@ -156,12 +156,8 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
           src = q_cls + pair * hidden + h * 64 + ((pc ^ r8) * 8);
         }
       }
-      if (qnt)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
-      else
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
     }
     {
       int64_t row, pair;
@@ -492,9 +488,7 @@ cross_attn_dma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict
       tile_row(tile, 8 * i + r8, row, valid, pair);
       if (AL || valid) {
         uint16_t* dst = out + row * hidden + h * 64 + pc * 8;
-        if (wt == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(orow[i]) : "memory");
-        else if (wt == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(orow[i]) : "memory");
-        else if (wt == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(orow[i]) : "memory");
+        if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(orow[i]) : "memory");
         else *reinterpret_cast<uint4*>(dst) = make_uint4(orow[i][0], orow[i][1], orow[i][2], orow[i][3]);
       }
     }
@@ -576,7 +570,7 @@ static int xd_launch(psg_ctx* ctx, const void* q, const void* k, const void* v, 
     }                                                                                                              \
     cross_attn_dma_kernel<E, NC_, W_><<<(unsigned)(G * heads), W_ * 64, lds, st>>>(                                   \
         (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, bits, words, pair_index, N, R, L, nq, heads,   \
-        policy, (uint16_t*)out, trace, (ctx->opt.xattn_poll & 1) | ((ctx->opt.xattn_wt & 3) << 1) | (ctx->opt.xattn_qnt ? 8 : 0), dyn, q_index, \
+        policy, (uint16_t*)out, trace, (ctx->opt.xattn_poll & 1) | (ctx->opt.xattn_wt ? 2 : 0), dyn, q_index,       \
         (const uint16_t*)q_cls);                                                                                    \
   } while (0)
   if (waves == 10) {
