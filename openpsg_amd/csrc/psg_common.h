@@ -42,6 +42,7 @@ struct psg_opts {
                                 // 1 = fp32 weight-streaming GEMM + rmsnorm / silu / attention (16-byte stores: -3 ms per
                                 // image), 2 = the PAIR GEMM of fp16-valued weights (4-byte stores: measured +4 ms, off),
                                 // 4 = rmsnorm_split2 / split_f16x2 (8-byte stores)
+  int qformer_split_cls_input_space = 1;   // fp32s mode: selection phase in the input space + prompt de-duplication (own products)
   int split_i2 = 1;             // fp32s own-GEMM products (Q-Former, row-invariant Llama prompt pass): interleaved hi / lo
                                 // operands through psg_dense_gemm_split (3 products from one staging; 0: the K' = 3K form)
   int decode_persistent = 0;    // fp32 decode steps: one persistent launch per decoder layer (psg_decode_layer) instead of the

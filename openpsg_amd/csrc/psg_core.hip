@@ -30,6 +30,7 @@ static const OptName kOpts[] = {
     {"skinny_f32_waves", &psg_opts::skinny_f32_waves}, {"decode_persistent", &psg_opts::decode_persistent},
     {"llm_fuse_split", &psg_opts::llm_fuse_split},
     {"split_i2", &psg_opts::split_i2},
+    {"qformer_split_cls_input_space", &psg_opts::qformer_split_cls_input_space},
     {"wt_stores", &psg_opts::wt_stores},
     {"selfattn_scalar", &psg_opts::selfattn_scalar},   {"decode_attn_1wave", &psg_opts::decode_attn_1wave},
     {"xattn_dma", &psg_opts::xattn_dma},               {"xattn_waves", &psg_opts::xattn_waves},

@@ -92,7 +92,12 @@ class RelationQueryEngine:
         # selection phase of the last layer: cls-row attention in the input space (no K | V projection of all rows)
         # (its two small batched products are library calls whose kernel choice follows the pair count: the row-count
         # invariant modes - split, qformer_own_gemm = 2 - project K | V through `_lin` instead)
-        self.cls_input_space = opt("qformer_cls_input_space") and not (self.split or self.own_gemm >= 2)
+        # (round 6: the split mode has row-count-invariant forms of the two products - block-diagonal weights through
+        # psg_dense_gemm_split, `_cls_keys_split` / `_cls_values_split` - so it takes the input-space phase and, with it, the
+        # per-prompt de-duplication; option qformer_split_cls_input_space = 0 restores the K | V projection of all rows)
+        self.cls_input_space = opt("qformer_cls_input_space") and not (self.own_gemm >= 2) and (
+            not self.split or (self.split_i2 and opt("qformer_split_cls_input_space")))
+        self._cls_big = None
         self._bmm_out_dtype = None       # torch.bmm(..., out_dtype=fp32) available? (probed at first use)
         # two-layer Q-Former: everything in front of layer 0's cross-attention and every text row entering the last
         # layer depend on the PROMPT (class pair) only - computed once per distinct prompt when the caller hands the
@@ -295,12 +300,18 @@ class RelationQueryEngine:
         if in_space:
             # keys / values never materialised: the cls queries go back through W_k (g_h = W_k,h^T q_h), the kernel
             # reads the layer's input rows once, the weighted row means go through W_v (psg_qformer_cls_attn_input)
-            g = self._bmm_f32(q_cls.view(P, q.heads, hd).transpose(0, 1), L["wk"], L["wk32"])  # fp32 [heads, P, H]
+            if self.split:
+                g = self._cls_keys_split(q_cls, L)                                                # fp32 [heads, P, H]
+            else:
+                g = self._bmm_f32(q_cls.view(P, q.heads, hd).transpose(0, 1), L["wk"], L["wk32"])  # fp32 [heads, P, H]
             if X is not None:
                 xbar = ops.qformer_cls_attn_input(X, g, mask, P, T, nq, q.heads)
             else:
                 xbar = ops.qformer_cls_attn_input(Xq, g, mask, P, T, nq, q.heads, x_text=Xt, text_index=text_index)
-            ctx = (torch.bmm(xbar, L["wv32t"]).permute(1, 0, 2).reshape(P, H) + L["bqkv"][2 * H:].float()).to(self.dtype)
+            if self.split:
+                ctx = self._cls_values_split(xbar, L)
+            else:
+                ctx = (torch.bmm(xbar, L["wv32t"]).permute(1, 0, 2).reshape(P, H) + L["bqkv"][2 * H:].float()).to(self.dtype)
             del g, xbar
         else:
             assert X is not None
@@ -454,6 +465,44 @@ class RelationQueryEngine:
         hk = self._layer(len(self.layers) - 1, Xs, Xs32, sel.numel(), T, tm, pi, state["kv"], state["bits"],
                          state["num_objects"], None)[0]
         return hk, mine
+
+    def _cls_big_weights(self, L):
+        """Block-diagonal forms of the last layer's key / value weights as interleaved hi / lo images (split mode): the two
+        per-head products of the input-space selection phase become ONE psg_dense_gemm_split call each - 12x the flops of
+        the batched product (zeros), still ~0.1 ms at 2500 pairs, and row-count invariant where the library's batched GEMM
+        is not (a pair shard reproduces the full pass bit for bit).
+          keys:   g[p, h H + c]  = sum_d q[p, 64 h + d] W_k[64 h + d, c]          W_kbig [heads H, H]
+          values: ctx[p, 64 h + d] = sum_c xbar[p, h H + c] W_v[64 h + d, c]     W_vbig [H, heads H]"""
+        if self._cls_big is None:
+            q = self.cfg.qformer
+            H, heads = q.hidden, q.heads
+            hd = H // heads
+            wk = L["wqkv"][H:2 * H].float()                                  # [H, H]: row 64 h + d = key feature d of head h
+            wv = L["wqkv"][2 * H:].float()
+            kbig = torch.zeros((heads * H, H), device=self.device, dtype=torch.float32)
+            vbig = torch.zeros((H, heads * H), device=self.device, dtype=torch.float32)
+            for h in range(heads):
+                kbig[h * H:(h + 1) * H, h * hd:(h + 1) * hd] = wk[h * hd:(h + 1) * hd].t()
+                vbig[h * hd:(h + 1) * hd, h * H:(h + 1) * H] = wv[h * hd:(h + 1) * hd]
+            self._cls_big = (ops.split_f16i2(kbig), ops.split_f16i2(vbig), L["bqkv"][2 * H:].float().contiguous())
+        return self._cls_big
+
+    def _cls_keys_split(self, q_cls, L):
+        """g_h = W_k,h^T q_h for every pair and head, fp32 [heads, P, H] (the layout psg_qformer_cls_attn_input reads)."""
+        q = self.cfg.qformer
+        P = q_cls.shape[0]
+        kb, _, _ = self._cls_big_weights(L)
+        a2, inv_r = ops.split_f16i2(q_cls.contiguous())
+        g = ops.dense_gemm_split(a2, kb[0], None, inv_r, kb[1], tile="auto" if P < 16384 else "256x256")
+        return g.view(P, q.heads, q.hidden).permute(1, 0, 2).contiguous()
+
+    def _cls_values_split(self, xbar, L):
+        """ctx = W_v applied to the weighted row means xbar [heads, P, H] (+ the value bias), fp32 [P, H]."""
+        q = self.cfg.qformer
+        P = xbar.shape[1]
+        _, vb, bias = self._cls_big_weights(L)
+        x2, inv_r = ops.split_f16i2(xbar.permute(1, 0, 2).reshape(P, q.heads * q.hidden).contiguous())
+        return ops.dense_gemm_split(x2, vb[0], bias, inv_r, vb[1], tile="auto" if P < 16384 else "256x256")
 
     def _bmm_f32(self, a, b, b32):
         """fp32 result of a batched product of activation-dtype operands (exact products, fp32 accumulation): the
