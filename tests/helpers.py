@@ -16,11 +16,25 @@ QFORMER_INSTRUCTION = "Is there a relation between {} and {}?"
 LLM_INSTRUCTION = "What are the relations between {} and {}? Assistant: "
 
 
+_WEIGHT_CACHE = {}
+
+
+def _case_weights(cfg, seed, name):
+    """The PCG64 weights of a golden case.  The 7B-width cases take 20+ s to draw and are loaded by eight test modules:
+    keep ONE master copy per process and hand out clones (tests round / reload weights in place)."""
+    if name not in _WEIGHT_CACHE:
+        w = make_weights_numpy(cfg, seed=seed)
+        if sum(v.numel() * v.element_size() for v in w.values()) < (64 << 20):
+            return w                                               # small cases: drawing them again is cheaper than a cache
+        _WEIGHT_CACHE[name] = w
+    return {k: v.clone() for k, v in _WEIGHT_CACHE[name].items()}
+
+
 def load_case(name):
     g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
     llm = tiny_llm(int(g["llm_hidden"]), int(g["llm_layers"]), int(g["llm_inter"]), int(g["llm_vocab"]))
     cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=llm, max_object_num=30)
-    w = make_weights_numpy(cfg, seed=int(g["weight_seed"]))
+    w = _case_weights(cfg, int(g["weight_seed"]), name)
     scene_kw = ast.literal_eval(str(g["scene_kw"]))
     scene = make_scene(**scene_kw)
     assert np.array_equal(scene["pan_results"].numpy(), g["pan_results"])
@@ -100,7 +114,7 @@ def load_train_case(name):
     g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
     llm = tiny_llm(int(g["llm_hidden"]), int(g["llm_layers"]), int(g["llm_inter"]), int(g["llm_vocab"]))
     cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=llm, max_object_num=30)
-    w = make_weights_numpy(cfg, seed=int(g["weight_seed"]))
+    w = _case_weights(cfg, int(g["weight_seed"]), name)
     inputs = make_train_scene(tuple(int(v) for v in g["pad_hw"]), [int(c) for c in g["categories"]],
                               [tuple(int(v) for v in r) for r in g["gt_rels"]], seed=int(g["scene_seed"]))
     return g, cfg, w, inputs
