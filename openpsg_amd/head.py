@@ -31,7 +31,7 @@ from .llm import LlamaDecodeEngine
 from .qformer import RelationQueryEngine
 from .registry import HEADS
 from .tokenizers import WordTokenizer
-from .weights import head_shapes, llm_shapes
+from .weights import head_shapes, is_hf_checkpoint_dir, llm_shapes, read_hf_llama_config, read_hf_llama_weights
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
            "fp16": torch.float16, "float16": torch.float16, "half": torch.float16, "mixed": torch.float16,
@@ -197,6 +197,10 @@ class RelationTransformerHeadV4(nn.Module):
                                                # (HF defaults 0.1 / 0.1, V4:78-84); False = deterministic (oracle checks)
                  slot_priorities=(0, -1),      # HIP stream priority of submit() slot k = slot_priorities[k % len]: streams
                                                # of different priority never share a hardware queue (see _slot_stream)
+                 load_pretrained_llm=True,     # llm_model_name is a LOCAL HuggingFace checkpoint directory: read its
+                                               # config.json (unless llm_config is given) and its weights, as the reference's
+                                               # from_pretrained does at V4:99-103 (llm_truncate_num layers only).  A hub name
+                                               # cannot be resolved here (no network): load_llm_weights() then
                  train_losses_without_grad=False,   # forward() in training mode returns the two losses WITHOUT a graph
                                                # (forward_train); off: it raises, so that an mmdet-style loop cannot sum
                                                # them and silently train nothing in this head
@@ -249,9 +253,17 @@ class RelationTransformerHeadV4(nn.Module):
         self.device = torch.device(self.default_device if device is None else device)
         if tokenizers is None:
             tokenizers = self.default_tokenizers
-        llm = llm_config if llm_config is not None else LlamaConfig(hidden=llm_feature_size,
-                                                                    heads=llm_feature_size // 128)
-        assert llm.hidden == llm_feature_size, "llm_feature_size must match llm_config.hidden"
+        self.llm_model_name = llm_model_name
+        pretrained_dir = bool(load_pretrained_llm) and is_hf_checkpoint_dir(llm_model_name)
+        if llm_config is not None:
+            llm = llm_config
+        elif pretrained_dir:
+            llm = read_hf_llama_config(llm_model_name)                     # the architecture from_pretrained would build
+        else:
+            llm = LlamaConfig(hidden=llm_feature_size, heads=llm_feature_size // 128)
+        if llm.hidden != llm_feature_size:
+            raise PsgHipError(f"llm_feature_size={llm_feature_size} must match the LLM's hidden size {llm.hidden} "
+                              "(language_projection maps onto its embedding rows, V4:97-98)")
         self.cfg = PSGConfig(
             qformer=QFormerConfig(hidden=qformer_feature_size, layers=qformer_layer_num, vocab=qformer_vocab_size,
                                   enc_hidden=object_feature_size),
@@ -313,6 +325,12 @@ class RelationTransformerHeadV4(nn.Module):
         self.serialize_decodes = False
         self._proj_stale = False
         self.train(False)                                                   # eval by default, as init_detector leaves it
+        if pretrained_dir:
+            # V4:99-103: the LLM comes from `llm_model_name`, not from the head's checkpoint (part_checkpoint_hook.py:96-116
+            # drops language_model.*).  language_projection is loaded later: the engine's copy follows it (_proj_stale)
+            n = self.cfg.llm.layers if self.llm_truncate_num <= 0 else self.llm_truncate_num
+            self.load_llm_weights(read_hf_llama_weights(llm_model_name, n_layers=n))
+            self._proj_stale = True
 
     # ---- weights ---------------------------------------------------------------------------------
     def load_weights(self, weights: dict):
@@ -394,8 +412,7 @@ class RelationTransformerHeadV4(nn.Module):
             if ver != getattr(self, "_proj_version", None):  # an optimizer step moved language_projection
                 self._proj_stale, self._proj_version = True, ver
         if getattr(self, "_proj_stale", False):               # language_projection was (re)loaded after the engine was built
-            self._llm_engine.proj_w = self.language_projection.weight.data.to(self.act_dtype).contiguous()
-            self._llm_engine.proj_b = self.language_projection.bias.data.to(self.act_dtype).contiguous()
+            self._llm_engine.set_projection(self.language_projection.weight.data, self.language_projection.bias.data)
             self._proj_stale = False
         return self._llm_engine
 

@@ -341,6 +341,17 @@ class LlamaDecodeEngine:
         y = _split_mm(a3, ws[0], _plan_split_mm(a3.shape[0], ws[0]) if self.plan_split else None)
         return ops.scale_rows_cols(y, inv_r, ws[1])
 
+    def set_projection(self, weight, bias):
+        """Replaces the packed copy of `language_projection` (a checkpoint loaded after the engine was built, an optimizer
+        step in training mode) TOGETHER with everything derived from it: the fp32s split image and the interleaved image
+        of the row-invariant path, whose cache is keyed by the tensor's address - which the allocator hands to the new
+        tensor as soon as the old one is released."""
+        self._i2_w.pop(self.proj_w.data_ptr(), None)
+        self.proj_w = weight.to(device=self.device, dtype=self.dtype).contiguous()
+        self.proj_b = bias.to(device=self.device, dtype=self.dtype).contiguous()
+        self._i2_w.pop(self.proj_w.data_ptr(), None)
+        self.proj_s = ops.split_f16x3(self.proj_w, weights=True) if self.prefill_split else None
+
     def _i2_weight(self, w):
         """The interleaved hi / lo image of a projection weight (+ its rows' inverse scales), made at first use: only the
         row-invariant path (the dealt decodes of a pair-sharded job) reads it - 4 bytes per weight next to the fp32 tensor."""

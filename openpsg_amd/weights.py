@@ -195,3 +195,98 @@ def make_weights_device(cfg: PSGConfig, seed: int, device, head_dtype=torch.floa
             t = t.to(llm_values).float()
         out[key] = t.to(dt) if len(shapes[key]) >= 2 else t
     return out
+
+
+# ---- the LLM of a local HuggingFace checkpoint directory (V4:99-103) --------------------------------------------------
+# The reference builds its LLM with `AutoModelForCausalLM.from_pretrained(llm_model_name, low_cpu_mem_usage=True)`
+# (V4:99-100): no dtype, so the fp16 tensors on disk are upcast to fp32; `llm_truncate_num` then keeps the first layers
+# (V4:101-103).  There is no hub here and no need for the HF module: the head reads the directory itself - config.json,
+# then `model.safetensors` / its sharded index / `pytorch_model*.bin` - and hands the tensors, under the names they have
+# inside the reference head (`language_model.` + the checkpoint's own names), to the decode engine, which upcasts them on
+# the device.  Tensors stay in their STORED dtype on the host: an fp16 checkpoint is then recognised as such by the
+# engine's per-tensor round-trip check (llm.py, option llm_w16) exactly as its fp32 upcast would be.
+def is_hf_checkpoint_dir(path) -> bool:
+    import os
+    return isinstance(path, (str, os.PathLike)) and os.path.isfile(os.path.join(path, "config.json"))
+
+
+def read_hf_llama_config(path):
+    """LlamaConfig of the checkpoint directory `path` (its config.json).  Raises PsgHipError for an architecture the
+    decode kernels are not built for (grouped-query attention, head_dim != 128, tied embeddings without an lm_head)."""
+    import json
+    import os
+    from .config import LlamaConfig
+    from ._lib import PsgHipError
+    with open(os.path.join(path, "config.json")) as f:
+        c = json.load(f)
+    heads = int(c["num_attention_heads"])
+    kv = int(c.get("num_key_value_heads") or heads)
+    if kv != heads:
+        raise PsgHipError(f"{path}: num_key_value_heads={kv} != num_attention_heads={heads} (grouped-query attention is "
+                          "not built; the reference's LLM is Llama-2-7b, multi-head)")
+    hidden = int(c["hidden_size"])
+    if hidden % heads or hidden // heads != 128:
+        raise PsgHipError(f"{path}: head_dim {hidden / heads:g} unsupported (kernels are built for 128)")
+    if c.get("rope_scaling"):
+        raise PsgHipError(f"{path}: rope_scaling={c['rope_scaling']!r} is not built (Llama-2 has none)")
+
+    def tok(name, default):
+        v = c.get(name, default)
+        return int(v[0] if isinstance(v, (list, tuple)) else default if v is None else v)
+    return LlamaConfig(hidden=hidden, heads=heads, layers=int(c["num_hidden_layers"]), inter=int(c["intermediate_size"]),
+                       vocab=int(c["vocab_size"]), rms_eps=float(c.get("rms_norm_eps", 1e-5)),
+                       rope_theta=float(c.get("rope_theta", 10000.0)), bos=tok("bos_token_id", 1),
+                       eos=tok("eos_token_id", 2), pad=0)
+
+
+def read_hf_llama_weights(path, n_layers=None, prefix="language_model."):
+    """{prefix + name: tensor (stored dtype, CPU)} of the LlamaForCausalLM checkpoint in directory `path`; layers at or
+    past `n_layers` (llm_truncate_num, V4:101-103) are not read.  Formats: model.safetensors, model.safetensors.index.json
+    + shards, pytorch_model.bin, pytorch_model.bin.index.json + shards (in that order, as from_pretrained prefers them)."""
+    import json
+    import os
+    from ._lib import PsgHipError
+
+    def wanted(name):
+        if name.endswith("rotary_emb.inv_freq"):                       # a buffer old checkpoints carry; recomputed (HF-LL:115-128)
+            return False
+        if n_layers is not None and n_layers > 0 and name.startswith("model.layers."):
+            return int(name.split(".")[2]) < n_layers
+        return True
+
+    def shards(index_name, single_name):
+        idx = os.path.join(path, index_name)
+        if os.path.isfile(idx):
+            with open(idx) as f:
+                wm = json.load(f)["weight_map"]
+            files = {}
+            for name, fn in wm.items():
+                if wanted(name):
+                    files.setdefault(fn, []).append(name)
+            return files
+        if os.path.isfile(os.path.join(path, single_name)):
+            return {single_name: None}
+        return None
+
+    out = {}
+    files = shards("model.safetensors.index.json", "model.safetensors")
+    if files is not None:
+        from safetensors import safe_open
+        for fn, names in sorted(files.items()):
+            with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as f:
+                for name in (names if names is not None else f.keys()):
+                    if wanted(name):
+                        out[prefix + name] = f.get_tensor(name)
+    else:
+        files = shards("pytorch_model.bin.index.json", "pytorch_model.bin")
+        if files is None:
+            raise PsgHipError(f"{path}: no model.safetensors / pytorch_model.bin (or their .index.json) found")
+        for fn, names in sorted(files.items()):
+            sd = torch.load(os.path.join(path, fn), map_location="cpu", weights_only=True)
+            for name in (names if names is not None else list(sd)):
+                if wanted(name):
+                    out[prefix + name] = sd[name]
+            del sd
+    if prefix + "lm_head.weight" not in out:
+        raise PsgHipError(f"{path}: no lm_head.weight (tied embeddings are not Llama-2's layout)")
+    return out
