@@ -159,3 +159,19 @@ def test_a_reloaded_language_projection_reaches_every_packed_copy_of_the_engine(
         assert torch.equal(a.last["tokens"], b.last["tokens"])
     finally:
         _lib.set_option(0, "split_i2", old)
+
+
+@pytest.mark.gpu
+def test_infer_tool_takes_the_llm_from_a_checkpoint_directory(tmp_path):
+    """tools/infer.py --llm-dir: the work-alike of the reference's tools/infer.py builds its head on a local checkpoint
+    directory (3 layers on disk, --llm-layers 2 keeps two: llm_truncate_num) and writes a submission."""
+    from tools import infer
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 3, 512, 512), max_object_num=30)
+    d = str(tmp_path / "llama")
+    _write_dir(d, cfg, make_weights_numpy(cfg, seed=5), "safetensors")
+    a = infer.parser().parse_args(["--images", "2", "--objects", "6", "--size", "512", "512", "--dtype", "fp32s",
+                                   "--llm-dir", d, "--llm-layers", "2", "--out", str(tmp_path / "out")])
+    head = infer.build_head(a, torch.device("cuda:0"))
+    assert head.cfg.llm == cfg.llm and head.llm_engine.n_layers == 2 and head.llm_engine._w16_all
+    results, path = infer.run(a, head=head)
+    assert len(results) == 2 and os.path.isfile(path)

@@ -45,6 +45,9 @@ def parser():
                          "taken, head.submit: 1.19x images per second, same results)")
     ap.add_argument("--keep-scores", action="store_true", help="tools/predict.py:91-97 output variant")
     ap.add_argument("--checkpoint", help="reference-style partial checkpoint (state_dict with relation_head.* keys)")
+    ap.add_argument("--llm-dir", help="local HuggingFace checkpoint directory of the LLM (config.json + model.safetensors / "
+                    "shards / pytorch_model*.bin): read by the head's constructor as the reference's from_pretrained does "
+                    "(V4:99-103); without it the LLM is seeded random weights of --llm-layers layers")
     return ap
 
 
@@ -52,11 +55,22 @@ def build_head(a, dev):
     from openpsg_amd.config import LlamaConfig, PSGConfig, QFormerConfig
     from openpsg_amd.head import RelationTransformerHeadV4
     from openpsg_amd.weights import make_weights_device
-    llm = LlamaConfig(layers=a.llm_layers)
-    cfg = PSGConfig(qformer=QFormerConfig(), llm=llm, max_object_num=a.objects)
-    head = RelationTransformerHeadV4(dtype=a.dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
-                                     llm_config=llm, on_parse_error="skip", pair_selector=a.selector)
-    head.load_weights(make_weights_device(cfg, 0, dev))
+    if getattr(a, "llm_dir", None):
+        # the LLM of a real checkpoint directory; --llm-layers > 0 keeps its first layers (llm_truncate_num, V4:101-103)
+        from openpsg_amd.weights import read_hf_llama_config
+        llm = read_hf_llama_config(a.llm_dir)
+        trunc = a.llm_layers if 0 < a.llm_layers < llm.layers else -1
+        head = RelationTransformerHeadV4(dtype=a.dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
+                                         llm_model_name=a.llm_dir, llm_feature_size=llm.hidden, llm_truncate_num=trunc,
+                                         on_parse_error="skip", pair_selector=a.selector)
+        cfg = PSGConfig(qformer=QFormerConfig(), llm=llm, max_object_num=a.objects)
+        head.load_weights(make_weights_device(cfg, 0, dev, with_llm=False))
+    else:
+        llm = LlamaConfig(layers=a.llm_layers)
+        cfg = PSGConfig(qformer=QFormerConfig(), llm=llm, max_object_num=a.objects)
+        head = RelationTransformerHeadV4(dtype=a.dtype, device=str(dev), tokenizers="word", max_object_num=a.objects,
+                                         llm_config=llm, on_parse_error="skip", pair_selector=a.selector)
+        head.load_weights(make_weights_device(cfg, 0, dev))
     if a.checkpoint:
         sd = torch.load(a.checkpoint, map_location="cpu")
         sd = sd.get("state_dict", sd)
