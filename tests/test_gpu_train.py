@@ -249,7 +249,11 @@ def _compare_grads(head, og, tol=2e-3):
         ref = torch.zeros_like(got) if ref is None else ref
         scale, err = float(ref.abs().max()), float((got - ref).abs().max())
         checked += scale > 0
-        assert err <= tol * scale + 5e-6, f"{k}: max |grad - autograd| = {err:.3e} at gradient scale {scale:.3e}"
+        # a key bias has an EXACT zero gradient (softmax ignores a per-query constant): both sides hold only the rounding
+        # noise of their own summation order there, which grows with the loss scale (5.9e-6 was the largest of the 83
+        # random scenes of the round-6 sweep, profiles/r06_fuzz_train.txt)
+        floor = 3e-5 if k.endswith("attention.key.bias") else 5e-6
+        assert err <= tol * scale + floor, f"{k}: max |grad - autograd| = {err:.3e} at gradient scale {scale:.3e}"
     return checked
 
 
@@ -328,3 +332,53 @@ def test_requires_grad_is_set_at_construction_and_engines_follow_the_masters():
     assert abs(float(after_vals["binary_rel_cls_loss"]) - float(before["binary_rel_cls_loss"])) > 1e-4
     assert abs(float(after_vals["binary_rel_cls_loss"]) - float(after_grad["binary_rel_cls_loss"].detach())) < 5e-3
     assert abs(float(after_vals["rel_llm_loss"]) - float(after_grad["rel_llm_loss"].detach())) < 2e-3
+
+
+def _train_fuzz_seeds():
+    import os
+    spec = os.environ.get("PSG_FUZZ_TRAIN_SEEDS")               # lo:hi - a one-off sweep (profiles/r06_fuzz_train.txt)
+    if not spec:
+        return [0, 1, 2]
+    lo, hi = (int(v) for v in spec.split(":"))
+    return list(range(lo, hi))
+
+
+@pytest.mark.parametrize("seed", _train_fuzz_seeds())
+def test_random_training_scene_losses_and_gradients_vs_autograd_on_the_oracle(seed):
+    """The training branch on scenes the two goldens do not cover: random padded geometry, 3-12 ground-truth segments
+    (things and stuff), 1-6 ground-truth relations, the sampler's and the selector's OWN draws (the head draws them from
+    torch / random as the reference does, V4:437-461, 260-262; the oracle is handed the same draws).  Both losses and
+    the gradient of every trainable tensor against torch.autograd through the CPU oracle."""
+    import random
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.synthetic import make_train_scene
+    from openpsg_amd.weights import make_weights_numpy
+    rng = np.random.default_rng(9000 + seed)
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 2, 512, 512), max_object_num=30)
+    w = make_weights_numpy(cfg, seed=40 + seed % 3)
+    pad = (64 * int(rng.integers(4, 17)), 64 * int(rng.integers(4, 17)))
+    n = int(rng.integers(3, 13))
+    cats = [int(c) for c in rng.integers(0, 133, n)]
+    if all(c >= 80 for c in cats):
+        cats[0] = int(rng.integers(0, 80))                       # at least one thing
+    pairs = [(i, j) for i in range(n) for j in range(n) if i != j]
+    rels = [pairs[int(k)] + (int(rng.integers(0, 56)),) for k in rng.choice(len(pairs), size=min(len(pairs), int(rng.integers(1, 7))), replace=False)]
+    inputs = make_train_scene(pad, cats, rels, seed=700 + seed)
+    head = _head(cfg, w, "fp32")
+    head.train(True)
+    torch.manual_seed(seed)
+    random.seed(seed)
+    out = head.forward_train_grad(_to_dev(inputs), dropout=False)                     # the head's own draws
+    (out["binary_rel_cls_loss"] + out["rel_llm_loss"]).backward()
+    torch.cuda.synchronize()
+    sampled = np.asarray(head.last["sampled"].tolist() if hasattr(head.last["sampled"], "tolist") else head.last["sampled"])
+    selected = [int(s) for s in head.last["selected"]]
+    g = None
+    o, og = _oracle_grads(g, cfg, w, inputs, sampled, selected)
+    e_bce = abs(float(out["binary_rel_cls_loss"].detach()) - float(o["binary_rel_cls_loss"].detach()))
+    e_llm = abs(float(out["rel_llm_loss"].detach()) - float(o["rel_llm_loss"].detach()))
+    checked = _compare_grads(head, og)
+    print(f"train seed {seed}: pad {pad}, {n} segments, {len(rels)} relations, {len(sampled)} sampled / {len(selected)} "
+          f"selected pairs; |bce| {e_bce:.1e} of {float(o['binary_rel_cls_loss']):.3f}, |llm| {e_llm:.1e} of "
+          f"{float(o['rel_llm_loss']):.3f}; {checked} gradients within 2e-3")
+    assert e_bce < 5e-3 and e_llm < 1e-3 and checked >= 60
