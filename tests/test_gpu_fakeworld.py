@@ -245,3 +245,83 @@ def test_image_constants_message_round_trip():
     here = be.query_shard(scene, patches, 40, 120)
     there = be.query_shard(be.scene_from_ids(ids2), patches2, 40, 120, bits2)
     assert torch.equal(here[1], there[1])
+
+
+def _shard_fuzz_seeds():
+    import os
+    spec = os.environ.get("PSG_FUZZ_SHARD_SEEDS")               # lo:hi - a one-off sweep (profiles/r06_fuzz_shard.txt)
+    if not spec:
+        return [0, 1, 2, 3]
+    lo, hi = (int(v) for v in spec.split(":"))
+    return list(range(lo, hi))
+
+
+@pytest.fixture(scope="module")
+def fp32s_head():
+    h = _mk_head("fp32s", 40)
+    h.llm_engine.row_invariant = True
+    return h
+
+
+@pytest.mark.parametrize("seed", _shard_fuzz_seeds())
+def test_random_image_sharded_over_a_random_world_is_bit_exact_in_the_headline_mode(fp32s_head, seed):
+    """SURVEY 8e "bit-exactness across R" away from the benchmark's shape: 1-40 objects (1 pair ... 1600 pairs), random
+    geometry, world sizes that do not divide the pair count and worlds LARGER than the pair count (empty shards, ranks
+    that are dealt no decode), selections shorter than 20 - the sharded job gives the single-GPU head's probabilities,
+    selection and every token, on every rank."""
+    from openpsg_amd.dist import HipBackend, LoopbackWorld
+    from openpsg_amd.synthetic import make_scene
+    rng = np.random.default_rng(4242 + seed)
+    head = fp32s_head
+    n = [1, 2, 3, 40][seed] if seed < 4 else int(rng.integers(1, 41))
+    world = [8, 3, 5, 7][seed] if seed < 4 else int(rng.integers(2, 9))
+    pad = (64 * int(rng.integers(4, 19)), 64 * int(rng.integers(4, 19)))
+    scene = make_scene(pad, n, seed=900 + seed, device="cuda:0", tiny_object=bool(seed % 3 == 0),
+                       num_categories=int(rng.integers(2, 134)))
+    n = len(scene["object_id_list"])
+    head(_inputs(scene))
+    torch.cuda.synchronize()
+    ref = dict(prob=head.last["exist_prob"].clone(), sel=head.last["selected"].clone(), tokens=head.last["tokens_host"].copy())
+    fw = LoopbackWorld(world)
+    outs = fw.run([p.step_one_image_gen(scene if r == 0 else None) for r, p in enumerate(fw.pipelines(HipBackend(head)))])
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(outs[r]["exist_prob"], ref["prob"]), f"rank {r}: probabilities differ from the single-GPU head"
+        assert torch.equal(outs[r]["selected"], ref["sel"]), f"rank {r}: selection"
+        assert np.array_equal(outs[r]["tokens"].cpu().numpy(), ref["tokens"]), f"rank {r}: tokens"
+    print(f"shard seed {seed}: pad {pad}, N = {n} ({n * n} pairs), world {world}, selected {ref['sel'].numel()}: bit-exact on every rank")
+
+
+@pytest.mark.parametrize("seed", _shard_fuzz_seeds())
+def test_random_step_of_unequal_images_is_bit_exact_in_the_headline_mode(fp32s_head, seed):
+    """The weak-scaling `step` (bench.py's N > 1 job) on random jobs: 2-8 ranks, one or two images per rank, every image
+    with its own geometry and 1-40 objects (images of ONE pair next to images of 1600, shards that are empty on most
+    ranks, selections shorter than 20): every image's probabilities, selection and tokens equal the single-GPU head's
+    on every rank."""
+    from openpsg_amd.dist import HipBackend, LoopbackWorld
+    from openpsg_amd.synthetic import make_scene
+    rng = np.random.default_rng(777 + seed)
+    head = fp32s_head
+    world = [2, 3, 8, 5][seed] if seed < 4 else int(rng.integers(2, 9))
+    per_rank = 2 if (seed == 0 or (seed >= 4 and rng.random() < 0.25 and world <= 4)) else 1
+    scenes = []
+    for m in range(world * per_rank):
+        n = 1 if (m == 1 and seed % 2 == 0) else int(rng.integers(1, 41))
+        pad = (64 * int(rng.integers(4, 19)), 64 * int(rng.integers(4, 19)))
+        scenes.append(make_scene(pad, n, seed=3000 + 50 * seed + m, device="cuda:0", num_categories=int(rng.integers(2, 134))))
+    refs = []
+    for s in scenes:
+        head(_inputs(s))
+        torch.cuda.synchronize()
+        refs.append(dict(prob=head.last["exist_prob"].clone(), sel=head.last["selected"].clone(),
+                         tokens=head.last["tokens_host"].copy()))
+    fw = LoopbackWorld(world)
+    outs = fw.run([p.step_gen(scenes) for p in fw.pipelines(HipBackend(head))])
+    torch.cuda.synchronize()
+    for m in range(len(scenes)):
+        for r in range(world):
+            assert torch.equal(outs[r]["exist_prob"][m], refs[m]["prob"]), (r, m)
+            assert torch.equal(outs[r]["selected"][m], refs[m]["sel"]), (r, m)
+            assert np.array_equal(outs[r]["tokens"][m].cpu().numpy(), refs[m]["tokens"]), (r, m)
+    print(f"step seed {seed}: world {world} x {per_rank} image(s) per rank, objects {[len(s['object_id_list']) for s in scenes]}: "
+          "bit-exact on every rank")
