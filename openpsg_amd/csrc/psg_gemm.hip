@@ -582,6 +582,7 @@ static int sg_plan(const psg_ctx* ctx, int M, int N, int K) {
 int psg_sgf_plan(const psg_ctx* ctx, int M, int N, int K);
 int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K, int splits,
                    void* stream, bool w16);
+bool psg_sgf_fits(const psg_ctx* ctx, int M, int K, int splits);
 
 extern "C" int psg_skinny_gemm_plan(psg_ctx* ctx, int M, int N, int K, int dtype, int* splits) {
   PSG_REQUIRE(ctx && splits, PSG_ERR_INVALID, "psg_skinny_gemm_plan: NULL argument");
@@ -590,6 +591,9 @@ extern "C" int psg_skinny_gemm_plan(psg_ctx* ctx, int M, int N, int K, int dtype
     PSG_REQUIRE(N >= 16 && N % 16 == 0 && K >= 32 && K % 32 == 0, PSG_ERR_UNSUPPORTED,
                 "psg_skinny_gemm(f32): N=%d must be a multiple of 16, K=%d a multiple of 32", N, K);
     *splits = psg_sgf_plan(ctx, M, N, K);
+    PSG_REQUIRE(psg_sgf_fits(ctx, M, K, *splits), PSG_ERR_UNSUPPORTED,
+                "psg_skinny_gemm(f32): %d rows of K=%d do not fit the LDS beside the weight rings at %d slices "
+                "(K <= 11776 at 32 rows, <= 20480 at 20); use the library GEMM for this shape", M, K, *splits);
     return PSG_OK;
   }
   PSG_REQUIRE(N > 0 && N % 16 == 0 && K >= 64 && K % 64 == 0, PSG_ERR_UNSUPPORTED,

@@ -314,6 +314,14 @@ int psg_sgf_plan(const psg_ctx* ctx, int M, int N, int K) {
   return S;
 }
 
+// Does a launch of M rows at this split count fit?  (The plan bounds the LDS at 32 rows with at most PSG_MAX_SPLITS
+// slices - what a consumer can sum: M = 32 fits up to K = 11776, M = 20 up to K = 20480.  Beyond that the kernel refuses
+// and the caller takes the library GEMM: psg_skinny_gemm_plan reports it before anything is launched.)
+bool psg_sgf_fits(const psg_ctx* ctx, int M, int K, int splits) {
+  (void)ctx;
+  return sgf_lds(M, K, splits, 8, 3) <= 160 * 1024;
+}
+
 int psg_sgf_launch(psg_ctx* ctx, const void* x, const void* w, float* part, int M, int N, int K, int splits,
                    void* stream, bool w16) {
   PSG_REQUIRE(ctx && x && w && part, PSG_ERR_INVALID, "psg_skinny_gemm(f32): NULL argument");

@@ -255,6 +255,7 @@ class LlamaDecodeEngine:
         # mode 'fp32s' as two fp16 products of the split activations (psg_split_gemm_w16, 2^-22).  Anything trained in
         # fp32 fails the check and keeps the fp32 stream.
         self._w16 = {}
+        self._skinny_ok = {}
         self._w16_all = False
         self._ones = {}
         from . import _lib as _lib0
@@ -360,13 +361,28 @@ class LlamaDecodeEngine:
             ent = self._i2_w[w.data_ptr()] = ops.split_f16i2(w)
         return ent
 
+    def _skinny_fits(self, x, w):
+        """The weight-streaming kernel keeps the rows' K slice in LDS beside its weight rings: the fp32 kernel takes 32 rows up
+        to K = 11776 and 20 rows up to K = 20480 (every Llama-2-7B / 13B shape at the reference's 20 selected pairs).  A wider
+        model falls through to the library GEMM for that projection (exact fp32, not batch-invariant) instead of failing."""
+        key = (x.shape[0], tuple(w.shape), x.dtype)
+        ok = self._skinny_ok.get(key)
+        if ok is None:
+            try:
+                ops.skinny_gemm_plan(x.shape[0], w.shape[0], w.shape[1], x.dtype, self.device)
+                ok = True
+            except PsgHipError:
+                ok = False
+            self._skinny_ok[key] = ok
+        return ok
+
     def linear(self, x, w, ws=None, decode=False):
         """Bias-free projection.  Decode-step shapes (<= 32 rows) use the hand-written weight-streaming kernel - in
         the 16-bit modes and in the fp32 mode (the reference's own precision, V4:99-100) alike; the prompt pass goes
         through hipBLASLt; decode steps of 33..160 rows (several images' pairs, 16-bit modes) through whichever of
         psg_batch_gemm's variants and the library was measured fastest for the shape (_plan_batch_mm)."""
         if (self.use_skinny and x.shape[0] <= 32 and x.dtype == w.dtype and w.shape[0] % 16 == 0
-                and w.shape[1] % 64 == 0 and w.shape[1] >= 256):
+                and w.shape[1] % 64 == 0 and w.shape[1] >= 256 and self._skinny_fits(x, w)):
             wh = self._w16.get(w.data_ptr()) if x.dtype == torch.float32 else None
             if wh is not None and self.prefill_split:         # fp32s: two fp16 products of the split rows, 2 bytes per weight
                 x2, inv = ops.split_f16x2(x)

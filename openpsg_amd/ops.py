@@ -534,6 +534,18 @@ def greedy_step(logits, step, max_new, eos, suppress_token, tokens, done, next_i
                               _p(tok_pos, torch.int32), ep, ed, hid, xp, xd, dt, st), "psg_greedy_step")
 
 
+def skinny_gemm_plan(M, N, K, dtype, device) -> int:
+    """Split count psg_skinny_gemm would use for x [M, K] of `dtype` against w [N, K]; raises PsgHipError where the kernel
+    does not take the shape (psg_skinny_gemm_plan: row count, divisibility, the fp32 kernel's LDS bound)."""
+    import ctypes
+    lib = _lib.load()
+    dev = torch.device(device)
+    s = ctypes.c_int(0)
+    check(lib.psg_skinny_gemm_plan(_lib.ctx(dev.index or 0), int(M), int(N), int(K), _DT[dtype], ctypes.byref(s)),
+          "psg_skinny_gemm_plan")
+    return s.value
+
+
 def skinny_gemm(x, w, splits=None) -> Partials:
     """Decode-step projection: fp32 split-K partials of x @ w.T (x: <= 32 rows of bf16 / fp16 / fp32, w of the
     same type); every weight byte streams from HBM once.  Hand the result to a consumer kernel or call .reduce()."""

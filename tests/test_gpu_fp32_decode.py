@@ -21,7 +21,17 @@ SHAPES = [(20, 4096, 4096), (20, 12288, 4096), (20, 22016, 4096), (20, 4096, 110
           (32, 48, 96), (5, 16, 32), (20, 1040, 256)]
 
 
-@pytest.mark.parametrize("M,N,K", SHAPES)
+def _fuzz_shapes():
+    """PSG_FUZZ_GEMM=count (a one-off sweep, profiles/r06_fuzz_gemm.txt): `count` random shapes - 1..32 rows, N any multiple
+    of 16 up to 8192, K any multiple of 32 up to 12288 - next to the fixed list."""
+    import os
+    import random
+    n = int(os.environ.get("PSG_FUZZ_GEMM", "0"))
+    r = random.Random(2024)
+    return [(r.randint(1, 32), 16 * r.randint(1, 512), 32 * r.randint(1, 384)) for _ in range(n)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES + _fuzz_shapes())
 def test_fp32_skinny_gemm_vs_fp64(M, N, K):
     from openpsg_amd import ops
     dev = _dev()
@@ -30,7 +40,12 @@ def test_fp32_skinny_gemm_vs_fp64(M, N, K):
     # cannot cancel
     x = torch.randn(M, K, generator=g).to(dev)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
-    part = ops.skinny_gemm(x, w)
+    from openpsg_amd import _lib
+    try:
+        part = ops.skinny_gemm(x, w)
+    except _lib.PsgHipError as e:                      # (sweep shapes only) more rows x K than the LDS holds beside the rings
+        assert K > 11776 and M > 20 and "do not fit the LDS" in str(e), (M, N, K, str(e))
+        return
     y = part.reduce(torch.float32)
     ref = x.double() @ w.double().t()
     bound = 4e-7 * (x.double().abs() @ w.double().abs().t()) + 1e-30
@@ -396,3 +411,31 @@ def test_fp32s_prompt_pass_with_fused_splits_matches_the_separate_kernels():
     for i in range(outs[1][0].shape[0]):
         want = g["gen_tokens"][i]
         assert [int(t) for t in outs[1][0][i] if t >= 0] == want[want >= 0].tolist()
+
+
+def test_engine_takes_the_library_gemm_where_the_streaming_kernel_cannot_hold_the_rows():
+    """The fp32 weight-streaming kernel keeps the rows' K slice in LDS: 32 rows fit up to K = 11776, 20 rows up to 20480.
+    Beyond that psg_skinny_gemm_plan refuses BEFORE anything is launched and the engine's projection falls through to the
+    library GEMM (dense result) instead of raising - a model wider than Llama-2-13B still decodes."""
+    from openpsg_amd import _lib, ops
+    from openpsg_amd.config import PSGConfig, QFormerConfig, tiny_llm
+    from openpsg_amd.llm import LlamaDecodeEngine
+    from openpsg_amd.weights import make_weights_numpy
+    dev = _dev()
+    assert ops.skinny_gemm_plan(32, 4096, 11008, torch.float32, dev) == 16 and ops.skinny_gemm_plan(20, 4096, 20480, torch.float32, dev) == 16
+    with pytest.raises(_lib.PsgHipError, match="do not fit the LDS"):
+        ops.skinny_gemm_plan(32, 4096, 12288, torch.float32, dev)
+    with pytest.raises(_lib.PsgHipError, match="do not fit the LDS"):
+        ops.skinny_gemm_plan(21, 4096, 20480, torch.float32, dev)
+    cfg = PSGConfig(qformer=QFormerConfig(vocab=512), llm=tiny_llm(256, 1, 512, 512), max_object_num=30)
+    w = make_weights_numpy(cfg, seed=3)
+    eng = LlamaDecodeEngine(w, cfg, dev, torch.float32)
+    g = torch.Generator().manual_seed(2)
+    wide = (torch.randn(256, 12288, generator=g) / 110.0).to(dev)
+    x = torch.randn(32, 12288, generator=g).to(dev)
+    y32 = eng.linear(x, wide, decode=True)
+    assert torch.is_tensor(y32) and torch.equal(y32, torch.nn.functional.linear(x, wide))     # the library's own result
+    y20 = eng.linear(x[:20].contiguous(), wide, decode=True)
+    assert isinstance(y20, ops.Partials)                                                     # 20 rows still stream
+    ref = x[:20].double() @ wide.double().t()
+    assert ((y20.reduce(torch.float32).double() - ref).abs() <= 4e-7 * (x[:20].double().abs() @ wide.double().abs().t())).all()

@@ -665,7 +665,18 @@ def test_no_cpu_fallback():
         ops.topk(torch.rand(8), 2)                                 # CPU tensor must be rejected loudly
 
 
-@pytest.mark.parametrize("M,N,K", [(20, 4096, 4096), (20, 4096, 11008), (1, 512, 256), (32, 768, 2752), (7, 32000, 4096)])
+def _fuzz_skinny_shapes():
+    """PSG_FUZZ_GEMM=count (a one-off sweep, profiles/r06_fuzz_gemm.txt): random shapes of the 16-bit streaming kernel - 1..32
+    rows, N any multiple of 16 up to 8192, K any multiple of 64 up to 16384."""
+    import os
+    import random
+    n = int(os.environ.get("PSG_FUZZ_GEMM", "0"))
+    r = random.Random(515)
+    return [(r.randint(1, 32), 16 * r.randint(1, 512), 64 * r.randint(1, 256)) for _ in range(n)]
+
+
+@pytest.mark.parametrize("M,N,K", [(20, 4096, 4096), (20, 4096, 11008), (1, 512, 256), (32, 768, 2752), (7, 32000, 4096)]
+                         + _fuzz_skinny_shapes())
 def test_skinny_gemm_vs_fp32_reference(M, N, K):
     from openpsg_amd import ops
     dev = _dev()
