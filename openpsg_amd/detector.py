@@ -86,6 +86,30 @@ class PrecomputedSegmenter:
                 torch.from_numpy(z["mask_features"]).to(self.device))
 
 
+class OpenSeeDSegmenter:
+    """Adapter around a LIVE OpenSeeD model (the un-vendored fork the reference builds at DET2:36-41: any object whose
+    `forward(batch_inputs)` returns `(outputs, mask_features)` with `outputs[0]['panoptic_seg'] = (id map, segments_info)`
+    and whose `.model.pixel_mean / .pixel_std` hold the normalisation constants).  Does what DET2:94-109 does around that
+    call: the mmdet-normalised image back to 0..255, the padding removed (`img_shape`), OpenSeeD told the original size
+    (`ori_shape`).  A deployment that has OpenSeeD installed passes `segmenter=OpenSeeDSegmenter(openseed)`."""
+
+    def __init__(self, openseed):
+        self.openseed = openseed
+
+    @torch.no_grad()
+    def __call__(self, img, img_meta):
+        model = self.openseed.model
+        mean = model.pixel_mean.clone().to(img.device).view(3, 1, 1)                      # DET2:98-100
+        std = model.pixel_std.clone().to(img.device).view(3, 1, 1)
+        img = img * std + mean
+        h, w = img_meta['img_shape'][:2]                                                 # DET2:102-103: no padding
+        img = img[:, :h, :w]
+        batch_inputs = [{'image': img, 'height': img_meta['ori_shape'][0], 'width': img_meta['ori_shape'][1]}]
+        outputs, mask_features = self.openseed.forward(batch_inputs)                     # DET2:107
+        seg, info = outputs[0]['panoptic_seg']
+        return seg, info, mask_features
+
+
 @DETECTORS.register_module()
 class OpenSeeDRelationV2(nn.Module):
     def __init__(self, openseed_config_path='', openseed_pretrained_path='', thing_classes=(), stuff_classes=(),

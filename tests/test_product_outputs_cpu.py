@@ -70,6 +70,34 @@ def test_detector_pack_contract():
     assert out['rel_scores'] == [1]
 
 
+def test_openseed_segmenter_adapter_feeds_openseed_what_the_reference_feeds_it():
+    """DET2:94-109 around a live OpenSeeD model: the mmdet-normalised image back on the 0..255 scale, the padding cut off,
+    the original size handed over - and the detector turns its panoptic output into the head's id map (DET2:112-132)."""
+    from types import SimpleNamespace
+    from openpsg_amd.detector import OpenSeeDRelationV2, OpenSeeDSegmenter
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    seen = {}
+
+    class FakeOpenSeeD:                                           # the surface DET2 uses: .model.pixel_mean/std, .forward
+        model = SimpleNamespace(pixel_mean=mean, pixel_std=std)
+
+        def forward(self, batch_inputs):
+            seen.update(batch_inputs[0])
+            seg = torch.tensor([[0, 1, 1], [2, 2, 3]])
+            info = [dict(id=1, category_id=0), dict(id=2, category_id=17), dict(id=3, category_id=0)]
+            return [dict(panoptic_seg=(seg, info))], torch.zeros(1, 256, 2, 2)
+    raw = torch.randint(0, 256, (3, 6, 8)).float()                                        # a 6 x 8 image, 0..255
+    padded = torch.zeros(1, 3, 8, 8)
+    padded[0, :, :6, :] = (raw - mean.view(3, 1, 1)) / std.view(3, 1, 1)                   # mmdet's Normalize + Pad
+    meta = dict(img_shape=(6, 8, 3), pad_shape=(8, 8, 3), ori_shape=(12, 16, 3), filename="a.jpg")
+    det = OpenSeeDRelationV2(relation_head=None, segmenter=OpenSeeDSegmenter(FakeOpenSeeD()))
+    results, feat = det.forward_openseed(padded, [meta])
+    assert seen["image"].shape == (3, 6, 8) and torch.allclose(seen["image"], raw, atol=1e-3)
+    assert (seen["height"], seen["width"]) == (12, 16)
+    assert [int(i) for i in results[0]["object_id_list"]] == [0, 17, 1000] and feat.shape == (1, 256, 2, 2)
+    assert results[0]["pan_results"].tolist() == [[0, 0, 0], [17, 17, 1000]]
+
+
 def test_build_detector_from_reference_config_dict():
     """CFG:52-68 as a dict, resolved by importing the dotted paths of `custom_imports` (CFG:7-13)."""
     for mod in ("kings_sgg.models.detectors.openseed_relation_v2",
