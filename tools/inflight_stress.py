@@ -21,8 +21,9 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 faulthandler.dump_traceback_later(int(os.environ.get("PSG_WATCHDOG_S", "240")), exit=True)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-a = bench.argparse.Namespace(objects=50, size=1024, llm_layers=32, workload="full", dtype="mixed", one_phase=False,
-                             pair_chunk=0, categories=133)
+# PSG_STRESS_DTYPE=fp32s (the headline mode: library GEMMs of the prompt pass inside both slots' graphs), PSG_STRESS_VALUES=fp16
+a = bench.argparse.Namespace(objects=50, size=1024, llm_layers=32, workload="full", dtype=os.environ.get("PSG_STRESS_DTYPE", "mixed"),
+                             one_phase=False, pair_chunk=0, categories=133, llm_values=os.environ.get("PSG_STRESS_VALUES", "fp32"))
 head = bench.setup_head(a, dev)
 if os.environ.get("PSG_NO_SKINNY") == "1":                      # decode projections on the library GEMM (inside the graphs)
     head.llm_engine.use_skinny = False
