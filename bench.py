@@ -531,10 +531,32 @@ DTYPE_LABEL = {"fp32s": "fp32", "fp32": "fp32", "mixed": "fp16", "fp16": "fp16",
 MATRIX_PEAK = {"fp32s": (2.5e15, 3), "fp32": (157.3e12, 1), "mixed": (2.5e15, 1), "fp16": (2.5e15, 1), "bf16": (2.5e15, 1)}
 
 
-def pmc_traffic(pmc_file):
-    """HBM bytes per launch from the committed PMC summary of a kernel (profiles/README.md: not re-measured in the run)."""
+def _sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def pmc_traffic_checked(pmc_file):
+    """(HBM bytes per launch, source note) from the committed PMC summary of a kernel - counters need their own rocprofv3
+    passes, so the figure is READ, not re-measured in the run (profiles/README.md).  The summary records the hashes of the
+    kernel's source files at collection time (`kernel_sources`, tools/pmc_summary.py): if any of them has changed since,
+    the figure no longer describes the kernel that was timed and `traffic` is reported as null with the reason."""
     pmc = os.path.join(REPO, "profiles", pmc_file)
-    return json.load(open(pmc)).get("hbm_bytes_per_launch") if os.path.exists(pmc) else None
+    if not os.path.exists(pmc):
+        return None, f"profiles/{pmc_file} is missing"
+    d = json.load(open(pmc))
+    src = d.get("kernel_sources") or {}
+    stale = [f for f, h in src.items() if not os.path.exists(os.path.join(REPO, f)) or _sha16(os.path.join(REPO, f)) != h]
+    if stale:
+        return None, (f"profiles/{pmc_file} is STALE: {', '.join(stale)} changed since its rocprofv3 --pmc passes "
+                      "(re-run tools/collect_profiles_r06.sh)")
+    note = (f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel; not re-measured in this "
+            "run" + ("; the kernel's sources are unchanged since: hashes checked" if src else "") + ")")
+    return d.get("hbm_bytes_per_launch"), note
+
+
+def pmc_traffic(pmc_file):
+    return pmc_traffic_checked(pmc_file)[0]
 
 
 def cross_attention_figures(dev, N, size):
@@ -612,11 +634,7 @@ def decode_roofline(head, N, pmc_file, kernel):
     r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(bpl),
          "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": n, "bytes_per_decode_step": int(bpl * n)}
-    pmc = os.path.join(REPO, "profiles", pmc_file)
-    if os.path.exists(pmc):
-        r["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        r["traffic_source"] = (f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel; "
-                               "not re-measured in this run)")
+    r["traffic"], r["traffic_source"] = pmc_traffic_checked(pmc_file)
     return r
 
 
@@ -1084,11 +1102,11 @@ def main():
                         ach = bpl / spl / 1e9
                         fz["roofline"] = {"bound": "hbm", "kernel": "batch_gemm_kernel<EF16, 2, 1, 1, PAIR> (psg_split_gemm_w16)",
                                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("pmc_split_gemm_w16.json"),
+                                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_checked("pmc_split_gemm_w16.json")[0],
                                           "bytes_per_launch": int(bpl),
                                           "us_per_launch": round(spl * 1e6, 2), "launches_per_decode_step": nl,
                                           "bytes_per_decode_step": int(bpl * nl),
-                                          "traffic_source": "profiles/pmc_split_gemm_w16.json (not re-measured in this run)",
+                                          "traffic_source": pmc_traffic_checked("pmc_split_gemm_w16.json")[1],
                                           # the same three terms as the headline's roofline.image, from this head's own shapes
                                           "image": image_floor(h, a, "fp32s", int(bpl * nl), el * 1e3, prompt_mult=2)}
                     if not a.no_batched:

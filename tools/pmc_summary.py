@@ -57,6 +57,14 @@ def main(fetch_db, write_db, out=None, esz=2):
                       "MI355X_MICROARCH.md); summarised by tools/pmc_summary.py",
                per_shape=per, launches_per_decode_step=129, hbm_bytes_per_launch=int(tot_h / 129),
                algorithmic_bytes_per_launch=int(tot_a / 129), ratio=round(tot_h / tot_a, 3))
+    # hashes of the kernel's sources at collection time: bench.py reports `traffic` only while they are unchanged
+    import hashlib
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = (["openpsg_amd/csrc/psg_batch_gemm.hip"] if PREFIX[0] != "skinny_gemm" else
+             ["openpsg_amd/csrc/psg_gemm.hip"] if esz == 2 else ["openpsg_amd/csrc/psg_gemm_f32.hip"]) + \
+        ["openpsg_amd/csrc/psg_common.h"]
+    res["kernel_sources"] = {f: hashlib.sha256(open(os.path.join(repo, f), "rb").read()).hexdigest()[:16] for f in files}
     text = json.dumps(res, indent=1)
     if out:
         open(out, "w").write(text + "\n")
