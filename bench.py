@@ -653,13 +653,26 @@ def image_floor(head, a, dtype, bytes_per_step, ms_measured, prompt_mult=None):
     T = max(v[2].shape[1] for k_, v in head._table_cache.items() if k_[0] == "q")
     fl_rq = relation_query_flops(a.objects, (a.size // 64) ** 2, T, head.cls_first, head.cfg.num_selected)
     t_dec = steps * bytes_per_step / (HBM_PEAK_GBS * 1e9)
+    # the decode attention reads every cached K and V row of every pair once per step (~5 % of a step that the
+    # weight-only floor left out): pairs x layers x context rows x hidden x 2 (K, V) x bytes of the cache's type; the
+    # context of step s is the pair's prompt (32 visual rows + its tokens) + s
+    plen = head.last.get("prompt_len") if head.last is not None else None
+    kv_item = 4 if dtype in ("fp32", "fp32s") else 2
+    if plen is not None:
+        ctx0 = plen.to(torch.float64).cpu() + head.cfg.qformer.num_query
+        ctx_rows = float(sum((ctx0 + s_).sum() for s_ in range(1, steps + 1)))
+    else:
+        ctx_rows = float(head.cfg.num_selected * sum(48 + s_ for s_ in range(1, steps + 1)))
+    kv_bytes = ctx_rows * a.llm_layers * m.hidden * 2 * kv_item
+    t_kv = kv_bytes / (HBM_PEAK_GBS * 1e9)
     t_pp = fl_prompt * pmult / peak
     t_rq = fl_rq * mult / peak
-    floor = (t_dec + t_pp + t_rq) * 1e3
+    floor = (t_dec + t_kv + t_pp + t_rq) * 1e3
     return {"floor_ms": round(floor, 2), "measured_ms": round(ms_measured, 2), "frac": round(floor / ms_measured, 4),
-            "terms_ms": {"decode_weight_passes": round(t_dec * 1e3, 2), "prompt_pass": round(t_pp * 1e3, 2),
-                         "relation_query": round(t_rq * 1e3, 2)},
-            "assumptions": f"{steps} decode steps x {bytes_per_step / 1e9:.2f} GB at {HBM_PEAK_GBS / 1e3:.0f} TB/s; prompt pass "
+            "terms_ms": {"decode_weight_passes": round(t_dec * 1e3, 2), "decode_kv_reads": round(t_kv * 1e3, 2),
+                         "prompt_pass": round(t_pp * 1e3, 2), "relation_query": round(t_rq * 1e3, 2)},
+            "assumptions": f"{steps} decode steps x {bytes_per_step / 1e9:.2f} GB of weights + {kv_bytes / 1e9:.1f} GB of cached "
+                           f"K / V rows over the steps, at {HBM_PEAK_GBS / 1e3:.0f} TB/s; prompt pass "
                            f"{fl_prompt / 1e12:.1f} TFLOP over {rows} rows x{pmult} matrix products and relation query "
                            f"{fl_rq / 1e12:.2f} TFLOP x{mult}, at {peak / 1e12:.0f} TFLOP/s"}
 
