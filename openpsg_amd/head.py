@@ -31,7 +31,8 @@ from .llm import LlamaDecodeEngine
 from .qformer import RelationQueryEngine
 from .registry import HEADS
 from .tokenizers import WordTokenizer
-from .weights import head_shapes, is_hf_checkpoint_dir, llm_shapes, read_hf_llama_config, read_hf_llama_weights
+from .weights import (head_shapes, hf_checkpoint_has_weights, is_hf_checkpoint_dir, llm_shapes, read_hf_llama_config,
+                      read_hf_llama_weights)
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
            "fp16": torch.float16, "float16": torch.float16, "half": torch.float16, "mixed": torch.float16,
@@ -325,7 +326,7 @@ class RelationTransformerHeadV4(nn.Module):
         self.serialize_decodes = False
         self._proj_stale = False
         self.train(False)                                                   # eval by default, as init_detector leaves it
-        if pretrained_dir:
+        if pretrained_dir and hf_checkpoint_has_weights(llm_model_name):     # (config + tokenizer only: load_llm_weights() later)
             # V4:99-103: the LLM comes from `llm_model_name`, not from the head's checkpoint (part_checkpoint_hook.py:96-116
             # drops language_model.*).  language_projection is loaded later: the engine's copy follows it (_proj_stale)
             n = self.cfg.llm.layers if self.llm_truncate_num <= 0 else self.llm_truncate_num

@@ -210,6 +210,13 @@ def is_hf_checkpoint_dir(path) -> bool:
     return isinstance(path, (str, os.PathLike)) and os.path.isfile(os.path.join(path, "config.json"))
 
 
+def hf_checkpoint_has_weights(path) -> bool:
+    """True when the directory holds a model file `read_hf_llama_weights` can read (a tokenizer-only directory does not)."""
+    import os
+    return any(os.path.isfile(os.path.join(path, f)) for f in
+               ("model.safetensors.index.json", "model.safetensors", "pytorch_model.bin.index.json", "pytorch_model.bin"))
+
+
 def read_hf_llama_config(path):
     """LlamaConfig of the checkpoint directory `path` (its config.json).  Raises PsgHipError for an architecture the
     decode kernels are not built for (grouped-query attention, head_dim != 128, tied embeddings without an lm_head)."""

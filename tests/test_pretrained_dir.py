@@ -90,6 +90,9 @@ def test_reader_refuses_what_the_kernels_are_not_built_for(tmp_path, tiny):
         json.dump(_hf_config(cfg.llm), f)
     with pytest.raises(PsgHipError, match="no model.safetensors"):
         read_hf_llama_weights(e)
+    from openpsg_amd.weights import hf_checkpoint_has_weights
+    assert not hf_checkpoint_has_weights(e) and hf_checkpoint_has_weights(d)    # a config / tokenizer-only directory: the head
+    # then takes the architecture from it and waits for load_llm_weights()
 
 
 @pytest.mark.gpu
